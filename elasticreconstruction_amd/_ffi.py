@@ -1,0 +1,97 @@
+"""ctypes binding of liber_hip.so -- the C ABI declared in include/er_hip.h.
+
+There is no CPU fallback: if the shared library is missing, or a constructor cannot find a HIP
+device, the call raises.  Nothing under oracle/ is imported from here.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liber_hip.so")
+
+# Every symbol include/er_hip.h declares (tests/test_abi.py checks header == this list == the .so).
+SYMBOLS = [
+    "er_last_error", "er_device_count", "er_abi_version",
+    "er_tsdf_create", "er_tsdf_destroy", "er_tsdf_set_stream", "er_tsdf_synchronize",
+    "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
+    "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
+    "er_tsdf_extract_world", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
+    "er_tsdf_set_profiling", "er_tsdf_get_profile",
+    "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
+    "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
+]
+
+
+class ErWarp(C.Structure):
+    """struct er_warp (include/er_hip.h)."""
+    _fields_ = [
+        ("ctr", C.POINTER(C.c_float)),
+        ("num_grids", C.c_int),
+        ("resolution", C.c_int),
+        ("length", C.c_float),
+        ("grid_index", C.POINTER(C.c_int)),
+        ("seg", C.POINTER(C.c_double)),
+        ("madj", C.POINTER(C.c_double)),
+    ]
+
+
+class ErError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load liber_hip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ErError(
+            "liber_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C elasticreconstruction_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, ip, dp, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float)
+    u16p = C.POINTER(C.c_uint16)
+    L.er_last_error.restype = C.c_char_p
+    L.er_last_error.argtypes = []
+    L.er_device_count.argtypes = []
+    L.er_abi_version.argtypes = []
+    L.er_tsdf_create.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.er_tsdf_destroy.argtypes = [vp]
+    L.er_tsdf_set_stream.argtypes = [vp, vp]
+    L.er_tsdf_synchronize.argtypes = [vp]
+    L.er_tsdf_scale_depth.argtypes = [vp, vp, vp]
+    L.er_tsdf_reproject.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp, vp]
+    L.er_tsdf_integrate.argtypes = [vp, vp, vp]
+    L.er_tsdf_integrate_frames.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.POINTER(ErWarp)]
+    L.er_tsdf_unit_count.argtypes = [vp, ip]
+    L.er_tsdf_unit_keys.argtypes = [vp, vp]
+    L.er_tsdf_read_unit.argtypes = [vp, C.c_int, vp, vp]
+    L.er_tsdf_sum_weight.argtypes = [vp, dp]
+    L.er_tsdf_extract_world.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_long)]
+    L.er_tsdf_export_weighted.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_import_weighted.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_set_profiling.argtypes = [vp, C.c_int]
+    L.er_tsdf_get_profile.argtypes = [vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    if hasattr(L, "er_cloud_create"):
+        L.er_cloud_create.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp)]
+        L.er_cloud_destroy.argtypes = [vp]
+        L.er_cloud_size.argtypes = [vp]
+        L.er_icp_count_inliers.argtypes = [vp, vp, vp, C.c_double, ip]
+        L.er_icp_align.argtypes = [vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, vp, ip, ip, dp]
+        L.er_find_correspondence.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, C.c_int, ip, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().er_last_error()
+        raise ErError("%s failed: %s" % (what, msg.decode("utf-8", "replace") if msg else "unknown error"))
+
+
+def ptr(a):
+    """numpy array -> void* (the array must stay alive for the duration of the call)."""
+    return a.ctypes.data_as(C.c_void_p)

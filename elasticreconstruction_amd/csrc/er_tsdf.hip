@@ -1,0 +1,918 @@
+// er_tsdf.hip -- path A of liber_hip.so: TSDF depth integration with control-grid warp on MI355X
+// (gfx950).  Replaces the reference's TSDFVolume / TSDFVolumeUnit / ControlGrid / CIntegrateApp::Reproject
+// (Integrate/TSDFVolume.cpp:19-132, TSDFVolumeUnit.cpp:4-21, ControlGrid.h:41-87, IntegrateApp.cpp:228-269).
+//
+// Data layout in HBM (one er_tsdf_s per GPU):
+//   pool      float2[max_units][64][64][64]   {sdf_, weight_} interleaved per voxel, k fastest
+//                                             (the reference keeps two float[64^3] per unit,
+//                                             TSDFVolumeUnit.h:108-109; interleaving makes the
+//                                             read-modify-write one 8-byte access per voxel)
+//   ht_*      open-addressing hash map  hash_key -> {pool slot, 64-bit frame mask}; the device-side
+//                                             twin of TSDFVolume::data_ (TSDFVolume.h:27)
+//   lambda    float[rows*cols]                ScaleDepth's per-pixel ray-length factor (camera constant)
+//   scaled    float[64][rows*cols]            scaled depth of every frame of the batch in flight
+//   zbuf      uint32[64][rows*cols]           Reproject's z-buffer (atomicMin; 0xFFFFFFFF = empty)
+//
+// Launch sequence for a batch of <= 64 frames (er_tsdf_integrate_frames):
+//   [k_reproject_scatter -> k_reproject_fix{1,2,3}]   per SOURCE pixel: warp + scatter-min   (A6/A7)
+//   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
+//                  allocates the unit on first ever touch, appends it to the batch list
+//   k_integrate    per (unit, i-slab): each voxel is loaded ONCE, run against every frame     (A4)
+//                  whose bit is set IN FRAME ORDER, stored once -> bit-identical to the
+//                  reference's frame-by-frame loop with 1/batch of its HBM traffic
+//   k_reset        clears the masks of the batch list
+// All kernels are HBM/latency/VALU work on scattered voxels and pixels: no MFMA.
+#include "er_common.h"
+#include "er_tsdf_math.h"
+
+#include "../../include/er_hip.h"
+
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+namespace {
+
+using namespace er;
+
+constexpr int kBlock = 256;
+constexpr int kEmptyKey = -1;
+constexpr uint32_t kZEmpty = 0xFFFFFFFFu;
+
+// counters[] slots
+enum { C_NUNITS = 0, C_NBATCH = 1, C_POOL_OVERFLOW = 2, C_TABLE_FULL = 3, C_OUT_OF_RANGE = 4, C_ZERO_WRITE = 5, C_COUNT = 8 };
+
+__device__ __forceinline__ unsigned hash_unit_key(int key, int shift) { return ((unsigned)key * 2654435761u) >> shift; }
+
+// Lock-free find-or-insert.  The entry index is stable, so callers never wait for anybody.
+__device__ int ht_find_or_insert(int* __restrict__ ht_key, int cap_mask, int shift, int key) {
+  unsigned h = hash_unit_key(key, shift);
+  for (int probe = 0; probe <= cap_mask; ++probe) {
+    int e = (int)((h + (unsigned)probe) & (unsigned)cap_mask);
+    int k = __hip_atomic_load(&ht_key[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return e;
+    if (k == kEmptyKey) {
+      int old = atomicCAS(&ht_key[e], kEmptyKey, key);
+      if (old == kEmptyKey || old == key) return e;
+    }
+  }
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ScaleDepth's camera-constant factor (TSDFVolume.cpp:24-26), tabulated once per volume.
+__global__ void k_lambda(float* __restrict__ lambda, int cols, int rows, Camera cam) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= cols * rows) return;
+  lambda[p] = scale_lambda(p % cols, p / cols, cam);
+}
+
+// Stand-alone ScaleDepth (TSDFVolume.cpp:19-36) for er_tsdf_scale_depth.
+__global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* __restrict__ lambda,
+                              float* __restrict__ scaled, int pixels, float itrunc) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  scaled[p] = scale_depth_px(depth[p], lambda[p], itrunc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Reproject, IntegrateApp.cpp:247-268: every source pixel is warped through its fragment's control
+// grid and scattered into the frame's z-buffer.  The reference's sequential "write if empty or
+// closer" is an order-independent min for dd != 0; a write of dd == 0 RESETS the cell (0 means
+// empty), which is order dependent, so such writes only record their source index and raise a flag;
+// k_reproject_fix* then replay the affected cells exactly (practically never taken).
+__global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_frames, int cols, int rows, Camera cam,
+                                    const double* __restrict__ seg12, const double* __restrict__ madj12,
+                                    const int* __restrict__ grid_index, const float* __restrict__ ctr, int res,
+                                    float grid_ul, int floats_per_grid, uint32_t* __restrict__ zbuf,
+                                    uint32_t* __restrict__ lastzero, int* __restrict__ counters, int replay) {
+  const int pixels = cols * rows;
+  const long total = (long)n_frames * pixels;
+  if (replay && counters[C_ZERO_WRITE] == 0) return;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+    const int f = (int)(t / pixels);
+    const int p = (int)(t - (long)f * pixels);
+    const uint16_t d = depth[t];
+    if (d == 0) continue;                                             // UVD2XYZ false
+    int cell;
+    uint16_t dd;
+    if (!reproject_px(p % cols, p / cols, d, cam, cols, seg12 + f * 12, madj12 + f * 12,
+                      ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
+      continue;
+    const size_t o = (size_t)f * pixels + cell;
+    if (!replay) {
+      if (dd != 0) {
+        atomicMin(&zbuf[o], (uint32_t)dd);
+      } else {
+        atomicMax(&lastzero[o], (uint32_t)p + 1u);
+        atomicOr(&counters[C_ZERO_WRITE], 1);
+      }
+    } else {
+      const uint32_t lz = lastzero[o];
+      if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&zbuf[o], (uint32_t)dd);
+    }
+  }
+}
+
+// Replay step 1: cells that saw a zero write forget everything (step 2 = scatter with replay = 1).
+__global__ void k_reproject_fix_clear(uint32_t* __restrict__ zbuf, const uint32_t* __restrict__ lastzero, long total,
+                                      const int* __restrict__ counters) {
+  if (counters[C_ZERO_WRITE] == 0) return;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x)
+    if (lastzero[t] > 0) zbuf[t] = kZEmpty;
+}
+
+// Replay step 3: re-arm (lastzero back to all zero, flag down).
+__global__ void k_reproject_fix_rearm(uint32_t* __restrict__ lastzero, long total, int* __restrict__ counters) {
+  if (counters[C_ZERO_WRITE] == 0) return;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x)
+    lastzero[t] = 0;
+}
+__global__ void k_reproject_fix_flag(int* __restrict__ counters) { counters[C_ZERO_WRITE] = 0; }
+
+__global__ void k_zbuf_to_depth(const uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
+  long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  uint32_t z = zbuf[t];
+  depth[t] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per pixel of every frame of the batch: ScaleDepth (TSDFVolume.cpp:19-36) and the unit-touch half
+// of TSDFVolume::Integrate (TSDFVolume.cpp:45-58).  A lane is a "leader" when its key differs from
+// its left neighbour's (consecutive pixels of a row nearly always share a unit), so only a handful
+// of lanes per wave go to the hash map.
+__global__ __launch_bounds__(kBlock) void k_prepare(
+    const uint16_t* __restrict__ depth, const uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
+    Camera cam, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
+    int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
+    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters) {
+  const int pixels = cols * rows;
+  const int f = blockIdx.y;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  int key = -1;
+  if (p < pixels) {
+    const size_t o = (size_t)f * pixels + p;
+    uint16_t d;
+    if (zbuf) {
+      uint32_t z = zbuf[o];
+      d = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
+    } else {
+      d = depth[o];
+    }
+    scaled[o] = scale_depth_px(d, lambda[p], cam.integration_trunc);
+    if (d > 0) {                                                        // TSDFVolume.cpp:47 (no range cut-off)
+      key = touch_key(p % cols, p / cols, d, cam, T12 + f * 12);
+      if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
+    }
+  }
+  const int left = __shfl_up(key, 1);
+  const bool leader = key >= 0 && (lane == 0 || left != key);
+  if (!leader) return;
+  const int e = ht_find_or_insert(ht_key, cap_mask, hash_shift, key);
+  if (e < 0) {
+    atomicOr(&counters[C_TABLE_FULL], 1);
+    return;
+  }
+  const unsigned long long bit = 1ull << f;
+  const unsigned long long seen = __hip_atomic_load(&ht_mask[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (seen & bit) return;                                               // touched_unit.find, TSDFVolume.cpp:53
+  const unsigned long long old = atomicOr(&ht_mask[e], bit);
+  if (old != 0ull) return;
+  // First toucher of this unit in this batch (exactly one lane per unit gets here).
+  if (ht_slot[e] < 0) {                                                 // data_.find( key ) == end, TSDFVolume.cpp:55
+    const int s = atomicAdd(&counters[C_NUNITS], 1);
+    if (s < max_units) {
+      ht_slot[e] = s;                                                   // pool memory is zero-filled up front
+      unit_key[s] = key;
+    } else {
+      atomicOr(&counters[C_POOL_OVERFLOW], 1);
+    }
+  }
+  batch[atomicAdd(&counters[C_NBATCH], 1)] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
+// Work item = (unit, i-slab): 64 x 64 voxels.  A wave owns 16 j-rows; lane = k, so one row is a
+// 512-byte coalesced float2 access.  kRows rows live in registers while the wave walks the unit's
+// frame mask in ascending frame order (wave-uniform loop: frame constants come in by scalar loads).
+constexpr int kRows = 4;
+
+__global__ __launch_bounds__(kBlock) void k_integrate(
+    float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
+    const unsigned long long* __restrict__ ht_mask, const int* __restrict__ batch, const int* __restrict__ counters,
+    const FrameXform* __restrict__ frames, const float* __restrict__ scaled, Camera cam, int cols, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int pixels = cols * rows;
+  const int n_items = counters[C_NBATCH] * kUnitRes;
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int e = batch[item >> 6];
+    const int i = item & 63;
+    const int slot = __builtin_amdgcn_readfirstlane(ht_slot[e]);
+    if (slot < 0) continue;                                             // pool overflow: reported by the host
+    const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
+    const unsigned long long mraw = ht_mask[e];
+    const unsigned long long mask =
+        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mraw >> 32)) << 32) |
+        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mraw & 0xFFFFFFFFull));
+    const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+    const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
+    const float g0 = grid_coord(i, xs);
+    const float g2 = grid_coord(lane, zs);
+    float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + lane;
+#pragma unroll 1
+    for (int jc = 0; jc < 16; jc += kRows) {
+      const int j0 = wave * 16 + jc;
+      float S[kRows], W[kRows], W0[kRows], g1[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const float2 v = slab[(j0 + r) * kUnitRes];
+        S[r] = v.x;
+        W[r] = v.y;
+        W0[r] = v.y;
+        g1[r] = grid_coord(j0 + r, ys);
+      }
+      unsigned long long m = mask;
+      while (m) {
+        const int f = __builtin_ctzll(m);
+        m &= m - 1;
+        const FrameXform fx = frames[f];
+        const float* __restrict__ sc = scaled + (size_t)f * pixels;
+#pragma unroll
+        for (int r = 0; r < kRows; r++) voxel_update(S[r], W[r], g0, g1[r], g2, fx, cam, cols, rows, sc);
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; r++)
+        if (W[r] != W0[r]) slab[(j0 + r) * kUnitRes] = make_float2(S[r], W[r]);
+    }
+  }
+}
+
+// Clears the frame masks of the batch list and accounts unit visits (sum of popcounts).
+__global__ void k_reset(const int* __restrict__ batch, int* __restrict__ counters, unsigned long long* __restrict__ ht_mask,
+                        unsigned long long* __restrict__ stats) {
+  const int n = counters[C_NBATCH];
+  unsigned long long visits = 0;
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int e = batch[t];
+    visits += (unsigned long long)__popcll(ht_mask[e]);
+    ht_mask[e] = 0ull;
+  }
+  if (visits) atomicAdd(&stats[0], visits);
+  __syncthreads();
+  if (threadIdx.x == 0) counters[C_NBATCH] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sum of weight_ (= number of voxel updates, TSDFVolume.cpp:90,94); wave shuffle -> one atomic per block.
+__global__ void k_sum_weight(const float2* __restrict__ pool, long n_vox, double* __restrict__ out) {
+  double s = 0.0;
+  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n_vox; t += (long)gridDim.x * blockDim.x)
+    s += (double)pool[t].y;
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  __shared__ double part[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double b = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) b += part[w];
+    atomicAdd(out, b);
+  }
+}
+
+// SaveWorld's filter (TSDFVolume.cpp:118).  One wave per (unit, i-slab); pass 0 counts, pass 1 writes
+// the points in i,j,k order at the slab's offset (stable compaction by ballot prefix).
+__device__ __forceinline__ bool world_keep(float2 v) { return v.y != 0.0f && v.x < 0.98f && v.x >= -0.98f; }
+
+__global__ __launch_bounds__(64) void k_world(const float2* __restrict__ pool, const int* __restrict__ slots,
+                                              const int* __restrict__ keys, long* __restrict__ slab_count,
+                                              const long* __restrict__ slab_offset, float4* __restrict__ out, int pass) {
+  const int rank = blockIdx.x >> 6;          // unit in ascending key order
+  const int i = blockIdx.x & 63;
+  const int lane = threadIdx.x;
+  const float2* slab = pool + (size_t)slots[rank] * kUnitVox + (size_t)i * 4096;
+  const int key = keys[rank];
+  const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+  long base = pass ? slab_offset[blockIdx.x] : 0;
+  long total = 0;
+  for (int j = 0; j < 64; j++) {
+    const float2 v = slab[j * 64 + lane];
+    const bool keep = world_keep(v);
+    const unsigned long long b = __ballot(keep);
+    if (pass && keep) {
+      const long o = base + total + __popcll(b & ((1ull << lane) - 1ull));
+      out[o] = make_float4((float)(i + (xi - 256) * 64), (float)(j + (yi - 256) * 64), (float)(lane + (zi - 256) * 64), v.x);
+    }
+    total += __popcll(b);
+  }
+  if (!pass && lane == 0) slab_count[blockIdx.x] = total;
+}
+
+// Multi-GPU frame split: planes [key][0] = sdf*weight, [key][1] = weight.
+__global__ void k_export_weighted(const float2* __restrict__ pool, const int* __restrict__ slots, float* __restrict__ buf) {
+  const int q = blockIdx.y;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = slots[q];
+  float sw = 0.0f, w = 0.0f;
+  if (slot >= 0) {
+    const float2 v = pool[(size_t)slot * kUnitVox + l];
+    sw = v.x * v.y;
+    w = v.y;
+  }
+  buf[((size_t)q * 2 + 0) * kUnitVox + l] = sw;
+  buf[((size_t)q * 2 + 1) * kUnitVox + l] = w;
+}
+
+__global__ void k_import_weighted(float2* __restrict__ pool, const int* __restrict__ slots, const float* __restrict__ buf) {
+  const int q = blockIdx.y;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int slot = slots[q];
+  if (slot < 0) return;
+  const float sw = buf[((size_t)q * 2 + 0) * kUnitVox + l];
+  const float w = buf[((size_t)q * 2 + 1) * kUnitVox + l];
+  pool[(size_t)slot * kUnitVox + l] = make_float2(w > 0.0f ? sw / w : 0.0f, w);
+}
+
+// Host-driven unit allocation (import of units this GPU never touched).
+__global__ void k_ensure_units(const int* __restrict__ keys, int n, int* __restrict__ ht_key, int* __restrict__ ht_slot,
+                               int cap_mask, int hash_shift, int* __restrict__ unit_key, int max_units,
+                               int* __restrict__ counters, int* __restrict__ slots_out, int allocate) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int key = keys[t];
+  int slot = -1;
+  if (allocate) {
+    const int e = ht_find_or_insert(ht_key, cap_mask, hash_shift, key);   // keys are unique: no race on the slot
+    if (e < 0) {
+      atomicOr(&counters[C_TABLE_FULL], 1);
+    } else {
+      slot = ht_slot[e];
+      if (slot < 0) {
+        const int s = atomicAdd(&counters[C_NUNITS], 1);
+        if (s < max_units) {
+          ht_slot[e] = s;
+          unit_key[s] = key;
+          slot = s;
+        } else {
+          atomicOr(&counters[C_POOL_OVERFLOW], 1);
+        }
+      }
+    }
+  } else {
+    unsigned h = hash_unit_key(key, hash_shift);
+    for (int probe = 0; probe <= cap_mask; ++probe) {
+      const int e = (int)((h + (unsigned)probe) & (unsigned)cap_mask);
+      const int k = ht_key[e];
+      if (k == key) { slot = ht_slot[e]; break; }
+      if (k == kEmptyKey) break;
+    }
+  }
+  slots_out[t] = slot;
+}
+
+}  // namespace
+
+// ================================================================================================
+struct er_tsdf_s {
+  int device = 0, cols = 0, rows = 0, pixels = 0, max_units = 0;
+  er::Camera cam{};
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  int n_cu = 256;
+  // device memory
+  float2* pool = nullptr;
+  int *ht_key = nullptr, *ht_slot = nullptr, *unit_key = nullptr, *counters = nullptr, *batch = nullptr;
+  unsigned long long *ht_mask = nullptr, *stats = nullptr;
+  int ht_cap = 0, ht_shift = 0;
+  float *lambda = nullptr, *scaled = nullptr, *ctr = nullptr;
+  uint16_t* depth_stage = nullptr;
+  uint32_t *zbuf = nullptr, *lastzero = nullptr;
+  er::FrameXform* frames = nullptr;
+  double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
+  int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
+  size_t ctr_cap = 0, key_scratch_cap = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double ms_total = 0.0;
+  long launches = 0, frames_done = 0;
+};
+
+namespace {
+
+int check_flags(er_tsdf_t h) {
+  int c[C_COUNT];
+  ER_HIP_TRY(hipMemcpyAsync(c, h->counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (c[C_POOL_OVERFLOW])
+    return er::fail("TSDF unit pool exhausted: %d units requested, capacity %d (raise max_units)", c[C_NUNITS], h->max_units);
+  if (c[C_TABLE_FULL]) return er::fail("TSDF unit hash table full (capacity %d)", h->ht_cap);
+  return 0;
+}
+
+int drain_events(er_tsdf_t h) {
+  for (auto& ev : h->events) {
+    float ms = 0.f;
+    ER_HIP_TRY(hipEventSynchronize(ev.second));
+    ER_HIP_TRY(hipEventElapsedTime(&ms, ev.first, ev.second));
+    h->ms_total += ms;
+    h->launches += 1;
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  h->events.clear();
+  return 0;
+}
+
+int ensure_key_scratch(er_tsdf_t h, size_t n) {
+  if (n <= h->key_scratch_cap) return 0;
+  if (h->key_scratch) (void)hipFree(h->key_scratch);
+  if (h->slot_scratch) (void)hipFree(h->slot_scratch);
+  h->key_scratch = h->slot_scratch = nullptr;
+  size_t cap = std::max<size_t>(n, 1024);
+  ER_HIP_TRY(hipMalloc(&h->key_scratch, cap * sizeof(int)));
+  ER_HIP_TRY(hipMalloc(&h->slot_scratch, cap * sizeof(int)));
+  h->key_scratch_cap = cap;
+  return 0;
+}
+
+// keys (host) -> slots (device slot_scratch), optionally allocating missing units.
+int resolve_slots(er_tsdf_t h, const int* keys_host, int n, bool allocate) {
+  if (ensure_key_scratch(h, (size_t)n)) return 1;
+  ER_HIP_TRY(hipMemcpyAsync(h->key_scratch, keys_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_ensure_units, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->key_scratch, n,
+                     h->ht_key, h->ht_slot, h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->counters,
+                     h->slot_scratch, allocate ? 1 : 0);
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int sorted_units(er_tsdf_t h, std::vector<int>& keys, std::vector<int>& slots) {
+  if (check_flags(h)) return 1;
+  int n = 0;
+  ER_HIP_TRY(hipMemcpy(&n, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  n = std::min(n, h->max_units);
+  std::vector<int> uk((size_t)n);
+  if (n) ER_HIP_TRY(hipMemcpy(uk.data(), h->unit_key, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  std::vector<std::pair<int, int>> ks((size_t)n);
+  for (int s = 0; s < n; s++) ks[(size_t)s] = std::make_pair(uk[(size_t)s], s);
+  std::sort(ks.begin(), ks.end());
+  keys.resize((size_t)n);
+  slots.resize((size_t)n);
+  for (int s = 0; s < n; s++) {
+    keys[(size_t)s] = ks[(size_t)s].first;
+    slots[(size_t)s] = ks[(size_t)s].second;
+  }
+  return 0;
+}
+
+// One batch (<= ER_MAX_BATCH frames) on the stream.  depth_dev: n * pixels uint16 on device.
+int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, const er_warp* warp, int frame0) {
+  std::vector<er::FrameXform> fx((size_t)n);
+  std::vector<double> t12((size_t)n * 12);
+  for (int f = 0; f < n; f++) {
+    const double* Tf = T + (size_t)f * 16;
+    double Tinv[16];
+    if (!er::mat4_inverse(Tf, Tinv)) return er::fail("frame %d: singular pose matrix", frame0 + f);
+    for (int q = 0; q < 12; q++) {
+      fx[(size_t)f].mi[q] = (float)Tinv[q];                      // trans_inv.cast<float>(), TSDFVolume.cpp:59
+      t12[(size_t)f * 12 + q] = Tf[q];
+    }
+    fx[(size_t)f].tx = (float)Tf[3];                             // transformation.cast<float>()(r,3)
+    fx[(size_t)f].ty = (float)Tf[7];
+    fx[(size_t)f].tz = (float)Tf[11];
+    fx[(size_t)f].pad = 0.f;
+  }
+  ER_HIP_TRY(hipMemcpyAsync(h->frames, fx.data(), fx.size() * sizeof(er::FrameXform), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->T12, t12.data(), t12.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+
+  const long total = (long)n * h->pixels;
+  const int wide_grid = h->n_cu * 8;
+  const uint32_t* zsrc = nullptr;
+  if (warp) {
+    std::vector<double> s12((size_t)n * 12), m12((size_t)n * 12);
+    for (int f = 0; f < n; f++)
+      for (int q = 0; q < 12; q++) {
+        s12[(size_t)f * 12 + q] = warp->seg[(size_t)(frame0 + f) * 16 + q];
+        m12[(size_t)f * 12 + q] = warp->madj[(size_t)(frame0 + f) * 16 + q];
+      }
+    for (int f = 0; f < n; f++) {
+      int g = warp->grid_index[frame0 + f];
+      if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
+    }
+    ER_HIP_TRY(hipMemcpyAsync(h->seg12, s12.data(), s12.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ER_HIP_TRY(hipMemcpyAsync(h->madj12, m12.data(), m12.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ER_HIP_TRY(hipMemcpyAsync(h->grid_index, warp->grid_index + frame0, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    ER_HIP_TRY(hipMemsetAsync(h->zbuf, 0xFF, (size_t)total * sizeof(uint32_t), h->stream));
+    const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
+    const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
+    for (int replay = 0; replay < 2; replay++) {
+      if (replay) {
+        hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
+      }
+      hipLaunchKernelGGL(k_reproject_scatter, dim3(replay ? wide_grid : (int)std::min<long>((total + kBlock - 1) / kBlock, 1 << 20)),
+                         dim3(kBlock), 0, h->stream, depth_dev, n, h->cols, h->rows, h->cam, h->seg12, h->madj12,
+                         h->grid_index, h->ctr, warp->resolution, grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
+    }
+    hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->lastzero, total, h->counters);
+    hipLaunchKernelGGL(k_reproject_fix_flag, dim3(1), dim3(1), 0, h->stream, h->counters);
+    ER_HIP_TRY(hipGetLastError());
+    zsrc = h->zbuf;
+  }
+
+  hipLaunchKernelGGL(k_prepare, dim3((h->pixels + kBlock - 1) / kBlock, n), dim3(kBlock), 0, h->stream, depth_dev, zsrc, n,
+                     h->cols, h->rows, h->cam, h->lambda, h->T12, h->scaled, h->ht_key, h->ht_slot, h->ht_mask,
+                     h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch, h->counters);
+  ER_HIP_TRY(hipGetLastError());
+
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (h->profiling) {
+    ER_HIP_TRY(hipEventCreate(&e0));
+    ER_HIP_TRY(hipEventCreate(&e1));
+    ER_HIP_TRY(hipEventRecord(e0, h->stream));
+  }
+  hipLaunchKernelGGL(k_integrate, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->pool, h->ht_key, h->ht_slot, h->ht_mask,
+                     h->batch, h->counters, h->frames, h->scaled, h->cam, h->cols, h->rows);
+  if (h->profiling) {
+    ER_HIP_TRY(hipEventRecord(e1, h->stream));
+    h->events.emplace_back(e0, e1);
+  }
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(kBlock), 0, h->stream, h->batch, h->counters, h->ht_mask, h->stats);
+  ER_HIP_TRY(hipGetLastError());
+  h->frames_done += n;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int device, er_tsdf_t* out) {
+  if (!out) return er::fail("er_tsdf_create: out is NULL");
+  *out = nullptr;
+  if (cols <= 0 || rows <= 0 || max_units <= 0) return er::fail("er_tsdf_create: bad dimensions");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return er::fail("er_tsdf_create: no HIP device available (liber_hip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return er::fail("er_tsdf_create: device %d out of range [0,%d)", device, ndev);
+  ER_HIP_TRY(hipSetDevice(device));
+  er_tsdf_t h = new er_tsdf_s();
+  h->device = device;
+  h->cols = cols;
+  h->rows = rows;
+  h->pixels = cols * rows;
+  h->max_units = max_units;
+  if (cam6) {
+    h->cam = er::Camera{cam6[0], cam6[1], cam6[2], cam6[3], cam6[4], cam6[5]};
+  } else {
+    h->cam = er::Camera{525.0f, 525.0f, 319.5f, 239.5f, 2.5f, 2.5f};   // TSDFVolumeUnit.h:69
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
+  int cap = 1024, lg = 10;
+  while (cap < 4 * max_units) { cap <<= 1; lg++; }
+  h->ht_cap = cap;
+  h->ht_shift = 32 - lg;
+  const size_t px = (size_t)h->pixels, B = ER_MAX_BATCH;
+#define ER_ALLOC(ptr, bytes)                                                                         \
+  do {                                                                                               \
+    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                              \
+    if (e_ != hipSuccess) {                                                                          \
+      er::fail("er_tsdf_create: hipMalloc(%zu bytes) for " #ptr " failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
+      er_tsdf_destroy(h);                                                                            \
+      return 1;                                                                                      \
+    }                                                                                                \
+  } while (0)
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return er::fail("er_tsdf_create: hipStreamCreate failed");
+  }
+  h->stream = h->own_stream;
+  ER_ALLOC(h->pool, (size_t)max_units * er::kUnitVox * sizeof(float2));
+  ER_ALLOC(h->ht_key, (size_t)cap * sizeof(int));
+  ER_ALLOC(h->ht_slot, (size_t)cap * sizeof(int));
+  ER_ALLOC(h->ht_mask, (size_t)cap * sizeof(unsigned long long));
+  ER_ALLOC(h->unit_key, (size_t)max_units * sizeof(int));
+  ER_ALLOC(h->counters, C_COUNT * sizeof(int));
+  ER_ALLOC(h->stats, 4 * sizeof(unsigned long long));
+  ER_ALLOC(h->batch, (size_t)cap * sizeof(int));
+  ER_ALLOC(h->lambda, px * sizeof(float));
+  ER_ALLOC(h->scaled, B * px * sizeof(float));
+  ER_ALLOC(h->depth_stage, B * px * sizeof(uint16_t));
+  ER_ALLOC(h->zbuf, B * px * sizeof(uint32_t));
+  ER_ALLOC(h->lastzero, B * px * sizeof(uint32_t));
+  ER_ALLOC(h->frames, B * sizeof(er::FrameXform));
+  ER_ALLOC(h->T12, B * 12 * sizeof(double));
+  ER_ALLOC(h->seg12, B * 12 * sizeof(double));
+  ER_ALLOC(h->madj12, B * 12 * sizeof(double));
+  ER_ALLOC(h->grid_index, B * sizeof(int));
+  ER_ALLOC(h->dsum, sizeof(double));
+#undef ER_ALLOC
+  hipStream_t s = h->stream;
+  bool ok = hipMemsetAsync(h->pool, 0, (size_t)max_units * er::kUnitVox * sizeof(float2), s) == hipSuccess &&
+            hipMemsetAsync(h->ht_key, 0xFF, (size_t)cap * sizeof(int), s) == hipSuccess &&
+            hipMemsetAsync(h->ht_slot, 0xFF, (size_t)cap * sizeof(int), s) == hipSuccess &&
+            hipMemsetAsync(h->ht_mask, 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess &&
+            hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s) == hipSuccess &&
+            hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), s) == hipSuccess &&
+            hipMemsetAsync(h->lastzero, 0, B * px * sizeof(uint32_t), s) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(k_lambda, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->lambda, cols, rows, h->cam);
+    ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+  }
+  if (!ok) {
+    er_tsdf_destroy(h);
+    return er::fail("er_tsdf_create: device initialisation failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  *out = h;
+  return 0;
+}
+
+int er_tsdf_destroy(er_tsdf_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& ev : h->events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask, h->unit_key, h->counters, h->stats, h->batch, h->lambda,
+                  h->scaled, h->depth_stage, h->zbuf, h->lastzero, h->frames, h->T12, h->seg12, h->madj12,
+                  h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+  return 0;
+}
+
+int er_tsdf_set_stream(er_tsdf_t h, void* hip_stream) {
+  if (!h) return er::fail("er_tsdf_set_stream: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return 0;
+}
+
+int er_tsdf_synchronize(er_tsdf_t h) {
+  if (!h) return er::fail("er_tsdf_synchronize: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_host) {
+  if (!h || !depth_host || !scaled_host) return er::fail("er_tsdf_scale_depth: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  const size_t px = (size_t)h->pixels;
+  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_scale_depth, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->depth_stage,
+                     h->lambda, h->scaled, h->pixels, h->cam.integration_trunc);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(scaled_host, h->scaled, px * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int upload_ctr(er_tsdf_t h, const float* ctr, size_t floats) {
+  if (floats > h->ctr_cap) {
+    if (h->ctr) (void)hipFree(h->ctr);
+    h->ctr = nullptr;
+    h->ctr_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->ctr, floats * sizeof(float)));
+    h->ctr_cap = floats;
+  }
+  ER_HIP_TRY(hipMemcpyAsync(h->ctr, ctr, floats * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_host, int resolution, float length,
+                      const double seg[16], const double madj[16]) {
+  if (!h || !depth_inout_host || !ctr_host || !seg || !madj) return er::fail("er_tsdf_reproject: NULL argument");
+  if (resolution <= 0) return er::fail("er_tsdf_reproject: bad resolution");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  const size_t px = (size_t)h->pixels;
+  const int verts = (resolution + 1) * (resolution + 1) * (resolution + 1);
+  if (upload_ctr(h, ctr_host, (size_t)verts * 3)) return 1;
+  const int gi = 0;
+  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->seg12, seg, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->madj12, madj, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->grid_index, &gi, sizeof(int), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->zbuf, 0xFF, px * sizeof(uint32_t), h->stream));
+  const float grid_ul = length / (float)resolution;
+  const long total = (long)px;
+  const int wide_grid = h->n_cu * 8;
+  for (int replay = 0; replay < 2; replay++) {
+    if (replay)
+      hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
+    hipLaunchKernelGGL(k_reproject_scatter, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+                       h->depth_stage, 1, h->cols, h->rows, h->cam, h->seg12, h->madj12, h->grid_index, h->ctr, resolution,
+                       grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
+  }
+  hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->lastzero, total, h->counters);
+  hipLaunchKernelGGL(k_reproject_fix_flag, dim3(1), dim3(1), 0, h->stream, h->counters);
+  hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
+                     h->depth_stage, total);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(depth_inout_host, h->depth_stage, px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int depth_on_device, const double* T,
+                             const er_warp* warp) {
+  if (!h || !depth || !T) return er::fail("er_tsdf_integrate_frames: NULL argument");
+  if (n < 0) return er::fail("er_tsdf_integrate_frames: negative frame count");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (warp) {
+    if (!warp->ctr || !warp->grid_index || !warp->seg || !warp->madj || warp->num_grids <= 0 || warp->resolution <= 0)
+      return er::fail("er_tsdf_integrate_frames: incomplete er_warp");
+    const size_t verts = (size_t)(warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
+    if (upload_ctr(h, warp->ctr, verts * 3 * (size_t)warp->num_grids)) return 1;
+  }
+  const size_t px = (size_t)h->pixels;
+  for (int start = 0; start < n; start += ER_MAX_BATCH) {
+    const int nb = std::min(ER_MAX_BATCH, n - start);
+    const uint16_t* ddev;
+    if (depth_on_device) {
+      ddev = depth + (size_t)start * px;
+    } else {
+      ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth + (size_t)start * px, (size_t)nb * px * sizeof(uint16_t),
+                                hipMemcpyHostToDevice, h->stream));
+      ddev = h->depth_stage;
+    }
+    if (run_batch(h, nb, ddev, T + (size_t)start * 16, warp, start)) return 1;
+  }
+  return 0;
+}
+
+int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16]) {
+  return er_tsdf_integrate_frames(h, 1, depth_host, 0, T, nullptr);
+}
+
+int er_tsdf_unit_count(er_tsdf_t h, int* count) {
+  if (!h || !count) return er::fail("er_tsdf_unit_count: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (check_flags(h)) return 1;
+  ER_HIP_TRY(hipMemcpy(count, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int er_tsdf_unit_keys(er_tsdf_t h, int* keys_host) {
+  if (!h || !keys_host) return er::fail("er_tsdf_unit_keys: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> keys, slots;
+  if (sorted_units(h, keys, slots)) return 1;
+  std::copy(keys.begin(), keys.end(), keys_host);
+  return 0;
+}
+
+int er_tsdf_read_unit(er_tsdf_t h, int key, float* sdf_host, float* weight_host) {
+  if (!h) return er::fail("er_tsdf_read_unit: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (check_flags(h)) return 1;
+  if (resolve_slots(h, &key, 1, false)) return 1;
+  int slot = -1;
+  ER_HIP_TRY(hipMemcpyAsync(&slot, h->slot_scratch, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (slot < 0) return er::fail("er_tsdf_read_unit: no unit with key %d", key);
+  std::vector<float2> tmp((size_t)er::kUnitVox);
+  ER_HIP_TRY(hipMemcpyAsync(tmp.data(), h->pool + (size_t)slot * er::kUnitVox, tmp.size() * sizeof(float2),
+                            hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int l = 0; l < er::kUnitVox; l++) {
+    if (sdf_host) sdf_host[l] = tmp[(size_t)l].x;
+    if (weight_host) weight_host[l] = tmp[(size_t)l].y;
+  }
+  return 0;
+}
+
+int er_tsdf_sum_weight(er_tsdf_t h, double* sum) {
+  if (!h || !sum) return er::fail("er_tsdf_sum_weight: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (check_flags(h)) return 1;
+  int n = 0;
+  ER_HIP_TRY(hipMemcpy(&n, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  ER_HIP_TRY(hipMemsetAsync(h->dsum, 0, sizeof(double), h->stream));
+  if (n > 0) {
+    hipLaunchKernelGGL(k_sum_weight, dim3(h->n_cu * 8), dim3(kBlock), 0, h->stream, h->pool, (long)n * er::kUnitVox, h->dsum);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  ER_HIP_TRY(hipMemcpyAsync(sum, h->dsum, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* count) {
+  if (!h || !count) return er::fail("er_tsdf_extract_world: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> keys, slots;
+  if (sorted_units(h, keys, slots)) return 1;
+  const int n = (int)keys.size();
+  *count = 0;
+  if (n == 0) return 0;
+  const int nslab = n * 64;
+  int *d_keys = nullptr, *d_slots = nullptr;
+  long *d_cnt = nullptr, *d_off = nullptr;
+  float4* d_out = nullptr;
+  int rc = 0;
+  std::vector<long> cnt((size_t)nslab), off((size_t)nslab);
+  long total = 0;
+#define ER_W(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      rc = er::fail("er_tsdf_extract_world: %s failed: %s", #expr, hipGetErrorString(e_));      \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+  ER_W(hipMalloc((void**)&d_keys, (size_t)n * sizeof(int)));
+  ER_W(hipMalloc((void**)&d_slots, (size_t)n * sizeof(int)));
+  ER_W(hipMalloc((void**)&d_cnt, (size_t)nslab * sizeof(long)));
+  ER_W(hipMalloc((void**)&d_off, (size_t)nslab * sizeof(long)));
+  ER_W(hipMemcpyAsync(d_keys, keys.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  ER_W(hipMemcpyAsync(d_slots, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, (float4*)nullptr, 0);
+  ER_W(hipGetLastError());
+  ER_W(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nslab * sizeof(long), hipMemcpyDeviceToHost, h->stream));
+  ER_W(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < nslab; s++) {
+    off[(size_t)s] = total;
+    total += cnt[(size_t)s];
+  }
+  *count = total;
+  if (out_host && total > 0) {
+    if (capacity < total) {
+      rc = er::fail("er_tsdf_extract_world: capacity %ld < %ld points", capacity, total);
+      goto done;
+    }
+    ER_W(hipMalloc((void**)&d_out, (size_t)total * sizeof(float4)));
+    ER_W(hipMemcpyAsync(d_off, off.data(), (size_t)nslab * sizeof(long), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, d_out, 1);
+    ER_W(hipGetLastError());
+    ER_W(hipMemcpyAsync(out_host, d_out, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
+    ER_W(hipStreamSynchronize(h->stream));
+  }
+#undef ER_W
+done:
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_slots) (void)hipFree(d_slots);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_off) (void)hipFree(d_off);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf) {
+  if (!h || !keys_host || !dev_buf) return er::fail("er_tsdf_export_weighted: NULL argument");
+  if (n_keys <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (resolve_slots(h, keys_host, n_keys, false)) return 1;
+  hipLaunchKernelGGL(k_export_weighted, dim3(er::kUnitVox / kBlock, n_keys), dim3(kBlock), 0, h->stream, h->pool,
+                     h->slot_scratch, dev_buf);
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf) {
+  if (!h || !keys_host || !dev_buf) return er::fail("er_tsdf_import_weighted: NULL argument");
+  if (n_keys <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (resolve_slots(h, keys_host, n_keys, true)) return 1;
+  hipLaunchKernelGGL(k_import_weighted, dim3(er::kUnitVox / kBlock, n_keys), dim3(kBlock), 0, h->stream, h->pool,
+                     h->slot_scratch, dev_buf);
+  ER_HIP_TRY(hipGetLastError());
+  return check_flags(h);
+}
+
+int er_tsdf_set_profiling(er_tsdf_t h, int enable) {
+  if (!h) return er::fail("er_tsdf_set_profiling: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (drain_events(h)) return 1;
+  h->profiling = enable != 0;
+  h->ms_total = 0.0;
+  h->launches = 0;
+  h->frames_done = 0;
+  ER_HIP_TRY(hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), h->stream));
+  return 0;
+}
+
+int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate_launches, long* frames,
+                        long* unit_visits) {
+  if (!h) return er::fail("er_tsdf_get_profile: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (drain_events(h)) return 1;
+  unsigned long long st[4] = {0, 0, 0, 0};
+  ER_HIP_TRY(hipMemcpy(st, h->stats, sizeof st, hipMemcpyDeviceToHost));
+  if (integrate_ms_total) *integrate_ms_total = h->ms_total;
+  if (integrate_launches) *integrate_launches = h->launches;
+  if (frames) *frames = h->frames_done;
+  if (unit_visits) *unit_visits = (long)st[0];
+  return 0;
+}
+
+}  // extern "C"

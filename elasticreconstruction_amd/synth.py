@@ -1,0 +1,231 @@
+"""Deterministic synthetic inputs for the parity tests and bench.py.
+
+Scene: the inside of an axis-aligned box room plus a sphere, ray cast analytically into 16-bit
+millimetre depth images (0 = no return), the way a Kinect stream would look to Integrate; and
+seeded surfel fragments with analytic normals for BuildCorrespondence.  No file or network input.
+
+The renderer is written with torch ops only so that bench.py can generate thousands of frames
+directly in HBM (device="cuda") while the CPU tests use the same code on small counts.  This is
+data plumbing, not part of the measured path.
+"""
+import math
+
+import numpy as np
+import torch
+
+SEED = 20150722
+ROOM_LO, ROOM_HI = 0.01, 2.99            # keeps every surface inside 8x8x8 volume units ("512^3")
+SPHERE_C, SPHERE_R = (1.5, 1.5, 1.5), 0.4
+CAM = (525.0, 525.0, 319.5, 239.5)       # reference defaults, TSDFVolumeUnit.h:69
+
+
+def look_at(eye, forward, up=(0.0, 1.0, 0.0)):
+    """world_T_camera (4x4 float64) for a camera at `eye` looking along `forward` (camera +z), +y down-ish."""
+    f = np.asarray(forward, np.float64)
+    f = f / np.linalg.norm(f)
+    u = np.asarray(up, np.float64)
+    r = np.cross(u, f)
+    r = r / np.linalg.norm(r)
+    d = np.cross(f, r)
+    T = np.eye(4)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = r, d, f, np.asarray(eye, np.float64)
+    return T
+
+
+def circle_trajectory(n, radius=0.6, center=(1.5, 1.5, 1.5), revolutions=1.0, radius_drift=0.0):
+    """n camera poses on a circle around the room centre looking outward with a slow pitch wobble
+    (config 2 of BASELINE.json; config 4 adds a radius drift)."""
+    out = np.empty((n, 4, 4), np.float64)
+    c = np.asarray(center, np.float64)
+    for i in range(n):
+        th = 2.0 * math.pi * revolutions * i / max(n, 1)
+        r = radius + radius_drift * i / max(n, 1)
+        eye = c + r * np.array([math.cos(th), 0.05 * math.sin(2.0 * th), math.sin(th)])
+        fwd = np.array([math.cos(th), 0.15 * math.sin(3.0 * th), math.sin(th)])
+        out[i] = look_at(eye, fwd)
+    return out
+
+
+def render_depth(poses, cols=640, rows=480, cam=CAM, lo=ROOM_LO, hi=ROOM_HI, sphere=True, max_depth=4.0,
+                 device="cpu", chunk=64):
+    """Ray cast the scene for every world_T_camera in `poses` [n,4,4].  Returns uint16 [n, rows*cols]
+    (torch tensor on `device`): round(z*1000), 0 where there is no hit closer than max_depth."""
+    fx, fy, cx, cy = cam
+    P = torch.as_tensor(np.asarray(poses, np.float64), dtype=torch.float64, device=device).reshape(-1, 4, 4)
+    n = P.shape[0]
+    u = torch.arange(cols, dtype=torch.float64, device=device)
+    v = torch.arange(rows, dtype=torch.float64, device=device)
+    dx = ((u - cx) / fx).repeat(rows)                      # row-major pixel order
+    dy = ((v - cy) / fy).repeat_interleave(cols)
+    out = torch.empty((n, rows * cols), dtype=torch.int32, device=device)
+    inf = float("inf")
+    # Only elementwise IEEE float64 ops in a fixed order (no matmul / library reductions), so the images
+    # are bit-reproducible across machines and devices; tests/golden digests depend on that.
+    for s in range(0, n, chunk):
+        R = P[s:s + chunk, :3, :3]
+        o = P[s:s + chunk, :3, 3]                                       # [b,3]
+        d = [(R[:, a, 0:1] * dx[None, :] + R[:, a, 1:2] * dy[None, :]) + R[:, a, 2:3] for a in range(3)]   # camera z = 1 -> t == depth
+        t = torch.full_like(d[0], inf)
+        for a in range(3):
+            da = d[a]
+            wall = torch.where(da > 0, torch.full_like(da, hi), torch.full_like(da, lo))
+            ta = (wall - o[:, a:a + 1]) / da
+            ta = torch.where(da.abs() < 1e-12, torch.full_like(ta, inf), ta)
+            t = torch.minimum(t, torch.where(ta > 0, ta, torch.full_like(ta, inf)))
+        if sphere:
+            oc = [o[:, a:a + 1] - SPHERE_C[a] for a in range(3)]        # [b,1] each
+            A = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+            B = 2.0 * ((d[0] * oc[0] + d[1] * oc[1]) + d[2] * oc[2])
+            Cc = ((oc[0] * oc[0] + oc[1] * oc[1]) + oc[2] * oc[2]) - SPHERE_R * SPHERE_R
+            disc = B * B - 4.0 * A * Cc
+            sq = torch.sqrt(disc.clamp(min=0))
+            ts = (-B - sq) / (2.0 * A)
+            ts = torch.where((disc > 0) & (ts > 1e-6), ts, torch.full_like(ts, inf))
+            t = torch.minimum(t, ts)
+        mm = torch.floor(t * 1000.0 + 0.5)
+        mm = torch.where(torch.isfinite(mm) & (t <= max_depth) & (mm < 65535.5), mm, torch.zeros_like(mm))
+        out[s:s + chunk] = mm.to(torch.int32)
+    return out.to(torch.uint16) if hasattr(torch, "uint16") else out.to(torch.int16)
+
+
+def to_numpy_u16(t):
+    """torch uint16/int16 tensor -> numpy uint16 (host)."""
+    a = t.cpu()
+    if a.dtype == torch.int16:
+        return a.numpy().view(np.uint16)
+    return a.view(torch.int16).numpy().view(np.uint16)
+
+
+# ----------------------------------------------------------------------------------------------
+# Fragment bookkeeping of the elastic pipeline (IntegrateApp.cpp:64-78, 242-243; the kinfu fragment
+# convention: every fragment's first camera sits at basepose = (L/2, L/2, -0.3) of its own L^3 cube,
+# BuildCorrespondence/CorresApp.cpp:45-48).
+def basepose(length=3.0):
+    B = np.eye(4)
+    B[0, 3], B[1, 3], B[2, 3] = length / 2.0, length / 2.0, -0.3
+    return B
+
+
+def split_trajectory(world_T_cam, interval=50, length=3.0):
+    """world_T_cam [n,4,4] -> (pose [n/interval], seg [n]) with world_T_cam[i*interval+j] == pose[i] @ seg[...]."""
+    n = world_T_cam.shape[0]
+    num = n // interval
+    B = basepose(length)
+    pose = np.empty((num, 4, 4))
+    seg = np.empty((num * interval, 4, 4))
+    for i in range(num):
+        pose[i] = world_T_cam[i * interval] @ np.linalg.inv(B)
+        pinv = np.linalg.inv(pose[i])
+        for j in range(interval):
+            seg[i * interval + j] = pinv @ world_T_cam[i * interval + j]
+    return pose, seg
+
+
+def control_grids(pose, resolution=8, length=3.0, amplitude=0.005, seed=SEED):
+    """One control lattice per fragment: the undeformed lattice pose[0]^-1 * pose[i] * (i,j,k)*length/res
+    (FragmentOptimizer/OptApp.cpp:691-703 defines the regular lattice; IntegrateApp.cpp:243 fixes the frame)
+    plus a smooth seeded sinusoidal deformation of `amplitude` metres.  float32 [num, (res+1)^3, 3],
+    vertex order i + j*(res+1) + k*(res+1)^2 (ControlGrid.h:41-43)."""
+    rng = np.random.RandomState(seed)
+    num = pose.shape[0]
+    n1 = resolution + 1
+    ul = length / resolution
+    k, j, i = np.meshgrid(np.arange(n1), np.arange(n1), np.arange(n1), indexing="ij")
+    verts = np.stack([i.reshape(-1), j.reshape(-1), k.reshape(-1)], axis=1).astype(np.float64) * ul   # index = i + j*n1 + k*n1^2
+    p0inv = np.linalg.inv(pose[0])
+    out = np.empty((num, n1 ** 3, 3), np.float32)
+    for g in range(num):
+        M = p0inv @ pose[g]
+        w = verts @ M[:3, :3].T + M[:3, 3]
+        ph = rng.uniform(0, 2 * math.pi, size=3)
+        fr = rng.uniform(1.0, 2.5, size=3)
+        defo = amplitude * np.stack([np.sin(fr[0] * verts[:, 1] + ph[0]), np.sin(fr[1] * verts[:, 2] + ph[1]),
+                                     np.sin(fr[2] * verts[:, 0] + ph[2])], axis=1)
+        out[g] = (w + defo).astype(np.float32)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+def sample_fragment(world_T_frag, n_points, seed, length=3.0, lo=ROOM_LO, hi=ROOM_HI, sphere=True):
+    """n_points surfels sampled uniformly (seeded) on the scene surfaces, expressed in the fragment's
+    own cube frame and kept only if inside [0,length]^3.  Returns (xyz float32 [m,3], normals float32 [m,3])."""
+    rng = np.random.RandomState(seed)
+    side = hi - lo
+    areas = [side * side] * 6 + ([4 * math.pi * SPHERE_R ** 2] if sphere else [])
+    p = np.array(areas) / sum(areas)
+    which = rng.choice(len(areas), size=n_points, p=p)
+    a = rng.uniform(lo, hi, size=n_points)
+    b = rng.uniform(lo, hi, size=n_points)
+    pts = np.empty((n_points, 3))
+    nrm = np.zeros((n_points, 3))
+    for f in range(6):
+        m = which == f
+        ax, sgn = f // 2, f % 2
+        o = [x for x in range(3) if x != ax]
+        pts[m, ax] = hi if sgn else lo
+        pts[m, o[0]] = a[m]
+        pts[m, o[1]] = b[m]
+        nrm[m, ax] = -1.0 if sgn else 1.0                                 # pointing into the room
+    if sphere:
+        m = which == 6
+        v = rng.normal(size=(int(m.sum()), 3))
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        pts[m] = np.asarray(SPHERE_C) + SPHERE_R * v
+        nrm[m] = v
+    F = np.linalg.inv(world_T_frag)
+    q = pts @ F[:3, :3].T + F[:3, 3]
+    qn = nrm @ F[:3, :3].T
+    keep = np.all((q >= 0.0) & (q <= length), axis=1)
+    return q[keep].astype(np.float32), qn[keep].astype(np.float32)
+
+
+def perturbation(seed, max_rot_deg=2.0, max_trans=0.02):
+    """Small seeded rigid perturbation (4x4 float64)."""
+    rng = np.random.RandomState(seed)
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    ang = math.radians(max_rot_deg) * rng.uniform(0.3, 1.0)
+    K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * (K @ K)
+    t = rng.normal(size=3)
+    t = t / np.linalg.norm(t) * max_trans * rng.uniform(0.3, 1.0)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return T
+
+
+# ----------------------------------------------------------------------------------------------
+def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, amplitude=0.005, revolutions=None,
+                  frame_offset=0, total_frames=None, radius_drift=0.0, device="cpu", seed=SEED):
+    """Everything one Integrate run needs (BASELINE.json configs 1/2/4), all in memory:
+      depth  uint16 [n, 480*640] torch tensor on `device`
+      traj   float64 [n,4,4]  world_T_camera as the reference composes it: pose[i] * seg[i*interval+j]
+      pose   float64 [n/interval,4,4], seg float64 [n,4,4]
+      grids  float32 [n/interval, (res+1)^3, 3] (None when warp is False)
+    frame_offset/total_frames select a window of a longer trajectory (multi-GPU frame split)."""
+    from .tsdf import mat4_mul
+    total = total_frames if total_frames is not None else n_frames
+    revs = revolutions if revolutions is not None else max(1.0, total / 3000.0)
+    full = circle_trajectory(total, revolutions=revs, radius_drift=radius_drift)
+    w = full[frame_offset:frame_offset + n_frames]
+    num = n_frames // interval
+    assert num * interval == n_frames, "n_frames must be a multiple of interval"
+    pose, seg = split_trajectory(w, interval, length)
+    traj = np.empty_like(w)
+    for i in range(num):
+        for j in range(interval):
+            traj[i * interval + j] = mat4_mul(pose[i], seg[i * interval + j])
+    grids = control_grids(pose, resolution, length, amplitude, seed) if warp else None
+    depth = render_depth(w, device=device)
+    return dict(depth=depth, traj=traj, pose=pose, seg=seg, grids=grids, interval=interval, resolution=resolution,
+                length=length, n=n_frames)
+
+
+def warp_arrays(sc, lo=0, hi=None):
+    """The er_warp arrays for frames [lo, hi) of a scenario (IntegrateApp.cpp:242-243,251)."""
+    from .tsdf import reproject_matrix
+    hi = sc["n"] if hi is None else hi
+    gi = np.array([f // sc["interval"] for f in range(lo, hi)], np.int32)
+    madj = np.stack([reproject_matrix(sc["traj"][f], sc["traj"][0], sc["seg"][0]) for f in range(lo, hi)])
+    return dict(ctr=sc["grids"], resolution=sc["resolution"], length=np.float32(sc["length"]), grid_index=gi,
+                seg=sc["seg"][lo:hi].copy(), madj=madj)

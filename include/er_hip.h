@@ -1,0 +1,140 @@
+/* er_hip.h -- C ABI of liber_hip.so, the MI355X (gfx950) implementation of the two data-parallel
+ * stages of qianyizh/ElasticReconstruction:
+ *
+ *   path A  TSDF depth integration with control-grid warp   (reference: Integrate/)
+ *   path B  pairwise ICP refinement + correspondences       (reference: BuildCorrespondence/)
+ *
+ * The reference has no FFI; its boundary is "executable + argv + files" (SURVEY.md 8b).  These
+ * entry points are the thin C ABI the new host programs (and any cgo/JNI/ctypes caller) bind.
+ * Each one cites the reference method it replaces.  Conventions:
+ *   - plain C types only; 4x4 matrices are ROW-MAJOR arrays of 16 (double unless stated);
+ *   - every function returns 0 on success, non-zero on failure; er_last_error() (thread-local)
+ *     explains the last failure; nothing throws across the ABI;
+ *   - handles are opaque and owned by the caller; calls on ONE handle must be serialised by the
+ *     caller, different handles may be driven from different host threads (this mirrors the
+ *     reference's "one OpenMP thread per pair" model, CorresApp.cpp:121,220);
+ *   - "host" pointers are ordinary host memory, "dev" pointers are HIP device memory on the
+ *     handle's device; there is NO CPU fallback: without a usable HIP device every constructor
+ *     fails with an error.
+ */
+#ifndef ER_HIP_H_
+#define ER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ER_UNIT_RES 64                 /* TSDFVolume.cpp:57: new TSDFVolumeUnit( 64, ... ) */
+#define ER_UNIT_VOX (64 * 64 * 64)
+#define ER_MAX_BATCH 64                /* frames fused per launch (one bit each in a 64-bit mask) */
+
+/* ------------------------------------------------------------------ misc ---- */
+const char* er_last_error(void);
+int er_device_count(void);                       /* number of visible HIP devices (0 if none) */
+int er_abi_version(void);
+
+/* ------------------------------------------------------------ path A: TSDF ---- */
+typedef struct er_tsdf_s* er_tsdf_t;
+
+/* Control-grid warp inputs for a batch of n frames (CIntegrateApp::Reproject, IntegrateApp.cpp:228-269).
+ * All pointers are HOST memory. */
+typedef struct er_warp {
+  const float* ctr;         /* num_grids * (resolution+1)^3 * 3 floats; vertex i + j*(res+1) + k*(res+1)^2
+                               (ControlGrid.h:41-43; file order of ControlGrid::Load, ControlGrid.cpp:15-34) */
+  int num_grids;            /* --num        (IntegrateApp.h:70 ctr_num_) */
+  int resolution;           /* --resolution (IntegrateApp.h:68) */
+  float length;             /* --length, stored as float by ControlGrid::Load (ControlGrid.cpp:17-18) */
+  const int* grid_index;    /* n ints: chunk = (frame_id-1)/interval of each frame (IntegrateApp.cpp:242) */
+  const double* seg;        /* n * 16: seg_traj_[frame_id-1] (IntegrateApp.cpp:251) */
+  const double* madj;       /* n * 16: traj[f-1]^-1 * traj[0] * seg[0]^-1 (IntegrateApp.cpp:243) */
+} er_warp;
+
+/* TSDFVolume::TSDFVolume( cols, rows ) + CameraParam (TSDFVolume.cpp:7-13, TSDFVolumeUnit.h:65-70).
+ * cam6 = fx fy cx cy ICP_trunc integration_trunc (NULL = reference defaults 525 525 319.5 239.5 2.5 2.5).
+ * max_units = capacity of the 64^3 volume-unit pool in HBM (2 MiB each, zero-filled up front). */
+int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int device, er_tsdf_t* out);
+int er_tsdf_destroy(er_tsdf_t h);
+
+/* Run all of the handle's work on an existing hipStream_t (e.g. torch's current stream).  NULL = the
+ * handle's own stream. */
+int er_tsdf_set_stream(er_tsdf_t h, void* hip_stream);
+int er_tsdf_synchronize(er_tsdf_t h);
+
+/* TSDFVolume::ScaleDepth (TSDFVolume.cpp:19-36): depth uint16[rows*cols] -> scaled float[rows*cols]. */
+int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_host);
+
+/* CIntegrateApp::Reproject pixel loop (IntegrateApp.cpp:236-268) for ONE frame, in place on host memory. */
+int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_host, int resolution, float length,
+                      const double seg[16], const double madj[16]);
+
+/* One frame of CIntegrateApp::Execute's numeric tail (IntegrateApp.cpp:224-225):
+ * ScaleDepth + TSDFVolume::Integrate (TSDFVolume.cpp:38-67 -> IntegrateVolumeUnit :69-102). */
+int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16]);
+
+/* n frames in order: [Reproject] + ScaleDepth + Integrate for each (IntegrateApp.cpp:217-225).
+ * Results are identical to n sequential er_tsdf_integrate calls; internally frames are fused
+ * ER_MAX_BATCH at a time so each voxel is read and written once per batch.
+ * depth: n*rows*cols uint16, host memory if depth_on_device == 0 else device memory (left untouched).
+ * T: n*16 host doubles (traj_[frame_id-1]).  warp may be NULL (rigid, --ref_traj). */
+int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int depth_on_device, const double* T,
+                             const er_warp* warp);
+
+/* data_ map access (TSDFVolume.h:27) as used by SaveWorld. */
+int er_tsdf_unit_count(er_tsdf_t h, int* count);
+int er_tsdf_unit_keys(er_tsdf_t h, int* keys_host);                  /* ascending hash_key order */
+int er_tsdf_read_unit(er_tsdf_t h, int key, float* sdf_host, float* weight_host);  /* 64^3 floats each */
+
+/* Sum of weight_ over the volume = number of voxel updates so far (TSDFVolume.cpp:90,94). */
+int er_tsdf_sum_weight(er_tsdf_t h, double* sum);
+
+/* TSDFVolume::SaveWorld's voxel filter (TSDFVolume.cpp:104-132) on device.  Writes (x,y,z,intensity)
+ * float4 per point, units in ascending key order, voxels in i,j,k order.  out_host may be NULL to query
+ * the count; capacity is in points. */
+int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* count);
+
+/* Multi-GPU frame split: for the given key list write sum-ready planes into dev_buf
+ * (n_keys * 2 * 64^3 floats: [key][0] = sdf*weight, [key][1] = weight; zeros for keys absent here), and
+ * after an external all-reduce(sum) read them back as weight = W, sdf = SW / W. */
+int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
+int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
+
+/* Kernel timing (HIP events on the handle's stream around every IntegrateVolumeUnit launch). */
+int er_tsdf_set_profiling(er_tsdf_t h, int enable);
+int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate_launches, long* frames,
+                        long* unit_visits);
+
+/* ------------------------------------------------------------- path B: ICP ---- */
+typedef struct er_cloud_s* er_cloud_t;
+
+/* pointclouds_[i] after the NaN-normal filter (CorresApp.cpp:94-98): n points, xyz and normals as
+ * separate float[3*n] host arrays (AoS xyz xyz ...).  grid_cell = edge of the uniform search grid
+ * built over this cloud when it is used as a TARGET; must be >= every max distance queried later
+ * (use reg_dist_, CorresApp.cpp:16). */
+int er_cloud_create(const float* xyz_host, const float* normal_host, int n, float grid_cell, int device,
+                    er_cloud_t* out);
+int er_cloud_destroy(er_cloud_t c);
+int er_cloud_size(er_cloud_t c);
+
+/* Registration pre-check (CorresApp.cpp:249-264): cnt = #{k : NN sqdist(T*src[k], tgt) < max_dist^2}. */
+int er_icp_count_inliers(er_cloud_t src, er_cloud_t tgt, const double T[16], double max_dist, int* count);
+
+/* pcl::IterativeClosestPoint::align with TransformationEstimationPointToPlaneLLS as configured at
+ * CorresApp.cpp:295-306 (source = src, target = tgt).  guess/out are ROW-MAJOR FLOAT 4x4.
+ * stop_rule: 0 = PCL 1.7 DefaultConvergenceCriteria, 1 = PCL <= 1.6 rule.
+ * fitness (may be NULL) = mean squared NN distance within max_dist after the final transform. */
+int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double max_dist, int max_iter,
+                 double transformation_epsilon, int stop_rule, float out[16], int* iterations, int* converged,
+                 double* fitness);
+
+/* FindCorrespondence (CorresApp.cpp:144-161, 186-208): pairs (tgt_index, src_index) ascending in
+ * src_index, for NN sqdist < dist^2 and normal dot > normal_cos; info36 (nullable) = row-major 6x6
+ * information matrix over the untransformed source points. pairs_host holds 2*capacity ints. */
+int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], double dist, double normal_cos,
+                           int* pairs_host, int capacity, int* n_pairs, double* info36);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ER_HIP_H_ */

@@ -1,0 +1,239 @@
+"""ctypes access to the CPU checkers -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  The
+product package (elasticreconstruction_amd/) never does.
+
+  OracleVolume   oracle/tsdf_oracle.c            scalar C restatement of path A ("port")
+  RefApp         oracle/_ref/libref_tsdf*.so     the reference's own CIntegrateApp / TSDFVolume,
+                                                 compiled unmodified from /root/reference ("reference")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+UNIT_VOX = 64 * 64 * 64
+_vp = C.c_void_p
+
+
+def build(targets=("own",), quiet=True):
+    """make -C oracle <targets>.  'ref' needs /root/reference (absent on the GPU box: the prebuilt
+    oracle/_ref/*.so travel with the repo snapshot instead)."""
+    cmd = ["make", "-C", HERE] + list(targets)
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL if quiet else None)
+
+
+def _load(rel):
+    p = os.path.join(HERE, rel)
+    if not os.path.exists(p):
+        raise FileNotFoundError("%s not built (run `make -C oracle`)" % p)
+    return C.CDLL(p)
+
+
+def have_ref():
+    return os.path.exists(os.path.join(HERE, "_ref", "libref_tsdf.so"))
+
+
+def _p(a):
+    return a.ctypes.data_as(_vp)
+
+
+class OracleVolume:
+    """oracle/tsdf_oracle.c behind the same method names as the reference's TSDFVolume."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = _load("_build/libtsdf_oracle.so")
+            L.oracle_volume_create.restype = _vp
+            L.oracle_volume_create.argtypes = [C.c_int, C.c_int, _vp]
+            L.oracle_volume_destroy.argtypes = [_vp]
+            L.oracle_scale_depth.argtypes = [_vp, _vp, _vp]
+            L.oracle_integrate.argtypes = [_vp, _vp, _vp, _vp]
+            L.oracle_reproject.argtypes = [_vp, _vp, _vp, C.c_int, C.c_float, _vp, _vp]
+            L.oracle_reproject_matrix.argtypes = [_vp, _vp, _vp, _vp]
+            L.oracle_compose.argtypes = [_vp, _vp, _vp]
+            L.oracle_mat4_inverse.argtypes = [_vp, _vp]
+            L.oracle_unit_count.argtypes = [_vp]
+            L.oracle_unit_keys.argtypes = [_vp, _vp]
+            L.oracle_read_unit.argtypes = [_vp, C.c_int, _vp, _vp]
+            L.oracle_sum_weight.restype = C.c_double
+            L.oracle_sum_weight.argtypes = [_vp]
+            L.oracle_extract_world.restype = C.c_long
+            L.oracle_extract_world.argtypes = [_vp, _vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, cols=640, rows=480, camera=None):
+        L = self.lib()
+        self.cols, self.rows = cols, rows
+        cam = None if camera is None else np.ascontiguousarray(camera, np.float32)
+        self._h = _vp(L.oracle_volume_create(cols, rows, None if cam is None else _p(cam)))
+
+    def close(self):
+        if self._h:
+            self.lib().oracle_volume_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ScaleDepth(self, depth):
+        d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+        out = np.empty(d.size, np.float32)
+        self.lib().oracle_scale_depth(self._h, _p(d), _p(out))
+        return out
+
+    def Integrate(self, depth, T, scaled=None):
+        d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+        s = self.ScaleDepth(d) if scaled is None else np.ascontiguousarray(scaled, np.float32)
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        self.lib().oracle_integrate(self._h, _p(d), _p(s), _p(Tm))
+
+    def Reproject(self, depth, ctr, resolution, length, seg, madj):
+        d = np.array(depth, np.uint16).reshape(-1)
+        g = np.ascontiguousarray(ctr, np.float32).reshape(-1)
+        s = np.ascontiguousarray(seg, np.float64).reshape(16)
+        m = np.ascontiguousarray(madj, np.float64).reshape(16)
+        self.lib().oracle_reproject(self._h, _p(d), _p(g), int(resolution), C.c_float(length), _p(s), _p(m))
+        return d
+
+    @classmethod
+    def reproject_matrix(cls, traj_f, traj_0, seg_0):
+        a = [np.ascontiguousarray(x, np.float64).reshape(16) for x in (traj_f, traj_0, seg_0)]
+        out = np.empty(16, np.float64)
+        cls.lib().oracle_reproject_matrix(_p(a[0]), _p(a[1]), _p(a[2]), _p(out))
+        return out.reshape(4, 4)
+
+    @classmethod
+    def compose(cls, pose, seg):
+        a = [np.ascontiguousarray(x, np.float64).reshape(16) for x in (pose, seg)]
+        out = np.empty(16, np.float64)
+        cls.lib().oracle_compose(_p(a[0]), _p(a[1]), _p(out))
+        return out.reshape(4, 4)
+
+    @classmethod
+    def inverse(cls, T):
+        a = np.ascontiguousarray(T, np.float64).reshape(16)
+        out = np.empty(16, np.float64)
+        cls.lib().oracle_mat4_inverse(_p(a), _p(out))
+        return out.reshape(4, 4)
+
+    def unit_keys(self):
+        n = self.lib().oracle_unit_count(self._h)
+        k = np.empty(n, np.int32)
+        if n:
+            self.lib().oracle_unit_keys(self._h, _p(k))
+        return k
+
+    def read_unit(self, key):
+        sdf = np.empty(UNIT_VOX, np.float32)
+        w = np.empty(UNIT_VOX, np.float32)
+        if self.lib().oracle_read_unit(self._h, int(key), _p(sdf), _p(w)) != 0:
+            raise KeyError(key)
+        return sdf, w
+
+    def sum_weight(self):
+        return float(self.lib().oracle_sum_weight(self._h))
+
+    def extract_world(self):
+        n = self.lib().oracle_extract_world(self._h, None)
+        out = np.empty((n, 4), np.float32)
+        if n:
+            self.lib().oracle_extract_world(self._h, _p(out))
+        return out
+
+
+class RefApp:
+    """The reference's CIntegrateApp driven through oracle/ref_driver.cpp (640x480 only, like the reference)."""
+    _libs = {}
+
+    @classmethod
+    def lib(cls, uncapped=False):
+        name = "_ref/libref_tsdf_uncapped.so" if uncapped else "_ref/libref_tsdf.so"
+        if name not in cls._libs:
+            L = _load(name)
+            L.ref_app_create.restype = _vp
+            L.ref_app_destroy.argtypes = [_vp]
+            L.ref_app_init.argtypes = [_vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int,
+                                       C.c_double, C.c_int]
+            L.ref_app_set_window.argtypes = [_vp, C.c_int, C.c_int]
+            L.ref_app_ctr_num.argtypes = [_vp]
+            L.ref_app_execute.argtypes = [_vp, C.c_int, _vp, _vp]
+            L.ref_scale_depth.argtypes = [_vp, _vp, _vp]
+            L.ref_integrate.argtypes = [_vp, _vp, _vp]
+            L.ref_set_camera.argtypes = [_vp, _vp]
+            L.ref_unit_count.argtypes = [_vp]
+            L.ref_unit_keys.argtypes = [_vp, _vp]
+            L.ref_read_unit.argtypes = [_vp, C.c_int, _vp, _vp]
+            L.ref_save_world.argtypes = [_vp, C.c_char_p]
+            cls._libs[name] = L
+        return cls._libs[name]
+
+    def __init__(self, uncapped=False):
+        os.environ.setdefault("ER_ORACLE_QUIET", "1")
+        self.L = self.lib(uncapped)
+        self._h = _vp(self.L.ref_app_create())
+
+    def close(self):
+        if self._h:
+            self.L.ref_app_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def init(self, ref_traj="", pose_traj="", seg_traj="", ctr="", camera="", num=0, resolution=8, length=3.0, interval=50):
+        e = lambda s: (s or "").encode()
+        return self.L.ref_app_init(self._h, e(ref_traj), e(pose_traj), e(seg_traj), e(ctr), e(camera), num, resolution,
+                                   float(length), interval)
+
+    def set_window(self, start_from, end_at):
+        self.L.ref_app_set_window(self._h, start_from, end_at)
+
+    def set_camera(self, cam6):
+        c = np.ascontiguousarray(cam6, np.float32)
+        self.L.ref_set_camera(self._h, _p(c))
+
+    def execute(self, frame_id, depth, want_scaled=False):
+        d = np.array(depth, np.uint16).reshape(-1)
+        s = np.empty(d.size, np.float32) if want_scaled else None
+        ex = self.L.ref_app_execute(self._h, frame_id, _p(d), None if s is None else _p(s))
+        return ex, d, s
+
+    def ScaleDepth(self, depth):
+        d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+        out = np.empty(d.size, np.float32)
+        self.L.ref_scale_depth(self._h, _p(d), _p(out))
+        return out
+
+    def Integrate(self, depth, T):
+        d = np.ascontiguousarray(depth, np.uint16).reshape(-1)
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        self.L.ref_integrate(self._h, _p(d), _p(Tm))
+
+    def unit_keys(self):
+        n = self.L.ref_unit_count(self._h)
+        k = np.empty(n, np.int32)
+        if n:
+            self.L.ref_unit_keys(self._h, _p(k))
+        return k
+
+    def read_unit(self, key):
+        sdf = np.empty(UNIT_VOX, np.float32)
+        w = np.empty(UNIT_VOX, np.float32)
+        if self.L.ref_read_unit(self._h, int(key), _p(sdf), _p(w)) != 0:
+            raise KeyError(key)
+        return sdf, w
+
+    def save_world(self, filename):
+        self.L.ref_save_world(self._h, filename.encode())
