@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X: depth frames/s integrated into a 512^3 TSDF
+(8x8x8 volume units of 64^3, 640x480 frames) with the control-grid warp on (config 2).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" = one fragment of the trajectory = --interval (50) consecutive depth frames handed to the hot
+path in ONE call: Reproject (control-grid warp) + ScaleDepth + unit touch + IntegrateVolumeUnit, i.e.
+what CIntegrateApp::Execute does for each of those frames (IntegrateApp.cpp:217-225).  Frames are
+synthetic (elasticreconstruction_amd/synth.py), rendered straight into HBM before the clock starts.
+Warm-up steps run on a scratch volume; the K timed steps fill a fresh one.
+
+N > 1 (weak scaling): every rank integrates its own contiguous K*interval-frame block of one long
+trajectory into a private volume (no data-path collective), then -- inside the timed region -- the
+per-GPU volumes are merged by ONE RCCL all-reduce(sum) of the sdf*weight / weight planes of the union
+of touched units.
+
+Output: one JSON line (rank 0).  roofline.achieved uses the ALGORITHMIC bytes of SURVEY.md 8d,
+B_A = 16 * N_upd + 1 843 200 (+ 1 228 800 with the warp) per frame with sum(N_upd) = sum(weight_),
+divided by the average duration of the dominant kernel (k_integrate) measured with HIP events on
+the stream it runs on.  cpu_baseline times the REFERENCE's own code (oracle/_ref, built from
+/root/reference/Integrate/*.cpp unmodified, 8 OpenMP threads as hard-coded there) on a bounded
+sample of the same frames; when that build is absent it falls back to the oracle port and says so.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+FRAME_BYTES_RAW = 640 * 480 * 2
+FRAME_BYTES_FIXED = 640 * 480 * (2 + 4)        # raw read + scaled write/read once
+
+
+def cpu_baseline(sc, depth_host, n_sample):
+    """Reference CPU path on the host cores of this box, same frames, same files-based setup as Integrate.exe."""
+    import numpy as np
+    from elasticreconstruction_amd import formats
+    from oracle import pyoracle
+    interval = sc["interval"]
+    num = n_sample // interval
+    if pyoracle.have_ref():
+        with tempfile.TemporaryDirectory() as d:
+            pose = [formats.FramedTransformation(i, i, i + 1, sc["pose"][i]) for i in range(num)]
+            seg = [formats.FramedTransformation(i, i, i + 1, sc["seg"][i]) for i in range(n_sample)]
+            # one extra fragment of entries so that frame n_sample is still integrated (reference off-by-one)
+            formats.save_log(os.path.join(d, "pose.log"), pose + [formats.FramedTransformation(num, num, num + 1, sc["pose"][num - 1])])
+            formats.save_log(os.path.join(d, "seg.log"), seg + [formats.FramedTransformation(n_sample + j, n_sample + j, n_sample + j + 1,
+                                                                                            sc["seg"][n_sample - 1]) for j in range(interval)])
+            formats.save_ctr(os.path.join(d, "g.ctr"), sc["grids"][:num])
+            ref = pyoracle.RefApp()
+            ref.init(pose_traj=os.path.join(d, "pose.log"), seg_traj=os.path.join(d, "seg.log"), ctr=os.path.join(d, "g.ctr"),
+                     num=num, resolution=sc["resolution"], length=sc["length"], interval=interval)
+            t0 = time.perf_counter()
+            for f in range(n_sample):
+                ref.execute(f + 1, depth_host[f])
+            dt = time.perf_counter() - t0
+            ref.close()
+        return {"value": n_sample / dt, "unit": "frames/s", "cores": 8, "kind": "reference",
+                "sample": "first %d frames of the same stream through the reference's own CIntegrateApp::Execute "
+                          "(Reproject+ScaleDepth+Integrate), compiled unmodified; %d host cores present" % (n_sample, os.cpu_count() or 0)}
+    from elasticreconstruction_amd import synth
+    ora = pyoracle.OracleVolume()
+    warp = synth.warp_arrays(sc, 0, n_sample)
+    t0 = time.perf_counter()
+    for f in range(n_sample):
+        dd = ora.Reproject(depth_host[f], sc["grids"][f // interval], sc["resolution"], sc["length"], warp["seg"][f], warp["madj"][f])
+        ora.Integrate(dd, sc["traj"][f])
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "frames/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": "first %d frames of the same stream through oracle/tsdf_oracle.c (oracle/_ref not present)" % n_sample}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--interval", type=int, default=50, help="frames per step (= frames per fragment / control grid)")
+    ap.add_argument("--no-warp", action="store_true", help="rigid --ref_traj style run (no control grid)")
+    ap.add_argument("--cpu-sample", type=int, default=200, help="frames timed on the CPU reference (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from elasticreconstruction_amd import synth
+    from elasticreconstruction_amd.tsdf import TSDFVolume
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, W, I = args.steps, args.warmup, args.interval
+    n_frames = K * I
+    warp_on = not args.no_warp
+    # one long trajectory split into contiguous per-rank blocks (config 4's frame-batch shard)
+    sc = synth.make_scenario(n_frames, interval=I, warp=warp_on, frame_offset=rank * n_frames,
+                             total_frames=world * n_frames, revolutions=max(1.0, world * n_frames / 3000.0),
+                             device=dev)
+    depth = sc["depth"]                                    # uint16 [n_frames, 307200] in HBM
+    warp_all = synth.warp_arrays(sc) if warp_on else None
+
+    def warp_slice(lo, hi):
+        if not warp_on:
+            return None
+        gi = warp_all["grid_index"][lo:hi]
+        g0, g1 = int(gi.min()), int(gi.max()) + 1                       # only the grids this step needs travel
+        return dict(ctr=warp_all["ctr"][g0:g1], resolution=warp_all["resolution"], length=warp_all["length"],
+                    grid_index=gi - g0, seg=warp_all["seg"][lo:hi], madj=warp_all["madj"][lo:hi])
+
+    # A dedicated (non-null) torch stream carries torch ops, RCCL ordering AND every kernel of the handle,
+    # so HIP-event timing and the all-reduce see one in-order queue.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(stream)
+    px = depth.shape[1]
+
+    def run_steps(vol, k):
+        for s in range(k):
+            lo, hi = s * I, (s + 1) * I
+            vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
+
+    def merge(vol):
+        """Frame-split merge: key all-gather + ONE all-reduce(sum) over the sdf*w / w planes."""
+        keys = vol.unit_keys()
+        cnt = torch.tensor([len(keys)], device=dev, dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        mx = int(max(int(c.item()) for c in cnts))
+        pad = torch.full((mx,), -1, device=dev, dtype=torch.int32)
+        pad[:len(keys)] = torch.from_numpy(keys).to(dev)
+        allk = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(allk, pad)
+        union = torch.unique(torch.cat(allk))
+        union = union[union >= 0].to(torch.int32).cpu().numpy()
+        buf = torch.empty((len(union), 2, 64 ** 3), dtype=torch.float32, device=dev)
+        vol.export_weighted(union, buf.data_ptr())
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        vol.import_weighted(union, buf.data_ptr())
+        return len(union)
+
+    max_units = 640 if world == 1 else 1024
+    # ---- warm-up on a scratch volume ---------------------------------------------------------
+    scratch = TSDFVolume(max_units=max_units, device=local)
+    scratch.set_stream(stream.cuda_stream)
+    run_steps(scratch, min(W, K))
+    scratch.synchronize()
+    scratch.close()
+    del scratch
+
+    vol = TSDFVolume(max_units=max_units, device=local)
+    vol.set_stream(stream.cuda_stream)
+    vol.set_profiling(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(vol, K)
+    n_union = merge(vol) if world > 1 else 0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = vol.get_profile()
+    sum_w = vol.sum_weight() if world == 1 else None
+    n_units = vol.unit_count()
+
+    if rank == 0:
+        total_frames = world * n_frames
+        out = {
+            "metric": "depth frames/sec into 512^3 TSDF (640x480)",
+            "value": total_frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1000.0 * dt / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %d synthetic 640x480 frames per GPU (box room + sphere, circular trajectory), "
+                                   "512^3 TSDF = 8x8x8 units of 64^3 at 3/512 m, %s, %d frames per step"
+                                   % (n_frames, "ControlGrid warp res 8 / %d grids" % K if warp_on else "rigid", I),
+                       "frames_per_step": I, "frames_per_gpu": n_frames, "volume_units_touched": n_units,
+                       "parallelism": "frame-block shard x%d + one all-reduce" % world if world > 1 else "single GPU",
+                       "inputs": "resident in HBM before the timed region"},
+        }
+        if world > 1:
+            out["config"]["merge_union_units"] = n_union
+        launches = max(prof["launches"], 1)
+        ms_launch = prof["integrate_ms"] / launches
+        if sum_w is not None and prof["integrate_ms"] > 0:
+            bytes_total = 16.0 * sum_w + FRAME_BYTES_FIXED * n_frames + (2 * FRAME_BYTES_RAW * n_frames if warp_on else 0)
+            per_launch = bytes_total / launches
+            ach = per_launch / (ms_launch * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("k_integrate_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms_launch, "launches": launches,
+                               "voxel_updates": sum_w, "unit_visits": prof["unit_visits"],
+                               "whole_job_frac": bytes_total / dt / 1e9 / HBM_PEAK_GBS}
+        else:
+            out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": None, "traffic": None, "avg_launch_ms": ms_launch, "launches": launches}
+        if world == 1 and args.cpu_sample > 0 and warp_on:
+            ns = min(n_frames, max(I, (args.cpu_sample // I) * I))
+            host = synth.to_numpy_u16(depth[:ns])
+            out["cpu_baseline"] = cpu_baseline(sc, host, ns)
+        print(json.dumps(out), flush=True)
+    vol.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,105 @@
+// tsdf_hostcheck.cpp -- TEST-ONLY host build of the per-pixel / per-voxel device functions in
+// elasticreconstruction_amd/csrc/er_tsdf_math.h (ER_HD expands to plain `inline` without hipcc).
+// It replays what the HIP kernels do with those functions -- frame masks per unit, frames applied in
+// ascending order per voxel, scatter-min re-projection -- in plain loops, so the arithmetic the GPU will
+// execute can be compared with the oracle on a machine that has no GPU.  Never shipped, never loaded by
+// the product: tests/test_hostcheck.py builds it into tests/hostcheck/_build/.
+#include "../../elasticreconstruction_amd/csrc/er_tsdf_math.h"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+using namespace er;
+
+struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
+struct HcVolume { Camera cam; int cols, rows; std::map<int, HcUnit> units; };
+
+static bool inverse4(const double* m, double* out);
+
+extern "C" {
+
+void* hc_create(int cols, int rows, const float* cam6) {
+  HcVolume* v = new HcVolume();
+  v->cam = Camera{cam6[0], cam6[1], cam6[2], cam6[3], cam6[4], cam6[5]};
+  v->cols = cols; v->rows = rows;
+  return v;
+}
+void hc_destroy(void* h) { delete static_cast<HcVolume*>(h); }
+
+void hc_scale_depth(void* h, const uint16_t* depth, float* scaled) {
+  HcVolume* v = static_cast<HcVolume*>(h);
+  for (int p = 0; p < v->cols * v->rows; p++)
+    scaled[p] = scale_depth_px(depth[p], scale_lambda(p % v->cols, p / v->cols, v->cam), v->cam.integration_trunc);
+}
+
+// Same contract as er_tsdf_reproject; sequential "write if empty or closer" (IntegrateApp.cpp:260-263).
+void hc_reproject(void* h, uint16_t* depth, const float* ctr, int res, float length, const double* seg, const double* madj) {
+  HcVolume* v = static_cast<HcVolume*>(h);
+  const int n = v->cols * v->rows;
+  std::vector<uint16_t> src(depth, depth + n);
+  std::fill(depth, depth + n, (uint16_t)0);
+  const float grid_ul = length / (float)res;
+  for (int p = 0; p < n; p++) {
+    if (src[p] == 0) continue;
+    int cell; uint16_t dd;
+    if (!reproject_px(p % v->cols, p / v->cols, src[p], v->cam, v->cols, seg, madj, ctr, res, grid_ul, cell, dd)) continue;
+    if (depth[cell] == 0 || depth[cell] > dd) depth[cell] = dd;
+  }
+}
+
+// Batch semantics of k_prepare + k_integrate: masks first, then per voxel all frames in order.
+int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, const double* Tinv) {
+  HcVolume* v = static_cast<HcVolume*>(h);
+  const int px = v->cols * v->rows;
+  std::vector<std::vector<float>> scaled(n, std::vector<float>(px));
+  std::vector<FrameXform> fx(n);
+  for (auto& kv : v->units) kv.second.frames.clear();
+  for (int f = 0; f < n; f++) {
+    const double* Tf = T + f * 16;
+    const double* Ti = Tinv + f * 16;
+    for (int q = 0; q < 12; q++) fx[f].mi[q] = (float)Ti[q];
+    fx[f].tx = (float)Tf[3]; fx[f].ty = (float)Tf[7]; fx[f].tz = (float)Tf[11];
+    for (int p = 0; p < px; p++) {
+      uint16_t d = depth[(size_t)f * px + p];
+      scaled[f][p] = scale_depth_px(d, scale_lambda(p % v->cols, p / v->cols, v->cam), v->cam.integration_trunc);
+      if (d == 0) continue;
+      int key = touch_key(p % v->cols, p / v->cols, d, v->cam, Tf);
+      if (key < 0) return -1;
+      HcUnit& u = v->units[key];
+      if (u.sdf.empty()) { u.sdf.assign(kUnitVox, 0.f); u.w.assign(kUnitVox, 0.f); }
+      if (u.frames.empty() || u.frames.back() != f) u.frames.push_back(f);
+    }
+  }
+  for (auto& kv : v->units) {
+    const int key = kv.first;
+    HcUnit& u = kv.second;
+    if (u.frames.empty()) continue;
+    const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+    const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
+    for (int i = 0; i < 64; i++)
+      for (int j = 0; j < 64; j++)
+        for (int k = 0; k < 64; k++) {
+          const int l = (i * 64 + j) * 64 + k;
+          float S = u.sdf[l], W = u.w[l];
+          for (int f : u.frames)
+            voxel_update(S, W, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), fx[f], v->cam, v->cols, v->rows, scaled[f].data());
+          u.sdf[l] = S; u.w[l] = W;
+        }
+  }
+  return 0;
+}
+
+int hc_unit_count(void* h) { return (int)static_cast<HcVolume*>(h)->units.size(); }
+void hc_unit_keys(void* h, int* keys) { int n = 0; for (auto& kv : static_cast<HcVolume*>(h)->units) keys[n++] = kv.first; }
+int hc_read_unit(void* h, int key, float* sdf, float* w) {
+  HcVolume* v = static_cast<HcVolume*>(h);
+  auto it = v->units.find(key);
+  if (it == v->units.end()) return -1;
+  memcpy(sdf, it->second.sdf.data(), kUnitVox * sizeof(float));
+  memcpy(w, it->second.w.data(), kUnitVox * sizeof(float));
+  return 0;
+}
+
+}  // extern "C"
