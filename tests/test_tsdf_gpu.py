@@ -81,7 +81,7 @@ def test_batch_boundary_and_device_resident_input(gpu):
     torch.cuda.synchronize()
     helpers.oracle_run(ora, sc, depth, warp)
     n = helpers.assert_volumes_identical(vol, ora, "70-frame warp")
-    assert n > 30
+    assert n > 20
     assert vol.sum_weight() == ora.sum_weight()
     # SaveWorld: same point set (the reference's unordered_map order is not canonical)
     wg, wo = vol.extract_world(), ora.extract_world()
