@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's BuildCorrespondence program over the C ABI (include/er_hip.h).
+
+  Cloud      <->  pointclouds_[i]  (BuildCorrespondence/CorresApp.h:32) resident in HBM with its search grid
+  CorresApp  <->  CCorresApp       (CorresApp.h:12-82, CorresApp.cpp): LoadData / Registration /
+                  FindCorrespondence / Finalize / Blacklist / Redux with the reference's member names,
+                  defaults and output files (reg_output.log/.info in the CWD, corres_<i>_<j>.txt next to the clouds).
+
+All per-point arithmetic (transform, exact NN, inlier counts, point-to-plane sums, correspondence filter,
+information matrix) runs in the HIP kernels of liber_hip.so.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi
+from . import formats
+from .tsdf import _inverse, mat4_mul
+
+
+class Cloud:
+    """One fragment in HBM: xyz + normals (file order) and the uniform grid used when it is a target."""
+
+    def __init__(self, xyz, normals, grid_cell=0.03, device=0):
+        self._lib = _ffi.lib()
+        x = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        assert x.shape == n.shape
+        self.n = x.shape[0]
+        self.grid_cell = float(grid_cell)
+        h = C.c_void_p()
+        _ffi.check(self._lib.er_cloud_create(_ffi.ptr(x), _ffi.ptr(n), self.n, C.c_float(grid_cell), int(device), C.byref(h)),
+                   "er_cloud_create")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.er_cloud_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return self.n
+
+
+def count_inliers(src, tgt, T, max_dist):
+    """Registration pre-check (CorresApp.cpp:249-264)."""
+    Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+    cnt = C.c_int(0)
+    _ffi.check(src._lib.er_icp_count_inliers(src._h, tgt._h, _ffi.ptr(Tm), float(max_dist), C.byref(cnt)), "er_icp_count_inliers")
+    return cnt.value
+
+
+def icp_align(src, tgt, guess, max_dist=0.03, max_iter=20, eps=1e-6, stop_rule=0, want_fitness=False):
+    """icp.align as configured at CorresApp.cpp:295-306.  Returns (float32 4x4, iterations, converged, fitness)."""
+    g = np.ascontiguousarray(guess, np.float32).reshape(16)
+    out = np.empty(16, np.float32)
+    it, cv, fit = C.c_int(0), C.c_int(0), C.c_double(0)
+    _ffi.check(src._lib.er_icp_align(src._h, tgt._h, _ffi.ptr(g), float(max_dist), int(max_iter), float(eps), int(stop_rule),
+                                     _ffi.ptr(out), C.byref(it), C.byref(cv), C.byref(fit) if want_fitness else None),
+               "er_icp_align")
+    return out.reshape(4, 4), it.value, bool(cv.value), (fit.value if want_fitness else None)
+
+
+def find_correspondence(src, tgt, T, dist, normal_cos=0.8660, want_info=False):
+    """FindCorrespondence (CorresApp.cpp:144-161,186-208).  Returns (pairs int32 [m,2] = (tgt idx, src idx), info 6x6 or None)."""
+    Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+    pairs = np.empty((max(src.n, 1), 2), np.int32)
+    m = C.c_int(0)
+    info = np.zeros(36, np.float64) if want_info else None
+    _ffi.check(src._lib.er_find_correspondence(src._h, tgt._h, _ffi.ptr(Tm), float(dist), float(normal_cos), _ffi.ptr(pairs),
+                                               src.n, C.byref(m), _ffi.ptr(info) if want_info else None), "er_find_correspondence")
+    return pairs[:m.value].copy(), (info.reshape(6, 6) if want_info else None)
+
+
+class CorresApp:
+    """CCorresApp (CorresApp.h:12-82).  Defaults from the constructor, CorresApp.cpp:8-24."""
+
+    def __init__(self, device=0, verbose=False):
+        self.save_xyzn_ = False
+        self.save_corres_ = True
+        self.dist_thresh_ = 0.015
+        self.normal_thresh_ = 0.8660
+        self.registration_ = False
+        self.output_information_ = False
+        self.reg_dist_ = 0.03
+        self.reg_ratio_ = 0.25
+        self.reg_num_ = 40000
+        self.redux_ = False
+        self.num_ = 0
+        self.length_ = 3.0
+        self.interval_ = 50
+        self.corres_traj_ = []
+        self.corres_info_ = []
+        self.blacklist_ = set()
+        self.redux_traj_ = []
+        self.redux_map_ = {}
+        self.pointclouds_ = []
+        self.m_pDirName = ""
+        self.device = device
+        self.verbose = verbose
+        self.stop_rule = 0
+        self.out_dir = "."           # reg_output.* go to the CWD in the reference (CorresApp.cpp:323,326)
+        self.icp_iterations_ = {}
+
+    # ---- CorresApp.h:64-81 -----------------------------------------------------------------------
+    def GetVolumeOverlapRatio(self, trans):
+        res = 20
+        ul = self.length_ / float(res)
+        c = (np.arange(res) + 0.5) * ul
+        i, j, k = np.meshgrid(c, c, c, indexing="ij")
+        T = np.asarray(trans, np.float64)
+        p = [((T[r, 0] * i + T[r, 1] * j) + T[r, 2] * k) + T[r, 3] * 1.0 for r in range(3)]
+        inside = np.ones_like(i, dtype=bool)
+        for a in range(3):
+            inside &= (p[a] >= 0) & (p[a] <= self.length_)
+        return float(inside.sum()) / res / res / res
+
+    # ---- CorresApp.cpp:31-110 --------------------------------------------------------------------
+    def LoadData(self, filename, num):
+        cut = max(filename.rfind("\\"), -1)
+        if cut < 0:
+            cut = filename.rfind("/")
+        self.m_pDirName = filename[:cut + 1]
+        if num > 0:
+            temp = formats.load_log(filename)
+            self.corres_traj_ = []
+            self.num_ = num
+            base = np.eye(4)
+            base[0, 3] = self.length_ / 2.0
+            base[1, 3] = self.length_ / 2.0
+            base[2, 3] = -0.3
+            baseinv = _inverse(base)
+            leftbase = mat4_mul(base, _inverse(temp[0].T))
+            ipose = [mat4_mul(mat4_mul(leftbase, temp[i * self.interval_].T), baseinv) for i in range(num)]
+            for i in range(num - 1):
+                self.corres_traj_.append(formats.FramedTransformation(i, i + 1, num, mat4_mul(_inverse(ipose[i]), ipose[i + 1])))
+                for j in range(i + 2, num):
+                    trans = mat4_mul(_inverse(ipose[i]), ipose[j])
+                    if self.GetVolumeOverlapRatio(trans) > 0.3:
+                        self.corres_traj_.append(formats.FramedTransformation(i, j, num, trans))
+        else:
+            self.corres_traj_ = formats.load_log(filename)
+            self.num_ = self.corres_traj_[0].frame
+        self.pointclouds_ = [None] * self.num_
+        grid_cell = max(self.reg_dist_, self.dist_thresh_)
+        for i in range(self.num_):
+            fn = "%scloud_bin_%d.pcd" % (self.m_pDirName, i)
+            raw = formats.load_pcd(fn)
+            xyz = np.stack([raw["x"], raw["y"], raw["z"]], axis=1).astype(np.float32)
+            nrm = np.stack([raw["normal_x"], raw["normal_y"], raw["normal_z"]], axis=1).astype(np.float32)
+            keep = ~np.isnan(nrm[:, 0])                                   # :94-98
+            xyz, nrm = xyz[keep], nrm[keep]
+            self.pointclouds_[i] = Cloud(xyz, nrm, grid_cell, self.device)
+            self.pointclouds_[i].host_xyz, self.pointclouds_[i].host_nrm = xyz, nrm
+            if self.save_xyzn_:                                           # :100-108
+                with open("%scloud_bin_xyzn_%d.xyzn" % (self.m_pDirName, i), "w") as f:
+                    for p, q in zip(xyz, nrm):
+                        f.write("%.6f %.6f %.6f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], q[0], q[1], q[2]))
+
+    def SetClouds(self, clouds, pairs):
+        """In-memory alternative to LoadData for tests/bench: clouds = [Cloud], pairs = [FramedTransformation]."""
+        self.pointclouds_ = list(clouds)
+        self.num_ = len(clouds)
+        self.corres_traj_ = list(pairs)
+        self.save_corres_ = False
+
+    # ---- CorresApp.cpp:330-359 -------------------------------------------------------------------
+    def Blacklist(self, filename):
+        self.blacklist_ = set()
+        if os.path.exists(filename):
+            with open(filename) as f:
+                for line in f:
+                    if len(line) > 0 and line[0] != "#" and line.strip():
+                        self.blacklist_.add(int(line.split()[0]))
+
+    def GetReduxIndex(self, i, j):
+        return i + j * self.num_
+
+    def Redux(self, filename):
+        self.redux_ = True
+        self.redux_traj_ = formats.load_log(filename)
+        self.redux_map_ = {}
+        for i, t in enumerate(self.redux_traj_):
+            self.redux_map_.setdefault(self.GetReduxIndex(t.id1, t.id2), i)
+
+    # ---- CorresApp.cpp:212-319 -------------------------------------------------------------------
+    def Registration(self):
+        self.registration_ = True
+        for ft in self.corres_traj_:
+            if ft.id1 in self.blacklist_ or ft.id2 in self.blacklist_:
+                ft.frame = -1
+                continue
+            if ft.frame == -1:
+                continue
+            pcd0, pcd1 = self.pointclouds_[ft.id1], self.pointclouds_[ft.id2]
+            cnt = count_inliers(pcd1, pcd0, ft.T, self.reg_dist_)                        # :249-264
+            r1 = float(cnt) / float(max(len(pcd0), 1)) if len(pcd0) else float("inf")
+            r2 = float(cnt) / float(max(len(pcd1), 1)) if len(pcd1) else float("inf")
+            accept = cnt >= self.reg_num_ or (r1 > self.reg_ratio_ and r2 > self.reg_ratio_)   # :267
+            if self.verbose:
+                print("    <%d, %d> : %d inliers with ratio %.2f(%d) and %.2f(%d) ... %s" % (
+                    ft.id1, ft.id2, cnt, r1, len(pcd0), r2, len(pcd1), "accept." if accept else "reject."))
+            if not accept:
+                ft.frame = -1
+                continue
+            ft.frame = cnt
+            if self.redux_:
+                it = self.redux_map_.get(self.GetReduxIndex(ft.id1, ft.id2))
+                if it is not None:
+                    ft.T = self.redux_traj_[it].T.copy()
+                    continue
+            final, iters, conv, _ = icp_align(pcd1, pcd0, ft.T.astype(np.float32), self.reg_dist_, 20, 1e-6, self.stop_rule)   # :295-306
+            ft.T = final.astype(np.float64)                                              # :312
+            self.icp_iterations_[(ft.id1, ft.id2)] = iters
+
+    # ---- CorresApp.cpp:112-210 -------------------------------------------------------------------
+    def FindCorrespondence(self):
+        if self.output_information_:
+            self.corres_info_ = [formats.FramedInformation(t.id1, t.id2, t.frame, np.zeros((6, 6))) for t in self.corres_traj_]
+        self.correspondences_ = {}
+        for idx, ft in enumerate(self.corres_traj_):
+            if ft.id1 in self.blacklist_ or ft.id2 in self.blacklist_:
+                continue
+            if ft.frame == -1:
+                continue
+            pcd0, pcd1 = self.pointclouds_[ft.id1], self.pointclouds_[ft.id2]
+            corres, info = find_correspondence(pcd1, pcd0, ft.T, self.dist_thresh_, self.normal_thresh_, self.output_information_)
+            n = corres.shape[0]
+            ratio = float(n) / float(ft.frame) if ft.frame != 0 else float("inf")
+            if ratio < 0.5:                                                              # :164-171
+                ft.frame = -1 if self.reg_num_ > 0 else n
+            else:
+                ft.frame = n
+            if self.save_corres_:                                                        # :175-184
+                formats.save_corres("%scorres_%d_%d.txt" % (self.m_pDirName, ft.id1, ft.id2), corres)
+            self.correspondences_[(ft.id1, ft.id2)] = corres
+            if self.output_information_:                                                 # :186-208
+                self.corres_info_[idx].frame = ft.frame
+                self.corres_info_[idx].info = info
+
+    # ---- CorresApp.cpp:321-328 -------------------------------------------------------------------
+    def Finalize(self):
+        formats.save_log(os.path.join(self.out_dir, "reg_output.log"), self.corres_traj_)
+        if self.output_information_:
+            formats.save_info(os.path.join(self.out_dir, "reg_output.info"), self.corres_info_)

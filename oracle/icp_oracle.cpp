@@ -206,7 +206,7 @@ void* icp_cloud_create(const float* xyz, const float* nrm, int n, float grid_cel
   c->n = n;
   c->xyz.assign(xyz, xyz + 3 * (size_t)n);
   c->nrm.assign(nrm, nrm + 3 * (size_t)n);
-  build_grid(*c, grid_cell);
+  build_grid(*c, grid_cell * 1.001f);   // strictly larger than any admissible radius (float-rounding safety)
   return c;
 }
 void icp_cloud_destroy(void* c) { delete static_cast<Cloud*>(c); }

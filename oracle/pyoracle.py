@@ -237,3 +237,70 @@ class RefApp:
 
     def save_world(self, filename):
         self.L.ref_save_world(self._h, filename.encode())
+
+
+class IcpOracle:
+    """oracle/icp_oracle.cpp: one fragment (xyz + normals) with its CPU search grid.  Methods take the
+    TARGET as first argument and use self as the SOURCE, like pcd1 (source) vs pcd0 (target) in
+    CorresApp.cpp:246-247."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = _load("_build/libicp_oracle.so")
+            L.icp_cloud_create.restype = _vp
+            L.icp_cloud_create.argtypes = [_vp, _vp, C.c_int, C.c_float]
+            L.icp_cloud_destroy.argtypes = [_vp]
+            L.icp_nn_pass.argtypes = [_vp, _vp, _vp, C.c_double, _vp, _vp]
+            L.icp_count_inliers.argtypes = [_vp, _vp, _vp, C.c_double]
+            L.icp_align.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _vp]
+            L.icp_find_correspondence.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int, _vp, _vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, xyz, normals, grid_cell=0.03):
+        L = self.lib()
+        self.xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        self.nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        self.n = self.xyz.shape[0]
+        self._h = _vp(L.icp_cloud_create(_p(self.xyz), _p(self.nrm), self.n, C.c_float(grid_cell)))
+
+    def close(self):
+        if self._h:
+            self.lib().icp_cloud_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def nn_pass(self, tgt, T, max_dist):
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        idx = np.empty(self.n, np.int32)
+        sqd = np.empty(self.n, np.float32)
+        self.lib().icp_nn_pass(self._h, tgt._h, _p(Tm), float(max_dist), _p(idx), _p(sqd))
+        return idx, sqd
+
+    def count_inliers(self, tgt, T, max_dist):
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        return int(self.lib().icp_count_inliers(self._h, tgt._h, _p(Tm), float(max_dist)))
+
+    def align(self, tgt, guess, max_dist=0.03, max_iter=20, eps=1e-6, stop_rule=0, want_fitness=False):
+        g = np.ascontiguousarray(guess, np.float32).reshape(16)
+        out = np.empty(16, np.float32)
+        it, cv, fit = C.c_int(0), C.c_int(0), C.c_double(0)
+        self.lib().icp_align(self._h, tgt._h, _p(g), float(max_dist), int(max_iter), float(eps), int(stop_rule), _p(out),
+                             C.byref(it), C.byref(cv), C.byref(fit) if want_fitness else None)
+        return out.reshape(4, 4), it.value, bool(cv.value), (fit.value if want_fitness else None)
+
+    def find_correspondence(self, tgt, T, dist, normal_cos=0.8660, want_info=False):
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        pairs = np.empty((max(self.n, 1), 2), np.int32)
+        m = C.c_int(0)
+        info = np.zeros(36, np.float64) if want_info else None
+        self.lib().icp_find_correspondence(self._h, tgt._h, _p(Tm), float(dist), float(normal_cos), _p(pairs), self.n,
+                                           C.byref(m), _p(info) if want_info else None)
+        return pairs[:m.value].copy(), (info.reshape(6, 6) if want_info else None)

@@ -1,0 +1,136 @@
+"""Parity tests proper for path B: HIP kernels (through the C ABI) against the CPU oracle on the same seeded
+fragments.  PARITY UNPINNED w.r.t. PCL (absent): the bar is HIP == oracle with
+  * integers (inlier counts, iteration counts, correspondence index lists) EXACT -- the NN search is exact and
+    deterministic (float32 L2_Simple distance, ties -> lower index) on both sides;
+  * ICP transforms within 1e-5 per float32 4x4 entry (the 27 point-to-plane sums are float64 but the GPU
+    adds them in a different order than the sequential CPU loop);
+  * information matrices within 1e-9 relative (float64 sums, different order)."""
+import numpy as np
+import pytest
+
+from elasticreconstruction_amd import formats, synth
+from elasticreconstruction_amd.icp import Cloud, CorresApp, count_inliers, find_correspondence, icp_align
+from oracle.pyoracle import IcpOracle
+from test_icp_oracle import make_pair
+
+pytestmark = pytest.mark.gpu
+TOL_T = 1e-5
+
+
+def clouds(pair_data, cell=0.03):
+    (x0, n0), (x1, n1), P = pair_data
+    return Cloud(x0, n0, cell), Cloud(x1, n1, cell), IcpOracle(x0, n0, cell), IcpOracle(x1, n1, cell), P
+
+
+def test_count_inliers_exact(gpu):
+    tgt, src, otgt, osrc, P = clouds(make_pair())
+    for T, r in ((np.eye(4), 0.03), (P, 0.03), (P, 0.01), (synth.perturbation(1, 25, 0.5), 0.03)):
+        assert count_inliers(src, tgt, T, r) == osrc.count_inliers(otgt, T, r)
+
+
+def test_icp_align_matches_oracle_and_ground_truth(gpu):
+    tgt, src, otgt, osrc, P = clouds(make_pair(n=120000, rot=2.0, trans=0.02))
+    for rule in (0, 1):
+        Tg, itg, cg, fg = icp_align(src, tgt, np.eye(4, dtype=np.float32), stop_rule=rule, want_fitness=True)
+        To, ito, co, fo = osrc.align(otgt, np.eye(4, dtype=np.float32), stop_rule=rule, want_fitness=True)
+        assert (itg, cg) == (ito, co), "iterations/converged differ: %s vs %s" % ((itg, cg), (ito, co))
+        assert np.abs(Tg - To).max() <= TOL_T, "transform differs by %.3g" % np.abs(Tg - To).max()
+        assert abs(fg - fo) <= 1e-9 * max(fo, 1e-12) + 1e-15
+        assert np.abs(Tg[:3, :3].astype(np.float64) - P[:3, :3]).max() < 1e-3
+        assert np.abs(Tg[:3, 3].astype(np.float64) - P[:3, 3]).max() < 1e-3
+    # a non-identity guess goes through the float32 pre-transform of the source
+    G = (P @ synth.perturbation(9, 0.5, 0.004)).astype(np.float32)
+    Tg, itg, cg, _ = icp_align(src, tgt, G)
+    To, ito, co, _ = osrc.align(otgt, G)
+    assert (itg, cg) == (ito, co) and np.abs(Tg - To).max() <= TOL_T
+
+
+def test_find_correspondence_lists_exact_and_information(gpu):
+    tgt, src, otgt, osrc, P = clouds(make_pair())
+    for dist in (0.015, 0.03):
+        pg, ig = find_correspondence(src, tgt, P, dist, 0.8660, want_info=True)
+        po, io = osrc.find_correspondence(otgt, P, dist, 0.8660, want_info=True)
+        assert pg.shape == po.shape and pg.shape[0] > 1000
+        assert np.array_equal(pg, po), "%d correspondence rows differ" % int((pg != po).any(1).sum())
+        assert np.array_equal(ig[:3, :3], io[:3, :3])
+        assert np.allclose(ig, io, rtol=1e-9, atol=1e-6)
+    pg, _ = find_correspondence(src, tgt, synth.perturbation(2, 40, 1.0), 0.015)     # no overlap -> empty list
+    assert pg.shape == (0, 2)
+
+
+def test_edge_cases(gpu):
+    (x0, n0), (x1, n1), P = make_pair(4000)
+    tgt = Cloud(x0, n0, 0.03)
+    empty = Cloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.03)
+    assert count_inliers(empty, tgt, np.eye(4), 0.03) == 0
+    assert count_inliers(Cloud(x1, n1, 0.03), empty, np.eye(4), 0.03) == 0
+    T, it, conv, _ = icp_align(empty, tgt, np.eye(4, dtype=np.float32))
+    assert it == 0 and not conv and np.array_equal(T, np.eye(4, dtype=np.float32))   # < 3 correspondences
+    from elasticreconstruction_amd import _ffi
+    with pytest.raises(_ffi.ErError, match="exceeds the target's grid cell"):
+        count_inliers(Cloud(x1, n1, 0.03), tgt, np.eye(4), 0.05)
+    # ragged size (not a multiple of the block), duplicated points (distance ties -> lower index)
+    xd = np.concatenate([x0[:1001], x0[:1001]])
+    nd = np.concatenate([n0[:1001], n0[:1001]])
+    td, od = Cloud(xd, nd, 0.03), IcpOracle(xd, nd, 0.03)
+    s, os_ = Cloud(x0[:777], n0[:777], 0.03), IcpOracle(x0[:777], n0[:777], 0.03)
+    pg, _ = find_correspondence(s, td, np.eye(4), 0.015)
+    po, _ = os_.find_correspondence(od, np.eye(4), 0.015)
+    assert np.array_equal(pg, po) and (pg[:, 0] < 1001).all() and pg.shape[0] == 777
+
+
+def test_corres_app_pipeline_matches_reference_flow(gpu, tmp_path):
+    """CorresApp mirrors CCorresApp end to end on files: cloud_bin_<i>.pcd (with NaN normals to drop), a
+    registration .log with a hopeless pair (rejected by the inlier pre-check) and a blacklisted fragment;
+    outputs reg_output.log/.info and corres_<i>_<j>.txt must equal the oracle-driven flow."""
+    import os
+    d = str(tmp_path) + "/"
+    frag = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
+    raw, truth = [], []
+    for i in range(4):
+        x, n = synth.sample_fragment(frag, 50000, seed=100 + i)
+        P = synth.perturbation(200 + i, 1.0, 0.01) if i else np.eye(4)
+        Pi = np.linalg.inv(P)
+        x, n = (x @ Pi[:3, :3].T + Pi[:3, 3]).astype(np.float32), (n @ Pi[:3, :3].T).astype(np.float32)
+        n[::97, 0] = np.nan                                              # dropped by LoadData (CorresApp.cpp:94-98)
+        formats.save_pcd_xyzn(d + "cloud_bin_%d.pcd" % i, x, n)
+        raw.append((x, n))
+        truth.append(P)
+    pairs = [formats.FramedTransformation(0, 1, 4, np.linalg.inv(truth[0]) @ truth[1] @ synth.perturbation(1, 0.5, 0.005)),
+             formats.FramedTransformation(0, 2, 4, synth.perturbation(2, 60, 1.5)),          # hopeless
+             formats.FramedTransformation(1, 2, 4, np.linalg.inv(truth[1]) @ truth[2]),
+             formats.FramedTransformation(2, 3, 4, np.linalg.inv(truth[2]) @ truth[3])]      # 3 is blacklisted
+    formats.save_log(d + "init.log", pairs)
+    with open(d + "black.txt", "w") as f:
+        f.write("3\n")
+    app = CorresApp()
+    app.out_dir = d
+    app.reg_dist_, app.dist_thresh_ = 0.03, 0.015
+    app.LoadData(d + "init.log", -1)
+    app.Blacklist(d + "black.txt")
+    app.output_information_ = True
+    app.Registration()
+    app.FindCorrespondence()
+    app.Finalize()
+    out = formats.load_log(d + "reg_output.log")
+    info = formats.load_info(d + "reg_output.info")
+    assert [t.frame == -1 for t in out] == [False, True, False, True]
+    # oracle-driven reference flow on what LoadData parsed
+    loaded = formats.load_log(d + "init.log")
+    oc = []
+    for x, n in raw:
+        keep = ~np.isnan(n[:, 0])
+        oc.append(IcpOracle(x[keep], n[keep], 0.03))
+    for k, t in enumerate(loaded):
+        if k in (1, 3):
+            continue
+        cnt = oc[t.id2].count_inliers(oc[t.id1], t.T, 0.03)
+        To, ito, _, _ = oc[t.id2].align(oc[t.id1], t.T.astype(np.float32))
+        assert np.abs(out[k].T - To.astype(np.float64)).max() <= TOL_T + 1e-8
+        # correspondences with the GPU's own (8-decimal) transform so that index lists are comparable exactly
+        po, io = oc[t.id2].find_correspondence(oc[t.id1], app.corres_traj_[k].T, 0.015, want_info=True)
+        pg = formats.load_corres(d + "corres_%d_%d.txt" % (t.id1, t.id2))
+        assert np.array_equal(pg, po)
+        assert out[k].frame == po.shape[0] and po.shape[0] >= 0.5 * cnt
+        assert np.allclose(info[k].info, io, rtol=1e-9, atol=1e-3) and info[k].frame == out[k].frame
+    assert not os.path.exists(d + "corres_0_2.txt") and not os.path.exists(d + "corres_2_3.txt")

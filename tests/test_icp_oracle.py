@@ -1,0 +1,103 @@
+"""CPU checks of the path-B oracle (oracle/icp_oracle.cpp).  PCL/FLANN are absent, so parity of the ICP
+step is UNPINNED; these are the pins that exist: an independent exact-NN implementation
+(scipy cKDTree), ground-truth recovery on synthetic pairs, the known-answer structure of the information
+matrix (also visible in the reference's Matlab example data), and the file formats."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial import cKDTree
+
+from elasticreconstruction_amd import formats, synth
+from oracle.pyoracle import IcpOracle
+
+REF_DATA = "/root/reference/Matlab_Toolbox/Example/Data"
+
+
+def make_pair(n=60000, seed=11, rot=1.5, trans=0.015):
+    frag = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
+    xyz0, nrm0 = synth.sample_fragment(frag, n, seed=seed)
+    xyz1, nrm1 = synth.sample_fragment(frag, n, seed=seed + 1)          # a DIFFERENT sampling of the same surfaces
+    P = synth.perturbation(seed + 2, rot, trans)                        # pcd1 lives in a perturbed frame
+    Pi = np.linalg.inv(P)
+    xyz1 = (xyz1 @ Pi[:3, :3].T + Pi[:3, 3]).astype(np.float32)
+    nrm1 = (nrm1 @ Pi[:3, :3].T).astype(np.float32)
+    return (xyz0, nrm0), (xyz1, nrm1), P                                # P maps pcd1 into pcd0's frame (ground truth)
+
+
+def test_exact_nn_against_ckdtree():
+    (x0, n0), (x1, n1), P = make_pair()
+    tgt, src = IcpOracle(x0, n0, 0.03), IcpOracle(x1, n1, 0.03)
+    for T, r in ((np.eye(4), 0.03), (P, 0.03), (P, 0.015)):
+        idx, sqd = src.nn_pass(tgt, T, r)
+        q = (x1.astype(np.float64) @ T[:3, :3].T + T[:3, 3]).astype(np.float32).astype(np.float64)
+        d, j = cKDTree(x0.astype(np.float64)).query(q)
+        clear_in = d < r * (1 - 1e-4)
+        clear_out = d > r * (1 + 1e-4)
+        assert (idx[clear_out] < 0).all()
+        assert (idx[clear_in] >= 0).all()
+        same = idx[clear_in] == j[clear_in]
+        # disagreements may only be float32-vs-float64 near-ties
+        dd = np.linalg.norm(q[clear_in][~same] - x0[idx[clear_in][~same]].astype(np.float64), axis=1)
+        assert np.allclose(dd, d[clear_in][~same], rtol=1e-5, atol=1e-7)
+        assert same.mean() > 0.999
+
+
+def test_icp_recovers_ground_truth_and_counts():
+    (x0, n0), (x1, n1), P = make_pair()
+    tgt, src = IcpOracle(x0, n0, 0.03), IcpOracle(x1, n1, 0.03)
+    cnt = src.count_inliers(tgt, np.eye(4), 0.03)
+    assert 0 < cnt <= src.n
+    T, it, conv, fit = src.align(tgt, np.eye(4, dtype=np.float32), want_fitness=True)
+    assert conv and 1 <= it <= 20
+    R_err = np.abs(T[:3, :3].astype(np.float64) - P[:3, :3]).max()
+    t_err = np.abs(T[:3, 3].astype(np.float64) - P[:3, 3]).max()
+    assert R_err < 1e-3 and t_err < 1e-3, (R_err, t_err)
+    assert src.count_inliers(tgt, T.astype(np.float64), 0.03) > cnt
+    # both PCL stop rules end at the same place on an easy pair
+    T6, it6, conv6, _ = src.align(tgt, np.eye(4, dtype=np.float32), stop_rule=1)
+    assert conv6 and np.abs(T6 - T).max() < 1e-3
+
+
+def test_information_matrix_known_answer_structure():
+    (x0, n0), (x1, n1), P = make_pair(20000)
+    tgt, src = IcpOracle(x0, n0, 0.03), IcpOracle(x1, n1, 0.03)
+    pairs, info = src.find_correspondence(tgt, P, 0.015, want_info=True)
+    m = pairs.shape[0]
+    assert m > 1000 and (np.diff(pairs[:, 1]) > 0).all()                # ascending source index
+    s = x1[pairs[:, 1]].astype(np.float64)
+    assert np.array_equal(info[:3, :3], m * np.eye(3))
+    S = 2 * s.sum(0)
+    B = np.array([[0, S[2], -S[1]], [-S[2], 0, S[0]], [S[1], -S[0], 0]])
+    assert np.allclose(info[:3, 3:], B, rtol=1e-12) and np.allclose(info[3:, :3], B.T, rtol=1e-12)
+    # full formula, float64 numpy
+    A = np.zeros((m, 3, 6))
+    A[:, 0, 0] = A[:, 1, 1] = A[:, 2, 2] = 1
+    A[:, 0, 4], A[:, 0, 5] = 2 * s[:, 2], -2 * s[:, 1]
+    A[:, 1, 3], A[:, 1, 5] = -2 * s[:, 2], 2 * s[:, 0]
+    A[:, 2, 3], A[:, 2, 4] = 2 * s[:, 1], -2 * s[:, 0]
+    assert np.allclose(info, np.einsum("kri,krj->ij", A, A), rtol=1e-10)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="reference example data not present")
+def test_reference_example_files_parse_and_roundtrip(tmp_path):
+    """The only real data files of the reference: format fixtures for RGBDTrajectory / RGBDInformation,
+    and the known-answer structure of gt.info (N*I3 block, antisymmetric off-diagonal blocks)."""
+    traj = formats.load_log(os.path.join(REF_DATA, "Trajectory", "traj_gt.log"))
+    assert len(traj) == 2538 and traj[0].frame == 1
+    assert np.allclose(traj[10].T[3], [0, 0, 0, 1])
+    p = str(tmp_path / "t.log")
+    formats.save_log(p, traj[:50])
+    back = formats.load_log(p)
+    assert all(np.abs(a.T - b.T).max() < 1e-8 and (a.id1, a.id2, a.frame) == (b.id1, b.id2, b.frame) for a, b in zip(traj[:50], back))
+    scene = os.path.join(REF_DATA, "RegistrationEvaluation", "livingroom1")
+    log, info = formats.load_log(os.path.join(scene, "gt.log")), formats.load_info(os.path.join(scene, "gt.info"))
+    assert len(log) == len(info) and len(info) > 10
+    for fi in info[:40]:
+        N = fi.info[0, 0]
+        assert N > 0 and np.array_equal(fi.info[:3, :3], N * np.eye(3))
+        assert np.allclose(fi.info[:3, 3:], -fi.info[:3, 3:].T, atol=1e-6 * N)      # antisymmetric +-2*sum(s)
+        assert np.allclose(fi.info, fi.info.T, atol=1e-6 * N)
+    p2 = str(tmp_path / "t.info")
+    formats.save_info(p2, info[:5])
+    assert all(np.allclose(a.info, b.info, atol=1e-8) for a, b in zip(info[:5], formats.load_info(p2)))
