@@ -137,23 +137,9 @@ def main():
             vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
 
     def merge(vol):
-        """Frame-split merge: key all-gather + ONE all-reduce(sum) over the sdf*w / w planes."""
-        keys = vol.unit_keys()
-        cnt = torch.tensor([len(keys)], device=dev, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        mx = int(max(int(c.item()) for c in cnts))
-        pad = torch.full((mx,), -1, device=dev, dtype=torch.int32)
-        pad[:len(keys)] = torch.from_numpy(keys).to(dev)
-        allk = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(allk, pad)
-        union = torch.unique(torch.cat(allk))
-        union = union[union >= 0].to(torch.int32).cpu().numpy()
-        buf = torch.empty((len(union), 2, 64 ** 3), dtype=torch.float32, device=dev)
-        vol.export_weighted(union, buf.data_ptr())
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        vol.import_weighted(union, buf.data_ptr())
-        return len(union)
+        """Frame-split merge: key all-gather + ONE all-reduce(sum) over the sdf*w / w planes (parallel.py)."""
+        from elasticreconstruction_amd import parallel
+        return parallel.merge_volumes(vol, dist, dev)
 
     max_units = 640 if world == 1 else 1024
     # ---- warm-up on a scratch volume ---------------------------------------------------------

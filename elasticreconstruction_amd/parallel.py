@@ -1,0 +1,78 @@
+"""Multi-GPU sharding of the two paths: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+  Path B (pairs)   fully independent units: pair p -> rank p mod G, fragments replicated on every GPU,
+                   results gathered on rank 0 in the original pair order.  NO data-path collective.
+  Path A (frames)  contiguous frame blocks per rank into private volumes, then ONE exchange step:
+                   all-gather of the touched unit keys -> union, one all-reduce(sum) over the
+                   [key][sdf*weight | weight] planes of the union, per-voxel divide on import.
+                   (The running mean with unit weights is a sum: w = sum_g w_g, sdf = sum_g sdf_g*w_g / w;
+                   TSDFVolume.cpp:93-94 applied sequentially gives the same value up to float rounding
+                   order, hence tolerance 1e-5 instead of bit parity for this mode.)
+
+The functions only need an object with unit_keys() / export_weighted(keys, ptr) / import_weighted(keys, ptr)
+/ synchronize(), so the CPU tests can drive the identical protocol over gloo with a host-memory volume.
+"""
+import numpy as np
+
+
+def frame_block(n_frames, rank, world):
+    """Contiguous block [lo, hi) of rank `rank` (config 4: frame-batch shard)."""
+    per = (n_frames + world - 1) // world
+    lo = min(rank * per, n_frames)
+    return lo, min(lo + per, n_frames)
+
+
+def pair_shard(n_pairs, rank, world):
+    """Static cyclic assignment of fragment pairs (the reference uses OpenMP schedule(dynamic), CorresApp.cpp:121,220)."""
+    return list(range(rank, n_pairs, world))
+
+
+def union_keys(local_keys, dist, device):
+    """All-gather of the per-rank touched unit keys -> sorted union (int32 numpy)."""
+    import torch
+    world = dist.get_world_size()
+    keys = np.ascontiguousarray(local_keys, np.int32)
+    cnt = torch.tensor([keys.size], device=device, dtype=torch.int64)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    mx = max(1, max(int(c.item()) for c in cnts))
+    pad = torch.full((mx,), -1, device=device, dtype=torch.int32)
+    if keys.size:
+        pad[:keys.size] = torch.from_numpy(keys).to(device)
+    allk = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allk, pad)
+    u = torch.unique(torch.cat(allk))
+    return u[u >= 0].to(torch.int32).cpu().numpy()
+
+
+def merge_volumes(vol, dist, device, sync_stream=None):
+    """Frame-split merge; afterwards every rank holds the complete volume.  Returns the union size.
+    sync_stream: callable that makes the communication stream wait for the volume's kernels and vice
+    versa (None when everything already runs on one in-order stream)."""
+    import torch
+    union = union_keys(vol.unit_keys(), dist, device)
+    if union.size == 0:
+        return 0
+    buf = torch.empty((union.size, 2, 64 ** 3), dtype=torch.float32, device=device)
+    vol.export_weighted(union, buf.data_ptr())
+    if sync_stream:
+        sync_stream()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)               # the ONLY data-path collective of the pipeline
+    if sync_stream:
+        sync_stream()
+    vol.import_weighted(union, buf.data_ptr())
+    vol.synchronize()
+    return int(union.size)
+
+
+def gather_pair_results(local_results, n_pairs, dist):
+    """Host gather of per-pair results (dicts keyed by pair index) onto every rank, original order."""
+    world = dist.get_world_size()
+    allr = [None] * world
+    dist.all_gather_object(allr, local_results)
+    out = [None] * n_pairs
+    for part in allr:
+        for k, v in part.items():
+            out[k] = v
+    return out

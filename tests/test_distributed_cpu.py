@@ -1,0 +1,120 @@
+"""The N > 1 paths on CPU: world_size 2 over gloo.  The frame-split merge protocol (key all-gather + ONE
+all-reduce of the sdf*weight / weight planes, elasticreconstruction_amd/parallel.py) is the same code
+bench.py runs over RCCL; here it is driven with a host-memory volume filled by the oracle so that it needs
+no GPU.  Pair sharding has no collective on the data path; only the host gather is exercised."""
+import ctypes as C
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VOX = 64 ** 3
+
+
+class HostVolume:
+    """unit_keys / export_weighted / import_weighted / synchronize over numpy, filled by the CPU oracle."""
+
+    def __init__(self):
+        self.units = {}
+
+    def integrate_with_oracle(self, depth, poses):
+        from oracle.pyoracle import OracleVolume
+        ora = OracleVolume()
+        for d, T in zip(depth, poses):
+            ora.Integrate(d, T)
+        for k in ora.unit_keys():
+            self.units[int(k)] = ora.read_unit(k)
+
+    def unit_keys(self):
+        return np.array(sorted(self.units), np.int32)
+
+    @staticmethod
+    def _view(ptr, n):
+        return np.ctypeslib.as_array((C.c_float * (n * 2 * VOX)).from_address(ptr)).reshape(n, 2, VOX)
+
+    def export_weighted(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            if int(k) in self.units:
+                s, w = self.units[int(k)]
+                buf[q, 0], buf[q, 1] = s * w, w
+            else:
+                buf[q] = 0
+
+    def import_weighted(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            sw, w = buf[q, 0].copy(), buf[q, 1].copy()
+            with np.errstate(divide="ignore", invalid="ignore"):
+                s = np.where(w > 0, sw / w, np.float32(0)).astype(np.float32)
+            self.units[int(k)] = (s, w)
+
+    def synchronize(self):
+        pass
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["ER_ORACLE_QUIET"] = "1"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    from elasticreconstruction_amd import parallel, synth
+    n = 6
+    poses = synth.circle_trajectory(3000, revolutions=1.0)[::40][:n]
+    depth = synth.to_numpy_u16(synth.render_depth(poses))
+    lo, hi = parallel.frame_block(n, rank, world)
+    vol = HostVolume()
+    vol.integrate_with_oracle(depth[lo:hi], poses[lo:hi])
+    local_keys = vol.unit_keys()
+    n_union = parallel.merge_volumes(vol, dist, torch.device("cpu"))
+    # pair sharding: every pair exactly once, results back in order
+    mine = {p: (p, rank) for p in parallel.pair_shard(7, rank, world)}
+    gathered = parallel.gather_pair_results(mine, 7, dist)
+    if rank == 0:
+        full = HostVolume()
+        full.integrate_with_oracle(depth, poses)
+        ok_keys = np.array_equal(vol.unit_keys(), full.unit_keys())
+        worst, wbad = 0.0, 0
+        for k in full.unit_keys():
+            s, w = vol.units[int(k)]
+            sf, wf = full.units[int(k)]
+            wbad += int((w != wf).sum())
+            worst = max(worst, float(np.abs(s - sf).max()))
+        q.put(dict(ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys),
+                   pairs=[g[0] for g in gathered], owners=[g[1] for g in gathered]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_frame_split_merge_and_pair_shard_world2_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["ok_keys"], "union of the per-rank unit keys != single-volume keys"
+    assert res["wbad"] == 0, "merged weights must be exact (integer-valued floats)"
+    assert res["worst"] <= 1e-5, "merged tsdf off by %.3g" % res["worst"]
+    assert res["n_union"] >= res["n_local"] > 0
+    assert res["pairs"] == list(range(7)) and res["owners"] == [0, 1, 0, 1, 0, 1, 0]
+
+
+def test_frame_block_partition():
+    from elasticreconstruction_amd import parallel
+    for n, w in ((10000, 8), (3000, 4), (7, 3), (2, 4)):
+        blocks = [parallel.frame_block(n, r, w) for r in range(w)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))

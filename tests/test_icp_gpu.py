@@ -88,7 +88,7 @@ def test_corres_app_pipeline_matches_reference_flow(gpu, tmp_path):
     frag = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
     raw, truth = [], []
     for i in range(4):
-        x, n = synth.sample_fragment(frag, 50000, seed=100 + i)
+        x, n = synth.sample_fragment(frag, 160000, seed=100 + i)
         P = synth.perturbation(200 + i, 1.0, 0.01) if i else np.eye(4)
         Pi = np.linalg.inv(P)
         x, n = (x @ Pi[:3, :3].T + Pi[:3, 3]).astype(np.float32), (n @ Pi[:3, :3].T).astype(np.float32)
