@@ -17,7 +17,8 @@
 //   [k_reproject_scatter -> k_reproject_fix{1,2,3}]   per SOURCE pixel: warp + scatter-min   (A6/A7)
 //   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
 //                  allocates the unit on first ever touch, appends it to the batch list
-//   k_integrate    per (unit, i-slab): each voxel is loaded ONCE, run against every frame     (A4)
+//   k_plan         sorts the batch's units by cost (frames in the mask) for a balanced static deal
+//   k_integrate    per (unit, i-slab, quarter): each voxel is loaded ONCE, run against every frame (A4)
 //                  whose bit is set IN FRAME ORDER, stored once -> bit-identical to the
 //                  reference's frame-by-frame loop with 1/batch of its HBM traffic
 //   k_reset        clears the masks of the batch list
@@ -28,6 +29,7 @@
 #include "../../include/er_hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -81,7 +83,7 @@ __global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* _
 // closer" is an order-independent min for dd != 0; a write of dd == 0 RESETS the cell (0 means
 // empty), which is order dependent, so such writes only record their source index and raise a flag;
 // k_reproject_fix* then replay the affected cells exactly (practically never taken).
-__global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_frames, int cols, int rows, Camera cam,
+__global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_frames, int cols, int rows, Camera cam, CameraInv cami,
                                     const double* __restrict__ seg12, const double* __restrict__ madj12,
                                     const int* __restrict__ grid_index, const float* __restrict__ ctr, int res,
                                     float grid_ul, int floats_per_grid, uint32_t* __restrict__ zbuf,
@@ -96,7 +98,7 @@ __global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_fr
     if (d == 0) continue;                                             // UVD2XYZ false
     int cell;
     uint16_t dd;
-    if (!reproject_px(p % cols, p / cols, d, cam, cols, seg12 + f * 12, madj12 + f * 12,
+    if (!reproject_px(p % cols, p / cols, d, cam, cami, cols, seg12 + f * 12, madj12 + f * 12,
                       ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
       continue;
     const size_t o = (size_t)f * pixels + cell;
@@ -139,37 +141,21 @@ __global__ void k_zbuf_to_depth(const uint32_t* __restrict__ zbuf, uint16_t* __r
 
 // ------------------------------------------------------------------------------------------------
 // Per pixel of every frame of the batch: ScaleDepth (TSDFVolume.cpp:19-36) and the unit-touch half
-// of TSDFVolume::Integrate (TSDFVolume.cpp:45-58).  A lane is a "leader" when its key differs from
-// its left neighbour's (consecutive pixels of a row nearly always share a unit), so only a handful
-// of lanes per wave go to the hash map.
-__global__ __launch_bounds__(kBlock) void k_prepare(
-    const uint16_t* __restrict__ depth, const uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
-    Camera cam, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
-    int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
-    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters) {
-  const int pixels = cols * rows;
-  const int f = blockIdx.y;
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  int key = -1;
-  if (p < pixels) {
-    const size_t o = (size_t)f * pixels + p;
-    uint16_t d;
-    if (zbuf) {
-      uint32_t z = zbuf[o];
-      d = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
-    } else {
-      d = depth[o];
-    }
-    scaled[o] = scale_depth_px(d, lambda[p], cam.integration_trunc);
-    if (d > 0) {                                                        // TSDFVolume.cpp:47 (no range cut-off)
-      key = touch_key(p % cols, p / cols, d, cam, T12 + f * 12);
-      if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
-    }
-  }
-  const int left = __shfl_up(key, 1);
-  const bool leader = key >= 0 && (lane == 0 || left != key);
-  if (!leader) return;
+// of TSDFVolume::Integrate (TSDFVolume.cpp:45-58).
+//
+// One 1024-thread workgroup owns a 32x32 pixel TILE of one frame (a 64^3 unit projects to >100x100
+// pixels at room scale, so a tile nearly always sees 1-3 units).  Lanes whose key differs from their
+// left neighbour's append it to a small LDS list; after the barrier the list is de-duplicated and only
+// the DISTINCT keys of the tile go to the global hash map.  Without this every wave hammered the same
+// few hash entries with device-scope atomics at the same moment (measured: 90 % of wave time waiting).
+constexpr int kTile = 32;
+constexpr int kTileKeys = 96;
+
+// Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
+// returned 0) allocates the pool slot on first ever touch and appends the unit to the batch list.
+__device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __restrict__ ht_slot,
+                           unsigned long long* __restrict__ ht_mask, int cap_mask, int hash_shift,
+                           int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters) {
   const int e = ht_find_or_insert(ht_key, cap_mask, hash_shift, key);
   if (e < 0) {
     atomicOr(&counters[C_TABLE_FULL], 1);
@@ -180,7 +166,6 @@ __global__ __launch_bounds__(kBlock) void k_prepare(
   if (seen & bit) return;                                               // touched_unit.find, TSDFVolume.cpp:53
   const unsigned long long old = atomicOr(&ht_mask[e], bit);
   if (old != 0ull) return;
-  // First toucher of this unit in this batch (exactly one lane per unit gets here).
   if (ht_slot[e] < 0) {                                                 // data_.find( key ) == end, TSDFVolume.cpp:55
     const int s = atomicAdd(&counters[C_NUNITS], 1);
     if (s < max_units) {
@@ -193,61 +178,162 @@ __global__ __launch_bounds__(kBlock) void k_prepare(
   batch[atomicAdd(&counters[C_NBATCH], 1)] = e;
 }
 
+__global__ __launch_bounds__(kTile * kTile) void k_prepare(
+    const uint16_t* __restrict__ depth, const uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
+    Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
+    int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
+    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters) {
+  __shared__ int s_keys[kTileKeys];
+  __shared__ int s_n;
+  const int pixels = cols * rows;
+  const int f = blockIdx.z;
+  const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;
+  const int x = blockIdx.x * kTile + tx, y = blockIdx.y * kTile + ty;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  int key = -1;
+  if (x < cols && y < rows) {
+    const int p = y * cols + x;
+    const size_t o = (size_t)f * pixels + p;
+    uint16_t d;
+    if (zbuf) {
+      const uint32_t z = zbuf[o];
+      d = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
+    } else {
+      d = depth[o];
+    }
+    scaled[o] = scale_depth_px(d, lambda[p], cam.integration_trunc);
+    if (d > 0) {                                                        // TSDFVolume.cpp:47 (no range cut-off)
+      key = touch_key(x, y, d, cam, cami, T12 + f * 12);
+      if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
+    }
+  }
+  const int left = __shfl_up(key, 1);
+  const bool leader = key >= 0 && (tx == 0 || left != key);
+  if (leader) {
+    const int slot = atomicAdd(&s_n, 1);
+    if (slot < kTileKeys) {
+      s_keys[slot] = key;
+    } else {                                                            // list full (pathological tile): go direct
+      touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, counters);
+    }
+  }
+  __syncthreads();
+  const int n = min(s_n, kTileKeys);
+  if ((int)threadIdx.x < n) {
+    const int k = s_keys[threadIdx.x];
+    bool dup = false;
+    for (int j = 0; j < (int)threadIdx.x; j++) dup = dup || (s_keys[j] == k);
+    if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, counters);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
+// batch list sorted by DESCENDING cost = popcount(frame mask), so that the static round-robin deal in
+// k_integrate hands every workgroup one item from each cost tier (longest-processing-time order).
+constexpr int kRows = 4;
+
+struct Plan {
+  int n_units;
+};
+
+__global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, const int* __restrict__ counters,
+                                              const unsigned long long* __restrict__ ht_mask, int* __restrict__ plan_entry,
+                                              Plan* __restrict__ plan) {
+  __shared__ int hist[65];
+  __shared__ int start[66];
+  const int n = counters[C_NBATCH];                 // <= hash capacity = size of plan_entry
+  for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&hist[__popcll(ht_mask[batch[t]])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 64; c >= 0; c--) {                 // descending cost
+      start[c] = acc;
+      acc += hist[c];
+    }
+    plan->n_units = n;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int e = batch[t];
+    plan_entry[atomicAdd(&start[__popcll(ht_mask[e])], 1)] = e;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
-// Work item = (unit, i-slab): 64 x 64 voxels.  A wave owns 16 j-rows; lane = k, so one row is a
-// 512-byte coalesced float2 access.  kRows rows live in registers while the wave walks the unit's
-// frame mask in ascending frame order (wave-uniform loop: frame constants come in by scalar loads).
-constexpr int kRows = 4;
+// Work item = (unit, i-slab, quarter) = 16 rows x 64 voxels for one 256-thread workgroup; each wave owns
+// kRows = 4 rows.  lane = k, so one voxel row is a 512-byte coalesced float2 access; the rows stay in
+// registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform loop: the
+// frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
+// Items are dealt round-robin in cost order (k_plan).  Schedules measured on MI355X (profiles/
+// r01_ab_variants.txt, ms per 50-frame launch): whole slabs 0.565; these quarter slabs 0.497 (VALU 90 %
+// busy, L2 hit rate 91 %); XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25.
+#ifdef ER_STATS
+__device__ unsigned long long g_stats[4];
+#endif
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFull));
+}
 
 __global__ __launch_bounds__(kBlock) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
-    const unsigned long long* __restrict__ ht_mask, const int* __restrict__ batch, const int* __restrict__ counters,
+    const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, const Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, Camera cam, int cols, int rows) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
-  const int n_items = counters[C_NBATCH] * kUnitRes;
+  const int n_items = plan->n_units * (kUnitRes * 4);
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int e = batch[item >> 6];
-    const int i = item & 63;
+    const int e = plan_entry[item >> 8];
+    const int i = (item >> 2) & 63;
+    const int j0 = (item & 3) * 16 + wave * kRows;
     const int slot = __builtin_amdgcn_readfirstlane(ht_slot[e]);
     if (slot < 0) continue;                                             // pool overflow: reported by the host
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
-    const unsigned long long mraw = ht_mask[e];
-    const unsigned long long mask =
-        ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mraw >> 32)) << 32) |
-        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(mraw & 0xFFFFFFFFull));
+    unsigned long long m = uniform_u64(ht_mask[e]);
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     const float g0 = grid_coord(i, xs);
     const float g2 = grid_coord(lane, zs);
     float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + lane;
-#pragma unroll 1
-    for (int jc = 0; jc < 16; jc += kRows) {
-      const int j0 = wave * 16 + jc;
-      float S[kRows], W[kRows], W0[kRows], g1[kRows];
+    float S[kRows], W[kRows], W0[kRows], g1[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; r++) {
+      const float2 v = slab[(j0 + r) * kUnitRes];
+      S[r] = v.x;
+      W[r] = v.y;
+      W0[r] = v.y;
+      g1[r] = grid_coord(j0 + r, ys);
+    }
+    while (m) {
+      const int f = __builtin_ctzll(m);
+      m &= m - 1;
+      const FrameXform fx = frames[f];
+      const float* __restrict__ sc = scaled + (size_t)f * pixels;
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
-        const float2 v = slab[(j0 + r) * kUnitRes];
-        S[r] = v.x;
-        W[r] = v.y;
-        W0[r] = v.y;
-        g1[r] = grid_coord(j0 + r, ys);
+        const bool upd = voxel_update(S[r], W[r], g0, g1[r], g2, fx, cam, cols, rows, sc);
+#ifdef ER_STATS
+        const unsigned long long b = __ballot(upd);
+        if (lane == 0) {
+          atomicAdd(&g_stats[0], 1ull);
+          if (b) atomicAdd(&g_stats[1], 1ull);
+          atomicAdd(&g_stats[2], (unsigned long long)__popcll(b));
+        }
+#else
+        (void)upd;
+#endif
       }
-      unsigned long long m = mask;
-      while (m) {
-        const int f = __builtin_ctzll(m);
-        m &= m - 1;
-        const FrameXform fx = frames[f];
-        const float* __restrict__ sc = scaled + (size_t)f * pixels;
-#pragma unroll
-        for (int r = 0; r < kRows; r++) voxel_update(S[r], W[r], g0, g1[r], g2, fx, cam, cols, rows, sc);
-      }
-#pragma unroll
-      for (int r = 0; r < kRows; r++)
-        if (W[r] != W0[r]) slab[(j0 + r) * kUnitRes] = make_float2(S[r], W[r]);
     }
+#pragma unroll
+    for (int r = 0; r < kRows; r++)
+      if (W[r] != W0[r]) slab[(j0 + r) * kUnitRes] = make_float2(S[r], W[r]);
   }
 }
 
@@ -379,6 +465,7 @@ __global__ void k_ensure_units(const int* __restrict__ keys, int n, int* __restr
 struct er_tsdf_s {
   int device = 0, cols = 0, rows = 0, pixels = 0, max_units = 0;
   er::Camera cam{};
+  er::CameraInv cami{};
   hipStream_t own_stream = nullptr, stream = nullptr;
   int n_cu = 256;
   // device memory
@@ -391,7 +478,8 @@ struct er_tsdf_s {
   uint32_t *zbuf = nullptr, *lastzero = nullptr;
   er::FrameXform* frames = nullptr;
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
-  int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
+  int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr, *plan_entry = nullptr;
+  Plan* plan = nullptr;
   size_t ctr_cap = 0, key_scratch_cap = 0;
   // profiling
   bool profiling = false;
@@ -513,7 +601,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
         hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
       }
       hipLaunchKernelGGL(k_reproject_scatter, dim3(replay ? wide_grid : (int)std::min<long>((total + kBlock - 1) / kBlock, 1 << 20)),
-                         dim3(kBlock), 0, h->stream, depth_dev, n, h->cols, h->rows, h->cam, h->seg12, h->madj12,
+                         dim3(kBlock), 0, h->stream, depth_dev, n, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12,
                          h->grid_index, h->ctr, warp->resolution, grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
     }
     hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->lastzero, total, h->counters);
@@ -522,9 +610,12 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     zsrc = h->zbuf;
   }
 
-  hipLaunchKernelGGL(k_prepare, dim3((h->pixels + kBlock - 1) / kBlock, n), dim3(kBlock), 0, h->stream, depth_dev, zsrc, n,
-                     h->cols, h->rows, h->cam, h->lambda, h->T12, h->scaled, h->ht_key, h->ht_slot, h->ht_mask,
+  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kTile * kTile), 0, h->stream, depth_dev, zsrc, n,
+                     h->cols, h->rows, h->cam, h->cami, h->lambda, h->T12, h->scaled, h->ht_key, h->ht_slot, h->ht_mask,
                      h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch, h->counters);
+  ER_HIP_TRY(hipGetLastError());
+
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, h->stream, h->batch, h->counters, h->ht_mask, h->plan_entry, h->plan);
   ER_HIP_TRY(hipGetLastError());
 
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -533,8 +624,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipEventCreate(&e1));
     ER_HIP_TRY(hipEventRecord(e0, h->stream));
   }
-  hipLaunchKernelGGL(k_integrate, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->pool, h->ht_key, h->ht_slot, h->ht_mask,
-                     h->batch, h->counters, h->frames, h->scaled, h->cam, h->cols, h->rows);
+hipLaunchKernelGGL(k_integrate, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->pool, h->ht_key, h->ht_slot, h->ht_mask,
+                     h->plan_entry, h->plan, h->frames, h->scaled, h->cam, h->cols, h->rows);
   if (h->profiling) {
     ER_HIP_TRY(hipEventRecord(e1, h->stream));
     h->events.emplace_back(e0, e1);
@@ -569,6 +660,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   } else {
     h->cam = er::Camera{525.0f, 525.0f, 319.5f, 239.5f, 2.5f, 2.5f};   // TSDFVolumeUnit.h:69
   }
+  h->cami.inv_fx = 1.0 / (double)h->cam.fx;
+  h->cami.inv_fy = 1.0 / (double)h->cam.fy;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   int cap = 1024, lg = 10;
@@ -609,6 +702,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->madj12, B * 12 * sizeof(double));
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
+  ER_ALLOC(h->plan_entry, (size_t)cap * sizeof(int));
+  ER_ALLOC(h->plan, sizeof(Plan));
 #undef ER_ALLOC
   hipStream_t s = h->stream;
   bool ok = hipMemsetAsync(h->pool, 0, (size_t)max_units * er::kUnitVox * sizeof(float2), s) == hipSuccess &&
@@ -640,7 +735,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   }
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask, h->unit_key, h->counters, h->stats, h->batch, h->lambda,
                   h->scaled, h->depth_stage, h->zbuf, h->lastzero, h->frames, h->T12, h->seg12, h->madj12,
-                  h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch};
+                  h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch, h->plan_entry, h->plan};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -709,7 +804,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
     if (replay)
       hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
     hipLaunchKernelGGL(k_reproject_scatter, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
-                       h->depth_stage, 1, h->cols, h->rows, h->cam, h->seg12, h->madj12, h->grid_index, h->ctr, resolution,
+                       h->depth_stage, 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution,
                        grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
   }
   hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->lastzero, total, h->counters);
@@ -914,5 +1009,18 @@ int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate
   if (unit_visits) *unit_visits = (long)st[0];
   return 0;
 }
+
+#ifdef ER_STATS
+// Debug build only (-DER_STATS): row-frames visited / row-frames with >= 1 update / voxel updates.
+int er_debug_stats(unsigned long long out[4], int reset) {
+  ER_HIP_TRY(hipDeviceSynchronize());
+  ER_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), 4 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    ER_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z));
+  }
+  return 0;
+}
+#endif
 
 }  // extern "C"

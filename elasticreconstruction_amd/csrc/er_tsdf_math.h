@@ -24,6 +24,11 @@ struct Camera {            // CameraParam, TSDFVolumeUnit.h:65-70
   float fx, fy, cx, cy, icp_trunc, integration_trunc;
 };
 
+// Host-computed float64 reciprocals used ONLY by the division-free fast paths below (never by an exact path).
+struct CameraInv {
+  double inv_fx, inv_fy;
+};
+
 constexpr double kUnitLength = 3.0 / 512.0;   // TSDFVolume.cpp:10
 constexpr double kTsdfTrunc = 0.03;           // TSDFVolume.cpp:11
 constexpr int kUnitRes = 64;                  // TSDFVolume.cpp:57
@@ -62,21 +67,46 @@ ER_HD void uvd2xyz(int u, int v, uint16_t d, const Camera& c, double& x, double&
 // T = rows 0..2 of the float64 pose (12 doubles).  Returns the hash_key (TSDFVolume.h:62-64) or -1
 // when a unit index falls outside [0,512) -- coordinates beyond +-96 m, where the reference's key
 // would alias another unit; such pixels are skipped and counted by the caller.
-ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const double* T) {
-  double x, y, z;
-  uvd2xyz(u, v, d, c, x, y, z);
-  double p0 = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
-  double p1 = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
-  double p2 = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
-  double v0 = floor(p0 / kUnitLength + 0.5);
-  double v1 = floor(p1 / kUnitLength + 0.5);
-  double v2 = floor(p2 / kUnitLength + 0.5);
+ER_HD int key_from_voxels(double v0, double v1, double v2) {
   const double lo = -(256.0 * 64.0), hi = 256.0 * 64.0;
   if (!(v0 >= lo && v0 < hi && v1 >= lo && v1 < hi && v2 >= lo && v2 < hi)) return -1;
   int xi = ((int)v0 + 256 * 64) / 64;
   int yi = ((int)v1 + 256 * 64) / 64;
   int zi = ((int)v2 + 256 * 64) / 64;
   return xi * 512 * 512 + yi * 512 + zi;
+}
+
+// The reference's expression, division for division (6 float64 divisions per pixel).
+ER_HD int touch_key_exact(int u, int v, uint16_t d, const Camera& c, const double* T) {
+  double x, y, z;
+  uvd2xyz(u, v, d, c, x, y, z);
+  double p0 = ((T[0] * x + T[1] * y) + T[2] * z) + T[3];
+  double p1 = ((T[4] * x + T[5] * y) + T[6] * z) + T[7];
+  double p2 = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
+  return key_from_voxels(floor(p0 / kUnitLength + 0.5), floor(p1 / kUnitLength + 0.5), floor(p2 / kUnitLength + 0.5));
+}
+
+// Division-free evaluation with an exactness guard.  Only floor( p/ul + 0.5 ) of the reference value is
+// observable.  Replacing every division by a multiplication with a rounded reciprocal perturbs p by at most
+// ~1e-14 * (|T0 x| + |T1 y| + |T2 z| + |T3|); for magnitudes below 20000 voxels (117 m, guarded) that is
+// < 1e-9 voxel.  If the approximate w = p'/ul + 0.5 keeps a distance > 1e-6 from the nearest integer, the
+// reference value lies in the same unit interval and has the same floor; otherwise (about 6 pixels per
+// million) the exact expression is evaluated.  Result: identical keys, ~5x fewer float64 instructions.
+ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, const double* T) {
+  const double z = (double)d * 0.001;
+  const double x = (double)((float)u - c.cx) * z * ci.inv_fx;
+  const double y = (double)((float)v - c.cy) * z * ci.inv_fy;
+  const double inv_ul = 512.0 / 3.0;
+  const double w0 = (((T[0] * x + T[1] * y) + T[2] * z) + T[3]) * inv_ul + 0.5;
+  const double w1 = (((T[4] * x + T[5] * y) + T[6] * z) + T[7]) * inv_ul + 0.5;
+  const double w2 = (((T[8] * x + T[9] * y) + T[10] * z) + T[11]) * inv_ul + 0.5;
+  const double f0 = floor(w0), f1 = floor(w1), f2 = floor(w2);
+  const double r0 = w0 - f0, r1 = w1 - f1, r2 = w2 - f2;
+  const double m = 1e-6;
+  const bool safe = fabs(w0) < 20000.0 && fabs(w1) < 20000.0 && fabs(w2) < 20000.0 &&
+                    r0 > m && r0 < 1.0 - m && r1 > m && r1 < 1.0 - m && r2 > m && r2 < 1.0 - m;
+  if (safe) return key_from_voxels(f0, f1, f2);
+  return touch_key_exact(u, v, d, c, T);
 }
 
 // I2F, TSDFVolume.h:66-68: float( (i - 256) * 64 * unit_length_ )
@@ -87,29 +117,37 @@ ER_HD float grid_coord(int i, float shift) { return (float)((double)i * kUnitLen
 
 // ---- A4: one voxel of IntegrateVolumeUnit against one frame, TSDFVolume.cpp:76-94 ----------------
 // S/W are the voxel's sdf_/weight_.  Returns true if the voxel was updated.
+//
+// Same arithmetic as the reference, arranged for a SIMT machine: the projection is evaluated
+// unconditionally (IEEE division never traps; lanes with t2 <= 0 are discarded by the predicate), the
+// five range tests are folded into ONE predicate and the depth / truncation tests into a second one, so
+// a voxel costs 2-3 divergent regions instead of 6.  Measured A/B on MI355X (same box, interleaved,
+// profiles/r01_ab_variants.txt): this form 0.565 ms per 50-frame launch vs 0.600 ms for the
+// test-by-test form; "cleverer" exact shortcuts (float32-only rounding, skipping the update division
+// when S == 1, a guarded multiply instead of the float64 band division) were SLOWER (0.672 ms): the
+// extra branches cost more than the float64 instructions they removed.
 ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
                         int cols, int rows, const float* __restrict__ scaled) {
-  float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
-  if (!(t2 > 0.0f)) return false;                                        // :77
-  float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
-  float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
-  // :78-79  round( float expr ) with TSDFVolume::round(double) = floor(x + 0.5); the range test is done
-  // on the float64 value so out-of-range / NaN never reaches an int conversion.
-  double px = floor((double)(t0 * c.fx / t2 + c.cx) + 0.5);
-  double py = floor((double)(t1 * c.fy / t2 + c.cy) + 0.5);
-  if (!(px >= 0.0 && px < (double)cols && py >= 0.0 && py < (double)rows)) return false;  // :80
-  float dp = scaled[(int)py * cols + (int)px];                           // :81
-  if (!(dp > 0.001f)) return false;                                      // :82
-  float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;                  // :83-85
-  float sdf = dp - sqrtf((rx * rx + ry * ry) + rz * rz);                 // :86
-  double sdfd = (double)sdf;
-  if (!(sdfd >= -kTsdfTrunc)) return false;                              // :87
-  // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1,
-  // so the (slow) float64 division is only evaluated inside the truncation band; the value is
-  // identical either way.
+  const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
+  const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
+  const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
+  // :78-79  round( float expr ) with TSDFVolume::round(double) = floor(x + 0.5); the range test is done on
+  // the float64 value so out-of-range / NaN never reaches an int conversion.
+  const double px = floor((double)(t0 * c.fx / t2 + c.cx) + 0.5);
+  const double py = floor((double)(t1 * c.fy / t2 + c.cy) + 0.5);
+  const bool valid = (t2 > 0.0f) & (px >= 0.0) & (px < (double)cols) & (py >= 0.0) & (py < (double)rows);   // :77,:80
+  if (!valid) return false;
+  const float dp = scaled[(int)py * cols + (int)px];                     // :81
+  const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
+  const float sdf = dp - sqrtf((rx * rx + ry * ry) + rz * rz);           // :86
+  const double sdfd = (double)sdf;
+  if (!((dp > 0.001f) & (sdfd >= -kTsdfTrunc))) return false;            // :82,:87
+  // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1
+  // <=> min(1, q) == 1, so the (slow) float64 division is only evaluated inside the truncation band;
+  // the value is identical either way.
   float tsdf = 1.0f;
   if (sdfd < kTsdfTrunc) {
-    float q = (float)(sdfd / kTsdfTrunc);
+    const float q = (float)(sdfd / kTsdfTrunc);
     tsdf = q < 1.0f ? q : 1.0f;
   }
   S = (S * W + tsdf) / (W + 1.0f);                                       // :93  (w == 1.0f, w * tsdf == tsdf)
@@ -118,17 +156,61 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 }
 
 // ---- A6/A7: one source pixel of Reproject, IntegrateApp.cpp:250-259 ------------------------------
+// float64 reciprocal to ~1 ulp without the IEEE division sequence (fast paths only).
+ER_HD double fast_rcp64(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+#else
+  return 1.0 / x;
+#endif
+}
+
+// Stage 1: the float32 fragment-cube coordinates Vector3f( seg * UVD2XYZ(u,v,d) ) (IntegrateApp.cpp:250-255).
+// Only the float32 ROUNDING of each float64 coordinate is observable.  The division-free value q' differs
+// from the reference's float64 value by < delta = 4e-15 * (sum of the magnitudes of the four terms); when
+// q' - delta and q' + delta round to the same float, so does the reference value (rounding is monotonic).
+// Otherwise (a few pixels per million) the exact expression with its three divisions is evaluated.
+ER_HD void cube_coords(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, const double* seg, float out[3]) {
+  const double z = (double)d * 0.001;
+  const double x = (double)((float)u - c.cx) * z * ci.inv_fx;
+  const double y = (double)((float)v - c.cy) * z * ci.inv_fy;
+  bool safe = true;
+  for (int r = 0; r < 3; r++) {
+    const double t0 = seg[4 * r] * x, t1 = seg[4 * r + 1] * y, t2 = seg[4 * r + 2] * z, t3 = seg[4 * r + 3];
+    const double q = ((t0 + t1) + t2) + t3;
+    const double delta = (((fabs(t0) + fabs(t1)) + fabs(t2)) + fabs(t3)) * 4e-15;
+    const float f = (float)q;
+    safe = safe && ((float)(q - delta) == f) && ((float)(q + delta) == f);
+    out[r] = f;
+  }
+  if (safe) return;
+  double xe, ye, ze;
+  uvd2xyz(u, v, d, c, xe, ye, ze);
+  for (int r = 0; r < 3; r++) out[r] = (float)(((seg[4 * r] * xe + seg[4 * r + 1] * ye) + seg[4 * r + 2] * ze) + seg[4 * r + 3]);
+}
+
+// Stage 3: TSDFVolume::round( x * f / z + c ) of XYZ2UVD (TSDFVolume.h:53-54) as an integer-valued double.
+// Fast path: one shared reciprocal of z; the approximate pixel coordinate is within 1e-8 of the reference's
+// for |coordinate| < 1e6, so if w = ua + 0.5 stays > 1e-6 away from an integer the floor is the same.
+ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc) {
+  const double qa = (e * f) * rcp_e2;
+  const double w = (qa + cc) + 0.5;
+  const double fl = floor(w), fr = w - fl;
+  if (fabs(qa) < 1e6 && fr > 1e-6 && fr < 1.0 - 1e-6) return fl;
+  return floor((e * f / e2 + cc) + 0.5);
+}
+
 // seg, madj: rows 0..2 of the float64 4x4s (12 doubles each).  ctr: one grid, (res+1)^3 * 3 floats.
 // On success returns true and the target cell (row-major pixel index) plus the 16-bit depth dd.
-ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, int cols, const double* seg, const double* madj,
-                        const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd) {
-  double x, y, z;
-  uvd2xyz(u, v, d, c, x, y, z);
-  double q0 = ((seg[0] * x + seg[1] * y) + seg[2] * z) + seg[3];
-  double q1 = ((seg[4] * x + seg[5] * y) + seg[6] * z) + seg[7];
-  double q2 = ((seg[8] * x + seg[9] * y) + seg[10] * z) + seg[11];
+ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, const double* seg,
+                        const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd) {
+  float pt[3];
+  cube_coords(u, v, d, c, ci, seg, pt);
   // ControlGrid::GetCoordinate, ControlGrid.h:44-81 (float32)
-  float a0 = (float)q0 / grid_ul, a1 = (float)q1 / grid_ul, a2 = (float)q2 / grid_ul;
+  float a0 = pt[0] / grid_ul, a1 = pt[1] / grid_ul, a2 = pt[2] / grid_ul;
   float f0 = floorf(a0), f1 = floorf(a1), f2 = floorf(a2);
   float fres = (float)res;
   if (!(f0 >= 0.0f && f0 < fres && f1 >= 0.0f && f1 < fres && f2 >= 0.0f && f2 < fres)) return false;
@@ -154,8 +236,9 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, int cols, con
   double e2 = ((madj[8] * pa + madj[9] * pb) + madj[10] * pc) + madj[11];
   // TSDFVolume::XYZ2UVD, TSDFVolume.h:51-60 (bounds are the literal 640 x 480)
   if (!(e2 > 0.0)) return false;
-  double uu = floor((e0 * (double)c.fx / e2 + (double)c.cx) + 0.5);
-  double vv = floor((e1 * (double)c.fy / e2 + (double)c.cy) + 0.5);
+  const double re = fast_rcp64(e2);
+  double uu = round_pixel(e0, (double)c.fx, e2, re, (double)c.cx);
+  double vv = round_pixel(e1, (double)c.fy, e2, re, (double)c.cy);
   if (!(uu >= 0.0 && uu < 640.0 && vv >= 0.0 && vv < 480.0)) return false;
   double dz = floor(e2 * 1000.0 + 0.5);
   // static_cast<unsigned short>( int ): modular.  Depths whose rounding overflows int32 are

@@ -14,7 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
-struct HcVolume { Camera cam; int cols, rows; std::map<int, HcUnit> units; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -23,6 +23,7 @@ extern "C" {
 void* hc_create(int cols, int rows, const float* cam6) {
   HcVolume* v = new HcVolume();
   v->cam = Camera{cam6[0], cam6[1], cam6[2], cam6[3], cam6[4], cam6[5]};
+  v->cami.inv_fx = 1.0 / (double)v->cam.fx; v->cami.inv_fy = 1.0 / (double)v->cam.fy;
   v->cols = cols; v->rows = rows;
   return v;
 }
@@ -44,7 +45,7 @@ void hc_reproject(void* h, uint16_t* depth, const float* ctr, int res, float len
   for (int p = 0; p < n; p++) {
     if (src[p] == 0) continue;
     int cell; uint16_t dd;
-    if (!reproject_px(p % v->cols, p / v->cols, src[p], v->cam, v->cols, seg, madj, ctr, res, grid_ul, cell, dd)) continue;
+    if (!reproject_px(p % v->cols, p / v->cols, src[p], v->cam, v->cami, v->cols, seg, madj, ctr, res, grid_ul, cell, dd)) continue;
     if (depth[cell] == 0 || depth[cell] > dd) depth[cell] = dd;
   }
 }
@@ -65,7 +66,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
       uint16_t d = depth[(size_t)f * px + p];
       scaled[f][p] = scale_depth_px(d, scale_lambda(p % v->cols, p / v->cols, v->cam), v->cam.integration_trunc);
       if (d == 0) continue;
-      int key = touch_key(p % v->cols, p / v->cols, d, v->cam, Tf);
+      int key = touch_key(p % v->cols, p / v->cols, d, v->cam, v->cami, Tf);
       if (key < 0) return -1;
       HcUnit& u = v->units[key];
       if (u.sdf.empty()) { u.sdf.assign(kUnitVox, 0.f); u.w.assign(kUnitVox, 0.f); }
