@@ -78,6 +78,64 @@ def cpu_baseline(sc, depth_host, n_sample):
             "sample": "first %d frames of the same stream through oracle/tsdf_oracle.c (oracle/_ref not present)" % n_sample}
 
 
+def icp_section(n_pairs, device):
+    """configs[2] shape: fragment pairs of ~250k points each (seeded surfels of the synthetic room, independent
+    samplings, ground truth o perturbation as the initial guess) through the reference flow of one pair:
+    inlier pre-check + ICP (<= 20 iterations) + FindCorrespondence + information matrix.  Secondary metric
+    (pairs/s); the oracle port is timed on 2 pairs for the CPU row (PCL itself is not available)."""
+    import numpy as np
+    from elasticreconstruction_amd import synth
+    from elasticreconstruction_amd.icp import Cloud, count_inliers, find_correspondence, icp_align
+    frag = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
+    clouds, hosts = [], []
+    for i in range(4):
+        x, n = synth.sample_fragment(frag, 600000, seed=500 + i)       # ~250k points survive the cube crop
+        P = synth.perturbation(600 + i, 1.0, 0.01) if i else np.eye(4)
+        Pi = np.linalg.inv(P)
+        x, n = (x @ Pi[:3, :3].T + Pi[:3, 3]).astype(np.float32), (n @ Pi[:3, :3].T).astype(np.float32)
+        clouds.append((Cloud(x, n, 0.03, device), P))
+        hosts.append((x, n))
+    pairs = []
+    for k in range(n_pairs):
+        a, b = k % 4, (k + 1 + (k // 4) % 3) % 4
+        if a == b:
+            b = (b + 1) % 4
+        T = np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(700 + k, 2.0, 0.02)
+        pairs.append((a, b, T))
+
+    def run_pair(a, b, T):
+        tgt, src = clouds[a][0], clouds[b][0]
+        cnt = count_inliers(src, tgt, T, 0.03)
+        fin, iters, conv, _ = icp_align(src, tgt, T.astype(np.float32), 0.03, 20, 1e-6, 0)
+        corr, info = find_correspondence(src, tgt, fin.astype(np.float64), 0.015, 0.8660, True)
+        return cnt, iters, corr.shape[0]
+
+    run_pair(*pairs[0])
+    t0 = time.perf_counter()
+    its, ncor = 0, 0
+    for p in pairs:
+        _, it, nc = run_pair(*p)
+        its += it
+        ncor += nc
+    dt = time.perf_counter() - t0
+    npts = sum(len(c[0]) for c in clouds) / 4.0
+    res = {"pairs_per_s": n_pairs / dt, "pairs": n_pairs, "points_per_fragment": npts, "mean_icp_iterations": its / n_pairs,
+           "mean_correspondences": ncor / n_pairs, "nn_queries_per_s": npts * (its + 2 * n_pairs) / dt}
+    try:
+        from oracle.pyoracle import IcpOracle
+        oc = [IcpOracle(x, n, 0.03) for x, n in hosts]
+        t0 = time.perf_counter()
+        for a, b, T in pairs[:2]:
+            oc[b].count_inliers(oc[a], T, 0.03)
+            fin, _, _, _ = oc[b].align(oc[a], T.astype(np.float32))
+            oc[b].find_correspondence(oc[a], fin.astype(np.float64), 0.015, 0.8660, True)
+        res["cpu_port_pairs_per_s"] = 2 / (time.perf_counter() - t0)
+        res["cpu_port_note"] = "oracle/icp_oracle.cpp (PCL 1.7 restatement, OpenMP NN over %d threads); PCL itself is absent" % (os.cpu_count() or 1)
+    except Exception as ex:                                            # the checker is optional for the bench
+        res["cpu_port_note"] = "oracle not available: %s" % ex
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +144,8 @@ def main():
     ap.add_argument("--interval", type=int, default=50, help="frames per step (= frames per fragment / control grid)")
     ap.add_argument("--no-warp", action="store_true", help="rigid --ref_traj style run (no control grid)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames timed on the CPU reference (0 = skip)")
+    ap.add_argument("--icp-pairs", type=int, default=0,
+                    help="also time N fragment pairs through Registration + FindCorrespondence (configs[2] shape) and add an 'icp' object")
     args = ap.parse_args()
 
     import numpy as np
@@ -208,7 +268,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("k_integrate_hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get("k_integrate_hbm_bytes_per_launch")   # measured on a 50-frame launch
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -223,6 +283,8 @@ def main():
             ns = min(n_frames, max(I, (args.cpu_sample // I) * I))
             host = synth.to_numpy_u16(depth[:ns])
             out["cpu_baseline"] = cpu_baseline(sc, host, ns)
+        if args.icp_pairs > 0 and world == 1:
+            out["icp"] = icp_section(args.icp_pairs, local)
         print(json.dumps(out), flush=True)
     vol.close()
     if world > 1:
