@@ -88,30 +88,36 @@ __global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_fr
                                     const int* __restrict__ grid_index, const float* __restrict__ ctr, int res,
                                     float grid_ul, int floats_per_grid, uint32_t* __restrict__ zbuf,
                                     uint32_t* __restrict__ lastzero, int* __restrict__ counters, int replay) {
+  // 64 x 4 pixel tiles per 256-thread workgroup, frame = blockIdx.z: no integer divisions for the indices.
+  // A workgroup strides over tiles so the (normally idle) replay pass can be launched with a small grid.
   const int pixels = cols * rows;
-  const long total = (long)n_frames * pixels;
   if (replay && counters[C_ZERO_WRITE] == 0) return;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-    const int f = (int)(t / pixels);
-    const int p = (int)(t - (long)f * pixels);
-    const uint16_t d = depth[t];
-    if (d == 0) continue;                                             // UVD2XYZ false
-    int cell;
-    uint16_t dd;
-    if (!reproject_px(p % cols, p / cols, d, cam, cami, cols, seg12 + f * 12, madj12 + f * 12,
-                      ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
-      continue;
-    const size_t o = (size_t)f * pixels + cell;
-    if (!replay) {
-      if (dd != 0) {
-        atomicMin(&zbuf[o], (uint32_t)dd);
+  const int f = blockIdx.z;
+  for (int ty = blockIdx.y; ty * 4 < rows; ty += gridDim.y) {
+    for (int tx = blockIdx.x; tx * 64 < cols; tx += gridDim.x) {
+      const int u = tx * 64 + (threadIdx.x & 63);
+      const int v = ty * 4 + (threadIdx.x >> 6);
+      if (u >= cols || v >= rows) continue;
+      const int p = v * cols + u;
+      const uint16_t d = depth[(size_t)f * pixels + p];
+      if (d == 0) continue;                                             // UVD2XYZ false
+      int cell;
+      uint16_t dd;
+      if (!reproject_px(u, v, d, cam, cami, cols, seg12 + f * 12, madj12 + f * 12,
+                        ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
+        continue;
+      const size_t o = (size_t)f * pixels + cell;
+      if (!replay) {
+        if (dd != 0) {
+          atomicMin(&zbuf[o], (uint32_t)dd);
+        } else {
+          atomicMax(&lastzero[o], (uint32_t)p + 1u);
+          atomicOr(&counters[C_ZERO_WRITE], 1);
+        }
       } else {
-        atomicMax(&lastzero[o], (uint32_t)p + 1u);
-        atomicOr(&counters[C_ZERO_WRITE], 1);
+        const uint32_t lz = lastzero[o];
+        if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&zbuf[o], (uint32_t)dd);
       }
-    } else {
-      const uint32_t lz = lastzero[o];
-      if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&zbuf[o], (uint32_t)dd);
     }
   }
 }
@@ -182,9 +188,11 @@ __global__ __launch_bounds__(kTile * kTile) void k_prepare(
     const uint16_t* __restrict__ depth, const uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
-    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters) {
+    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters,
+    float* __restrict__ tile_max) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
+  __shared__ float s_wmax[kTile * kTile / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
   const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;
@@ -192,6 +200,7 @@ __global__ __launch_bounds__(kTile * kTile) void k_prepare(
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   int key = -1;
+  float sc = 0.0f;
   if (x < cols && y < rows) {
     const int p = y * cols + x;
     const size_t o = (size_t)f * pixels + p;
@@ -202,12 +211,17 @@ __global__ __launch_bounds__(kTile * kTile) void k_prepare(
     } else {
       d = depth[o];
     }
-    scaled[o] = scale_depth_px(d, lambda[p], cam.integration_trunc);
+    sc = scale_depth_px(d, lambda[p], cam.integration_trunc);
+    scaled[o] = sc;
     if (d > 0) {                                                        // TSDFVolume.cpp:47 (no range cut-off)
       key = touch_key(x, y, d, cam, cami, T12 + f * 12);
       if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
     }
   }
+  // max of the scaled depth over the tile (consumed by patch_may_update in k_integrate)
+  float wmax = sc;
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmax;
   const int left = __shfl_up(key, 1);
   const bool leader = key >= 0 && (tx == 0 || left != key);
   if (leader) {
@@ -219,6 +233,11 @@ __global__ __launch_bounds__(kTile * kTile) void k_prepare(
     }
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = 0.0f;
+    for (int w = 0; w < kTile * kTile / 64; w++) m = fmaxf(m, s_wmax[w]);
+    tile_max[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
+  }
   const int n = min(s_n, kTileKeys);
   if ((int)threadIdx.x < n) {
     const int k = s_keys[threadIdx.x];
@@ -284,7 +303,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 __global__ __launch_bounds__(kBlock) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, const Plan* __restrict__ plan,
-    const FrameXform* __restrict__ frames, const float* __restrict__ scaled, Camera cam, int cols, int rows) {
+    const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
+    int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
@@ -310,6 +330,15 @@ __global__ __launch_bounds__(kBlock) void k_integrate(
       W[r] = v.y;
       W0[r] = v.y;
       g1[r] = grid_coord(j0 + r, ys);
+    }
+    // Exact culling: lane f tests frame f of the batch against this wave's 4 x 64 voxel patch; frames that
+    // provably cannot update any voxel of the patch leave the mask (er_tsdf_math.h: patch_may_update).
+    {
+      bool keep = ((m >> lane) & 1ull) != 0ull;
+      if (keep)
+        keep = patch_may_update(g0, g1[0], g1[kRows - 1], grid_coord(0, zs), grid_coord(kUnitRes - 1, zs), frames[lane], cam, cols,
+                                rows, tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y);
+      m = __ballot(keep);
     }
     while (m) {
       const int f = __builtin_ctzll(m);
@@ -473,7 +502,7 @@ struct er_tsdf_s {
   int *ht_key = nullptr, *ht_slot = nullptr, *unit_key = nullptr, *counters = nullptr, *batch = nullptr;
   unsigned long long *ht_mask = nullptr, *stats = nullptr;
   int ht_cap = 0, ht_shift = 0;
-  float *lambda = nullptr, *scaled = nullptr, *ctr = nullptr;
+  float *lambda = nullptr, *scaled = nullptr, *ctr = nullptr, *tile_max = nullptr;
   uint16_t* depth_stage = nullptr;
   uint32_t *zbuf = nullptr, *lastzero = nullptr;
   er::FrameXform* frames = nullptr;
@@ -600,7 +629,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
       if (replay) {
         hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
       }
-      hipLaunchKernelGGL(k_reproject_scatter, dim3(replay ? wide_grid : (int)std::min<long>((total + kBlock - 1) / kBlock, 1 << 20)),
+      hipLaunchKernelGGL(k_reproject_scatter, replay ? dim3(4, 8, n) : dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n),
                          dim3(kBlock), 0, h->stream, depth_dev, n, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12,
                          h->grid_index, h->ctr, warp->resolution, grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
     }
@@ -612,7 +641,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kTile * kTile), 0, h->stream, depth_dev, zsrc, n,
                      h->cols, h->rows, h->cam, h->cami, h->lambda, h->T12, h->scaled, h->ht_key, h->ht_slot, h->ht_mask,
-                     h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch, h->counters);
+                     h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch, h->counters, h->tile_max);
   ER_HIP_TRY(hipGetLastError());
 
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, h->stream, h->batch, h->counters, h->ht_mask, h->plan_entry, h->plan);
@@ -625,7 +654,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipEventRecord(e0, h->stream));
   }
 hipLaunchKernelGGL(k_integrate, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->pool, h->ht_key, h->ht_slot, h->ht_mask,
-                     h->plan_entry, h->plan, h->frames, h->scaled, h->cam, h->cols, h->rows);
+                     h->plan_entry, h->plan, h->frames, h->scaled, h->tile_max, (h->cols + kTile - 1) / kTile,
+                     (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows);
   if (h->profiling) {
     ER_HIP_TRY(hipEventRecord(e1, h->stream));
     h->events.emplace_back(e0, e1);
@@ -702,6 +732,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->madj12, B * 12 * sizeof(double));
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
+  ER_ALLOC(h->tile_max, B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   ER_ALLOC(h->plan_entry, (size_t)cap * sizeof(int));
   ER_ALLOC(h->plan, sizeof(Plan));
 #undef ER_ALLOC
@@ -735,7 +766,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   }
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask, h->unit_key, h->counters, h->stats, h->batch, h->lambda,
                   h->scaled, h->depth_stage, h->zbuf, h->lastzero, h->frames, h->T12, h->seg12, h->madj12,
-                  h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch, h->plan_entry, h->plan};
+                  h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch, h->plan_entry, h->plan, h->tile_max};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -803,7 +834,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   for (int replay = 0; replay < 2; replay++) {
     if (replay)
       hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
-    hipLaunchKernelGGL(k_reproject_scatter, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream,
+    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, 1), dim3(kBlock), 0, h->stream,
                        h->depth_stage, 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution,
                        grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
   }

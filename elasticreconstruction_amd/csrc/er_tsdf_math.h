@@ -155,6 +155,58 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
   return true;
 }
 
+// ---- exact culling of (voxel patch, frame) pairs -------------------------------------------------
+// A wave of k_integrate owns a PATCH of kRows x 64 voxels: an axis-aligned rectangle of the world plane
+// x = g0, spanning [g1lo,g1hi] x [g2lo,g2hi].  41 % of the (row, frame) visits of the straightforward kernel
+// update nothing (outside the frustum, no usable depth under them, or behind the surface by more than the
+// truncation).  This test proves -- conservatively, with margins far above float32 rounding -- that NO voxel
+// of the patch can be updated by a frame, so the frame can be dropped from the patch's mask without
+// changing a single voxel:
+//   * all four corners behind the camera plane                  -> every voxel has t2 <= 0 (TSDFVolume.cpp:77)
+//   * the pixel bounding box of the corners misses the image    -> the :80 range test fails everywhere
+//     (a planar convex patch in front of the camera projects inside the convex hull of its corners)
+//   * M = max of the scaled depth over the 32x32-pixel tiles under the box is <= 0.001 -> :82 fails everywhere
+//   * M - (distance from the camera centre to the rectangle) < -trunc - 1e-4          -> :87 fails everywhere
+// tile_max: per frame, tiles_x * tiles_y floats written by k_prepare.  Returns false only if provably dead.
+ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
+                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y) {
+  float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
+  for (int a = 0; a < 2; a++) {
+    const float g1 = a ? g1hi : g1lo;
+    for (int b = 0; b < 2; b++) {
+      const float g2 = b ? g2hi : g2lo;
+      const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
+      const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
+      const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
+      const float u = t0 * c.fx / t2 + c.cx, v = t1 * c.fy / t2 + c.cy;
+      t2min = fminf(t2min, t2);
+      t2max = fmaxf(t2max, t2);
+      umin = fminf(umin, u); umax = fmaxf(umax, u);
+      vmin = fminf(vmin, v); vmax = fmaxf(vmax, v);
+    }
+  }
+  if (t2max < -1e-3f) return false;                       // whole patch behind the camera
+  float dmax_tile = 3.0e38f;                              // upper bound of the scaled depth any voxel can see
+  if (t2min > 0.02f) {                                    // hull argument needs the patch clear of the camera plane
+    if (umax < -1.5f || umin > (float)cols + 0.5f || vmax < -1.5f || vmin > (float)rows + 0.5f) return false;
+    const int x0 = (int)fmaxf(umin - 1.5f, 0.0f) >> 5, x1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> 5;
+    const int y0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> 5, y1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> 5;
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) <= 48) {
+      float m = 0.0f;
+      for (int ty = y0; ty <= y1; ty++)
+        for (int tx = x0; tx <= x1; tx++) m = fmaxf(m, tile_max[ty * tiles_x + tx]);
+      dmax_tile = m;
+    }
+  }
+  if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
+  const float dx = g0 - f.tx;
+  const float dy = f.ty < g1lo ? g1lo - f.ty : (f.ty > g1hi ? f.ty - g1hi : 0.0f);
+  const float dz = f.tz < g2lo ? g2lo - f.tz : (f.tz > g2hi ? f.tz - g2hi : 0.0f);
+  const float dmin = sqrtf((dx * dx + dy * dy) + dz * dz);
+  if (dmax_tile - dmin < -(float)kTsdfTrunc - 1e-4f) return false;   // every voxel is behind the surface by more than trunc
+  return true;
+}
+
 // ---- A6/A7: one source pixel of Reproject, IntegrateApp.cpp:250-259 ------------------------------
 // float64 reciprocal to ~1 ulp without the IEEE division sequence (fast paths only).
 ER_HD double fast_rcp64(double x) {

@@ -14,7 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
-struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -73,6 +73,15 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
       if (u.frames.empty() || u.frames.back() != f) u.frames.push_back(f);
     }
   }
+  // tile maxima of the scaled depth, as k_prepare writes them (32 x 32 pixel tiles)
+  const int tiles_x = (v->cols + 31) / 32, tiles_y = (v->rows + 31) / 32;
+  std::vector<std::vector<float>> tile_max(n, std::vector<float>((size_t)tiles_x * tiles_y, 0.f));
+  for (int f = 0; f < n; f++)
+    for (int p = 0; p < px; p++) {
+      float& m = tile_max[f][(size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32];
+      m = std::max(m, scaled[f][p]);
+    }
+  long culled = 0, kept = 0;
   for (auto& kv : v->units) {
     const int key = kv.first;
     HcUnit& u = kv.second;
@@ -80,18 +89,35 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     for (int i = 0; i < 64; i++)
-      for (int j = 0; j < 64; j++)
-        for (int k = 0; k < 64; k++) {
-          const int l = (i * 64 + j) * 64 + k;
-          float S = u.sdf[l], W = u.w[l];
-          for (int f : u.frames)
-            voxel_update(S, W, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), fx[f], v->cam, v->cols, v->rows, scaled[f].data());
-          u.sdf[l] = S; u.w[l] = W;
+      for (int j0 = 0; j0 < 64; j0 += 4) {
+        // the same (4 rows x 64 voxels, frame) culling k_integrate applies before its frame loop
+        std::vector<int> frames;
+        for (int f : u.frames) {
+          if (patch_may_update(grid_coord(i, xs), grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs),
+                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y)) {
+            frames.push_back(f);
+            kept++;
+          } else {
+            culled++;
+          }
         }
+        for (int j = j0; j < j0 + 4; j++)
+          for (int k = 0; k < 64; k++) {
+            const int l = (i * 64 + j) * 64 + k;
+            float S = u.sdf[l], W = u.w[l];
+            for (int f : frames)
+              voxel_update(S, W, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), fx[f], v->cam, v->cols, v->rows, scaled[f].data());
+            u.sdf[l] = S; u.w[l] = W;
+          }
+      }
   }
+  v->culled += culled;
+  v->kept += kept;
   return 0;
 }
 
+long hc_culled(void* h) { return static_cast<HcVolume*>(h)->culled; }
+long hc_kept(void* h) { return static_cast<HcVolume*>(h)->kept; }
 int hc_unit_count(void* h) { return (int)static_cast<HcVolume*>(h)->units.size(); }
 void hc_unit_keys(void* h, int* keys) { int n = 0; for (auto& kv : static_cast<HcVolume*>(h)->units) keys[n++] = kv.first; }
 int hc_read_unit(void* h, int key, float* sdf, float* w) {

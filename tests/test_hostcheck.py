@@ -34,6 +34,10 @@ def hc():
     L.hc_reproject.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp, vp]
     L.hc_integrate_frames.argtypes = [vp, C.c_int, vp, vp, vp]
     L.hc_unit_count.argtypes = [vp]
+    L.hc_culled.restype = C.c_long
+    L.hc_culled.argtypes = [vp]
+    L.hc_kept.restype = C.c_long
+    L.hc_kept.argtypes = [vp]
     L.hc_unit_keys.argtypes = [vp, vp]
     L.hc_read_unit.argtypes = [vp, C.c_int, vp, vp]
     return L
@@ -85,6 +89,9 @@ def test_device_math_rigid_matches_golden(hc):
     v.integrate(depth[4:], poses[4:])
     d = helpers.volume_digest(v)
     assert d["keys"] == g["rigid"]["keys"] and d["sha256"] == g["rigid"]["sha256"]
+    # the exact (patch, frame) culling must both fire and change nothing
+    culled, kept = hc.hc_culled(v.h), hc.hc_kept(v.h)
+    assert culled > 0.15 * (culled + kept), "patch culling removed only %d of %d patch-frames" % (culled, culled + kept)
 
 
 def test_device_math_warp_matches_golden(hc):
