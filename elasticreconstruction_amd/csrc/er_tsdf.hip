@@ -103,7 +103,7 @@ __global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_fr
       if (d == 0) continue;                                             // UVD2XYZ false
       int cell;
       uint16_t dd;
-      if (!reproject_px(u, v, d, cam, cami, cols, seg12 + f * 12, madj12 + f * 12,
+      if (!reproject_px(u, v, d, cam, cami, cols, seg12 + f * 16, madj12 + f * 12,
                         ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
         continue;
       const size_t o = (size_t)f * pixels + cell;
@@ -138,10 +138,11 @@ __global__ void k_reproject_fix_rearm(uint32_t* __restrict__ lastzero, long tota
 }
 __global__ void k_reproject_fix_flag(int* __restrict__ counters) { counters[C_ZERO_WRITE] = 0; }
 
-__global__ void k_zbuf_to_depth(const uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
+__global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t z = zbuf[t];
+  zbuf[t] = kZEmpty;                                                    // leave the z-buffer re-armed
   depth[t] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
 }
 
@@ -184,58 +185,78 @@ __device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __rest
   batch[atomicAdd(&counters[C_NBATCH], 1)] = e;
 }
 
-__global__ __launch_bounds__(kTile * kTile) void k_prepare(
-    const uint16_t* __restrict__ depth, const uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
+constexpr int kPrepThreads = 256;                       // 32 x 8 threads, 4 pixel rows each
+constexpr int kPrepPix = kTile * kTile / kPrepThreads;  // pixels per thread
+
+__global__ __launch_bounds__(kPrepThreads) void k_prepare(
+    const uint16_t* __restrict__ depth, uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ counters,
     float* __restrict__ tile_max) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
-  __shared__ float s_wmax[kTile * kTile / 64];
+  __shared__ float s_wmax[kPrepThreads / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
-  const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;
-  const int x = blockIdx.x * kTile + tx, y = blockIdx.y * kTile + ty;
+  const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;      // ty in [0, 8)
+  const int x = blockIdx.x * kTile + tx;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  int key = -1;
-  float sc = 0.0f;
-  if (x < cols && y < rows) {
-    const int p = y * cols + x;
-    const size_t o = (size_t)f * pixels + p;
-    uint16_t d;
-    if (zbuf) {
-      const uint32_t z = zbuf[o];
-      d = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
-    } else {
-      d = depth[o];
+  // Each thread owns 4 pixels of its column (rows ty, ty+8, ty+16, ty+24 of the tile): the four loads are
+  // issued together, which is what hides the HBM/L2 latency here (the kernel is latency-, not VALU-bound).
+  uint16_t d[kPrepPix];
+  float lam[kPrepPix];
+#pragma unroll
+  for (int q = 0; q < kPrepPix; q++) {
+    const int y = blockIdx.y * kTile + ty + q * (kTile / kPrepPix);
+    d[q] = 0;
+    lam[q] = 0.0f;
+    if (x < cols && y < rows) {
+      const int p = y * cols + x;
+      const size_t o = (size_t)f * pixels + p;
+      if (zbuf) {
+        const uint32_t z = zbuf[o];
+        zbuf[o] = kZEmpty;                                              // re-arm the z-buffer for the next batch
+        d[q] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
+      } else {
+        d[q] = depth[o];
+      }
+      lam[q] = lambda[p];
     }
-    sc = scale_depth_px(d, lambda[p], cam.integration_trunc);
-    scaled[o] = sc;
-    if (d > 0) {                                                        // TSDFVolume.cpp:47 (no range cut-off)
-      key = touch_key(x, y, d, cam, cami, T12 + f * 12);
-      if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
+  }
+  float wmax = 0.0f;
+#pragma unroll
+  for (int q = 0; q < kPrepPix; q++) {
+    const int y = blockIdx.y * kTile + ty + q * (kTile / kPrepPix);
+    int key = -1;
+    if (x < cols && y < rows) {
+      const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
+      scaled[(size_t)f * pixels + y * cols + x] = sc;
+      wmax = fmaxf(wmax, sc);
+      if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
+        key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
+        if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
+      }
+    }
+    const int left = __shfl_up(key, 1);
+    const bool leader = key >= 0 && (tx == 0 || left != key);
+    if (leader) {
+      const int slot = atomicAdd(&s_n, 1);
+      if (slot < kTileKeys) {
+        s_keys[slot] = key;
+      } else {                                                          // list full (pathological tile): go direct
+        touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, counters);
+      }
     }
   }
   // max of the scaled depth over the tile (consumed by patch_may_update in k_integrate)
-  float wmax = sc;
   for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
   if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmax;
-  const int left = __shfl_up(key, 1);
-  const bool leader = key >= 0 && (tx == 0 || left != key);
-  if (leader) {
-    const int slot = atomicAdd(&s_n, 1);
-    if (slot < kTileKeys) {
-      s_keys[slot] = key;
-    } else {                                                            // list full (pathological tile): go direct
-      touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, counters);
-    }
-  }
   __syncthreads();
   if (threadIdx.x == 0) {
     float m = 0.0f;
-    for (int w = 0; w < kTile * kTile / 64; w++) m = fmaxf(m, s_wmax[w]);
+    for (int w = 0; w < kPrepThreads / 64; w++) m = fmaxf(m, s_wmax[w]);
     tile_max[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
   }
   const int n = min(s_n, kTileKeys);
@@ -607,14 +628,16 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 
   const long total = (long)n * h->pixels;
   const int wide_grid = h->n_cu * 8;
-  const uint32_t* zsrc = nullptr;
+  uint32_t* zsrc = nullptr;
   if (warp) {
-    std::vector<double> s12((size_t)n * 12), m12((size_t)n * 12);
-    for (int f = 0; f < n; f++)
+    std::vector<double> s12((size_t)n * 16, 0.0), m12((size_t)n * 12);
+    for (int f = 0; f < n; f++) {
       for (int q = 0; q < 12; q++) {
-        s12[(size_t)f * 12 + q] = warp->seg[(size_t)(frame0 + f) * 16 + q];
+        s12[(size_t)f * 16 + q] = warp->seg[(size_t)(frame0 + f) * 16 + q];
         m12[(size_t)f * 12 + q] = warp->madj[(size_t)(frame0 + f) * 16 + q];
       }
+      er::cube_coord_deltas(&s12[(size_t)f * 16], h->cam, h->cols, h->rows, &s12[(size_t)f * 16 + 12]);
+    }
     for (int f = 0; f < n; f++) {
       int g = warp->grid_index[frame0 + f];
       if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
@@ -622,7 +645,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipMemcpyAsync(h->seg12, s12.data(), s12.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     ER_HIP_TRY(hipMemcpyAsync(h->madj12, m12.data(), m12.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     ER_HIP_TRY(hipMemcpyAsync(h->grid_index, warp->grid_index + frame0, (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ER_HIP_TRY(hipMemsetAsync(h->zbuf, 0xFF, (size_t)total * sizeof(uint32_t), h->stream));
+    // zbuf is all-empty here: filled at create, re-armed by its consumer (k_prepare / k_zbuf_to_depth)
     const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     for (int replay = 0; replay < 2; replay++) {
@@ -639,7 +662,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     zsrc = h->zbuf;
   }
 
-  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kTile * kTile), 0, h->stream, depth_dev, zsrc, n,
+  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, h->stream, depth_dev, zsrc, n,
                      h->cols, h->rows, h->cam, h->cami, h->lambda, h->T12, h->scaled, h->ht_key, h->ht_slot, h->ht_mask,
                      h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch, h->counters, h->tile_max);
   ER_HIP_TRY(hipGetLastError());
@@ -728,7 +751,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->lastzero, B * px * sizeof(uint32_t));
   ER_ALLOC(h->frames, B * sizeof(er::FrameXform));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
-  ER_ALLOC(h->seg12, B * 12 * sizeof(double));
+  ER_ALLOC(h->seg12, B * 16 * sizeof(double));
   ER_ALLOC(h->madj12, B * 12 * sizeof(double));
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
@@ -743,7 +766,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
             hipMemsetAsync(h->ht_mask, 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess &&
             hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s) == hipSuccess &&
             hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), s) == hipSuccess &&
-            hipMemsetAsync(h->lastzero, 0, B * px * sizeof(uint32_t), s) == hipSuccess;
+            hipMemsetAsync(h->lastzero, 0, B * px * sizeof(uint32_t), s) == hipSuccess &&
+            hipMemsetAsync(h->zbuf, 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(k_lambda, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->lambda, cols, rows, h->cam);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
@@ -824,10 +848,12 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   if (upload_ctr(h, ctr_host, (size_t)verts * 3)) return 1;
   const int gi = 0;
   ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
-  ER_HIP_TRY(hipMemcpyAsync(h->seg12, seg, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  double seg16[16] = {0};
+  memcpy(seg16, seg, 12 * sizeof(double));
+  er::cube_coord_deltas(seg16, h->cam, h->cols, h->rows, seg16 + 12);
+  ER_HIP_TRY(hipMemcpyAsync(h->seg12, seg16, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   ER_HIP_TRY(hipMemcpyAsync(h->madj12, madj, 12 * sizeof(double), hipMemcpyHostToDevice, h->stream));
   ER_HIP_TRY(hipMemcpyAsync(h->grid_index, &gi, sizeof(int), hipMemcpyHostToDevice, h->stream));
-  ER_HIP_TRY(hipMemsetAsync(h->zbuf, 0xFF, px * sizeof(uint32_t), h->stream));
   const float grid_ul = length / (float)resolution;
   const long total = (long)px;
   const int wide_grid = h->n_cu * 8;

@@ -222,7 +222,8 @@ ER_HD double fast_rcp64(double x) {
 
 // Stage 1: the float32 fragment-cube coordinates Vector3f( seg * UVD2XYZ(u,v,d) ) (IntegrateApp.cpp:250-255).
 // Only the float32 ROUNDING of each float64 coordinate is observable.  The division-free value q' differs
-// from the reference's float64 value by < delta = 4e-15 * (sum of the magnitudes of the four terms); when
+// from the reference's float64 value by < delta_r = 4e-15 * (|s_r0| Xmax + |s_r1| Ymax + |s_r2| Zmax + |s_r3|),
+// a per-frame bound the host computes from the camera and the 16-bit depth range (seg[12..14]); when
 // q' - delta and q' + delta round to the same float, so does the reference value (rounding is monotonic).
 // Otherwise (a few pixels per million) the exact expression with its three divisions is evaluated.
 ER_HD void cube_coords(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, const double* seg, float out[3]) {
@@ -231,17 +232,25 @@ ER_HD void cube_coords(int u, int v, uint16_t d, const Camera& c, const CameraIn
   const double y = (double)((float)v - c.cy) * z * ci.inv_fy;
   bool safe = true;
   for (int r = 0; r < 3; r++) {
-    const double t0 = seg[4 * r] * x, t1 = seg[4 * r + 1] * y, t2 = seg[4 * r + 2] * z, t3 = seg[4 * r + 3];
-    const double q = ((t0 + t1) + t2) + t3;
-    const double delta = (((fabs(t0) + fabs(t1)) + fabs(t2)) + fabs(t3)) * 4e-15;
+    const double q = ((seg[4 * r] * x + seg[4 * r + 1] * y) + seg[4 * r + 2] * z) + seg[4 * r + 3];
+    const double delta = seg[12 + r];
     const float f = (float)q;
-    safe = safe && ((float)(q - delta) == f) && ((float)(q + delta) == f);
+    safe = safe & ((float)(q - delta) == f) & ((float)(q + delta) == f);
     out[r] = f;
   }
   if (safe) return;
   double xe, ye, ze;
   uvd2xyz(u, v, d, c, xe, ye, ze);
   for (int r = 0; r < 3; r++) out[r] = (float)(((seg[4 * r] * xe + seg[4 * r + 1] * ye) + seg[4 * r + 2] * ze) + seg[4 * r + 3]);
+}
+
+// Host side of the bound above (cols x rows image, depth <= 65535 mm).
+inline void cube_coord_deltas(const double* seg, const Camera& c, int cols, int rows, double out3[3]) {
+  const double zmax = 65.535;
+  const double xa = fmax(fabs(0.0 - (double)c.cx), fabs((double)(cols - 1) - (double)c.cx)) * zmax / (double)c.fx;
+  const double ya = fmax(fabs(0.0 - (double)c.cy), fabs((double)(rows - 1) - (double)c.cy)) * zmax / (double)c.fy;
+  for (int r = 0; r < 3; r++)
+    out3[r] = 4e-15 * (fabs(seg[4 * r]) * xa + fabs(seg[4 * r + 1]) * ya + fabs(seg[4 * r + 2]) * zmax + fabs(seg[4 * r + 3]));
 }
 
 // Stage 3: TSDFVolume::round( x * f / z + c ) of XYZ2UVD (TSDFVolume.h:53-54) as an integer-valued double.
@@ -255,7 +264,8 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
   return floor((e * f / e2 + cc) + 0.5);
 }
 
-// seg, madj: rows 0..2 of the float64 4x4s (12 doubles each).  ctr: one grid, (res+1)^3 * 3 floats.
+// seg: rows 0..2 of the float64 4x4 followed by the three rounding bounds of cube_coords (15 doubles used, stride 16);
+// madj: rows 0..2 (12 doubles).  ctr: one grid, (res+1)^3 * 3 floats.
 // On success returns true and the target cell (row-major pixel index) plus the 16-bit depth dd.
 ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, const double* seg,
                         const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd) {

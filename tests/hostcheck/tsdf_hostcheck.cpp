@@ -42,6 +42,10 @@ void hc_reproject(void* h, uint16_t* depth, const float* ctr, int res, float len
   std::vector<uint16_t> src(depth, depth + n);
   std::fill(depth, depth + n, (uint16_t)0);
   const float grid_ul = length / (float)res;
+  double seg16[16] = {0};
+  memcpy(seg16, seg, 12 * sizeof(double));
+  cube_coord_deltas(seg16, v->cam, v->cols, v->rows, seg16 + 12);
+  seg = seg16;
   for (int p = 0; p < n; p++) {
     if (src[p] == 0) continue;
     int cell; uint16_t dd;
