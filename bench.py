@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--interval", type=int, default=50, help="frames per step (= frames per fragment / control grid)")
     ap.add_argument("--no-warp", action="store_true", help="rigid --ref_traj style run (no control grid)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames timed on the CPU reference (0 = skip)")
+    ap.add_argument("--force-merge", action="store_true",
+                    help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
     ap.add_argument("--icp-pairs", type=int, default=0,
                     help="also time N fragment pairs through Registration + FindCorrespondence (configs[2] shape) and add an 'icp' object")
     args = ap.parse_args()
@@ -162,9 +164,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_merge
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     K, W, I = args.steps, args.warmup, args.interval
     n_frames = K * I
@@ -206,6 +211,8 @@ def main():
     scratch = TSDFVolume(max_units=max_units, device=local)
     scratch.set_stream(stream.cuda_stream)
     run_steps(scratch, min(W, K))
+    if use_dist:
+        merge(scratch)            # also warms RCCL (communicator set-up, allocator) outside the timed region
     scratch.synchronize()
     scratch.close()
     del scratch
@@ -214,24 +221,24 @@ def main():
     vol.set_stream(stream.cuda_stream)
     vol.set_profiling(True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(vol, K)
-    n_union = merge(vol) if world > 1 else 0
+    n_union = merge(vol) if use_dist else 0
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     prof = vol.get_profile()
-    sum_w = vol.sum_weight() if world == 1 else None
+    sum_w = vol.sum_weight() if world == 1 else None      # after a real merge every rank holds the sum over ranks
     n_units = vol.unit_count()
 
     if rank == 0:
@@ -256,7 +263,7 @@ def main():
                        "parallelism": "frame-block shard x%d + one all-reduce" % world if world > 1 else "single GPU",
                        "inputs": "resident in HBM before the timed region"},
         }
-        if world > 1:
+        if use_dist:
             out["config"]["merge_union_units"] = n_union
         launches = max(prof["launches"], 1)
         ms_launch = prof["integrate_ms"] / launches
@@ -287,7 +294,7 @@ def main():
             out["icp"] = icp_section(args.icp_pairs, local)
         print(json.dumps(out), flush=True)
     vol.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -28,21 +28,20 @@ def pair_shard(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def union_keys(local_keys, dist, device):
-    """All-gather of the per-rank touched unit keys -> sorted union (int32 numpy)."""
+def union_keys(local_keys, dist, device, max_keys=4096):
+    """ONE fixed-size all-gather of the per-rank touched unit keys (padded with -1) -> sorted union (int32 numpy)."""
     import torch
     world = dist.get_world_size()
     keys = np.ascontiguousarray(local_keys, np.int32)
-    cnt = torch.tensor([keys.size], device=device, dtype=torch.int64)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt)
-    mx = max(1, max(int(c.item()) for c in cnts))
-    pad = torch.full((mx,), -1, device=device, dtype=torch.int32)
+    while max_keys < keys.size:
+        max_keys *= 2
+    pad = torch.full((max_keys,), -1, dtype=torch.int32)
     if keys.size:
-        pad[:keys.size] = torch.from_numpy(keys).to(device)
+        pad[:keys.size] = torch.from_numpy(keys)
+    pad = pad.to(device)
     allk = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(allk, pad)
-    u = torch.unique(torch.cat(allk))
+    dist.all_gather(allk, pad)                               # (list form: also supported by gloo in the CPU tests)
+    u = torch.unique(torch.stack(allk))
     return u[u >= 0].to(torch.int32).cpu().numpy()
 
 
