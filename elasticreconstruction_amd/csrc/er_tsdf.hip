@@ -103,7 +103,7 @@ __global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_fr
       if (d == 0) continue;                                             // UVD2XYZ false
       int cell;
       uint16_t dd;
-      if (!reproject_px(u, v, d, cam, cami, cols, seg12 + f * 16, madj12 + f * 12,
+      if (!reproject_px(u, v, d, cam, cami, cols, rows, seg12 + f * 16, madj12 + f * 12,
                         ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
         continue;
       const size_t o = (size_t)f * pixels + cell;

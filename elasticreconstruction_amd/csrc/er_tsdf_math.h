@@ -268,7 +268,7 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
 // seg: rows 0..2 of the float64 4x4 followed by the three rounding bounds of cube_coords (15 doubles used, stride 16);
 // madj: rows 0..2 (12 doubles).  ctr: one grid, (res+1)^3 * 3 floats.
 // On success returns true and the target cell (row-major pixel index) plus the 16-bit depth dd.
-ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, const double* seg,
+ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, int rows, const double* seg,
                         const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd) {
   float pt[3];
   cube_coords(u, v, d, c, ci, seg, pt);
@@ -297,12 +297,16 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   double e0 = ((madj[0] * pa + madj[1] * pb) + madj[2] * pc) + madj[3];
   double e1 = ((madj[4] * pa + madj[5] * pb) + madj[6] * pc) + madj[7];
   double e2 = ((madj[8] * pa + madj[9] * pb) + madj[10] * pc) + madj[11];
-  // TSDFVolume::XYZ2UVD, TSDFVolume.h:51-60 (bounds are the literal 640 x 480)
+  // TSDFVolume::XYZ2UVD, TSDFVolume.h:51-60.  The reference's bounds are the literal 640 x 480 whatever the
+  // image size; for images smaller than that its write at vv * cols_ + uu would run past the buffer
+  // (undefined behaviour), so the bounds are min(640, cols) x min(480, rows) here -- identical for the
+  // 640 x 480 streams the reference supports, and for larger images the 640 x 480 clip is preserved.
   if (!(e2 > 0.0)) return false;
   const double re = fast_rcp64(e2);
   double uu = round_pixel(e0, (double)c.fx, e2, re, (double)c.cx);
   double vv = round_pixel(e1, (double)c.fy, e2, re, (double)c.cy);
-  if (!(uu >= 0.0 && uu < 640.0 && vv >= 0.0 && vv < 480.0)) return false;
+  const double ulim = cols < 640 ? (double)cols : 640.0, vlim = rows < 480 ? (double)rows : 480.0;
+  if (!(uu >= 0.0 && uu < ulim && vv >= 0.0 && vv < vlim)) return false;
   double dz = floor(e2 * 1000.0 + 0.5);
   // static_cast<unsigned short>( int ): modular.  Depths whose rounding overflows int32 are
   // undefined behaviour in the reference (> 2147 km); they are dropped here.

@@ -49,7 +49,7 @@ void hc_reproject(void* h, uint16_t* depth, const float* ctr, int res, float len
   for (int p = 0; p < n; p++) {
     if (src[p] == 0) continue;
     int cell; uint16_t dd;
-    if (!reproject_px(p % v->cols, p / v->cols, src[p], v->cam, v->cami, v->cols, seg, madj, ctr, res, grid_ul, cell, dd)) continue;
+    if (!reproject_px(p % v->cols, p / v->cols, src[p], v->cam, v->cami, v->cols, v->rows, seg, madj, ctr, res, grid_ul, cell, dd)) continue;
     if (depth[cell] == 0 || depth[cell] > dd) depth[cell] = dd;
   }
 }

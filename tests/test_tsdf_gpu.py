@@ -243,3 +243,19 @@ def test_config1_identity_trajectory_properties(gpu):
         assert np.array_equal(w, wo * F)
         assert np.abs(s - so).max() <= 2e-5
     vol.close()
+
+
+def test_non_vga_image_size(gpu):
+    """Generic cols x rows (not multiples of the 32-pixel tiles, smaller than the reference's 640 x 480):
+    rigid integration against the oracle, which takes the image size as a parameter."""
+    cols, rows = 300, 210
+    cam = np.array([250.0, 251.0, 149.5, 104.5, 2.5, 2.5], np.float32)
+    poses = synth.circle_trajectory(3000)[9::650][:3]
+    depth = synth.to_numpy_u16(synth.render_depth(poses, cols=cols, rows=rows, cam=tuple(cam[:4])))
+    vol, ora = TSDFVolume(cols, rows, cam, max_units=256), OracleVolume(cols, rows, cam)
+    assert np.array_equal(vol.ScaleDepth(depth[0]).view(np.uint32), ora.ScaleDepth(depth[0]).view(np.uint32))
+    vol.IntegrateFrames(depth, poses)
+    for i in range(3):
+        ora.Integrate(depth[i], poses[i])
+    assert helpers.assert_volumes_identical(vol, ora, "300x210") > 10
+    vol.close()
