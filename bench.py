@@ -249,7 +249,8 @@ def main():
         dt = float(t.item())
 
     prof = vol.get_profile()
-    sum_w = vol.sum_weight() if world == 1 else None      # after a real merge every rank holds the sum over ranks
+    # unit weights add exactly, so after the merge every rank holds the job-wide number of voxel updates
+    sum_w = vol.sum_weight() / world
     n_units = vol.unit_count()
 
     if rank == 0:
@@ -278,7 +279,7 @@ def main():
             out["config"]["merge_union_units"] = n_union
         launches = max(prof["launches"], 1)
         ms_launch = prof["integrate_ms"] / launches
-        if sum_w is not None and prof["integrate_ms"] > 0:
+        if prof["integrate_ms"] > 0:
             bytes_total = 16.0 * sum_w + FRAME_BYTES_FIXED * n_frames + (2 * FRAME_BYTES_RAW * n_frames if warp_on else 0)
             per_launch = bytes_total / launches
             ach = per_launch / (ms_launch * 1e-3) / 1e9
@@ -293,6 +294,7 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms_launch, "launches": launches,
                                "voxel_updates": sum_w, "unit_visits": prof["unit_visits"],
+                               "note": "rank 0 kernel; voxel updates = job total / ranks" if world > 1 else "",
                                "whole_job_frac": bytes_total / dt / 1e9 / HBM_PEAK_GBS}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
