@@ -57,8 +57,8 @@ typedef struct er_warp {
 int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int device, er_tsdf_t* out);
 int er_tsdf_destroy(er_tsdf_t h);
 
-/* Run all of the handle's work on an existing hipStream_t (e.g. torch's current stream).  NULL = the
- * handle's own stream. */
+/* Run the handle's voxel pass and every other call on an existing hipStream_t (e.g. torch's current stream).
+ * NULL = the handle's own stream.  (The pre-pass always uses an internal auxiliary stream.) */
 int er_tsdf_set_stream(er_tsdf_t h, void* hip_stream);
 int er_tsdf_synchronize(er_tsdf_t h);
 
@@ -77,6 +77,9 @@ int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16
  * Results are identical to n sequential er_tsdf_integrate calls; internally frames are fused
  * ER_MAX_BATCH at a time so each voxel is read and written once per batch.
  * depth: n*rows*cols uint16, host memory if depth_on_device == 0 else device memory (left untouched).
+ * Device depth must be COMPLETE when the call is made (synchronise the stream that produced it): the
+ * per-pixel pre-pass of a batch runs on the handle's auxiliary stream so that it overlaps the voxel pass of
+ * the previous batch, and that stream does not wait for the caller's.
  * T: n*16 host doubles (traj_[frame_id-1]).  warp may be NULL (rigid, --ref_traj). */
 int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int depth_on_device, const double* T,
                              const er_warp* warp);
