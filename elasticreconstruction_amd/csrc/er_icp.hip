@@ -12,12 +12,15 @@
 //                               nearest neighbour inside the radius lies in the 3x3x3 neighbourhood;
 //                               cell id = (z*ny + y)*nx + x, so each (z,y) row is ONE contiguous range
 //   X, match...  per-cloud scratch used when the cloud is the SOURCE of a pair
-// Kernels (one thread per source point; candidates stream from L2 as 16-byte loads):
+// Queries run in the SOURCE cloud's own cell-sorted order (thread t takes sorted[t]), so the lanes of a wave
+// walk the same few target cells together (coalesced / broadcast candidate loads); results are written back
+// by original index.  NN kernels use 8 lanes per source point (each lane scans part of the 9 cell rows, shuffle-min);
+// candidates stream from L2 as 16-byte loads:
 //   k_count_inliers   transform (float64 -> float32) + NN + count           (Registration pre-check)
-//   k_icp_iter        [apply last increment] + NN + point-to-plane rows -> 27+2 float64 sums
-//                     (wave shuffle -> LDS -> one atomicAdd per block and sum)
-//   k_find_corr       transform points+normals + NN + distance/normal tests -> match[], block counts,
-//                     information-matrix sums;  k_scan_blocks + k_compact = stable compaction
+//   k_icp_nn          [apply last increment] + NN -> nn[], d2[];  k_icp_accum: point-to-plane rows -> 27+2 float64
+//                     sums (wave shuffle -> LDS -> one atomicAdd per block and sum)
+//   k_find_corr       transform points+normals + NN + distance/normal tests -> match[orig index];
+//                     k_count_blocks (+ information-matrix sums) + k_scan_blocks + k_compact = stable compaction in file order
 // Reductions and scans, not contractions: no MFMA.
 #include "er_common.h"
 
@@ -45,37 +48,64 @@ struct Grid {
 struct Mat12d { double m[12]; };
 struct Mat12f { float m[12]; };
 
-// Exact 1-NN of q among target points inside the 27 neighbouring cells.  float32 squared distance
-// ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.  Returns original index or -1.
-__device__ __forceinline__ int nn_search(const Grid& g, float qx, float qy, float qz, float& best_d) {
-  const float cx = floorf((qx - g.org[0]) / g.cell);
-  const float cy = floorf((qy - g.org[1]) / g.cell);
-  const float cz = floorf((qz - g.org[2]) / g.cell);
-  if (!(cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2]))
-    return -1;
-  const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-  const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.dim[0] - 1);
+// Exact 1-NN of q among target points inside the 27 neighbouring cells, searched by a group of kGroup
+// consecutive lanes per query: lane `sub` scans the rows of cells sub, sub + kGroup, ... of the 9 (z,y) rows
+// (home row first; rows that cannot beat the best so far are skipped), then the group reduces (distance, index)
+// lexicographically with shuffles.  The pass is latency bound (dependent cell_start -> candidate loads).
+// float32 squared distance ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.
+// limit2 = squared search radius: callers discard anything farther, so rows of cells lying entirely beyond
+// the radius are skipped (margin 1e-4 relative for the float32 cell assignment).  All lanes of the group
+// return the same (index or -1, distance).
+#ifndef ER_ICP_GROUP
+#define ER_ICP_GROUP 2      /* measured on MI355X: 1/2/4/8 lanes per query -> NN pass 58/51/57/64 us per 253 k queries */
+#endif
+constexpr int kGroup = ER_ICP_GROUP;
+
+__device__ __forceinline__ int nn_search(const Grid& g, float qx, float qy, float qz, float limit2, int sub, float& best_d) {
+  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
+  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
   int best = -1;
   float bd = FLT_MAX;
-  if (x0 > x1) return -1;
-  for (int dz = -1; dz <= 1; dz++) {
-    const int z = iz + dz;
-    if (z < 0 || z >= g.dim[2]) continue;
-    for (int dy = -1; dy <= 1; dy++) {
-      const int y = iy + dy;
-      if (y < 0 || y >= g.dim[1]) continue;
-      const int row = (z * g.dim[1] + y) * g.dim[0];
-      const int s0 = g.cell_start[row + x0], s1 = g.cell_start[row + x1 + 1];
-      for (int s = s0; s < s1; s++) {
-        const float4 p = g.pts[s];
-        const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
-        const float d = ((dx * dx) + dy2 * dy2) + dz2 * dz2;
-        const int idx = __float_as_int(p.w);
-        if (d < bd || (d == bd && idx < best)) {
-          bd = d;
-          best = idx;
+  const bool inside = cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
+  if (inside) {
+    const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
+    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.dim[0] - 1);
+    // distance from q to the lower / upper face of its own cell along y and z (metres)
+    const float ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell, zhi = g.cell - zlo;
+    float bound = limit2 * 1.0001f + 1e-12f;
+    if (x0 <= x1) {
+#pragma unroll 1
+      for (int it = sub; it < 9; it += kGroup) {
+        const int pass = it == 0 ? 4 : (it == 4 ? 0 : it);              // home row (dy = dz = 0) first
+        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+        const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
+        if (ey * ey + ez * ez > bound) continue;
+        const int y = iy + dy, z = iz + dz;
+        if (y < 0 || y >= g.dim[1] || z < 0 || z >= g.dim[2]) continue;
+        const int row = (z * g.dim[1] + y) * g.dim[0];
+        const int s0 = g.cell_start[row + x0], s1 = g.cell_start[row + x1 + 1];
+        for (int s = s0; s < s1; s++) {
+          const float4 p = g.pts[s];
+          const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
+          const float d = ((dx * dx) + dy2 * dy2) + dz2 * dz2;
+          const int idx = __float_as_int(p.w);
+          if (d < bd || (d == bd && idx < best)) {
+            bd = d;
+            best = idx;
+          }
         }
+        bound = fminf(bound, bd * 1.0001f + 1e-12f);                     // later rows must beat the best so far
       }
+    }
+  }
+  // lexicographic (distance, index) minimum over the group; -1 (nothing found) loses against any hit
+#pragma unroll
+  for (int off = 1; off < kGroup; off <<= 1) {
+    const float od = __shfl_xor(bd, off, kGroup);
+    const int oi = __shfl_xor(best, off, kGroup);
+    if (oi >= 0 && (best < 0 || od < bd || (od == bd && oi < best))) {
+      bd = od;
+      best = oi;
     }
   }
   best_d = bd;
@@ -110,26 +140,36 @@ __device__ __forceinline__ void xform_d(const Mat12d& T, float x, float y, float
   oz = (float)(((T.m[8] * dx + T.m[9] * dy) + T.m[10] * dz) + T.m[11]);
 }
 
-// Registration pre-check, CorresApp.cpp:257-264.
-__global__ __launch_bounds__(kBlock) void k_count_inliers(const float* __restrict__ xyz, int n, Mat12d T, Grid g, float radius,
+// Registration pre-check, CorresApp.cpp:257-264.  kGroup lanes per source point; a fixed grid strides over the
+// points and issues ONE atomic per workgroup (one per wave serialised thousands of atomics on one word).
+__global__ __launch_bounds__(kBlock) void k_count_inliers(const float4* __restrict__ src_sorted, int n, Mat12d T, Grid g, float radius,
                                                           double maxd2, int* __restrict__ count) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  bool in = false;
-  if (k < n) {
+  const int sub = threadIdx.x % kGroup;
+  int local = 0;
+  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup; k < n; k += gridDim.x * (blockDim.x / kGroup)) {
     float qx, qy, qz, d;
-    xform_d(T, xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], qx, qy, qz);
-    const int i = nn_search(g, qx, qy, qz, d);
-    in = i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2;
+    const float4 s = src_sorted[k];
+    xform_d(T, s.x, s.y, s.z, qx, qy, qz);
+    const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
+    if (sub == 0 && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
-  const unsigned long long b = __ballot(in);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, __popcll(b));
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  __shared__ int part[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; w++) s += part[w];
+    if (s) atomicAdd(count, s);
+  }
 }
 
 // guess * source in float32 (IterativeClosestPoint::transformCloud), or a plain copy for an identity guess.
-__global__ void k_init_x(const float* __restrict__ xyz, float* __restrict__ X, int n, Mat12f M, int apply) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restrict__ X, int n, Mat12f M, int apply) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;       // k = position in the source's cell-sorted order
   if (k >= n) return;
-  const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
+  const float4 s = src_sorted[k];
+  const float x = s.x, y = s.y, z = s.z;
   if (apply) {
     X[3 * k] = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
     X[3 * k + 1] = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
@@ -141,117 +181,132 @@ __global__ void k_init_x(const float* __restrict__ xyz, float* __restrict__ X, i
   }
 }
 
-// One ICP iteration: X <- delta * X (the previous iteration's increment, float32), correspondence
-// estimation (keep if d^2 <= max_dist^2), and the sums of TransformationEstimationPointToPlaneLLS.
-// acc: [0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
-__global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int n, Mat12f delta, int apply, Grid g,
-                                                     const float* __restrict__ tgt_xyz, const float* __restrict__ tgt_nrm,
-                                                     float radius, double maxd2, double* __restrict__ acc) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  double v[29];
-#pragma unroll
-  for (int i = 0; i < 29; i++) v[i] = 0.0;
-  if (k < n) {
-    float sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
+// One ICP iteration, part 1 (kGroup lanes per point): X <- delta * X (the previous iteration's increment,
+// float32) and correspondence estimation: nn[k] = target index kept if d^2 <= max_dist^2, else -1.
+__global__ __launch_bounds__(kBlock) void k_icp_nn(float* __restrict__ X, int n, Mat12f delta, int apply, Grid g, float radius,
+                                                   double maxd2, int* __restrict__ nn, float* __restrict__ nd) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = t / kGroup, sub = t % kGroup;
+  if (k >= n) return;
+  float sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
+  if (apply) {
+    const float x = sx, y = sy, z = sz;
+    sx = ((delta.m[0] * x + delta.m[1] * y) + delta.m[2] * z) + delta.m[3];
+    sy = ((delta.m[4] * x + delta.m[5] * y) + delta.m[6] * z) + delta.m[7];
+    sz = ((delta.m[8] * x + delta.m[9] * y) + delta.m[10] * z) + delta.m[11];
+  }
+  float d;
+  const int i = nn_search(g, sx, sy, sz, radius * radius, sub, d);   // (all lanes read X before anybody overwrites it)
+  if (sub == 0) {
     if (apply) {
-      const float x = sx, y = sy, z = sz;
-      sx = ((delta.m[0] * x + delta.m[1] * y) + delta.m[2] * z) + delta.m[3];
-      sy = ((delta.m[4] * x + delta.m[5] * y) + delta.m[6] * z) + delta.m[7];
-      sz = ((delta.m[8] * x + delta.m[9] * y) + delta.m[10] * z) + delta.m[11];
       X[3 * k] = sx;
       X[3 * k + 1] = sy;
       X[3 * k + 2] = sz;
     }
-    float d;
-    const int i = nn_search(g, sx, sy, sz, d);
-    if (i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
+    const bool keep = i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2);
+    nn[k] = keep ? i : -1;
+    nd[k] = d;
+  }
+}
+
+// One ICP iteration, part 2 (one lane per point): the sums of TransformationEstimationPointToPlaneLLS.
+// acc: [0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
+__global__ __launch_bounds__(kBlock) void k_icp_accum(const float* __restrict__ X, int n, const int* __restrict__ nn,
+                                                      const float* __restrict__ nd, const float* __restrict__ tgt_xyz,
+                                                      const float* __restrict__ tgt_nrm, double* __restrict__ acc) {
+  double v[29];
+#pragma unroll
+  for (int i = 0; i < 29; i++) v[i] = 0.0;
+  // a fixed grid strides over the points: each thread folds several rows before the (expensive) 29-value reduction
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const int i = nn[k];
+    if (i >= 0) {
+      const float sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
       const float dx = tgt_xyz[3 * i], dy = tgt_xyz[3 * i + 1], dz = tgt_xyz[3 * i + 2];
       const float nx = tgt_nrm[3 * i], ny = tgt_nrm[3 * i + 1], nz = tgt_nrm[3 * i + 2];
-      v[27] = (double)d;
-      v[28] = 1.0;
+      v[27] += (double)nd[k];
+      v[28] += 1.0;
       if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
         const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
         const double b = (double)(nx * sz - nz * sx);
         const double c = (double)(ny * sx - nx * sy);
         const double dnx = nx, dny = ny, dnz = nz;
-        v[0] = a * a;  v[1] = a * b;  v[2] = a * c;  v[3] = a * dnx;  v[4] = a * dny;  v[5] = a * dnz;
-        v[6] = b * b;  v[7] = b * c;  v[8] = b * dnx; v[9] = b * dny; v[10] = b * dnz;
-        v[11] = c * c; v[12] = c * dnx; v[13] = c * dny; v[14] = c * dnz;
-        v[15] = dnx * dnx; v[16] = dnx * dny; v[17] = dnx * dnz;
-        v[18] = dny * dny; v[19] = dny * dnz;
-        v[20] = dnz * dnz;
+        v[0] += a * a;  v[1] += a * b;  v[2] += a * c;  v[3] += a * dnx;  v[4] += a * dny;  v[5] += a * dnz;
+        v[6] += b * b;  v[7] += b * c;  v[8] += b * dnx; v[9] += b * dny; v[10] += b * dnz;
+        v[11] += c * c; v[12] += c * dnx; v[13] += c * dny; v[14] += c * dnz;
+        v[15] += dnx * dnx; v[16] += dnx * dny; v[17] += dnx * dnz;
+        v[18] += dny * dny; v[19] += dny * dnz;
+        v[20] += dnz * dnz;
         const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-        v[21] = a * e; v[22] = b * e; v[23] = c * e; v[24] = dnx * e; v[25] = dny * e; v[26] = dnz * e;
+        v[21] += a * e; v[22] += b * e; v[23] += c * e; v[24] += dnx * e; v[25] += dny * e; v[26] += dnz * e;
       }
     }
   }
   block_reduce_atomic<29>(v, acc);
 }
 
-// getFitnessScore-style diagnostic: mean squared NN distance of final * source inside the search radius.
-__global__ __launch_bounds__(kBlock) void k_fitness(const float* __restrict__ xyz, int n, Mat12f M, Grid g, float radius,
-                                                    double* __restrict__ acc) {
+// getFitnessScore-style diagnostic: squared NN distance of final * source inside the search radius (-1 = none).
+__global__ __launch_bounds__(kBlock) void k_fitness_nn(const float4* __restrict__ src_sorted, int n, Mat12f M, Grid g, float radius,
+                                                       float* __restrict__ nd) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = t / kGroup, sub = t % kGroup;
+  if (k >= n) return;
+  const float4 s = src_sorted[k];
+  const float x = s.x, y = s.y, z = s.z;
+  const float qx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
+  const float qy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
+  const float qz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+  float d;
+  const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
+  if (sub == 0) nd[k] = (i >= 0 && (double)d <= (double)radius * (double)radius) ? d : -1.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fitness_sum(const float* __restrict__ nd, int n, double* __restrict__ acc) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   double v[2] = {0.0, 0.0};
-  if (k < n) {
-    const float x = xyz[3 * k], y = xyz[3 * k + 1], z = xyz[3 * k + 2];
-    const float qx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
-    const float qy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
-    const float qz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
-    float d;
-    const int i = nn_search(g, qx, qy, qz, d);
-    if (i >= 0 && (double)d <= (double)radius * (double)radius) {
-      v[0] = (double)d;
-      v[1] = 1.0;
-    }
+  if (k < n && nd[k] >= 0.0f) {
+    v[0] = (double)nd[k];
+    v[1] = 1.0;
   }
   block_reduce_atomic<2>(v, acc);
 }
 
-// FindCorrespondence, CorresApp.cpp:144-161 + information matrix :186-208.
-// match[k] = NN index or -1; block_count[b] = matches in block b;
+// FindCorrespondence, CorresApp.cpp:144-161 (kGroup lanes per source point): match[original index] = NN index
+// passing the distance and normal tests, else -1.
+__global__ __launch_bounds__(kBlock) void k_find_corr(const float4* __restrict__ src_sorted, const float* __restrict__ nrm, int n,
+                                                      Mat12d T, Grid g, const float* __restrict__ tgt_nrm, float radius,
+                                                      double dist2, double normal_cos, int* __restrict__ match) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int q = t / kGroup, sub = t % kGroup;                  // q = position in the source's cell-sorted order
+  if (q >= n) return;
+  const float4 s = src_sorted[q];
+  const int k = __float_as_int(s.w);                           // original (file-order) index of this source point
+  float qx, qy, qz, d;
+  xform_d(T, s.x, s.y, s.z, qx, qy, qz);
+  const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
+  if (sub != 0) return;
+  int m = -1;
+  if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {         // :154
+    const double nx = nrm[3 * k], ny = nrm[3 * k + 1], nz = nrm[3 * k + 2];
+    const float tnx = (float)((T.m[0] * nx + T.m[1] * ny) + T.m[2] * nz);                     // n' = R n (double -> float)
+    const float tny = (float)((T.m[4] * nx + T.m[5] * ny) + T.m[6] * nz);
+    const float tnz = (float)((T.m[8] * nx + T.m[9] * ny) + T.m[10] * nz);
+    // NormalDot, CorresApp.h:58-60: float32 products/sums, compared as double
+    const float dot = (tgt_nrm[3 * i] * tnx + tgt_nrm[3 * i + 1] * tny) + tgt_nrm[3 * i + 2] * tnz;
+    if ((double)dot > normal_cos) m = i;                                                       // :155
+  }
+  match[k] = m;
+}
+
+// Matches per block of 256 consecutive ORIGINAL indices (the order of the output list) and, optionally, the
+// information matrix of CorresApp.cpp:186-208 over the matched, UNtransformed source points:
 // info[0..2] = sum 2sx,2sy,2sz; [3..5] = sum (4sz^2+4sy^2),(4sz^2+4sx^2),(4sy^2+4sx^2);
 // [6..8] = sum -4sysx, -4szsx, -4szsy; [9] = count   (the distinct terms of sum A^T A, A = [I | 2*skew-like(s)])
-__global__ __launch_bounds__(kBlock) void k_find_corr(const float* __restrict__ xyz, const float* __restrict__ nrm, int n,
-                                                      Mat12d T, Grid g, const float* __restrict__ tgt_nrm, float radius,
-                                                      double dist2, double normal_cos, int* __restrict__ match,
-                                                      int* __restrict__ block_count, double* __restrict__ info,
-                                                      int want_info) {
+__global__ __launch_bounds__(kBlock) void k_count_blocks(const int* __restrict__ match, const float* __restrict__ xyz, int n,
+                                                         int* __restrict__ block_count, double* __restrict__ info, int want_info) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  int m = -1;
-  double v[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) v[i] = 0.0;
-  if (k < n) {
-    const float sx = xyz[3 * k], sy = xyz[3 * k + 1], sz = xyz[3 * k + 2];
-    float qx, qy, qz, d;
-    xform_d(T, sx, sy, sz, qx, qy, qz);
-    const int i = nn_search(g, qx, qy, qz, d);
-    if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {       // :154
-      const double nx = nrm[3 * k], ny = nrm[3 * k + 1], nz = nrm[3 * k + 2];
-      const float tnx = (float)((T.m[0] * nx + T.m[1] * ny) + T.m[2] * nz);                   // n' = R n (double -> float)
-      const float tny = (float)((T.m[4] * nx + T.m[5] * ny) + T.m[6] * nz);
-      const float tnz = (float)((T.m[8] * nx + T.m[9] * ny) + T.m[10] * nz);
-      // NormalDot, CorresApp.h:58-60: float32 products/sums, compared as double
-      const float dot = (tgt_nrm[3 * i] * tnx + tgt_nrm[3 * i + 1] * tny) + tgt_nrm[3 * i + 2] * tnz;
-      if ((double)dot > normal_cos) {                                                          // :155
-        m = i;
-        if (want_info) {                                                                       // :192-204
-          const double ax = (double)(2 * sx), ay = (double)(2 * sy), az = (double)(2 * sz);
-          v[0] = ax; v[1] = ay; v[2] = az;
-          v[3] = az * az + ay * ay;     // (0*0 + (-2sz)(-2sz)) + (2sy)(2sy)
-          v[4] = az * az + ax * ax;     // ((2sz)(2sz) + 0*0) + (-2sx)(-2sx)
-          v[5] = ay * ay + ax * ax;     // ((-2sy)(-2sy) + (2sx)(2sx)) + 0*0
-          v[6] = ay * (-ax);            // (3,4): (2sy)(-2sx)
-          v[7] = (-az) * ax;            // (3,5): (-2sz)(2sx)
-          v[8] = az * (-ay);            // (4,5): (2sz)(-2sy)
-          v[9] = 1.0;
-        }
-      }
-    }
-    match[k] = m;
-  }
-  const unsigned long long b = __ballot(m >= 0);
+  const bool hit = k < n && match[k] >= 0;
+  const unsigned long long b = __ballot(hit);
   __shared__ int wcnt[kBlock / 64];
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(b);
   __syncthreads();
@@ -261,6 +316,21 @@ __global__ __launch_bounds__(kBlock) void k_find_corr(const float* __restrict__ 
     block_count[blockIdx.x] = s;
   }
   if (want_info) {
+    double v[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) v[i] = 0.0;
+    if (hit) {                                                                                 // :192-204
+      const float sx = xyz[3 * k], sy = xyz[3 * k + 1], sz = xyz[3 * k + 2];
+      const double ax = (double)(2 * sx), ay = (double)(2 * sy), az = (double)(2 * sz);
+      v[0] = ax; v[1] = ay; v[2] = az;
+      v[3] = az * az + ay * ay;     // (0*0 + (-2sz)(-2sz)) + (2sy)(2sy)
+      v[4] = az * az + ax * ax;     // ((2sz)(2sz) + 0*0) + (-2sx)(-2sx)
+      v[5] = ay * ay + ax * ax;     // ((-2sy)(-2sy) + (2sx)(2sx)) + 0*0
+      v[6] = ay * (-ax);            // (3,4): (2sy)(-2sx)
+      v[7] = (-az) * ax;            // (3,5): (-2sz)(2sx)
+      v[8] = az * (-ay);            // (4,5): (2sz)(-2sy)
+      v[9] = 1.0;
+    }
     __syncthreads();
     block_reduce_atomic<10>(v, info);
   }
@@ -377,10 +447,11 @@ struct er_cloud_s {
   hipStream_t stream = nullptr;
   // scratch for the SOURCE role
   std::mutex src_mutex;
-  float* X = nullptr;
+  float *X = nullptr, *nd = nullptr;
   int *match = nullptr, *block_count = nullptr, *block_offset = nullptr, *pairs = nullptr, *icount = nullptr;
   double* acc = nullptr;
-  int nblocks = 0;
+  int nblocks = 0;              // one lane per point
+  int gblocks = 0;              // kGroup lanes per point
 };
 
 namespace {
@@ -454,6 +525,7 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
   }
   const size_t nn = (size_t)std::max(n, 1);
   c->nblocks = (int)((nn + kBlock - 1) / kBlock);
+  c->gblocks = (int)((nn * kGroup + kBlock - 1) / kBlock);
 #define ER_CALLOC(ptr, bytes)                                                                 \
   do {                                                                                        \
     hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                       \
@@ -473,6 +545,7 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
   ER_CALLOC(c->cell_start, ((size_t)ncell + 1) * sizeof(int));
   ER_CALLOC(c->X, nn * 3 * sizeof(float));
   ER_CALLOC(c->match, nn * sizeof(int));
+  ER_CALLOC(c->nd, nn * sizeof(float));
   ER_CALLOC(c->pairs, nn * 2 * sizeof(int));
   ER_CALLOC(c->block_count, (size_t)c->nblocks * sizeof(int));
   ER_CALLOC(c->block_offset, (size_t)c->nblocks * sizeof(int));
@@ -505,7 +578,7 @@ int er_cloud_destroy(er_cloud_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->xyz, c->nrm, c->sorted, c->cell_start, c->X, c->match, c->pairs, c->block_count, c->block_offset, c->icount, c->acc};
+  void* ptrs[] = {c->xyz, c->nrm, c->sorted, c->cell_start, c->X, c->nd, c->match, c->pairs, c->block_count, c->block_offset, c->icount, c->acc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -532,7 +605,7 @@ int er_icp_count_inliers(er_cloud_t src, er_cloud_t tgt, const double T[16], dou
   for (int q = 0; q < 12; q++) M.m[q] = T[q];
   ER_HIP_TRY(hipMemsetAsync(src->icount, 0, sizeof(int), src->stream));
   if (src->n > 0 && tgt->n > 0) {
-    hipLaunchKernelGGL(k_count_inliers, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->xyz, src->n, M, grid_of(tgt),
+    hipLaunchKernelGGL(k_count_inliers, dim3(std::min(src->gblocks, 2048)), dim3(kBlock), 0, src->stream, src->sorted, src->n, M, grid_of(tgt),
                        (float)max_dist, max_dist * max_dist, src->icount);
     ER_HIP_TRY(hipGetLastError());
   }
@@ -556,7 +629,7 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
   Mat12f G;
   for (int q = 0; q < 12; q++) G.m[q] = guess[q];
   if (n > 0) {
-    hipLaunchKernelGGL(k_init_x, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->xyz, src->X, n, G, ident ? 0 : 1);
+    hipLaunchKernelGGL(k_init_x, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->sorted, src->X, n, G, ident ? 0 : 1);
     ER_HIP_TRY(hipGetLastError());
   }
   float delta[16], prev_delta[16];
@@ -573,8 +646,10 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
     double acc[kAcc];
     ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
     if (n > 0 && tgt->n > 0) {
-      hipLaunchKernelGGL(k_icp_iter, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->X, n, D, iter > 0 ? 1 : 0, g,
-                         tgt->xyz, tgt->nrm, (float)max_dist, maxd2, src->acc);
+      hipLaunchKernelGGL(k_icp_nn, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->X, n, D, iter > 0 ? 1 : 0, g,
+                         (float)max_dist, maxd2, src->match, src->nd);
+      hipLaunchKernelGGL(k_icp_accum, dim3(std::min(src->nblocks, 256)), dim3(kBlock), 0, src->stream, src->X, n, src->match, src->nd, tgt->xyz,
+                         tgt->nrm, src->acc);
       ER_HIP_TRY(hipGetLastError());
     }
     ER_HIP_TRY(hipMemcpyAsync(acc, src->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, src->stream));
@@ -613,7 +688,8 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
     double acc[2] = {0, 0};
     ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
     if (n > 0 && tgt->n > 0) {
-      hipLaunchKernelGGL(k_fitness, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->xyz, n, F, g, (float)max_dist, src->acc);
+      hipLaunchKernelGGL(k_fitness_nn, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->sorted, n, F, g, (float)max_dist, src->nd);
+      hipLaunchKernelGGL(k_fitness_sum, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->nd, n, src->acc);
       ER_HIP_TRY(hipGetLastError());
     }
     ER_HIP_TRY(hipMemcpyAsync(acc, src->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, src->stream));
@@ -636,8 +712,10 @@ int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], d
   if (info36) memset(info36, 0, 36 * sizeof(double));
   if (n == 0 || tgt->n == 0) return 0;
   ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
-  hipLaunchKernelGGL(k_find_corr, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->xyz, src->nrm, n, M, grid_of(tgt),
-                     tgt->nrm, (float)dist, dist * dist, normal_cos, src->match, src->block_count, src->acc, info36 ? 1 : 0);
+  hipLaunchKernelGGL(k_find_corr, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->sorted, src->nrm, n, M, grid_of(tgt),
+                     tgt->nrm, (float)dist, dist * dist, normal_cos, src->match);
+  hipLaunchKernelGGL(k_count_blocks, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->match, src->xyz, n, src->block_count,
+                     src->acc, info36 ? 1 : 0);
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, src->stream, src->block_count, src->block_offset, src->nblocks, src->icount + 1);
   hipLaunchKernelGGL(k_compact, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->match, n, src->block_offset, src->pairs, n);
   ER_HIP_TRY(hipGetLastError());
