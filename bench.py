@@ -39,7 +39,26 @@ FRAME_BYTES_RAW = 640 * 480 * 2
 FRAME_BYTES_FIXED = 640 * 480 * (2 + 4)        # raw read + scaled write/read once
 
 
+class _StdoutToStderr:
+    """The reference's own code prints to stdout (cout / printf); keep stdout for the ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def cpu_baseline(sc, depth_host, n_sample):
+    with _StdoutToStderr():
+        return _cpu_baseline(sc, depth_host, n_sample)
+
+
+def _cpu_baseline(sc, depth_host, n_sample):
     """Reference CPU path on the host cores of this box, same frames, same files-based setup as Integrate.exe."""
     import numpy as np
     from elasticreconstruction_amd import formats
@@ -155,6 +174,9 @@ def main():
     ap.add_argument("--interval", type=int, default=50, help="frames per step (= frames per fragment / control grid)")
     ap.add_argument("--no-warp", action="store_true", help="rigid --ref_traj style run (no control grid)")
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames timed on the CPU reference (0 = skip)")
+    ap.add_argument("--host-input", action="store_true",
+                    help="hand the depth frames over as HOST memory (what bin/Integrate does): the PCIe-inclusive rate; "
+                         "never the headline value")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
     ap.add_argument("--icp-pairs", type=int, default=0,
@@ -207,10 +229,15 @@ def main():
     torch.cuda.set_stream(stream)
     px = depth.shape[1]
 
+    depth_host = synth.to_numpy_u16(depth) if args.host_input else None
+
     def run_steps(vol, k):
         for s in range(k):
             lo, hi = s * I, (s + 1) * I
-            vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
+            if depth_host is not None:
+                vol.IntegrateFrames(depth_host[lo:hi], sc["traj"][lo:hi], warp_slice(lo, hi))
+            else:
+                vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
 
     def merge(vol):
         """Frame-split merge: key all-gather + ONE all-reduce(sum) over the sdf*w / w planes (parallel.py)."""
@@ -273,7 +300,8 @@ def main():
                                    % (n_frames, "ControlGrid warp res 8 / %d grids" % K if warp_on else "rigid", I),
                        "frames_per_step": I, "frames_per_gpu": n_frames, "volume_units_touched": n_units,
                        "parallelism": "frame-block shard x%d + one all-reduce" % world if world > 1 else "single GPU",
-                       "inputs": "resident in HBM before the timed region"},
+                       "inputs": "HOST memory, copied over PCIe inside the timed region (not the headline configuration)"
+                       if args.host_input else "resident in HBM before the timed region"},
         }
         if use_dist:
             out["config"]["merge_union_units"] = n_union
