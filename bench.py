@@ -13,8 +13,8 @@ Warm-up steps run on a scratch volume; the K timed steps fill a fresh one.
 
 N > 1 (weak scaling): every rank integrates its own contiguous K*interval-frame block of one long
 trajectory into a private volume (no data-path collective), then -- inside the timed region -- the
-per-GPU volumes are merged by ONE RCCL all-reduce(sum) of the sdf*weight / weight planes of the union
-of touched units.
+per-GPU volumes are merged by ONE RCCL reduce(sum) to rank 0 of the sdf*weight / weight planes of the union
+of touched units (`parallel.merge_volumes(mode="all_reduce")` leaves the result on every rank).
 
 Output: one JSON line (rank 0).  roofline.achieved uses the ALGORITHMIC bytes of SURVEY.md 8d,
 B_A = 16 * N_upd + 1 843 200 (+ 1 228 800 with the warp) per frame with sum(N_upd) = sum(weight_),
@@ -240,7 +240,7 @@ def main():
                 vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
 
     def merge(vol):
-        """Frame-split merge: key all-gather + ONE all-reduce(sum) over the sdf*w / w planes (parallel.py)."""
+        """Frame-split merge: key all-gather + ONE reduce(sum) to rank 0 over the sdf*w / w planes (parallel.py)."""
         from elasticreconstruction_amd import parallel
         return parallel.merge_volumes(vol, dist, dev)
 
@@ -299,7 +299,7 @@ def main():
                                    "512^3 TSDF = 8x8x8 units of 64^3 at 3/512 m, %s, %d frames per step"
                                    % (n_frames, "ControlGrid warp res 8 / %d grids" % K if warp_on else "rigid", I),
                        "frames_per_step": I, "frames_per_gpu": n_frames, "volume_units_touched": n_units,
-                       "parallelism": "frame-block shard x%d + one all-reduce" % world if world > 1 else "single GPU",
+                       "parallelism": "frame-block shard x%d + one final reduce to rank 0" % world if world > 1 else "single GPU",
                        "inputs": "HOST memory, copied over PCIe inside the timed region (not the headline configuration)"
                        if args.host_input else "resident in HBM before the timed region"},
         }

@@ -4,8 +4,8 @@
   Path B (pairs)   fully independent units: pair p -> rank p mod G, fragments replicated on every GPU,
                    results gathered on rank 0 in the original pair order.  NO data-path collective.
   Path A (frames)  contiguous frame blocks per rank into private volumes, then ONE exchange step:
-                   all-gather of the touched unit keys -> union, one all-reduce(sum) over the
-                   [key][sdf*weight | weight] planes of the union, per-voxel divide on import.
+                   all-gather of the touched unit keys -> union, ONE reduce(sum) to rank 0 (or all-reduce) over
+                   the [key][sdf*weight | weight] planes of the union, per-voxel divide on import.
                    (The running mean with unit weights is a sum: w = sum_g w_g, sdf = sum_g sdf_g*w_g / w;
                    TSDFVolume.cpp:93-94 applied sequentially gives the same value up to float rounding
                    order, hence tolerance 1e-5 instead of bit parity for this mode.)
@@ -45,8 +45,11 @@ def union_keys(local_keys, dist, device, max_keys=4096):
     return u[u >= 0].to(torch.int32).cpu().numpy()
 
 
-def merge_volumes(vol, dist, device, sync_stream=None):
-    """Frame-split merge; afterwards every rank holds the complete volume.  Returns the union size.
+def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
+    """Frame-split merge.  mode "reduce" (default): ONE reduce(sum) to `root` -- the "final reduce of per-GPU TSDF
+    volume-unit weights" of BASELINE.json; afterwards `root` holds the complete volume (the other ranks keep
+    their partial volumes).  mode "all_reduce": every rank ends with the complete volume (about 1.75x the
+    link traffic of the reduce on a ring).  Returns the union size.
     sync_stream: callable that makes the communication stream wait for the volume's kernels and vice
     versa (None when everything already runs on one in-order stream)."""
     import torch
@@ -57,10 +60,14 @@ def merge_volumes(vol, dist, device, sync_stream=None):
     vol.export_weighted(union, buf.data_ptr())
     if sync_stream:
         sync_stream()
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)               # the ONLY data-path collective of the pipeline
+    if mode == "all_reduce":
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # the ONLY data-path collective of the pipeline
+    else:
+        dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
     if sync_stream:
         sync_stream()
-    vol.import_weighted(union, buf.data_ptr())
+    if mode == "all_reduce" or dist.get_rank() == root:
+        vol.import_weighted(union, buf.data_ptr())
     vol.synchronize()
     return int(union.size)
 

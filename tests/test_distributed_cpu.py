@@ -71,7 +71,11 @@ def _worker(rank, world, port, q):
     vol = HostVolume()
     vol.integrate_with_oracle(depth[lo:hi], poses[lo:hi])
     local_keys = vol.unit_keys()
-    n_union = parallel.merge_volumes(vol, dist, torch.device("cpu"))
+    import copy
+    vol_ar = copy.deepcopy(vol)
+    n_union = parallel.merge_volumes(vol, dist, torch.device("cpu"))                       # reduce to rank 0
+    n_union_ar = parallel.merge_volumes(vol_ar, dist, torch.device("cpu"), mode="all_reduce")
+    same = n_union == n_union_ar and all(np.array_equal(vol_ar.units[k][1], vol.units[k][1]) for k in vol.units) if rank == 0 else True
     # pair sharding: every pair exactly once, results back in order
     mine = {p: (p, rank) for p in parallel.pair_shard(7, rank, world)}
     gathered = parallel.gather_pair_results(mine, 7, dist)
@@ -85,7 +89,7 @@ def _worker(rank, world, port, q):
             sf, wf = full.units[int(k)]
             wbad += int((w != wf).sum())
             worst = max(worst, float(np.abs(s - sf).max()))
-        q.put(dict(ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys),
+        q.put(dict(ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys), modes_agree=bool(same),
                    pairs=[g[0] for g in gathered], owners=[g[1] for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
@@ -108,7 +112,7 @@ def test_frame_split_merge_and_pair_shard_world2_gloo():
     assert res["ok_keys"], "union of the per-rank unit keys != single-volume keys"
     assert res["wbad"] == 0, "merged weights must be exact (integer-valued floats)"
     assert res["worst"] <= 1e-5, "merged tsdf off by %.3g" % res["worst"]
-    assert res["n_union"] >= res["n_local"] > 0
+    assert res["n_union"] >= res["n_local"] > 0 and res["modes_agree"]
     assert res["pairs"] == list(range(7)) and res["owners"] == [0, 1, 0, 1, 0, 1, 0]
 
 
