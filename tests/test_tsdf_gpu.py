@@ -259,3 +259,35 @@ def test_non_vga_image_size(gpu):
         ora.Integrate(depth[i], poses[i])
     assert helpers.assert_volumes_identical(vol, ora, "300x210") > 10
     vol.close()
+
+
+def test_full_config2_batching_invariance(gpu):
+    """BASELINE.json config 2 at FULL size (3000 frames, control-grid warp, 512^3 region): the result must not
+    depend on how the stream is cut into batches -- 60 calls of 50 frames (bench.py's steps) vs one call that the
+    library cuts into 64-frame launches vs a ragged cut -- and sum(weight) must equal the number of voxel updates
+    reported per launch.  Bit-exact comparison of every unit."""
+    import torch
+    sc = synth.make_scenario(3000, interval=50, warp=True, device="cuda:0")
+    warp = synth.warp_arrays(sc)
+    depth = sc["depth"]
+    torch.cuda.synchronize()
+    px = depth.shape[1]
+
+    def run(cuts):
+        vol = TSDFVolume(max_units=640)
+        for lo, hi in cuts:
+            w = dict(ctr=warp["ctr"], resolution=warp["resolution"], length=warp["length"], grid_index=warp["grid_index"][lo:hi],
+                     seg=warp["seg"][lo:hi], madj=warp["madj"][lo:hi])
+            vol.IntegrateFrames(None, sc["traj"][lo:hi], w, device_ptr=depth.data_ptr() + lo * px * 2)
+        return vol
+
+    a = run([(s * 50, s * 50 + 50) for s in range(60)])
+    b = run([(0, 3000)])
+    edges = [0, 1, 7, 70, 71, 500, 1999, 3000]
+    c = run(list(zip(edges[:-1], edges[1:])))
+    n = helpers.assert_volumes_identical(a, b, "50-frame steps vs 64-frame launches")
+    helpers.assert_volumes_identical(a, c, "50-frame steps vs ragged cuts")
+    assert 100 <= n <= 512, "config 2 must stay inside the 512-unit (512^3) region, got %d units" % n
+    assert a.sum_weight() == b.sum_weight() == c.sum_weight() > 4e9
+    for v in (a, b, c):
+        v.close()
