@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liber_hip.so")
+# ER_HIP_LIB selects another build of the same library (A/B measurements of kernel variants); never a fallback.
+LIB_PATH = os.environ.get("ER_HIP_LIB") or os.path.join(_HERE, "liber_hip.so")
 
 # Every symbol include/er_hip.h declares (tests/test_abi.py checks header == this list == the .so).
 SYMBOLS = [

@@ -116,31 +116,92 @@ ER_HD float unit_shift(int idx) { return (float)((double)((idx - 256) * 64) * kU
 ER_HD float grid_coord(int i, float shift) { return (float)((double)i * kUnitLength + (double)shift); }
 
 // ---- A4: one voxel of IntegrateVolumeUnit against one frame, TSDFVolume.cpp:76-94 ----------------
+// Correctly rounded float32 division and square root WITHOUT the range-scaling wrapper.
+// hipcc lowers an IEEE '/' to  v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup
+// and sqrtf to a scale / v_sqrt / +-1 ulp residual test / unscale / class-fixup sequence.  The scale, fmas and
+// fixup steps only act when an operand is denormal, tiny (|x| < 2^-103), huge or non-finite; for operands in
+// [2^-100, 2^100] they are the identity, so the bare Newton/residual core below produces the SAME bits.  A
+// timing probe on MI355X put the three divisions and the sqrt of one voxel update at 44 % of k_integrate
+// (quarter-rate transcendentals + the wrapper ops), which is why this matters.  The callers guard the range
+// and fall back to the plain operators otherwise; on the host (tests/hostcheck) the plain operators are used.
+ER_HD void div2_inrange(float n0, float n1, float d, float& q0, float& q1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  float m = n0 * r;
+  m = fmaf(fmaf(-d, m, n0), r, m);
+  q0 = fmaf(fmaf(-d, m, n0), r, m);
+  m = n1 * r;
+  m = fmaf(fmaf(-d, m, n1), r, m);
+  q1 = fmaf(fmaf(-d, m, n1), r, m);
+#else
+  q0 = n0 / d;
+  q1 = n1 / d;
+#endif
+}
+
+ER_HD float div_inrange(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  float m = n * r;
+  m = fmaf(fmaf(-d, m, n), r, m);
+  return fmaf(fmaf(-d, m, n), r, m);
+#else
+  return n / d;
+#endif
+}
+
+ER_HD float sqrt_inrange(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  float s = __builtin_amdgcn_sqrtf(x);                       // <= 1 ulp
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float r1 = fmaf(-sm, s, x), r2 = fmaf(-sp, s, x);    // residuals against the two neighbours
+  s = (r1 <= 0.0f) ? sm : s;
+  s = (r2 > 0.0f) ? sp : s;
+  return s;
+#else
+  return sqrtf(x);
+#endif
+}
+
 // S/W are the voxel's sdf_/weight_.  Returns true if the voxel was updated.
 //
 // Same arithmetic as the reference, arranged for a SIMT machine: the projection is evaluated
-// unconditionally (IEEE division never traps; lanes with t2 <= 0 are discarded by the predicate), the
-// five range tests are folded into ONE predicate and the depth / truncation tests into a second one, so
-// a voxel costs 2-3 divergent regions instead of 6.  Measured A/B on MI355X (same box, interleaved,
-// profiles/r01_ab_variants.txt): this form 0.565 ms per 50-frame launch vs 0.600 ms for the
-// test-by-test form; "cleverer" exact shortcuts (float32-only rounding, skipping the update division
-// when S == 1, a guarded multiply instead of the float64 band division) were SLOWER (0.672 ms): the
-// extra branches cost more than the float64 instructions they removed; float32-only rounding alone,
-// without extra branches, measured neutral (0.460 vs 0.455 ms) and was not kept.
+// unconditionally (lanes with t2 <= 0 are discarded by the predicate), the five range tests are folded
+// into ONE predicate and the depth / truncation tests into a second one, so a voxel costs 2-3 divergent
+// regions instead of 6.  Measured A/B on MI355X (same box, interleaved, profiles/r01_ab_variants.txt):
+// folded predicates 0.565 ms per 50-frame launch vs 0.600 ms test by test; extra-branch "shortcuts"
+// (skipping the update division when S == 1, guarded multiply for the band division) were slower.
 ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
                         int cols, int rows, const float* __restrict__ scaled) {
   const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
   const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
   const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
+  const float n0 = t0 * c.fx, n1 = t1 * c.fy;
+  float qu, qv;
+  div2_inrange(n0, n1, t2, qu, qv);                                      // shared reciprocal of the depth
+  // Range of the unscaled sequence: depth in [1e-30, 1e30] m.  A numerator below 2^-100 gives a quotient
+  // that vanishes in "+ cx" whatever its last bits; one above 2^100 lands far outside the image either way.
+  if (!((t2 >= 1e-30f) & (t2 <= 1e30f))) {
+    qu = n0 / t2;
+    qv = n1 / t2;
+  }
   // :78-79  round( float expr ) with TSDFVolume::round(double) = floor(x + 0.5); the range test is done on
   // the float64 value so out-of-range / NaN never reaches an int conversion.
-  const double px = floor((double)(t0 * c.fx / t2 + c.cx) + 0.5);
-  const double py = floor((double)(t1 * c.fy / t2 + c.cy) + 0.5);
+  const double px = floor((double)(qu + c.cx) + 0.5);
+  const double py = floor((double)(qv + c.cy) + 0.5);
   const bool valid = (t2 > 0.0f) & (px >= 0.0) & (px < (double)cols) & (py >= 0.0) & (py < (double)rows);   // :77,:80
   if (!valid) return false;
   const float dp = scaled[(int)py * cols + (int)px];                     // :81
   const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
-  const float sdf = dp - sqrtf((rx * rx + ry * ry) + rz * rz);           // :86
+  const float d2 = (rx * rx + ry * ry) + rz * rz;
+  // No range guard: for d2 < 2^-96 (voxel within 4e-15 m of the camera centre; hipcc's sqrtf would rescale)
+  // the core still returns a non-negative value below 1e-14, and "dp - dist" with dp > 0.001 (the only case
+  // that survives the next test) equals dp for any dist below half an ulp of dp (>= 2.9e-11).  +inf and
+  // every finite d2 above that go through the core unchanged.
+  const float dist = sqrt_inrange(d2);
+  const float sdf = dp - dist;                                           // :86
   const double sdfd = (double)sdf;
   if (!((dp > 0.001f) & (sdfd >= -kTsdfTrunc))) return false;            // :82,:87
   // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1
@@ -151,7 +212,9 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
     const float q = (float)(sdfd / kTsdfTrunc);
     tsdf = q < 1.0f ? q : 1.0f;
   }
-  S = (S * W + tsdf) / (W + 1.0f);                                       // :93  (w == 1.0f, w * tsdf == tsdf)
+  // :93  (w == 1.0f, w * tsdf == tsdf).  W + 1 is in [1, 2^25] and the numerator is 0 or >= ~1e-17 in magnitude
+  // (|S| <= 1, tsdf is 0 or >= 3e-9): always inside the range of the unscaled division.
+  S = div_inrange(S * W + tsdf, W + 1.0f);
   W = W + 1.0f;                                                          // :94
   return true;
 }
