@@ -118,12 +118,14 @@ ER_HD float grid_coord(int i, float shift) { return (float)((double)i * kUnitLen
 // ---- A4: one voxel of IntegrateVolumeUnit against one frame, TSDFVolume.cpp:76-94 ----------------
 // Correctly rounded float32 division and square root WITHOUT the range-scaling wrapper.
 // hipcc lowers an IEEE '/' to  v_div_scale x2, v_rcp, fma, fma, mul, fma, fma, fma, v_div_fmas, v_div_fixup
-// and sqrtf to a scale / v_sqrt / +-1 ulp residual test / unscale / class-fixup sequence.  The scale, fmas and
-// fixup steps only act when an operand is denormal, tiny (|x| < 2^-103), huge or non-finite; for operands in
-// [2^-100, 2^100] they are the identity, so the bare Newton/residual core below produces the SAME bits.  A
-// timing probe on MI355X put the three divisions and the sqrt of one voxel update at 44 % of k_integrate
-// (quarter-rate transcendentals + the wrapper ops), which is why this matters.  The callers guard the range
-// and fall back to the plain operators otherwise; on the host (tests/hostcheck) the plain operators are used.
+// and sqrtf to a scale / v_sqrt / +-1 ulp residual test / unscale / class-fixup sequence.  v_div_scale only
+// acts (and v_div_fmas / v_div_fixup are only more than an fma / a move) when the denominator or its reciprocal
+// is denormal, |numerator| < ~2^-102, the exponents differ by >= 96, the quotient is denormal, or an operand is
+// 0 / inf / NaN; otherwise the bare Newton core below executes the SAME operations and returns the same bits.
+// The callers state why their operands stay inside that domain (or why the result does not matter outside);
+// tests/hip/arith_check.hip compares cores and operators on the GPU, exhaustively for sqrt.  On the host
+// (tests/hostcheck) the plain operators are used.  Measured: k_integrate 0.50 -> 0.43 ms per 50-frame launch
+// (v_rcp/v_sqrt issue at half rate on MI355X, every other f32/f64 VALU op at full rate: scripts/ubench).
 ER_HD void div2_inrange(float n0, float n1, float d, float& q0, float& q1) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
   float r = __builtin_amdgcn_rcpf(d);
@@ -165,6 +167,19 @@ ER_HD float sqrt_inrange(float x) {
 #endif
 }
 
+// TSDFVolume::round (TSDFVolume.h:70-72) of a float expression plus the image-range test of :80, in float32:
+//   p = floor( (double)x + 0.5 ),  0 <= p < lim    <=>    -0.5 <= x < lim - 0.5
+// (x + 0.5 is exact in float64 and both bounds are floats, so the two float compares decide exactly; NaN fails).
+// floor(x + 0.5) itself is NOT computed as a float sum (0.49999997f + 0.5f rounds to 1): for x >= -0.5 it is
+// floor(x) + [x - floor(x) >= 0.5], where the float difference is exact for x >= 0 and rounds monotonically
+// (to 1.0 at most) for x in [-0.5, 0).  lim_m_half = (float)lim - 0.5f.  p is only meaningful when true is returned.
+// Checked against the float64 expression for EVERY float by tests/hip/arith_check.hip.
+ER_HD bool pixel_index(float x, float lim_m_half, int& p) {
+  const float fl = floorf(x);
+  p = (int)fl + ((x - fl) >= 0.5f ? 1 : 0);
+  return (x >= -0.5f) & (x < lim_m_half);
+}
+
 // S/W are the voxel's sdf_/weight_.  Returns true if the voxel was updated.
 //
 // Same arithmetic as the reference, arranged for a SIMT machine: the projection is evaluated
@@ -181,19 +196,20 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
   const float n0 = t0 * c.fx, n1 = t1 * c.fy;
   float qu, qv;
   div2_inrange(n0, n1, t2, qu, qv);                                      // shared reciprocal of the depth
-  // Range of the unscaled sequence: depth in [1e-30, 1e30] m.  A numerator below 2^-100 gives a quotient
-  // that vanishes in "+ cx" whatever its last bits; one above 2^100 lands far outside the image either way.
-  if (!((t2 >= 1e-30f) & (t2 <= 1e30f))) {
+  // Depth outside [2^-30, 2^30] m: plain operators.  Inside, the core can only differ from '/' when
+  // |n| < 2^-100 or the quotient is denormal (then both quotients are below 2^-72 in magnitude and "+ cx" followed
+  // by pixel_index gives the same pixel: the sum is cx itself, or, for cx == 0, a value whose floor and range
+  // test do not depend on its low bits; likewise a -0 numerator yields +0 instead of -0) or when |n / t2| >= 2^95 (both land outside the image or are NaN).
+  if (!((t2 >= 0x1p-30f) & (t2 <= 0x1p30f))) {
     qu = n0 / t2;
     qv = n1 / t2;
   }
-  // :78-79  round( float expr ) with TSDFVolume::round(double) = floor(x + 0.5); the range test is done on
-  // the float64 value so out-of-range / NaN never reaches an int conversion.
-  const double px = floor((double)(qu + c.cx) + 0.5);
-  const double py = floor((double)(qv + c.cy) + 0.5);
-  const bool valid = (t2 > 0.0f) & (px >= 0.0) & (px < (double)cols) & (py >= 0.0) & (py < (double)rows);   // :77,:80
+  // :78-80  round( float expr ) and the image-range test, see pixel_index.
+  int px, py;
+  const bool vx = pixel_index(qu + c.cx, (float)cols - 0.5f, px), vy = pixel_index(qv + c.cy, (float)rows - 0.5f, py);
+  const bool valid = (t2 > 0.0f) & vx & vy;                              // :77,:80
   if (!valid) return false;
-  const float dp = scaled[(int)py * cols + (int)px];                     // :81
+  const float dp = scaled[(unsigned)(py * cols + px)];                     // :81
   const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
   const float d2 = (rx * rx + ry * ry) + rz * rz;
   // No range guard: for d2 < 2^-96 (voxel within 4e-15 m of the camera centre; hipcc's sqrtf would rescale)
@@ -202,18 +218,22 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
   // every finite d2 above that go through the core unchanged.
   const float dist = sqrt_inrange(d2);
   const float sdf = dp - dist;                                           // :86
-  const double sdfd = (double)sdf;
-  if (!((dp > 0.001f) & (sdfd >= -kTsdfTrunc))) return false;            // :82,:87
+  // :82,:87  "sdf >= -tsdf_trunc_" compares the float with the DOUBLE 0.03.  (float)0.03 = 0.0299999993 lies
+  // below 0.03 and is the float nearest to it, so for a float sdf:  sdf >= -0.03 <=> sdf >= -0.03f  and
+  // sdf < 0.03 <=> sdf <= 0.03f -- float compares, no conversion on the common path.
+  static_assert((double)0.03f < kTsdfTrunc && (double)0.030000003f > kTsdfTrunc, "float neighbours of tsdf_trunc_");
+  if (!((dp > 0.001f) & (sdf >= -0.03f))) return false;
   // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1
   // <=> min(1, q) == 1, so the (slow) float64 division is only evaluated inside the truncation band;
   // the value is identical either way.
   float tsdf = 1.0f;
-  if (sdfd < kTsdfTrunc) {
-    const float q = (float)(sdfd / kTsdfTrunc);
+  if (sdf <= 0.03f) {
+    const float q = (float)((double)sdf / kTsdfTrunc);
     tsdf = q < 1.0f ? q : 1.0f;
   }
-  // :93  (w == 1.0f, w * tsdf == tsdf).  W + 1 is in [1, 2^25] and the numerator is 0 or >= ~1e-17 in magnitude
-  // (|S| <= 1, tsdf is 0 or >= 3e-9): always inside the range of the unscaled division.
+  // :93  (w == 1.0f, w * tsdf == tsdf).  W + 1 is an integer-valued float in [1, 2^25]; the numerator is 0 or at
+  // least ~1e-17 in magnitude (|S| <= 1, |tsdf| is 0 or >= 3e-9 because |sdf| is 0 or >= ulp(0.001)) and at most
+  // 2^25: always inside the domain of the core.
   S = div_inrange(S * W + tsdf, W + 1.0f);
   W = W + 1.0f;                                                          // :94
   return true;

@@ -291,3 +291,19 @@ def test_full_config2_batching_invariance(gpu):
     assert a.sum_weight() == b.sum_weight() == c.sum_weight() > 4e9
     for v in (a, b, c):
         v.close()
+
+
+@pytest.mark.gpu
+def test_exact_arithmetic_cores_exhaustive(gpu):
+    """The voxel update replaces hipcc's IEEE '/' and sqrtf by their un-wrapped cores and the float64 pixel rounding
+    by a float32 form (er_tsdf_math.h: div2_inrange, div_inrange, sqrt_inrange, pixel_index).  tests/hip/arith_check
+    compares them ON THE GPU with the plain operators: every float for sqrt and pixel rounding (two image limits),
+    2^31 hashed operand triples per division scenario.  Zero mismatches required."""
+    import subprocess
+    import __graft_entry__ as g
+    exe = g._build_arith_check()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l.split() for l in r.stdout.strip().splitlines()]
+    assert len(lines) == 5 and all(int(l[2]) > 10 ** 9 and int(l[4]) == 0 for l in lines), r.stdout
