@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ER_HIP_LIB") or os.path.join(_HERE, "liber_hip.so")
 
 # Every symbol include/er_hip.h declares (tests/test_abi.py checks header == this list == the .so).
 SYMBOLS = [
-    "er_last_error", "er_device_count", "er_abi_version",
+    "er_last_error", "er_device_count", "er_abi_version", "er_host_alloc", "er_host_free",
     "er_tsdf_create", "er_tsdf_destroy", "er_tsdf_set_stream", "er_tsdf_synchronize",
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
     "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
@@ -20,6 +20,7 @@ SYMBOLS = [
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
+    "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces",
 ]
 
 
@@ -59,6 +60,9 @@ def lib():
     L.er_last_error.argtypes = []
     L.er_device_count.argtypes = []
     L.er_abi_version.argtypes = []
+    L.er_host_alloc.restype = vp
+    L.er_host_alloc.argtypes = [C.c_size_t]
+    L.er_host_free.argtypes = [vp]
     L.er_tsdf_create.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.POINTER(vp)]
     L.er_tsdf_destroy.argtypes = [vp]
     L.er_tsdf_set_stream.argtypes = [vp, vp]
@@ -83,6 +87,10 @@ def lib():
         L.er_icp_count_inliers.argtypes = [vp, vp, vp, C.c_double, ip]
         L.er_icp_align.argtypes = [vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, vp, ip, ip, dp]
         L.er_find_correspondence.argtypes = [vp, vp, vp, C.c_double, C.c_double, vp, C.c_int, ip, vp]
+        L.er_icp_count_inliers_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, vp]
+        L.er_icp_align_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
+        L.er_find_correspondence_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
+        L.er_icp_release_workspaces.argtypes = []
     _lib = L
     return L
 
@@ -91,6 +99,50 @@ def check(rc, what):
     if rc != 0:
         msg = lib().er_last_error()
         raise ErError("%s failed: %s" % (what, msg.decode("utf-8", "replace") if msg else "unknown error"))
+
+
+class PinnedArena:
+    """Grow-only block of page-locked host memory (er_host_alloc) handed out as numpy views.  Results written into
+    it arrive by asynchronous device-to-host copies with no staging pass; take(...) views stay valid until the next
+    reset() of the same arena."""
+
+    def __init__(self):
+        self._lib, self._p, self._cap, self._off, self._old = lib(), None, 0, 0, []
+
+    def reset(self, need_bytes):
+        self._off = 0
+        for p in self._old:
+            self._lib.er_host_free(p)
+        self._old = []
+        if need_bytes > self._cap:
+            if self._p:
+                self._lib.er_host_free(self._p)
+            self._cap = int(need_bytes * 1.25) + 4096
+            self._p = self._lib.er_host_alloc(self._cap)
+            if not self._p:
+                self._cap = 0
+                raise ErError("er_host_alloc: " + self._lib.er_last_error().decode())
+
+    def take(self, shape, dtype):
+        import numpy as np
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        off = (self._off + 63) & ~63
+        assert off + n <= self._cap, "PinnedArena.reset() was sized too small"
+        self._off = off + n
+        buf = (C.c_char * max(n, 1)).from_address(self._p + off)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self._lib.er_host_free(self._p)
+            self._p, self._cap = None, 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ptr(a):

@@ -30,6 +30,20 @@ int er_device_count(void) {
   return n;
 }
 
-int er_abi_version(void) { return 1; }
+int er_abi_version(void) { return 2; }
+
+void* er_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    er::fail("er_host_alloc: hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  return p;
+}
+
+int er_host_free(void* p) {
+  if (p) ER_HIP_TRY(hipHostFree(p));
+  return 0;
+}
 
 }  // extern "C"

@@ -11,14 +11,14 @@
 //   cell_start   int[cells+1]   uniform grid, cell edge >= the largest search radius, so an exact
 //                               nearest neighbour inside the radius lies in the 3x3x3 neighbourhood;
 //                               cell id = (z*ny + y)*nx + x, so each (z,y) row is ONE contiguous range
-//   X, match...  per-cloud scratch used when the cloud is the SOURCE of a pair
+// plus per-pair workspaces (stream, X, match, nd, pair list, sums, pinned result block) borrowed from a per-device
+// pool, so clouds are immutable and any number of pairs can be in flight.
 // Queries run in the SOURCE cloud's own cell-sorted order (thread t takes sorted[t]), so the lanes of a wave
 // walk the same few target cells together (coalesced / broadcast candidate loads); results are written back
-// by original index.  NN kernels use 8 lanes per source point (each lane scans part of the 9 cell rows, shuffle-min);
-// candidates stream from L2 as 16-byte loads:
+// by original index.  The NN search is block-cooperative (see nn_block); candidates stream from L2 as 16-byte loads:
 //   k_count_inliers   transform (float64 -> float32) + NN + count           (Registration pre-check)
-//   k_icp_nn          [apply last increment] + NN -> nn[], d2[];  k_icp_accum: point-to-plane rows -> 27+2 float64
-//                     sums (wave shuffle -> LDS -> one atomicAdd per block and sum)
+//   k_icp_iter        one ICP iteration: [apply last increment] + NN + point-to-plane rows -> 27+2 float64 sums
+//                     (wave shuffle -> LDS -> per-workgroup partial -> fixed-order final sum by the last workgroup)
 //   k_find_corr       transform points+normals + NN + distance/normal tests -> match[orig index];
 //                     k_count_blocks (+ information-matrix sums) + k_scan_blocks + k_compact = stable compaction in file order
 // Reductions and scans, not contractions: no MFMA.
@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -48,68 +49,114 @@ struct Grid {
 struct Mat12d { double m[12]; };
 struct Mat12f { float m[12]; };
 
-// Exact 1-NN of q among target points inside the 27 neighbouring cells, searched by a group of kGroup
-// consecutive lanes per query: lane `sub` scans the rows of cells sub, sub + kGroup, ... of the 9 (z,y) rows
-// (home row first; rows that cannot beat the best so far are skipped), then the group reduces (distance, index)
-// lexicographically with shuffles.  The pass is latency bound (dependent cell_start -> candidate loads).
-// float32 squared distance ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.
-// limit2 = squared search radius: callers discard anything farther, so rows of cells lying entirely beyond
-// the radius are skipped (margin 1e-4 relative for the float32 cell assignment).  All lanes of the group
-// return the same (index or -1, distance).
-#ifndef ER_ICP_GROUP
-#define ER_ICP_GROUP 2      /* measured on MI355X: 1/2/4/8 lanes per query -> NN pass 58/51/57/64 us per 253 k queries */
+// Exact 1-NN of q among target points inside the 27 neighbouring cells: float32 squared distance
+// ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.  limit2 = squared search radius:
+// callers discard anything farther, so rows of cells lying entirely beyond the radius are skipped (margin 1e-4
+// relative for the float32 cell assignment).
+//
+// Block-cooperative, two phases (one query per thread, kBlock queries per workgroup):
+//   phase 0  every thread scans the HOME row of its query (the three cells x-1..x+1 of its own (y,z) row, one
+//            contiguous range) and learns a first best distance; the eight neighbouring rows that can still hold
+//            a closer point (distance from q to the row's cell slab <= best so far) are appended to an LDS task
+//            list as (query, row) pairs;
+//   phase 1  the threads of the workgroup share the task list -- one row scan per thread and trip -- and fold the
+//            results into the query's packed (distance bits, index) key with a 64-bit LDS atomicMin, which IS the
+//            lexicographic (distance, index) minimum.
+// Why: only ~1.7 of the 8 neighbour rows survive the test for an average query, but in a SIMT loop a wave runs
+// every row that ANY of its 64 lanes needs -- practically all of them.  Compacting the surviving (query, row)
+// pairs across the workgroup removes that waste (NN pass over 253 k queries: 34 -> 21 us).  Candidates are scanned
+// kUnroll at a time (the 16-byte loads are issued together; the index is clamped to the row's last candidate,
+// whose repeat cannot change the result).
+#ifndef ER_ICP_UNROLL
+#define ER_ICP_UNROLL 4
 #endif
-constexpr int kGroup = ER_ICP_GROUP;
+constexpr int kUnroll = ER_ICP_UNROLL;
+constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // (FLT_MAX, -1)
 
-__device__ __forceinline__ int nn_search(const Grid& g, float qx, float qy, float qz, float limit2, int sub, float& best_d) {
-  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
-  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
-  int best = -1;
-  float bd = FLT_MAX;
-  const bool inside = cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
-  if (inside) {
-    const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.dim[0] - 1);
-    // distance from q to the lower / upper face of its own cell along y and z (metres)
-    const float ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell, zhi = g.cell - zlo;
-    float bound = limit2 * 1.0001f + 1e-12f;
-    if (x0 <= x1) {
-#pragma unroll 1
-      for (int it = sub; it < 9; it += kGroup) {
-        const int pass = it == 0 ? 4 : (it == 4 ? 0 : it);              // home row (dy = dz = 0) first
-        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-        const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
-        if (ey * ey + ez * ez > bound) continue;
-        const int y = iy + dy, z = iz + dz;
-        if (y < 0 || y >= g.dim[1] || z < 0 || z >= g.dim[2]) continue;
-        const int row = (z * g.dim[1] + y) * g.dim[0];
-        const int s0 = g.cell_start[row + x0], s1 = g.cell_start[row + x1 + 1];
-        for (int s = s0; s < s1; s++) {
-          const float4 p = g.pts[s];
-          const float dx = qx - p.x, dy2 = qy - p.y, dz2 = qz - p.z;
-          const float d = ((dx * dx) + dy2 * dy2) + dz2 * dz2;
-          const int idx = __float_as_int(p.w);
-          if (d < bd || (d == bd && idx < best)) {
-            bd = d;
-            best = idx;
+struct NnShared {
+  unsigned long long best[kBlock];
+  float q[3][kBlock];
+  int x01[2][kBlock];
+  int task_row[kBlock * 8];
+  unsigned char task_q[kBlock * 8];
+  int ntask;
+};
+
+__device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int x0, int x1, float qx, float qy, float qz,
+                                                       unsigned long long key) {
+  const int s0 = g.cell_start[row + x0], s1 = g.cell_start[row + x1 + 1];
+  for (int s = s0; s < s1; s += kUnroll) {
+    float4 p[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) p[u] = g.pts[min(s + u, s1 - 1)];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d = ((dx * dx) + dy * dy) + dz * dz;
+      // d >= 0, so its bit pattern orders like its value; NaN / inf patterns exceed FLT_MAX's and never win
+      const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+      key = k < key ? k : key;
+    }
+  }
+  return key;
+}
+
+// Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
+// Returns the index (or -1) and the squared distance of the nearest target point.
+__device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
+                                        float& best_d) {
+  const int tid = threadIdx.x;
+  __syncthreads();                                            // the previous call's readers are done with `sh`
+  if (tid == 0) sh.ntask = 0;
+  __syncthreads();
+  unsigned long long key = kNoHit;
+  if (active) {
+    const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
+    const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
+    const bool inside = cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
+    if (inside) {
+      const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
+      const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.dim[0] - 1);
+      if (x0 <= x1) {
+        // distance from q to the lower / upper face of its own cell along y and z (metres)
+        const float ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell, zhi = g.cell - zlo;
+        float bound = limit2 * 1.0001f + 1e-12f;
+        if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
+          key = scan_row(g, (iz * g.dim[1] + iy) * g.dim[0], x0, x1, qx, qy, qz, key);
+          bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // neighbours must beat the home row
+        }
+        sh.q[0][tid] = qx;
+        sh.q[1][tid] = qy;
+        sh.q[2][tid] = qz;
+        sh.x01[0][tid] = x0;
+        sh.x01[1][tid] = x1;
+#pragma unroll
+        for (int pass = 0; pass < 9; pass++) {
+          if (pass == 4) continue;
+          const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+          const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
+          const int y = iy + dy, z = iz + dz;
+          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && ey * ey + ez * ez <= bound) {
+            const int t = atomicAdd(&sh.ntask, 1);
+            sh.task_row[t] = (z * g.dim[1] + y) * g.dim[0];
+            sh.task_q[t] = (unsigned char)tid;
           }
         }
-        bound = fminf(bound, bd * 1.0001f + 1e-12f);                     // later rows must beat the best so far
       }
     }
   }
-  // lexicographic (distance, index) minimum over the group; -1 (nothing found) loses against any hit
-#pragma unroll
-  for (int off = 1; off < kGroup; off <<= 1) {
-    const float od = __shfl_xor(bd, off, kGroup);
-    const int oi = __shfl_xor(best, off, kGroup);
-    if (oi >= 0 && (best < 0 || od < bd || (od == bd && oi < best))) {
-      bd = od;
-      best = oi;
-    }
+  sh.best[tid] = key;
+  __syncthreads();
+  const int nt = sh.ntask;
+  for (int t = tid; t < nt; t += kBlock) {
+    const int q = sh.task_q[t];
+    const unsigned long long k = scan_row(g, sh.task_row[t], sh.x01[0][q], sh.x01[1][q], sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+    if (k != kNoHit) atomicMin(&sh.best[q], k);
   }
-  best_d = bd;
-  return best;
+  __syncthreads();
+  key = sh.best[tid];
+  best_d = __uint_as_float((unsigned)(key >> 32));
+  return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
 }
 
 // Block reduction of NV float64 values per thread: wave shuffle (64 lanes) -> LDS -> lane 0 atomics.
@@ -140,18 +187,21 @@ __device__ __forceinline__ void xform_d(const Mat12d& T, float x, float y, float
   oz = (float)(((T.m[8] * dx + T.m[9] * dy) + T.m[10] * dz) + T.m[11]);
 }
 
-// Registration pre-check, CorresApp.cpp:257-264.  kGroup lanes per source point; a fixed grid strides over the
-// points and issues ONE atomic per workgroup (one per wave serialised thousands of atomics on one word).
+// Registration pre-check, CorresApp.cpp:257-264.  A fixed grid strides over the points and issues ONE atomic per
+// workgroup (one per wave serialised thousands of atomics on one word).
 __global__ __launch_bounds__(kBlock) void k_count_inliers(const float4* __restrict__ src_sorted, int n, Mat12d T, Grid g, float radius,
                                                           double maxd2, int* __restrict__ count) {
-  const int sub = threadIdx.x % kGroup;
+  __shared__ NnShared sh;
   int local = 0;
-  for (int k = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup; k < n; k += gridDim.x * (blockDim.x / kGroup)) {
-    float qx, qy, qz, d;
-    const float4 s = src_sorted[k];
-    xform_d(T, s.x, s.y, s.z, qx, qy, qz);
-    const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
-    if (sub == 0 && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
+  for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const int k = base + (int)threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f, d;
+    if (k < n) {
+      const float4 s = src_sorted[k];
+      xform_d(T, s.x, s.y, s.z, qx, qy, qz);
+    }
+    const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
+    if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
   __shared__ int part[kBlock / 64];
@@ -181,84 +231,112 @@ __global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restric
   }
 }
 
-// One ICP iteration, part 1 (kGroup lanes per point): X <- delta * X (the previous iteration's increment,
-// float32) and correspondence estimation: nn[k] = target index kept if d^2 <= max_dist^2, else -1.
-__global__ __launch_bounds__(kBlock) void k_icp_nn(float* __restrict__ X, int n, Mat12f delta, int apply, Grid g, float radius,
-                                                   double maxd2, int* __restrict__ nn, float* __restrict__ nd) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = t / kGroup, sub = t % kGroup;
-  if (k >= n) return;
-  float sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
-  if (apply) {
-    const float x = sx, y = sy, z = sz;
-    sx = ((delta.m[0] * x + delta.m[1] * y) + delta.m[2] * z) + delta.m[3];
-    sy = ((delta.m[4] * x + delta.m[5] * y) + delta.m[6] * z) + delta.m[7];
-    sz = ((delta.m[8] * x + delta.m[9] * y) + delta.m[10] * z) + delta.m[11];
-  }
-  float d;
-  const int i = nn_search(g, sx, sy, sz, radius * radius, sub, d);   // (all lanes read X before anybody overwrites it)
-  if (sub == 0) {
+// One ICP iteration in one launch:
+//   X <- delta * X (the previous iteration's increment, float32); correspondence estimation (exact NN, kept if
+//   d^2 <= max_dist^2); the sums of TransformationEstimationPointToPlaneLLS over the kept correspondences:
+//   acc[0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
+// Reduction: thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in `partial`; k_icp_final adds
+// the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from run to run (they
+// still differ from a sequential CPU sum in the last bits).
+__global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int n, Mat12f delta, int apply, Grid g, float radius,
+                                                     double maxd2, const float* __restrict__ tgt_xyz, const float* __restrict__ tgt_nrm,
+                                                     double* __restrict__ partial) {
+  __shared__ NnShared sh;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (k < n) {
+    sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
     if (apply) {
+      const float x = sx, y = sy, z = sz;
+      sx = ((delta.m[0] * x + delta.m[1] * y) + delta.m[2] * z) + delta.m[3];
+      sy = ((delta.m[4] * x + delta.m[5] * y) + delta.m[6] * z) + delta.m[7];
+      sz = ((delta.m[8] * x + delta.m[9] * y) + delta.m[10] * z) + delta.m[11];
       X[3 * k] = sx;
       X[3 * k + 1] = sy;
       X[3 * k + 2] = sz;
     }
-    const bool keep = i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2);
-    nn[k] = keep ? i : -1;
-    nd[k] = d;
+  }
+  float d;
+  const int i = nn_block(sh, g, k < n, sx, sy, sz, radius * radius, d);
+  double v[29];
+#pragma unroll
+  for (int t = 0; t < 29; t++) v[t] = 0.0;
+  if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
+    const float dx = tgt_xyz[3 * i], dy = tgt_xyz[3 * i + 1], dz = tgt_xyz[3 * i + 2];
+    const float nx = tgt_nrm[3 * i], ny = tgt_nrm[3 * i + 1], nz = tgt_nrm[3 * i + 2];
+    v[27] = (double)d;
+    v[28] = 1.0;
+    if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
+      const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
+      const double b = (double)(nx * sz - nz * sx);
+      const double c = (double)(ny * sx - nx * sy);
+      const double dnx = nx, dny = ny, dnz = nz;
+      v[0] = a * a;  v[1] = a * b;  v[2] = a * c;  v[3] = a * dnx;  v[4] = a * dny;  v[5] = a * dnz;
+      v[6] = b * b;  v[7] = b * c;  v[8] = b * dnx; v[9] = b * dny; v[10] = b * dnz;
+      v[11] = c * c; v[12] = c * dnx; v[13] = c * dny; v[14] = c * dnz;
+      v[15] = dnx * dnx; v[16] = dnx * dny; v[17] = dnx * dnz;
+      v[18] = dny * dny; v[19] = dny * dnz;
+      v[20] = dnz * dnz;
+      const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
+      v[21] = a * e; v[22] = b * e; v[23] = c * e; v[24] = dnx * e; v[25] = dny * e; v[26] = dnz * e;
+    }
+  }
+  // workgroup partial
+  __shared__ double part[kBlock / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 29; t++) {
+    double q = v[t];
+    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
+    if (lane == 0) part[wave][t] = q;
+  }
+  __syncthreads();
+  if (threadIdx.x < 29) {
+    double q = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) q += part[w][threadIdx.x];
+    partial[(size_t)blockIdx.x * 32 + threadIdx.x] = q;
   }
 }
 
-// One ICP iteration, part 2 (one lane per point): the sums of TransformationEstimationPointToPlaneLLS.
-// acc: [0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
-__global__ __launch_bounds__(kBlock) void k_icp_accum(const float* __restrict__ X, int n, const int* __restrict__ nn,
-                                                      const float* __restrict__ nd, const float* __restrict__ tgt_xyz,
-                                                      const float* __restrict__ tgt_nrm, double* __restrict__ acc) {
-  double v[29];
-#pragma unroll
-  for (int i = 0; i < 29; i++) v[i] = 0.0;
-  // a fixed grid strides over the points: each thread folds several rows before the (expensive) 29-value reduction
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    const int i = nn[k];
-    if (i >= 0) {
-      const float sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
-      const float dx = tgt_xyz[3 * i], dy = tgt_xyz[3 * i + 1], dz = tgt_xyz[3 * i + 2];
-      const float nx = tgt_nrm[3 * i], ny = tgt_nrm[3 * i + 1], nz = tgt_nrm[3 * i + 2];
-      v[27] += (double)nd[k];
-      v[28] += 1.0;
-      if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
-        const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
-        const double b = (double)(nx * sz - nz * sx);
-        const double c = (double)(ny * sx - nx * sy);
-        const double dnx = nx, dny = ny, dnz = nz;
-        v[0] += a * a;  v[1] += a * b;  v[2] += a * c;  v[3] += a * dnx;  v[4] += a * dny;  v[5] += a * dnz;
-        v[6] += b * b;  v[7] += b * c;  v[8] += b * dnx; v[9] += b * dny; v[10] += b * dnz;
-        v[11] += c * c; v[12] += c * dnx; v[13] += c * dny; v[14] += c * dnz;
-        v[15] += dnx * dnx; v[16] += dnx * dny; v[17] += dnx * dnz;
-        v[18] += dny * dny; v[19] += dny * dnz;
-        v[20] += dnz * dnz;
-        const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-        v[21] += a * e; v[22] += b * e; v[23] += c * e; v[24] += dnx * e; v[25] += dny * e; v[26] += dnz * e;
-      }
-    }
+// Second half of the reduction: ONE workgroup adds the per-workgroup partial vectors in a fixed order (8 strided
+// slices per value, then the slices in order) -> acc[0..28].  A separate launch on purpose: finishing inside
+// k_icp_iter ("last workgroup done" ticket + __threadfence) costs an L2 write-back per workgroup on this
+// multi-XCD part (measured: 100-600 us per launch instead of ~25).
+__global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__ partial, int nparts, double* __restrict__ acc) {
+  const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;   // 32 x 8
+  double q = 0.0;
+  if (val < 29) {
+#pragma unroll 8
+    for (int b = slice; b < nparts; b += 8) q += partial[(size_t)b * 32 + val];
   }
-  block_reduce_atomic<29>(v, acc);
+  __shared__ double fin[8][32];
+  fin[slice][val] = q;
+  __syncthreads();
+  if (threadIdx.x < 29) {
+    double r = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 8; sl++) r += fin[sl][threadIdx.x];
+    acc[threadIdx.x] = r;
+  }
 }
 
 // getFitnessScore-style diagnostic: squared NN distance of final * source inside the search radius (-1 = none).
 __global__ __launch_bounds__(kBlock) void k_fitness_nn(const float4* __restrict__ src_sorted, int n, Mat12f M, Grid g, float radius,
                                                        float* __restrict__ nd) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = t / kGroup, sub = t % kGroup;
-  if (k >= n) return;
-  const float4 s = src_sorted[k];
-  const float x = s.x, y = s.y, z = s.z;
-  const float qx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
-  const float qy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
-  const float qz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+  __shared__ NnShared sh;
+  const int k = blockIdx.x * kBlock + threadIdx.x;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (k < n) {
+    const float4 s = src_sorted[k];
+    const float x = s.x, y = s.y, z = s.z;
+    qx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
+    qy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
+    qz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+  }
   float d;
-  const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
-  if (sub == 0) nd[k] = (i >= 0 && (double)d <= (double)radius * (double)radius) ? d : -1.0f;
+  const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
+  if (k < n) nd[k] = (i >= 0 && (double)d <= (double)radius * (double)radius) ? d : -1.0f;
 }
 
 __global__ __launch_bounds__(kBlock) void k_fitness_sum(const float* __restrict__ nd, int n, double* __restrict__ acc) {
@@ -271,20 +349,22 @@ __global__ __launch_bounds__(kBlock) void k_fitness_sum(const float* __restrict_
   block_reduce_atomic<2>(v, acc);
 }
 
-// FindCorrespondence, CorresApp.cpp:144-161 (kGroup lanes per source point): match[original index] = NN index
+// FindCorrespondence, CorresApp.cpp:144-161: match[original index] = NN index
 // passing the distance and normal tests, else -1.
 __global__ __launch_bounds__(kBlock) void k_find_corr(const float4* __restrict__ src_sorted, const float* __restrict__ nrm, int n,
                                                       Mat12d T, Grid g, const float* __restrict__ tgt_nrm, float radius,
                                                       double dist2, double normal_cos, int* __restrict__ match) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = t / kGroup, sub = t % kGroup;                  // q = position in the source's cell-sorted order
+  __shared__ NnShared sh;
+  const int q = blockIdx.x * kBlock + threadIdx.x;             // q = position in the source's cell-sorted order
+  float qx = 0.f, qy = 0.f, qz = 0.f, d;
+  int k = 0;
+  if (q < n) {
+    const float4 s = src_sorted[q];
+    k = __float_as_int(s.w);                                   // original (file-order) index of this source point
+    xform_d(T, s.x, s.y, s.z, qx, qy, qz);
+  }
+  const int i = nn_block(sh, g, q < n, qx, qy, qz, radius * radius, d);
   if (q >= n) return;
-  const float4 s = src_sorted[q];
-  const int k = __float_as_int(s.w);                           // original (file-order) index of this source point
-  float qx, qy, qz, d;
-  xform_d(T, s.x, s.y, s.z, qx, qy, qz);
-  const int i = nn_search(g, qx, qy, qz, radius * radius, sub, d);
-  if (sub != 0) return;
   int m = -1;
   if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {         // :154
     const double nx = nrm[3 * k], ny = nrm[3 * k + 1], nz = nrm[3 * k + 2];
@@ -444,18 +524,399 @@ struct er_cloud_s {
   int* cell_start = nullptr;
   Grid grid{};
   float radius_cap = 0.f;       // largest search radius the grid supports
-  hipStream_t stream = nullptr;
-  // scratch for the SOURCE role
-  std::mutex src_mutex;
-  float *X = nullptr, *nd = nullptr;
-  int *match = nullptr, *block_count = nullptr, *block_offset = nullptr, *pairs = nullptr, *icount = nullptr;
-  double* acc = nullptr;
-  int nblocks = 0;              // one lane per point
-  int gblocks = 0;              // kGroup lanes per point
 };
 
 namespace {
 Grid grid_of(const er_cloud_s* c) { return c->grid; }
+
+// ---- workspaces --------------------------------------------------------------------------------
+// Everything a pair needs while it is being processed (clouds are immutable and shared): one HIP stream, the
+// per-source-point scratch and a small pinned block the kernels' results are copied into.  Workspaces live in
+// a per-device pool: a single-pair call borrows one, a *_batch call borrows several and software-pipelines
+// its pairs over them so that one pair's host round trip (6x6 solve, convergence test) overlaps the kernels
+// of the others.  The pool is never freed behind the HIP runtime's back (er_icp_release_workspaces does it).
+struct HostBlock {
+  double acc[kAcc];
+  int count[4];
+};
+
+struct IcpWs {
+  int device = 0;
+  size_t cap = 0;               // points
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  float *X = nullptr, *nd = nullptr;
+  int *match = nullptr, *block_count = nullptr, *block_offset = nullptr, *pairs = nullptr, *icount = nullptr;
+  double* acc = nullptr;
+  double* partial = nullptr;    // one 32-double vector per workgroup of k_icp_iter
+  HostBlock* host = nullptr;    // pinned
+  int* stage = nullptr;         // pinned, cap * 2 ints: pair lists on their way to pageable caller memory (lazy)
+  size_t stage_cap = 0;
+};
+
+void ws_free_buffers(IcpWs* w) {
+  void* ptrs[] = {w->X, w->nd, w->match, w->block_count, w->block_offset, w->pairs, w->partial};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  w->partial = nullptr;
+  w->X = w->nd = nullptr;
+  w->match = w->block_count = w->block_offset = w->pairs = nullptr;
+  w->cap = 0;
+}
+
+void ws_destroy(IcpWs* w) {
+  if (!w) return;
+  (void)hipSetDevice(w->device);
+  if (w->stream) (void)hipStreamSynchronize(w->stream);
+  ws_free_buffers(w);
+  if (w->icount) (void)hipFree(w->icount);
+  if (w->acc) (void)hipFree(w->acc);
+  if (w->host) (void)hipHostFree(w->host);
+  if (w->stage) (void)hipHostFree(w->stage);
+  if (w->ev) (void)hipEventDestroy(w->ev);
+  if (w->stream) (void)hipStreamDestroy(w->stream);
+  delete w;
+}
+
+int ws_reserve(IcpWs* w, size_t n) {
+  n = std::max<size_t>(n, 1);
+  if (n <= w->cap) return 0;
+  ER_HIP_TRY(hipStreamSynchronize(w->stream));
+  ws_free_buffers(w);
+  const size_t cap = n + n / 8;
+  const size_t nb = (cap + kBlock - 1) / kBlock;
+  ER_HIP_TRY(hipMalloc((void**)&w->X, cap * 3 * sizeof(float)));
+  ER_HIP_TRY(hipMalloc((void**)&w->nd, cap * sizeof(float)));
+  ER_HIP_TRY(hipMalloc((void**)&w->match, cap * sizeof(int)));
+  ER_HIP_TRY(hipMalloc((void**)&w->pairs, cap * 2 * sizeof(int)));
+  ER_HIP_TRY(hipMalloc((void**)&w->block_count, nb * sizeof(int)));
+  ER_HIP_TRY(hipMalloc((void**)&w->block_offset, nb * sizeof(int)));
+  ER_HIP_TRY(hipMalloc((void**)&w->partial, nb * 32 * sizeof(double)));
+  w->cap = cap;
+  return 0;
+}
+
+struct WsPool {
+  std::mutex mu;
+  std::vector<IcpWs*> idle;
+};
+WsPool& pool() {
+  static WsPool* p = new WsPool();      // intentionally leaked: must outlive every static destructor
+  return *p;
+}
+
+IcpWs* ws_acquire(int device, size_t n) {
+  IcpWs* w = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(pool().mu);
+    auto& v = pool().idle;
+    for (size_t i = 0; i < v.size(); i++)
+      if (v[i]->device == device) {
+        w = v[i];
+        v.erase(v.begin() + (long)i);
+        break;
+      }
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    er::fail("hipSetDevice(%d) failed", device);
+    return nullptr;
+  }
+  if (!w) {
+    w = new IcpWs();
+    w->device = device;
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void**)&w->icount, 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&w->acc, kAcc * sizeof(double)) != hipSuccess ||
+        hipHostMalloc((void**)&w->host, sizeof(HostBlock), hipHostMallocDefault) != hipSuccess) {
+      er::fail("ICP workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
+      ws_destroy(w);
+      return nullptr;
+    }
+  }
+  if (ws_reserve(w, n)) {
+    ws_destroy(w);
+    return nullptr;
+  }
+  return w;
+}
+
+void ws_release(IcpWs* w) {
+  if (!w) return;
+  std::lock_guard<std::mutex> lock(pool().mu);
+  pool().idle.push_back(w);
+}
+
+struct WsSet {                  // RAII: the workspaces of one API call
+  std::vector<IcpWs*> ws;
+  ~WsSet() {
+    for (IcpWs* w : ws) {
+      if (w->stream) (void)hipStreamSynchronize(w->stream);
+      ws_release(w);
+    }
+  }
+  int acquire(int device, size_t n, int count) {
+    for (int i = 0; i < count; i++) {
+      IcpWs* w = ws_acquire(device, n);
+      if (!w) return 1;
+      ws.push_back(w);
+    }
+    return 0;
+  }
+};
+
+static int lanes_cfg() { const char* e = getenv("ER_ICP_LANES"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }
+#define kLanes (lanes_cfg())
+
+int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
+int gblocks_of(int n) { return nblocks_of(n); }                // NN kernels: one query per thread
+
+int check_pair(er_cloud_t src, er_cloud_t tgt, double radius, const char* who) {
+  if (!src || !tgt) return er::fail("%s: NULL cloud", who);
+  if (src->device != tgt->device) return er::fail("%s: source and target live on different devices", who);
+  if (!(radius > 0.0) || radius > (double)tgt->radius_cap * (1.0 + 1e-6))
+    return er::fail("%s: search radius %g exceeds the target's grid cell %g (er_cloud_create grid_cell)", who, radius, (double)tgt->radius_cap);
+  return 0;
+}
+
+// ---- Registration pre-check ---------------------------------------------------------------------
+int count_enqueue(IcpWs* w, er_cloud_t src, er_cloud_t tgt, const double* T, double max_dist) {
+  Mat12d M;
+  for (int q = 0; q < 12; q++) M.m[q] = T[q];
+  ER_HIP_TRY(hipMemsetAsync(w->icount, 0, sizeof(int), w->stream));
+  if (src->n > 0 && tgt->n > 0) {
+    hipLaunchKernelGGL(k_count_inliers, dim3(std::min(gblocks_of(src->n), 2048)), dim3(kBlock), 0, w->stream, src->sorted, src->n, M,
+                       grid_of(tgt), (float)max_dist, max_dist * max_dist, w->icount);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[0], w->icount, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  return 0;
+}
+
+// ---- ICP as a resumable job ---------------------------------------------------------------------
+struct AlignJob {
+  er_cloud_t src = nullptr, tgt = nullptr;
+  float fin[16], delta[16], prev_delta[16];
+  int iter = 0;
+  bool conv = false;
+  double prev_mse = DBL_MAX, fitness = DBL_MAX;
+  enum { ITERATING, FITNESS, DONE } state = ITERATING;
+};
+
+struct AlignParams {
+  double max_dist, eps;
+  int max_iter, stop_rule;
+  bool want_fitness;
+};
+
+int align_enqueue_iteration(IcpWs* w, AlignJob& j, const AlignParams& P) {
+  const int n = j.src->n;
+  memcpy(j.prev_delta, j.delta, sizeof j.delta);
+  Mat12f D;
+  for (int q = 0; q < 12; q++) D.m[q] = j.delta[q];
+  if (n > 0 && j.tgt->n > 0) {
+    hipLaunchKernelGGL(k_icp_iter, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->X, n, D, j.iter > 0 ? 1 : 0, grid_of(j.tgt),
+                       (float)P.max_dist, P.max_dist * P.max_dist, j.tgt->xyz, j.tgt->nrm, w->partial);
+    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(kBlock), 0, w->stream, w->partial, nblocks_of(n), w->acc);
+    ER_HIP_TRY(hipGetLastError());
+  } else {
+    ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
+  }
+  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  return 0;
+}
+
+int align_enqueue_fitness(IcpWs* w, AlignJob& j, const AlignParams& P) {
+  const int n = j.src->n;
+  Mat12f F;
+  for (int q = 0; q < 12; q++) F.m[q] = j.fin[q];
+  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
+  if (n > 0 && j.tgt->n > 0) {
+    hipLaunchKernelGGL(k_fitness_nn, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, j.src->sorted, n, F, grid_of(j.tgt), (float)P.max_dist, w->nd);
+    hipLaunchKernelGGL(k_fitness_sum, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->nd, n, w->acc);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  j.state = AlignJob::FITNESS;
+  return 0;
+}
+
+int align_start(IcpWs* w, AlignJob& j, er_cloud_t src, er_cloud_t tgt, const float* guess, const AlignParams& P) {
+  j = AlignJob();
+  j.src = src;
+  j.tgt = tgt;
+  memcpy(j.fin, guess, sizeof j.fin);                        // final_transformation_ = guess
+  bool ident = true;
+  for (int i = 0; i < 16; i++) ident = ident && guess[i] == ((i % 5 == 0) ? 1.f : 0.f);
+  for (int i = 0; i < 16; i++) j.delta[i] = j.prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
+  Mat12f G;
+  for (int q = 0; q < 12; q++) G.m[q] = guess[q];
+  if (src->n > 0) {
+    hipLaunchKernelGGL(k_init_x, dim3(nblocks_of(src->n)), dim3(kBlock), 0, w->stream, src->sorted, w->X, src->n, G, ident ? 0 : 1);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  return align_enqueue_iteration(w, j, P);
+}
+
+// The host half of a step: wait for the lane's event, decide, enqueue what follows.
+int align_advance(IcpWs* w, AlignJob& j, const AlignParams& P) {
+  ER_HIP_TRY(hipEventSynchronize(w->ev));
+  const double* acc = w->host->acc;
+  if (j.state == AlignJob::FITNESS) {
+    j.fitness = acc[1] > 0 ? acc[0] / acc[1] : DBL_MAX;
+    j.state = AlignJob::DONE;
+    return 0;
+  }
+  bool stop = false;
+  const double cnt = acc[28];
+  double A[6][6], b[6], x[6];
+  if (cnt < 3.0) {                                           // min_number_correspondences_
+    j.conv = false;
+    stop = true;
+  } else {
+    int t = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
+    for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
+    if (!solve6x6(A, b, x)) {
+      j.conv = false;
+      stop = true;
+    }
+  }
+  if (!stop) {
+    construct_increment(x, j.delta);
+    mul4f(j.delta, j.fin, j.fin);                            // final = increment * final
+    ++j.iter;
+    if (j.iter >= P.max_iter) {
+      j.conv = true;
+      stop = true;
+    } else if (P.stop_rule == 0) {                           // PCL 1.7 DefaultConvergenceCriteria
+      const double cos_angle = 0.5 * (double)(j.delta[0] + j.delta[5] + j.delta[10] - 1.f);
+      const double tr2 = (double)(j.delta[3] * j.delta[3] + j.delta[7] * j.delta[7] + j.delta[11] * j.delta[11]);
+      const double cur = acc[27] / cnt;
+      if (cos_angle >= 1.0 - P.eps && tr2 <= P.eps) {
+        j.conv = true;
+        stop = true;
+      } else if (std::fabs(cur - j.prev_mse) < 1e-12) {
+        j.conv = true;
+        stop = true;
+      }
+      j.prev_mse = cur;
+    } else {                                                 // PCL <= 1.6
+      float s = 0.f;
+      for (int i = 0; i < 16; i++) s += j.delta[i] - j.prev_delta[i];
+      if (std::fabs((double)s) < P.eps) {
+        j.conv = true;
+        stop = true;
+      }
+    }
+  }
+  if (!stop) return align_enqueue_iteration(w, j, P);
+  if (P.want_fitness) return align_enqueue_fitness(w, j, P);
+  j.state = AlignJob::DONE;
+  return 0;
+}
+
+// ---- FindCorrespondence ---------------------------------------------------------------------------
+int corr_enqueue(IcpWs* w, er_cloud_t src, er_cloud_t tgt, const double* T, double dist, double normal_cos, bool want_info) {
+  const int n = src->n;
+  Mat12d M;
+  for (int q = 0; q < 12; q++) M.m[q] = T[q];
+  const int nb = nblocks_of(n);
+  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
+  hipLaunchKernelGGL(k_find_corr, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, src->sorted, src->nrm, n, M, grid_of(tgt), tgt->nrm,
+                     (float)dist, dist * dist, normal_cos, w->match);
+  hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kBlock), 0, w->stream, w->match, src->xyz, n, w->block_count, w->acc, want_info ? 1 : 0);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, w->stream, w->block_count, w->block_offset, nb, w->icount + 1);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kBlock), 0, w->stream, w->match, n, w->block_offset, w->pairs, n);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[1], w->icount + 1, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, 10 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  return 0;
+}
+
+bool is_pinned_host(const void* p) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();                                 // plain malloc memory: "invalid value", not an error for us
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+
+// Stage 2 of a pair (after the lane's kernel event): the pair count is known; start the copy of exactly that many
+// pairs -- straight into the caller's buffer when it is page-locked (er_host_alloc), else into the lane's pinned
+// staging block -- and expand the information matrix.  *staged tells corr_finish whether a host memcpy remains.
+int corr_start_copy(IcpWs* w, int* pairs_host, int capacity, int* n_pairs, double* info36, bool* staged) {
+  ER_HIP_TRY(hipEventSynchronize(w->ev));
+  const int total = w->host->count[1];
+  *n_pairs = total;
+  *staged = false;
+  const int ncopy = std::min(total, capacity);
+  if (ncopy > 0) {
+    int* dst = pairs_host;
+    if (!is_pinned_host(pairs_host)) {
+      if (w->stage_cap < w->cap) {
+        if (w->stage) (void)hipHostFree(w->stage);
+        w->stage = nullptr;
+        w->stage_cap = 0;
+        ER_HIP_TRY(hipHostMalloc((void**)&w->stage, w->cap * 2 * sizeof(int), hipHostMallocDefault));
+        w->stage_cap = w->cap;
+      }
+      dst = w->stage;
+      *staged = true;
+    }
+    ER_HIP_TRY(hipMemcpyAsync(dst, w->pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, w->stream));
+    ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  }
+  if (info36) {
+    // sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203)
+    const double* acc = w->host->acc;
+    double* I = info36;
+    memset(I, 0, 36 * sizeof(double));
+    const double N = acc[9];
+    I[0 * 6 + 0] = I[1 * 6 + 1] = I[2 * 6 + 2] = N;
+    I[0 * 6 + 4] = I[4 * 6 + 0] = acc[2];      //  sum 2sz
+    I[0 * 6 + 5] = I[5 * 6 + 0] = -acc[1];     // -sum 2sy
+    I[1 * 6 + 3] = I[3 * 6 + 1] = -acc[2];
+    I[1 * 6 + 5] = I[5 * 6 + 1] = acc[0];      //  sum 2sx
+    I[2 * 6 + 3] = I[3 * 6 + 2] = acc[1];
+    I[2 * 6 + 4] = I[4 * 6 + 2] = -acc[0];
+    I[3 * 6 + 3] = acc[3];
+    I[4 * 6 + 4] = acc[4];
+    I[5 * 6 + 5] = acc[5];
+    I[3 * 6 + 4] = I[4 * 6 + 3] = acc[6];
+    I[3 * 6 + 5] = I[5 * 6 + 3] = acc[7];
+    I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
+  }
+  return 0;
+}
+
+// Stage 3: the copy has landed.
+int corr_finish(IcpWs* w, int* pairs_host, int capacity, int total, bool staged) {
+  const int ncopy = std::min(total, capacity);
+  if (ncopy > 0) {
+    ER_HIP_TRY(hipEventSynchronize(w->ev));
+    if (staged) memcpy(pairs_host, w->stage, (size_t)ncopy * 2 * sizeof(int));
+  }
+  return total > capacity ? er::fail("er_find_correspondence: %d pairs exceed the capacity %d", total, capacity) : 0;
+}
+
+int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double radius, const char* who, int* device, size_t* max_n) {
+  if (n < 0 || (n > 0 && (!src || !tgt))) return er::fail("%s: bad arguments", who);
+  *device = n > 0 && src[0] ? src[0]->device : 0;
+  *max_n = 1;
+  for (int i = 0; i < n; i++) {
+    if (check_pair(src[i], tgt[i], radius, who)) return 1;
+    if (src[i]->device != *device) return er::fail("%s: all pairs of one batch must live on one device", who);
+    *max_n = std::max(*max_n, (size_t)src[i]->n);
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -524,8 +985,6 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
     }
   }
   const size_t nn = (size_t)std::max(n, 1);
-  c->nblocks = (int)((nn + kBlock - 1) / kBlock);
-  c->gblocks = (int)((nn * kGroup + kBlock - 1) / kBlock);
 #define ER_CALLOC(ptr, bytes)                                                                 \
   do {                                                                                        \
     hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                       \
@@ -535,22 +994,10 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
       return 1;                                                                               \
     }                                                                                         \
   } while (0)
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-    delete c;
-    return er::fail("er_cloud_create: hipStreamCreate failed");
-  }
   ER_CALLOC(c->xyz, nn * 3 * sizeof(float));
   ER_CALLOC(c->nrm, nn * 3 * sizeof(float));
   ER_CALLOC(c->sorted, nn * sizeof(float4));
   ER_CALLOC(c->cell_start, ((size_t)ncell + 1) * sizeof(int));
-  ER_CALLOC(c->X, nn * 3 * sizeof(float));
-  ER_CALLOC(c->match, nn * sizeof(int));
-  ER_CALLOC(c->nd, nn * sizeof(float));
-  ER_CALLOC(c->pairs, nn * 2 * sizeof(int));
-  ER_CALLOC(c->block_count, (size_t)c->nblocks * sizeof(int));
-  ER_CALLOC(c->block_offset, (size_t)c->nblocks * sizeof(int));
-  ER_CALLOC(c->icount, 4 * sizeof(int));
-  ER_CALLOC(c->acc, kAcc * sizeof(double));
 #undef ER_CALLOC
   bool ok = true;
   if (n > 0) {
@@ -577,40 +1024,88 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
 int er_cloud_destroy(er_cloud_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->xyz, c->nrm, c->sorted, c->cell_start, c->X, c->nd, c->match, c->pairs, c->block_count, c->block_offset, c->icount, c->acc};
+  void* ptrs[] = {c->xyz, c->nrm, c->sorted, c->cell_start};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
 
 int er_cloud_size(er_cloud_t c) { return c ? c->n : -1; }
 
-static int check_pair(er_cloud_t src, er_cloud_t tgt, double radius, const char* who) {
-  if (!src || !tgt) return er::fail("%s: NULL cloud", who);
-  if (src->device != tgt->device) return er::fail("%s: source and target live on different devices", who);
-  if (!(radius > 0.0) || radius > (double)tgt->radius_cap * (1.0 + 1e-6))
-    return er::fail("%s: search radius %g exceeds the target's grid cell %g (er_cloud_create grid_cell)", who, radius, (double)tgt->radius_cap);
+int er_icp_release_workspaces(void) {
+  std::vector<IcpWs*> all;
+  {
+    std::lock_guard<std::mutex> lock(pool().mu);
+    all.swap(pool().idle);
+  }
+  for (IcpWs* w : all) ws_destroy(w);
+  return 0;
+}
+
+int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double max_dist, int* counts) {
+  int device;
+  size_t max_n;
+  if (n > 0 && (!T || !counts)) return er::fail("er_icp_count_inliers_batch: NULL argument");
+  if (batch_prologue(n, src, tgt, max_dist, "er_icp_count_inliers", &device, &max_n)) return 1;
+  if (n == 0) return 0;
+  WsSet set;
+  const int lanes = std::min(n, kLanes);
+  if (set.acquire(device, 1, lanes)) return 1;               // the pre-check needs no per-point scratch
+  for (int i = 0; i < n + lanes; i++) {
+    IcpWs* w = set.ws[(size_t)(i % lanes)];
+    if (i >= lanes) {
+      ER_HIP_TRY(hipEventSynchronize(w->ev));
+      counts[i - lanes] = w->host->count[0];
+    }
+    if (i < n && count_enqueue(w, src[i], tgt[i], T + (size_t)i * 16, max_dist)) return 1;
+  }
   return 0;
 }
 
 int er_icp_count_inliers(er_cloud_t src, er_cloud_t tgt, const double T[16], double max_dist, int* count) {
   if (!T || !count) return er::fail("er_icp_count_inliers: NULL argument");
-  if (check_pair(src, tgt, max_dist, "er_icp_count_inliers")) return 1;
-  ER_HIP_TRY(hipSetDevice(src->device));
-  std::lock_guard<std::mutex> lock(src->src_mutex);
-  Mat12d M;
-  for (int q = 0; q < 12; q++) M.m[q] = T[q];
-  ER_HIP_TRY(hipMemsetAsync(src->icount, 0, sizeof(int), src->stream));
-  if (src->n > 0 && tgt->n > 0) {
-    hipLaunchKernelGGL(k_count_inliers, dim3(std::min(src->gblocks, 2048)), dim3(kBlock), 0, src->stream, src->sorted, src->n, M, grid_of(tgt),
-                       (float)max_dist, max_dist * max_dist, src->icount);
-    ER_HIP_TRY(hipGetLastError());
+  return er_icp_count_inliers_batch(1, &src, &tgt, T, max_dist, count);
+}
+
+int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const float* guess, double max_dist, int max_iter,
+                       double transformation_epsilon, int stop_rule, float* out, int* iterations, int* converged, double* fitness) {
+  int device;
+  size_t max_n;
+  if (n > 0 && (!guess || !out)) return er::fail("er_icp_align: NULL argument");
+  if (batch_prologue(n, src, tgt, max_dist, "er_icp_align", &device, &max_n)) return 1;
+  if (n == 0) return 0;
+  const AlignParams P{max_dist, transformation_epsilon, max_iter, stop_rule, fitness != nullptr};
+  WsSet set;
+  const int lanes = std::min(n, kLanes);
+  if (set.acquire(device, max_n, lanes)) return 1;
+  std::vector<AlignJob> job((size_t)lanes);
+  std::vector<int> which((size_t)lanes, -1);
+  int next = 0, done = 0;
+  for (int l = 0; l < lanes; l++) {
+    which[(size_t)l] = next;
+    if (align_start(set.ws[(size_t)l], job[(size_t)l], src[next], tgt[next], guess + (size_t)next * 16, P)) return 1;
+    next++;
   }
-  ER_HIP_TRY(hipMemcpyAsync(count, src->icount, sizeof(int), hipMemcpyDeviceToHost, src->stream));
-  ER_HIP_TRY(hipStreamSynchronize(src->stream));
+  // round robin over the lanes: every lane always has work queued, so waiting on one never idles the GPU
+  for (int l = 0; done < n; l = (l + 1) % lanes) {
+    const int i = which[(size_t)l];
+    if (i < 0) continue;
+    AlignJob& j = job[(size_t)l];
+    if (align_advance(set.ws[(size_t)l], j, P)) return 1;
+    if (j.state != AlignJob::DONE) continue;
+    memcpy(out + (size_t)i * 16, j.fin, sizeof j.fin);
+    if (iterations) iterations[i] = j.iter;
+    if (converged) converged[i] = j.conv ? 1 : 0;
+    if (fitness) fitness[i] = j.fitness;
+    done++;
+    which[(size_t)l] = -1;
+    if (next < n) {
+      which[(size_t)l] = next;
+      if (align_start(set.ws[(size_t)l], j, src[next], tgt[next], guess + (size_t)next * 16, P)) return 1;
+      next++;
+    }
+  }
   return 0;
 }
 
@@ -618,137 +1113,61 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
                  double transformation_epsilon, int stop_rule, float out[16], int* iterations, int* converged,
                  double* fitness) {
   if (!guess || !out) return er::fail("er_icp_align: NULL argument");
-  if (check_pair(src, tgt, max_dist, "er_icp_align")) return 1;
-  ER_HIP_TRY(hipSetDevice(src->device));
-  std::lock_guard<std::mutex> lock(src->src_mutex);
-  const int n = src->n;
-  float fin[16];
-  memcpy(fin, guess, sizeof fin);                          // final_transformation_ = guess
-  bool ident = true;
-  for (int i = 0; i < 16; i++) ident = ident && guess[i] == ((i % 5 == 0) ? 1.f : 0.f);
-  Mat12f G;
-  for (int q = 0; q < 12; q++) G.m[q] = guess[q];
-  if (n > 0) {
-    hipLaunchKernelGGL(k_init_x, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->sorted, src->X, n, G, ident ? 0 : 1);
-    ER_HIP_TRY(hipGetLastError());
-  }
-  float delta[16], prev_delta[16];
-  for (int i = 0; i < 16; i++) delta[i] = prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
-  int iter = 0;
-  bool conv = false;
-  double prev_mse = DBL_MAX;
-  const double maxd2 = max_dist * max_dist;
-  const Grid g = grid_of(tgt);
-  for (;;) {
-    memcpy(prev_delta, delta, sizeof delta);
-    Mat12f D;
-    for (int q = 0; q < 12; q++) D.m[q] = delta[q];
-    double acc[kAcc];
-    ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
-    if (n > 0 && tgt->n > 0) {
-      hipLaunchKernelGGL(k_icp_nn, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->X, n, D, iter > 0 ? 1 : 0, g,
-                         (float)max_dist, maxd2, src->match, src->nd);
-      hipLaunchKernelGGL(k_icp_accum, dim3(std::min(src->nblocks, 256)), dim3(kBlock), 0, src->stream, src->X, n, src->match, src->nd, tgt->xyz,
-                         tgt->nrm, src->acc);
-      ER_HIP_TRY(hipGetLastError());
+  return er_icp_align_batch(1, &src, &tgt, guess, max_dist, max_iter, transformation_epsilon, stop_rule, out, iterations, converged,
+                            fitness);
+}
+
+int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist, double normal_cos,
+                                 int* const* pairs_host, const int* capacity, int* n_pairs, double* info36) {
+  int device;
+  size_t max_n;
+  if (n > 0 && (!T || !n_pairs || !pairs_host || !capacity)) return er::fail("er_find_correspondence: NULL argument");
+  if (batch_prologue(n, src, tgt, dist, "er_find_correspondence", &device, &max_n)) return 1;
+  if (n == 0) return 0;
+  for (int i = 0; i < n; i++)
+    if (capacity[i] > 0 && !pairs_host[i]) return er::fail("er_find_correspondence: NULL pair buffer for pair %d", i);
+  WsSet set;
+  const int lanes = std::min(n, kLanes);
+  if (set.acquire(device, max_n, lanes)) return 1;
+  // per lane: IDLE -> KERNELS (search + compaction queued) -> COPY (pair list on its way to the host) -> IDLE
+  enum { IDLE, KERNELS, COPY };
+  struct Lane { int state = IDLE, pair = -1; bool staged = false; };
+  std::vector<Lane> lane((size_t)lanes);
+  int next = 0, done = 0, rc = 0;
+  for (int l = 0; done < n; l = (l + 1) % lanes) {
+    Lane& L = lane[(size_t)l];
+    IcpWs* w = set.ws[(size_t)l];
+    if (L.state == COPY) {
+      if (corr_finish(w, pairs_host[L.pair], capacity[L.pair], n_pairs[L.pair], L.staged)) rc = 1;   // keep draining the other lanes
+      L.state = IDLE;
+      done++;
+    } else if (L.state == KERNELS) {
+      const int k = L.pair;
+      if (corr_start_copy(w, pairs_host[k], capacity[k], &n_pairs[k], info36 ? info36 + (size_t)k * 36 : nullptr, &L.staged)) return 1;
+      L.state = COPY;
+      continue;                                              // the lane's buffers stay busy until the copy is collected
     }
-    ER_HIP_TRY(hipMemcpyAsync(acc, src->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, src->stream));
-    ER_HIP_TRY(hipStreamSynchronize(src->stream));
-    const double cnt = acc[28];
-    if (cnt < 3.0) { conv = false; break; }                // min_number_correspondences_
-    double A[6][6], b[6], x[6];
-    int t = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
-    for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
-    if (!solve6x6(A, b, x)) { conv = false; break; }
-    construct_increment(x, delta);
-    mul4f(delta, fin, fin);                                // final = increment * final
-    ++iter;
-    if (iter >= max_iter) { conv = true; break; }
-    if (stop_rule == 0) {                                  // PCL 1.7 DefaultConvergenceCriteria
-      const double cos_angle = 0.5 * (double)(delta[0] + delta[5] + delta[10] - 1.f);
-      const double tr2 = (double)(delta[3] * delta[3] + delta[7] * delta[7] + delta[11] * delta[11]);
-      if (cos_angle >= 1.0 - transformation_epsilon && tr2 <= transformation_epsilon) { conv = true; break; }
-      const double cur = acc[27] / cnt;
-      if (std::fabs(cur - prev_mse) < 1e-12) { conv = true; break; }
-      prev_mse = cur;
-    } else {                                               // PCL <= 1.6
-      float s = 0.f;
-      for (int i = 0; i < 16; i++) s += delta[i] - prev_delta[i];
-      if (std::fabs((double)s) < transformation_epsilon) { conv = true; break; }
+    if (L.state == IDLE && next < n) {
+      const int k = next++;
+      if (src[k]->n == 0 || tgt[k]->n == 0) {
+        n_pairs[k] = 0;
+        if (info36) memset(info36 + (size_t)k * 36, 0, 36 * sizeof(double));
+        done++;
+        continue;
+      }
+      if (corr_enqueue(w, src[k], tgt[k], T + (size_t)k * 16, dist, normal_cos, info36 != nullptr)) return 1;
+      L.pair = k;
+      L.state = KERNELS;
     }
   }
-  memcpy(out, fin, sizeof fin);
-  if (iterations) *iterations = iter;
-  if (converged) *converged = conv ? 1 : 0;
-  if (fitness) {
-    Mat12f F;
-    for (int q = 0; q < 12; q++) F.m[q] = fin[q];
-    double acc[2] = {0, 0};
-    ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
-    if (n > 0 && tgt->n > 0) {
-      hipLaunchKernelGGL(k_fitness_nn, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->sorted, n, F, g, (float)max_dist, src->nd);
-      hipLaunchKernelGGL(k_fitness_sum, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->nd, n, src->acc);
-      ER_HIP_TRY(hipGetLastError());
-    }
-    ER_HIP_TRY(hipMemcpyAsync(acc, src->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, src->stream));
-    ER_HIP_TRY(hipStreamSynchronize(src->stream));
-    *fitness = acc[1] > 0 ? acc[0] / acc[1] : DBL_MAX;
-  }
-  return 0;
+  return rc;
 }
 
 int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], double dist, double normal_cos,
                            int* pairs_host, int capacity, int* n_pairs, double* info36) {
   if (!T || !n_pairs || (capacity > 0 && !pairs_host)) return er::fail("er_find_correspondence: NULL argument");
-  if (check_pair(src, tgt, dist, "er_find_correspondence")) return 1;
-  ER_HIP_TRY(hipSetDevice(src->device));
-  std::lock_guard<std::mutex> lock(src->src_mutex);
-  const int n = src->n;
-  Mat12d M;
-  for (int q = 0; q < 12; q++) M.m[q] = T[q];
-  *n_pairs = 0;
-  if (info36) memset(info36, 0, 36 * sizeof(double));
-  if (n == 0 || tgt->n == 0) return 0;
-  ER_HIP_TRY(hipMemsetAsync(src->acc, 0, kAcc * sizeof(double), src->stream));
-  hipLaunchKernelGGL(k_find_corr, dim3(src->gblocks), dim3(kBlock), 0, src->stream, src->sorted, src->nrm, n, M, grid_of(tgt),
-                     tgt->nrm, (float)dist, dist * dist, normal_cos, src->match);
-  hipLaunchKernelGGL(k_count_blocks, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->match, src->xyz, n, src->block_count,
-                     src->acc, info36 ? 1 : 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, src->stream, src->block_count, src->block_offset, src->nblocks, src->icount + 1);
-  hipLaunchKernelGGL(k_compact, dim3(src->nblocks), dim3(kBlock), 0, src->stream, src->match, n, src->block_offset, src->pairs, n);
-  ER_HIP_TRY(hipGetLastError());
-  int total = 0;
-  double acc[10];
-  ER_HIP_TRY(hipMemcpyAsync(&total, src->icount + 1, sizeof(int), hipMemcpyDeviceToHost, src->stream));
-  ER_HIP_TRY(hipMemcpyAsync(acc, src->acc, sizeof acc, hipMemcpyDeviceToHost, src->stream));
-  ER_HIP_TRY(hipStreamSynchronize(src->stream));
-  *n_pairs = total;
-  const int ncopy = std::min(total, capacity);
-  if (ncopy > 0) {
-    ER_HIP_TRY(hipMemcpyAsync(pairs_host, src->pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, src->stream));
-    ER_HIP_TRY(hipStreamSynchronize(src->stream));
-  }
-  if (info36) {
-    // sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203)
-    double* I = info36;
-    const double N = acc[9];
-    I[0 * 6 + 0] = I[1 * 6 + 1] = I[2 * 6 + 2] = N;
-    I[0 * 6 + 4] = I[4 * 6 + 0] = acc[2];      //  sum 2sz
-    I[0 * 6 + 5] = I[5 * 6 + 0] = -acc[1];     // -sum 2sy
-    I[1 * 6 + 3] = I[3 * 6 + 1] = -acc[2];
-    I[1 * 6 + 5] = I[5 * 6 + 1] = acc[0];      //  sum 2sx
-    I[2 * 6 + 3] = I[3 * 6 + 2] = acc[1];
-    I[2 * 6 + 4] = I[4 * 6 + 2] = -acc[0];
-    I[3 * 6 + 3] = acc[3];
-    I[4 * 6 + 4] = acc[4];
-    I[5 * 6 + 5] = acc[5];
-    I[3 * 6 + 4] = I[4 * 6 + 3] = acc[6];
-    I[3 * 6 + 5] = I[5 * 6 + 3] = acc[7];
-    I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
-  }
-  return total > capacity ? er::fail("er_find_correspondence: %d pairs exceed the capacity %d", total, capacity) : 0;
+  int* const bufs[1] = {pairs_host};
+  return er_find_correspondence_batch(1, &src, &tgt, T, dist, normal_cos, bufs, &capacity, n_pairs, info36);
 }
 
 }  // extern "C"

@@ -216,69 +216,100 @@ struct App {
 
   bool Blacklisted(const FramedTransformation& t) const { return blacklist_.count(t.id1) || blacklist_.count(t.id2); }
 
+  // The reference's two loops are "#pragma omp parallel for" over the pair list (CorresApp.cpp:121,220).  Here each
+  // GPU takes the pairs i with i % gpus == g (one host thread per GPU) and hands them to the *_batch entry points
+  // in chunks; inside a chunk the library pipelines the pairs over several streams.
+  static constexpr int kChunk = 64;
+
   bool Registration() {                                                // CorresApp.cpp:212-319
     registration_ = true;
     printf("Registration with dist %.6f, num %d and ratio %.6f\n", reg_dist_, reg_num_, reg_ratio_);
     int nprocessed = 0;
     bool ok = true;
-#pragma omp parallel for num_threads(gpus_ * 2) schedule(dynamic)
-    for (int i = 0; i < (int)corres_traj_.size(); i++) {
-      FramedTransformation& ft = corres_traj_[(size_t)i];
-      const int g = i % gpus_;
-      if (Blacklisted(ft)) {
-#pragma omp atomic
-        nprocessed++;
-        ft.frame = -1;
-        printf("Blacklist pair <%d, %d> ... \n", ft.id1, ft.id2);
-        continue;
-      }
-      if (ft.frame == -1) {
-#pragma omp atomic
-        nprocessed++;
-        continue;
-      }
-      er_cloud_t pcd0 = pointclouds_[(size_t)g][(size_t)ft.id1], pcd1 = pointclouds_[(size_t)g][(size_t)ft.id2];
-      int cnt = 0;
-      if (er_icp_count_inliers(pcd1, pcd0, ft.T, reg_dist_, &cnt) != 0) {   // :249-264
-        fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
-#pragma omp atomic write
-        ok = false;
-        continue;
-      }
-      const double r1 = (double)cnt / (double)er_cloud_size(pcd0), r2 = (double)cnt / (double)er_cloud_size(pcd1);
-      const bool accept = (cnt >= reg_num_ || (r1 > reg_ratio_ && r2 > reg_ratio_));   // :267
-      printf("    <%d, %d> : %d inliers with ratio %.2f(%d) and %.2f(%d) ... %s\n", ft.id1, ft.id2, cnt, r1, er_cloud_size(pcd0), r2,
-             er_cloud_size(pcd1), accept ? "accept." : "reject.");
-      if (!accept) {
-        ft.frame = -1;
-#pragma omp atomic
-        nprocessed++;
-        continue;
-      }
-      ft.frame = cnt;
-      if (redux_) {                                                    // :283-293
-        auto it = redux_map_.find(GetReduxIndex(ft.id1, ft.id2));
-        if (it != redux_map_.end()) {
-          memcpy(ft.T, redux_traj_[(size_t)it->second].T, sizeof ft.T);
-#pragma omp atomic
+#pragma omp parallel for num_threads(gpus_) schedule(static, 1) reduction(+ : nprocessed)
+    for (int g = 0; g < gpus_; g++) {
+      std::vector<int> live;
+      for (int i = g; i < (int)corres_traj_.size(); i += gpus_) {
+        FramedTransformation& ft = corres_traj_[(size_t)i];
+        if (Blacklisted(ft)) {
+          nprocessed++;
+          ft.frame = -1;
+          printf("Blacklist pair <%d, %d> ... \n", ft.id1, ft.id2);
+          continue;
+        }
+        if (ft.frame == -1) {
           nprocessed++;
           continue;
         }
+        live.push_back(i);
       }
-      float guess[16], fin[16];
-      for (int q = 0; q < 16; q++) guess[q] = (float)ft.T[q];          // transformation_.cast<float>(), :306
-      int iters = 0, conv = 0;
-      double fitness = 0;
-      if (er_icp_align(pcd1, pcd0, guess, reg_dist_, 20, 1e-6, stop_rule_, fin, &iters, &conv, &fitness) != 0) {   // :295-306
-        fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
+      for (size_t c0 = 0; c0 < live.size(); c0 += kChunk) {
+        const int m = (int)std::min<size_t>(kChunk, live.size() - c0);
+        std::vector<er_cloud_t> src((size_t)m), tgt((size_t)m);
+        std::vector<double> T((size_t)m * 16);
+        std::vector<int> cnt((size_t)m, 0);
+        for (int k = 0; k < m; k++) {
+          const FramedTransformation& ft = corres_traj_[(size_t)live[c0 + (size_t)k]];
+          tgt[(size_t)k] = pointclouds_[(size_t)g][(size_t)ft.id1];    // pcd0 = target, pcd1 = source (:238,:250)
+          src[(size_t)k] = pointclouds_[(size_t)g][(size_t)ft.id2];
+          memcpy(&T[(size_t)k * 16], ft.T, sizeof ft.T);
+        }
+        if (er_icp_count_inliers_batch(m, src.data(), tgt.data(), T.data(), reg_dist_, cnt.data()) != 0) {   // :249-264
+          fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
 #pragma omp atomic write
-        ok = false;
-        continue;
+          ok = false;
+          continue;
+        }
+        std::vector<int> todo;
+        for (int k = 0; k < m; k++) {
+          FramedTransformation& ft = corres_traj_[(size_t)live[c0 + (size_t)k]];
+          const int n0 = er_cloud_size(tgt[(size_t)k]), n1 = er_cloud_size(src[(size_t)k]);
+          const double r1 = (double)cnt[(size_t)k] / (double)n0, r2 = (double)cnt[(size_t)k] / (double)n1;
+          const bool accept = (cnt[(size_t)k] >= reg_num_ || (r1 > reg_ratio_ && r2 > reg_ratio_));   // :267
+          printf("    <%d, %d> : %d inliers with ratio %.2f(%d) and %.2f(%d) ... %s\n", ft.id1, ft.id2, cnt[(size_t)k], r1, n0, r2, n1,
+                 accept ? "accept." : "reject.");
+          if (!accept) {
+            ft.frame = -1;
+            nprocessed++;
+            continue;
+          }
+          ft.frame = cnt[(size_t)k];
+          if (redux_) {                                                // :283-293
+            auto it = redux_map_.find(GetReduxIndex(ft.id1, ft.id2));
+            if (it != redux_map_.end()) {
+              memcpy(ft.T, redux_traj_[(size_t)it->second].T, sizeof ft.T);
+              nprocessed++;
+              continue;
+            }
+          }
+          todo.push_back(k);
+        }
+        const int a = (int)todo.size();
+        if (a == 0) continue;
+        std::vector<er_cloud_t> asrc((size_t)a), atgt((size_t)a);
+        std::vector<float> guess((size_t)a * 16), fin((size_t)a * 16);
+        std::vector<int> iters((size_t)a, 0), conv((size_t)a, 0);
+        std::vector<double> fitness((size_t)a, 0.0);
+        for (int q = 0; q < a; q++) {
+          const int k = todo[(size_t)q];
+          asrc[(size_t)q] = src[(size_t)k];
+          atgt[(size_t)q] = tgt[(size_t)k];
+          for (int e = 0; e < 16; e++) guess[(size_t)q * 16 + (size_t)e] = (float)T[(size_t)k * 16 + (size_t)e];   // transformation_.cast<float>(), :306
+        }
+        if (er_icp_align_batch(a, asrc.data(), atgt.data(), guess.data(), reg_dist_, 20, 1e-6, stop_rule_, fin.data(), iters.data(),
+                               conv.data(), fitness.data()) != 0) {    // :295-306
+          fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
+#pragma omp atomic write
+          ok = false;
+          continue;
+        }
+        for (int q = 0; q < a; q++) {
+          FramedTransformation& ft = corres_traj_[(size_t)live[c0 + (size_t)todo[(size_t)q]]];
+          printf("    <%d, %d> : ICP fitness score is %.6f (%d iterations)\n", ft.id1, ft.id2, fitness[(size_t)q], iters[(size_t)q]);
+          for (int e = 0; e < 16; e++) ft.T[e] = (double)fin[(size_t)q * 16 + (size_t)e];   // getFinalTransformation().cast<double>(), :312
+          nprocessed++;
+        }
       }
-      printf("    <%d, %d> : ICP fitness score is %.6f (%d iterations)\n", ft.id1, ft.id2, fitness, iters);
-      for (int q = 0; q < 16; q++) ft.T[q] = (double)fin[q];           // getFinalTransformation().cast<double>(), :312
-#pragma omp atomic
-      nprocessed++;
     }
     printf("%d / %d\n", nprocessed, (int)corres_traj_.size());
     return ok;
@@ -295,42 +326,65 @@ struct App {
       }
     }
     bool ok = true;
-#pragma omp parallel for num_threads(gpus_ * 2) schedule(dynamic)
-    for (int i = 0; i < (int)corres_traj_.size(); i++) {
-      FramedTransformation& ft = corres_traj_[(size_t)i];
-      const int g = i % gpus_;
-      if (Blacklisted(ft)) continue;
-      if (ft.frame == -1) continue;
-      printf("Processing pair <%d, %d>\n", ft.id1, ft.id2);
-      er_cloud_t pcd0 = pointclouds_[(size_t)g][(size_t)ft.id1], pcd1 = pointclouds_[(size_t)g][(size_t)ft.id2];
-      const int cap = std::max(er_cloud_size(pcd1), 1);
-      std::vector<int> pairs((size_t)cap * 2);
-      int n = 0;
-      double info[36];
-      if (er_find_correspondence(pcd1, pcd0, ft.T, dist_thresh_, normal_thresh_, pairs.data(), cap, &n, output_information_ ? info : nullptr) != 0) {
-        fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
-#pragma omp atomic write
-        ok = false;
-        continue;
+    omp_set_max_active_levels(2);                                      // the corres_*.txt writers below nest inside the per-GPU threads
+#pragma omp parallel for num_threads(gpus_) schedule(static, 1)
+    for (int g = 0; g < gpus_; g++) {
+      std::vector<int> live;
+      for (int i = g; i < (int)corres_traj_.size(); i += gpus_) {
+        const FramedTransformation& ft = corres_traj_[(size_t)i];
+        if (Blacklisted(ft) || ft.frame == -1) continue;
+        live.push_back(i);
       }
-      printf("    <%d, %d> : Corresponce number is %d, ratio is %.2f(%d)\n", ft.id1, ft.id2, n, (double)n / (double)ft.frame, ft.frame);
-      if ((double)n / (double)ft.frame < 0.5) {                        // :164-171
-        printf("    <%d, %d> : Reduced too much!!\n", ft.id1, ft.id2);
-        ft.frame = reg_num_ > 0 ? -1 : n;
-      } else {
-        ft.frame = n;
-      }
-      if (save_corres_) {                                              // :175-184
-        char fn[1024];
-        snprintf(fn, sizeof fn, "%scorres_%d_%d.txt", m_pDirName.c_str(), ft.id1, ft.id2);
-        if (FILE* f = fopen(fn, "w")) {
-          for (int k = 0; k < n; k++) fprintf(f, "%d %d\n", pairs[2 * (size_t)k], pairs[2 * (size_t)k + 1]);
-          fclose(f);
+      for (size_t c0 = 0; c0 < live.size(); c0 += kChunk) {
+        const int m = (int)std::min<size_t>(kChunk, live.size() - c0);
+        std::vector<er_cloud_t> src((size_t)m), tgt((size_t)m);
+        std::vector<double> T((size_t)m * 16), info((size_t)m * 36, 0.0);
+        std::vector<std::vector<int>> pairs((size_t)m);
+        std::vector<int*> bufs((size_t)m);
+        std::vector<int> cap((size_t)m), n((size_t)m, 0);
+        for (int k = 0; k < m; k++) {
+          const FramedTransformation& ft = corres_traj_[(size_t)live[c0 + (size_t)k]];
+          printf("Processing pair <%d, %d>\n", ft.id1, ft.id2);
+          tgt[(size_t)k] = pointclouds_[(size_t)g][(size_t)ft.id1];
+          src[(size_t)k] = pointclouds_[(size_t)g][(size_t)ft.id2];
+          memcpy(&T[(size_t)k * 16], ft.T, sizeof ft.T);
+          cap[(size_t)k] = std::max(er_cloud_size(src[(size_t)k]), 1);
+          pairs[(size_t)k].resize((size_t)cap[(size_t)k] * 2);
+          bufs[(size_t)k] = pairs[(size_t)k].data();
         }
-      }
-      if (output_information_) {                                       // :186-208
-        corres_info_[(size_t)i].frame = ft.frame;
-        memcpy(corres_info_[(size_t)i].info, info, sizeof info);
+        if (er_find_correspondence_batch(m, src.data(), tgt.data(), T.data(), dist_thresh_, normal_thresh_, bufs.data(), cap.data(), n.data(),
+                                         output_information_ ? info.data() : nullptr) != 0) {
+          fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
+#pragma omp atomic write
+          ok = false;
+          continue;
+        }
+#pragma omp parallel for num_threads(8) schedule(dynamic)
+        for (int k = 0; k < m; k++) {
+          const int i = live[c0 + (size_t)k];
+          FramedTransformation& ft = corres_traj_[(size_t)i];
+          const int nk = n[(size_t)k];
+          printf("    <%d, %d> : Corresponce number is %d, ratio is %.2f(%d)\n", ft.id1, ft.id2, nk, (double)nk / (double)ft.frame, ft.frame);
+          if ((double)nk / (double)ft.frame < 0.5) {                   // :164-171
+            printf("    <%d, %d> : Reduced too much!!\n", ft.id1, ft.id2);
+            ft.frame = reg_num_ > 0 ? -1 : nk;
+          } else {
+            ft.frame = nk;
+          }
+          if (save_corres_) {                                          // :175-184
+            char fn[1024];
+            snprintf(fn, sizeof fn, "%scorres_%d_%d.txt", m_pDirName.c_str(), ft.id1, ft.id2);
+            if (FILE* f = fopen(fn, "w")) {
+              const std::vector<int>& pl = pairs[(size_t)k];
+              for (int q = 0; q < nk; q++) fprintf(f, "%d %d\n", pl[2 * (size_t)q], pl[2 * (size_t)q + 1]);
+              fclose(f);
+            }
+          }
+          if (output_information_) {                                   // :186-208
+            corres_info_[(size_t)i].frame = ft.frame;
+            memcpy(corres_info_[(size_t)i].info, &info[(size_t)k * 36], 36 * sizeof(double));
+          }
+        }
       }
     }
     return ok;

@@ -78,6 +78,62 @@ def find_correspondence(src, tgt, T, dist, normal_cos=0.8660, want_info=False):
     return pairs[:m.value].copy(), (info.reshape(6, 6) if want_info else None)
 
 
+def _handles(clouds):
+    return (C.c_void_p * len(clouds))(*[c._h for c in clouds])
+
+
+def count_inliers_batch(srcs, tgts, Ts, max_dist):
+    """The pre-check of every pair of one Registration loop in one call (pairs pipelined over several streams)."""
+    n = len(srcs)
+    if n == 0:
+        return np.zeros(0, np.int32)
+    Tm = np.ascontiguousarray(Ts, np.float64).reshape(n, 16)
+    out = np.zeros(n, np.int32)
+    _ffi.check(srcs[0]._lib.er_icp_count_inliers_batch(n, _handles(srcs), _handles(tgts), _ffi.ptr(Tm), float(max_dist), _ffi.ptr(out)),
+               "er_icp_count_inliers_batch")
+    return out
+
+
+def icp_align_batch(srcs, tgts, guesses, max_dist=0.03, max_iter=20, eps=1e-6, stop_rule=0, want_fitness=False):
+    """icp.align for a list of pairs.  Returns (float32 [n,4,4], iterations [n], converged [n], fitness [n] or None)."""
+    n = len(srcs)
+    g = np.ascontiguousarray(guesses, np.float32).reshape(n, 16)
+    out = np.empty((n, 16), np.float32)
+    it, cv = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    fit = np.zeros(n, np.float64) if want_fitness else None
+    if n:
+        _ffi.check(srcs[0]._lib.er_icp_align_batch(n, _handles(srcs), _handles(tgts), _ffi.ptr(g), float(max_dist), int(max_iter), float(eps),
+                                                   int(stop_rule), _ffi.ptr(out), _ffi.ptr(it), _ffi.ptr(cv),
+                                                   _ffi.ptr(fit) if want_fitness else None), "er_icp_align_batch")
+    return out.reshape(n, 4, 4), it, cv.astype(bool), fit
+
+
+_arena = None
+
+
+def find_correspondence_batch(srcs, tgts, Ts, dist, normal_cos=0.8660, want_info=False, copy=True):
+    """FindCorrespondence for a list of pairs.  Returns ([pairs int32 [m_i,2]], info [n,6,6] or None).
+    The lists are written into a process-wide page-locked arena (no staging copy on the way from the GPU);
+    copy=False returns views into it, valid until the next find_correspondence_batch call."""
+    global _arena
+    n = len(srcs)
+    if n == 0:
+        return [], (np.zeros((0, 6, 6)) if want_info else None)
+    if _arena is None:
+        _arena = _ffi.PinnedArena()
+    Tm = np.ascontiguousarray(Ts, np.float64).reshape(n, 16)
+    _arena.reset(sum(max(s.n, 1) * 8 + 64 for s in srcs))
+    bufs = [_arena.take((max(s.n, 1), 2), np.int32) for s in srcs]
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    cap = np.array([s.n for s in srcs], np.int32)
+    m = np.zeros(n, np.int32)
+    info = np.zeros((n, 36), np.float64) if want_info else None
+    _ffi.check(srcs[0]._lib.er_find_correspondence_batch(n, _handles(srcs), _handles(tgts), _ffi.ptr(Tm), float(dist), float(normal_cos),
+                                                         ptrs, _ffi.ptr(cap), _ffi.ptr(m), _ffi.ptr(info) if want_info else None),
+               "er_find_correspondence_batch")
+    return [(b[:k].copy() if copy else b[:k]) for b, k in zip(bufs, m)], (info.reshape(n, 6, 6) if want_info else None)
+
+
 class CorresApp:
     """CCorresApp (CorresApp.h:12-82).  Defaults from the constructor, CorresApp.cpp:8-24."""
 
@@ -107,6 +163,7 @@ class CorresApp:
         self.stop_rule = 0
         self.out_dir = "."           # reg_output.* go to the CWD in the reference (CorresApp.cpp:323,326)
         self.icp_iterations_ = {}
+        self.keep_correspondences_ = True   # also keep the lists in memory (tests, small runs)
 
     # ---- CorresApp.h:64-81 -----------------------------------------------------------------------
     def GetVolumeOverlapRatio(self, trans):
@@ -191,15 +248,23 @@ class CorresApp:
 
     # ---- CorresApp.cpp:212-319 -------------------------------------------------------------------
     def Registration(self):
+        """Both steps run over the whole pair list at once (the reference's loop is an OpenMP parallel for):
+        pre-check of every live pair, then ICP of every accepted pair."""
         self.registration_ = True
+        live = []
         for ft in self.corres_traj_:
             if ft.id1 in self.blacklist_ or ft.id2 in self.blacklist_:
                 ft.frame = -1
                 continue
             if ft.frame == -1:
                 continue
-            pcd0, pcd1 = self.pointclouds_[ft.id1], self.pointclouds_[ft.id2]
-            cnt = count_inliers(pcd1, pcd0, ft.T, self.reg_dist_)                        # :249-264
+            live.append(ft)
+        P = self.pointclouds_
+        cnts = count_inliers_batch([P[ft.id2] for ft in live], [P[ft.id1] for ft in live], [ft.T for ft in live], self.reg_dist_)   # :249-264
+        todo = []
+        for ft, cnt in zip(live, cnts):
+            cnt = int(cnt)
+            pcd0, pcd1 = P[ft.id1], P[ft.id2]
             r1 = float(cnt) / float(max(len(pcd0), 1)) if len(pcd0) else float("inf")
             r2 = float(cnt) / float(max(len(pcd1), 1)) if len(pcd1) else float("inf")
             accept = cnt >= self.reg_num_ or (r1 > self.reg_ratio_ and r2 > self.reg_ratio_)   # :267
@@ -215,34 +280,41 @@ class CorresApp:
                 if it is not None:
                     ft.T = self.redux_traj_[it].T.copy()
                     continue
-            final, iters, conv, _ = icp_align(pcd1, pcd0, ft.T.astype(np.float32), self.reg_dist_, 20, 1e-6, self.stop_rule)   # :295-306
+            todo.append(ft)
+        finals, iters, _, _ = icp_align_batch([P[ft.id2] for ft in todo], [P[ft.id1] for ft in todo],
+                                              [ft.T.astype(np.float32) for ft in todo], self.reg_dist_, 20, 1e-6, self.stop_rule)   # :295-306
+        for ft, final, it in zip(todo, finals, iters):
             ft.T = final.astype(np.float64)                                              # :312
-            self.icp_iterations_[(ft.id1, ft.id2)] = iters
+            self.icp_iterations_[(ft.id1, ft.id2)] = int(it)
 
     # ---- CorresApp.cpp:112-210 -------------------------------------------------------------------
     def FindCorrespondence(self):
         if self.output_information_:
             self.corres_info_ = [formats.FramedInformation(t.id1, t.id2, t.frame, np.zeros((6, 6))) for t in self.corres_traj_]
         self.correspondences_ = {}
-        for idx, ft in enumerate(self.corres_traj_):
-            if ft.id1 in self.blacklist_ or ft.id2 in self.blacklist_:
-                continue
-            if ft.frame == -1:
-                continue
-            pcd0, pcd1 = self.pointclouds_[ft.id1], self.pointclouds_[ft.id2]
-            corres, info = find_correspondence(pcd1, pcd0, ft.T, self.dist_thresh_, self.normal_thresh_, self.output_information_)
-            n = corres.shape[0]
-            ratio = float(n) / float(ft.frame) if ft.frame != 0 else float("inf")
-            if ratio < 0.5:                                                              # :164-171
-                ft.frame = -1 if self.reg_num_ > 0 else n
-            else:
-                ft.frame = n
-            if self.save_corres_:                                                        # :175-184
-                formats.save_corres("%scorres_%d_%d.txt" % (self.m_pDirName, ft.id1, ft.id2), corres)
-            self.correspondences_[(ft.id1, ft.id2)] = corres
-            if self.output_information_:                                                 # :186-208
-                self.corres_info_[idx].frame = ft.frame
-                self.corres_info_[idx].info = info
+        live = [(idx, ft) for idx, ft in enumerate(self.corres_traj_)
+                if not (ft.id1 in self.blacklist_ or ft.id2 in self.blacklist_) and ft.frame != -1]
+        P = self.pointclouds_
+        for c0 in range(0, len(live), 64):                       # chunks bound the page-locked result arena
+            chunk = live[c0:c0 + 64]
+            lists, infos = find_correspondence_batch([P[ft.id2] for _, ft in chunk], [P[ft.id1] for _, ft in chunk],
+                                                     [ft.T for _, ft in chunk], self.dist_thresh_, self.normal_thresh_,
+                                                     self.output_information_, copy=False)
+            for k, (idx, ft) in enumerate(chunk):
+                corres = lists[k]
+                n = corres.shape[0]
+                ratio = float(n) / float(ft.frame) if ft.frame != 0 else float("inf")
+                if ratio < 0.5:                                                          # :164-171
+                    ft.frame = -1 if self.reg_num_ > 0 else n
+                else:
+                    ft.frame = n
+                if self.save_corres_:                                                    # :175-184
+                    formats.save_corres("%scorres_%d_%d.txt" % (self.m_pDirName, ft.id1, ft.id2), corres)
+                if self.keep_correspondences_:
+                    self.correspondences_[(ft.id1, ft.id2)] = corres.copy()
+                if self.output_information_:                                             # :186-208
+                    self.corres_info_[idx].frame = ft.frame
+                    self.corres_info_[idx].info = infos[k]
 
     # ---- CorresApp.cpp:321-328 -------------------------------------------------------------------
     def Finalize(self):

@@ -20,6 +20,7 @@
 #ifndef ER_HIP_H_
 #define ER_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -34,6 +35,11 @@ extern "C" {
 const char* er_last_error(void);
 int er_device_count(void);                       /* number of visible HIP devices (0 if none) */
 int er_abi_version(void);
+
+/* Page-locked host memory.  Every "host" pointer of this ABI may be ordinary (pageable) memory; result buffers
+ * that come from er_host_alloc are written by asynchronous device-to-host copies without a staging pass. */
+void* er_host_alloc(size_t bytes);               /* NULL on failure (see er_last_error) */
+int er_host_free(void* p);
 
 /* ------------------------------------------------------------ path A: TSDF ---- */
 typedef struct er_tsdf_s* er_tsdf_t;
@@ -136,6 +142,24 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
  * information matrix over the untransformed source points. pairs_host holds 2*capacity ints. */
 int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], double dist, double normal_cos,
                            int* pairs_host, int capacity, int* n_pairs, double* info36);
+
+/* The reference runs its two loops over the pair list with "#pragma omp parallel for" (CorresApp.cpp:121,220).
+ * The *_batch forms take the whole list of one loop: n pairs (src[i], tgt[i]) on ONE device, per-pair inputs and
+ * outputs as arrays (T: n*16 doubles, guess/out: n*16 floats, info36: n*36 doubles, ...).  Results are identical
+ * to n single calls; internally the pairs are software-pipelined over a few independent streams/workspaces so
+ * that one pair's host round trip (6x6 solve, convergence test, result copy) overlaps the kernels of the others.
+ * The single-pair functions above are the n == 1 case of these.  Clouds are immutable: any number of host threads
+ * may use the same cloud concurrently (each call borrows its workspaces from a per-device pool). */
+int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double max_dist, int* counts);
+int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const float* guess, double max_dist, int max_iter,
+                       double transformation_epsilon, int stop_rule, float* out, int* iterations, int* converged,
+                       double* fitness);
+int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist,
+                                 double normal_cos, int* const* pairs_host, const int* capacity, int* n_pairs,
+                                 double* info36);
+
+/* Frees the pooled ICP workspaces (streams, scratch, pinned blocks).  Optional; call when no ICP call is running. */
+int er_icp_release_workspaces(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,29 @@
+"""Phase timings of the batched ICP flow for the ER_ICP_LANES given in the environment (A/B helper)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from elasticreconstruction_amd import synth
+from elasticreconstruction_amd.icp import Cloud, count_inliers_batch, find_correspondence_batch, icp_align_batch
+frag = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
+clouds = []
+for i in range(4):
+    x, n = synth.sample_fragment(frag, 600000, seed=500 + i)
+    P = synth.perturbation(600 + i, 1.0, 0.01) if i else np.eye(4)
+    Pi = np.linalg.inv(P)
+    x, n = (x @ Pi[:3, :3].T + Pi[:3, 3]).astype(np.float32), (n @ Pi[:3, :3].T).astype(np.float32)
+    clouds.append((Cloud(x, n, 0.03, 0), P))
+pairs = []
+for k in range(40):
+    a, b = k % 4, (k + 1 + (k // 4) % 3) % 4
+    if a == b:
+        b = (b + 1) % 4
+    pairs.append((a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(700 + k, 2.0, 0.02)))
+srcs, tgts = [clouds[b][0] for _, b, _ in pairs], [clouds[a][0] for a, _, _ in pairs]
+Ts = [T for _, _, T in pairs]
+for rep in range(2):
+    t0 = time.perf_counter(); c = count_inliers_batch(srcs, tgts, Ts, 0.03)
+    t1 = time.perf_counter(); F, it, _, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for T in Ts])
+    t2 = time.perf_counter(); L, _ = find_correspondence_batch(srcs, tgts, [f.astype(np.float64) for f in F], 0.015, 0.866, True, copy=False)
+    t3 = time.perf_counter()
+print("lanes %s: count %.2f ms  align %.2f ms (%d its)  corr %.2f ms  -> %.0f pairs/s" % (
+    os.environ.get("ER_ICP_LANES", "default"), (t1 - t0) * 1e3, (t2 - t1) * 1e3, int(it.sum()), (t3 - t2) * 1e3, 40 / (t3 - t0)))

@@ -134,3 +134,51 @@ def test_corres_app_pipeline_matches_reference_flow(gpu, tmp_path):
         assert out[k].frame == po.shape[0] and po.shape[0] >= 0.5 * cnt
         assert np.allclose(info[k].info, io, rtol=1e-9, atol=1e-3) and info[k].frame == out[k].frame
     assert not os.path.exists(d + "corres_0_2.txt") and not os.path.exists(d + "corres_2_3.txt")
+
+
+def test_batch_entry_points_equal_single_calls(gpu):
+    """er_*_batch pipelines pairs over several streams/workspaces; the results must be those of the single-pair calls
+    (integers and index lists exact; transforms bit-identical: same kernels, same float64 atomics order is NOT
+    guaranteed, so 1e-6), for more pairs than lanes, mixed sizes, a rejected pair and shared clouds, and from
+    several host threads at once (clouds are immutable and shareable)."""
+    import threading
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch, icp_align_batch
+    data = [make_pair(n=60000 + 9000 * i, rot=1.0 + 0.3 * i, trans=0.01, seed=40 + i) for i in range(3)]
+    cl = [(Cloud(x0, n0, 0.03), Cloud(x1, n1, 0.03), P) for (x0, n0), (x1, n1), P in data]
+    empty = Cloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.03)
+    srcs, tgts, Ts = [], [], []
+    for k in range(11):                                   # > kLanes pairs, clouds reused by several pairs
+        tgt, src, P = cl[k % 3]
+        srcs.append(src); tgts.append(tgt)
+        Ts.append(P @ synth.perturbation(80 + k, 0.8, 0.006) if k != 4 else synth.perturbation(3, 40, 1.0))
+    srcs.append(empty); tgts.append(cl[0][0]); Ts.append(np.eye(4))
+    cb = count_inliers_batch(srcs, tgts, Ts, 0.03)
+    assert [int(c) for c in cb] == [count_inliers(s, t, T, 0.03) for s, t, T in zip(srcs, tgts, Ts)]
+    assert cb[4] < 2000 and cb[-1] == 0
+    Fb, itb, cvb, fitb = icp_align_batch(srcs, tgts, [T.astype(np.float32) for T in Ts], want_fitness=True)
+    for k, (s, t, T) in enumerate(zip(srcs, tgts, Ts)):
+        F1, it1, cv1, fit1 = icp_align(s, t, T.astype(np.float32), want_fitness=True)
+        assert (int(itb[k]), bool(cvb[k])) == (it1, cv1), "pair %d" % k
+        assert np.abs(Fb[k] - F1).max() <= 1e-6
+        assert fitb[k] == pytest.approx(fit1, rel=1e-9) or (fitb[k] > 1e300 and fit1 > 1e300)
+    lists, infos = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in Fb], 0.015, 0.8660, want_info=True)
+    for k, (s, t) in enumerate(zip(srcs, tgts)):
+        p1, i1 = find_correspondence(s, t, Fb[k].astype(np.float64), 0.015, 0.8660, want_info=True)
+        assert np.array_equal(lists[k], p1), "pair %d" % k
+        assert np.allclose(infos[k], i1, rtol=1e-9, atol=1e-6)
+    assert lists[4].shape[0] == 0 and lists[-1].shape[0] == 0
+
+    # concurrent callers sharing clouds
+    out, errs = {}, []
+
+    def worker(w):
+        try:
+            out[w] = [int(c) for c in count_inliers_batch(srcs, tgts, Ts, 0.03)], icp_align_batch(srcs[:5], tgts[:5], [T.astype(np.float32) for T in Ts[:5]])[1].tolist()
+        except Exception as ex:                               # pragma: no cover
+            errs.append(ex)
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for w in range(4):
+        assert out[w][0] == [int(c) for c in cb] and out[w][1] == [int(v) for v in itb[:5]]
