@@ -142,30 +142,46 @@ def icp_section(n_pairs, device):
         corr, info = find_correspondence(src, tgt, fin.astype(np.float64), 0.015, 0.8660, True)
         return cnt, iters, corr.shape[0]
 
+    phase = [0.0, 0.0, 0.0]
+
     def run_list(plist):
         """The reference's flow over a pair list: Registration loop (pre-check + ICP), then the FindCorrespondence loop."""
         srcs, tgts = [clouds[b][0] for _, b, _ in plist], [clouds[a][0] for a, _, _ in plist]
+        t0 = time.perf_counter()
         cnts = count_inliers_batch(srcs, tgts, [T for _, _, T in plist], 0.03)
+        t1 = time.perf_counter()
         fins, iters, _, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for _, _, T in plist], 0.03, 20, 1e-6, 0)
+        t2 = time.perf_counter()
         lists, _ = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in fins], 0.015, 0.8660, True, copy=False)
+        t3 = time.perf_counter()
+        phase[:] = [(t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3]
         return cnts, iters, [l.shape[0] for l in lists]
 
     run_pair(*pairs[0])
-    run_list(pairs[:8])
+    run_list(pairs)          # steady state: workspaces, the page-locked result arena and the caches are warm
     t0 = time.perf_counter()
     its1 = 0
     nseq = min(n_pairs, 8)
     for p in pairs[:nseq]:
         its1 += run_pair(*p)[1]
     dt1 = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, iters, ncs = run_list(pairs)
-    dt = time.perf_counter() - t0
+    # the whole list takes ~10 ms, the same order as one scheduling hiccup on a shared host: median of 7 passes
+    dts, phases = [], []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        _, iters, ncs = run_list(pairs)
+        dts.append(time.perf_counter() - t0)
+        phases.append(list(phase))
+    order = sorted(range(len(dts)), key=lambda q: dts[q])
+    dt = dts[order[len(dts) // 2]]
+    phase = phases[order[len(dts) // 2]]
     its, ncor = int(np.sum(iters)), int(np.sum(ncs))
     npts = sum(len(c[0]) for c in clouds) / 4.0
     res = {"pairs_per_s": n_pairs / dt, "pairs": n_pairs, "points_per_fragment": npts, "mean_icp_iterations": its / n_pairs,
            "mean_correspondences": ncor / n_pairs, "nn_queries_per_s": npts * (its + 2 * n_pairs) / dt,
            "flow": "er_icp_count_inliers_batch + er_icp_align_batch, then er_find_correspondence_batch over the pair list",
+           "phase_ms": {"pre_check": phase[0], "icp": phase[1], "find_correspondence": phase[2]},
+           "timing": "median of 7 passes over the pair list; min %.2f ms, max %.2f ms per pass" % (min(dts) * 1e3, max(dts) * 1e3),
            "single_call_pairs_per_s": nseq / dt1}
     try:
         from oracle.pyoracle import IcpOracle

@@ -127,7 +127,7 @@ class PinnedArena:
         import numpy as np
         dt = np.dtype(dtype)
         n = int(np.prod(shape)) * dt.itemsize
-        off = (self._off + 63) & ~63
+        off = (self._off + 4095) & ~4095
         assert off + n <= self._cap, "PinnedArena.reset() was sized too small"
         self._off = off + n
         buf = (C.c_char * max(n, 1)).from_address(self._p + off)

@@ -847,6 +847,8 @@ bool is_pinned_host(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// (Letting k_compact store the list straight into page-locked host memory -- zero-copy -- was tried: one stage
+// fewer, but 3.5 instead of 2.9 ms per 40 pairs.)
 // Stage 2 of a pair (after the lane's kernel event): the pair count is known; start the copy of exactly that many
 // pairs -- straight into the caller's buffer when it is page-locked (er_host_alloc), else into the lane's pinned
 // staging block -- and expand the information matrix.  *staged tells corr_finish whether a host memcpy remains.

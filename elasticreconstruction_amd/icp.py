@@ -122,7 +122,7 @@ def find_correspondence_batch(srcs, tgts, Ts, dist, normal_cos=0.8660, want_info
     if _arena is None:
         _arena = _ffi.PinnedArena()
     Tm = np.ascontiguousarray(Ts, np.float64).reshape(n, 16)
-    _arena.reset(sum(max(s.n, 1) * 8 + 64 for s in srcs))
+    _arena.reset(sum(max(s.n, 1) * 8 + 4096 for s in srcs))
     bufs = [_arena.take((max(s.n, 1), 2), np.int32) for s in srcs]
     ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
     cap = np.array([s.n for s in srcs], np.int32)

@@ -1,6 +1,11 @@
 """Phase timings of the batched ICP flow for the ER_ICP_LANES given in the environment (A/B helper)."""
 import os, sys, time
 import numpy as np
+if os.environ.get('PROBE_TORCH'):
+    import torch
+    _t = torch.zeros(1, device='cuda')
+    if os.environ.get('PROBE_TORCH') == '2':
+        _s = torch.cuda.Stream()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from elasticreconstruction_amd import synth
 from elasticreconstruction_amd.icp import Cloud, count_inliers_batch, find_correspondence_batch, icp_align_batch
