@@ -108,7 +108,7 @@ def _cpu_baseline(sc, depth_host, n_sample):
             "sample": "first %d frames of the same stream through oracle/tsdf_oracle.c (oracle/_ref not present)" % n_sample}
 
 
-def icp_section(n_pairs, device):
+def icp_section(n_pairs, device, with_cpu=True):
     """configs[2] shape: fragment pairs of ~250k points each (seeded surfels of the synthetic room, independent
     samplings, ground truth o perturbation as the initial guess) through the reference flow of one pair:
     inlier pre-check + ICP (<= 20 iterations) + FindCorrespondence + information matrix.  Secondary metric
@@ -183,6 +183,9 @@ def icp_section(n_pairs, device):
            "phase_ms": {"pre_check": phase[0], "icp": phase[1], "find_correspondence": phase[2]},
            "timing": "median of 7 passes over the pair list; min %.2f ms, max %.2f ms per pass" % (min(dts) * 1e3, max(dts) * 1e3),
            "single_call_pairs_per_s": nseq / dt1}
+    res["_pass_s"] = dt
+    if not with_cpu:
+        return res
     try:
         from oracle.pyoracle import IcpOracle
         oc = [IcpOracle(x, n, 0.03) for x, n in hosts]
@@ -211,8 +214,9 @@ def main():
                          "never the headline value")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
-    ap.add_argument("--icp-pairs", type=int, default=0,
-                    help="also time N fragment pairs through Registration + FindCorrespondence (configs[2] shape) and add an 'icp' object")
+    ap.add_argument("--icp-pairs", type=int, default=40,
+                    help="also time N fragment pairs per GPU through Registration + FindCorrespondence (configs[2] shape) and add an "
+                         "'icp' object with BASELINE.json's second figure, pairs/s (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -312,6 +316,20 @@ def main():
     sum_w = vol.sum_weight() / world
     n_units = vol.unit_count()
 
+    icp = None
+    if args.icp_pairs > 0:
+        # secondary metric on every rank (pairs shard with no collective: each GPU runs the same pair list, weak scaling)
+        icp = icp_section(args.icp_pairs, local, with_cpu=(rank == 0 and world == 1))
+        pass_s = icp.pop("_pass_s")
+        if use_dist:
+            t = torch.tensor([pass_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pass_s = float(t.item())
+            icp["pairs_per_s"] = world * args.icp_pairs / pass_s
+            icp["pairs"] = world * args.icp_pairs
+            icp["nn_queries_per_s"] = None
+            icp["sharding"] = "%d GPUs x %d pairs, no collective; slowest rank's median pass" % (world, args.icp_pairs)
+
     if rank == 0:
         total_frames = world * n_frames
         out = {
@@ -363,8 +381,8 @@ def main():
             ns = min(n_frames, max(I, (args.cpu_sample // I) * I))
             host = synth.to_numpy_u16(depth[:ns])
             out["cpu_baseline"] = cpu_baseline(sc, host, ns)
-        if args.icp_pairs > 0 and world == 1:
-            out["icp"] = icp_section(args.icp_pairs, local)
+        if icp is not None:
+            out["icp"] = icp
         print(json.dumps(out), flush=True)
     vol.close()
     if use_dist:
