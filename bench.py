@@ -184,6 +184,19 @@ def icp_section(n_pairs, device, with_cpu=True):
            "timing": "median of 7 passes over the pair list; min %.2f ms, max %.2f ms per pass" % (min(dts) * 1e3, max(dts) * 1e3),
            "single_call_pairs_per_s": nseq / dt1}
     res["_pass_s"] = dt
+    # RansacCurvature::getFitness over a hypothesis list (down-sampled source, as GlobalRegistration uses it)
+    from elasticreconstruction_amd.icp import ransac_fitness_batch
+    sub = np.sort(np.random.default_rng(11).choice(hosts[1][0].shape[0], 5000, replace=False))
+    small = Cloud(hosts[1][0][sub], hosts[1][1][sub], 0.03, device)
+    base = np.linalg.inv(clouds[0][1]) @ clouds[1][1]
+    H = np.stack([(base @ synth.perturbation(900 + k, 3.0, 0.05)).astype(np.float32) for k in range(256)])
+    H = np.tile(H, (64, 1, 1))
+    ransac_fitness_batch(small, clouds[0][0], H[:256], 0.03)
+    t0 = time.perf_counter()
+    ransac_fitness_batch(small, clouds[0][0], H, 0.03)
+    dth = time.perf_counter() - t0
+    res["ransac_fitness"] = {"hypotheses_per_s": H.shape[0] / dth, "hypotheses": int(H.shape[0]), "source_points": 5000,
+                             "target_points": len(clouds[0][0]), "what": "er_ransac_fitness_batch = RansacCurvature::getFitness per hypothesis"}
     if not with_cpu:
         return res
     try:
@@ -195,6 +208,11 @@ def icp_section(n_pairs, device, with_cpu=True):
             fin, _, _, _ = oc[b].align(oc[a], T.astype(np.float32))
             oc[b].find_correspondence(oc[a], fin.astype(np.float64), 0.015, 0.8660, True)
         res["cpu_port_pairs_per_s"] = 2 / (time.perf_counter() - t0)
+        osm = IcpOracle(hosts[1][0][sub], hosts[1][1][sub], 0.03)
+        t0 = time.perf_counter()
+        for k in range(32):
+            osm.ransac_fitness(oc[0], H[k], 0.03)
+        res["ransac_fitness"]["cpu_port_hypotheses_per_s"] = 32 / (time.perf_counter() - t0)
         res["cpu_port_note"] = "oracle/icp_oracle.cpp (PCL 1.7 restatement, OpenMP NN over %d threads); PCL itself is absent" % (os.cpu_count() or 1)
     except Exception as ex:                                            # the checker is optional for the bench
         res["cpu_port_note"] = "oracle not available: %s" % ex

@@ -20,7 +20,7 @@ SYMBOLS = [
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
-    "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces",
+    "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_ransac_fitness_batch",
 ]
 
 
@@ -91,6 +91,7 @@ def lib():
         L.er_icp_align_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
         L.er_find_correspondence_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
         L.er_icp_release_workspaces.argtypes = []
+        L.er_ransac_fitness_batch.argtypes = [vp, vp, C.c_int, vp, C.c_float, vp, vp]
     _lib = L
     return L
 

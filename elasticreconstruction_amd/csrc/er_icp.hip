@@ -214,6 +214,60 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const float4* __restri
   }
 }
 
+// RansacCurvature::getFitness (GlobalRegistration/RansacCurvature.h:661-704) for MANY pose hypotheses of one
+// (source, target) pair: blockIdx.y = hypothesis, blockIdx.x strides over the source points.  Float32 transform
+// ([PCL] transformPointCloud with a Matrix4f), exact NN, inlier iff d < threshold^2 (float compare, :670,:687);
+// per hypothesis the inlier count (exact) and the float64 sum of the inlier distances.
+__global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restrict__ src_sorted, int n, const float* __restrict__ hyp,
+                                                           int hyp0, Grid g, float radius, float max_range,
+                                                           int* __restrict__ count, double* __restrict__ sum) {
+  __shared__ NnShared sh;
+  const int h = hyp0 + blockIdx.y;
+  float M[12];
+#pragma unroll
+  for (int q = 0; q < 12; q++) M[q] = hyp[(size_t)h * 16 + q];
+  int local = 0;
+  double dsum = 0.0;
+  for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const int k = base + (int)threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f, d;
+    if (k < n) {
+      const float4 s = src_sorted[k];
+      qx = ((M[0] * s.x + M[1] * s.y) + M[2] * s.z) + M[3];
+      qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
+      qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
+    }
+    const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
+    if (k < n && i >= 0 && d < max_range) {
+      local++;
+      dsum += (double)d;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    local += __shfl_down(local, off);
+    dsum += __shfl_down(dsum, off);
+  }
+  __shared__ int pc[kBlock / 64];
+  __shared__ double ps[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) {
+    pc[threadIdx.x >> 6] = local;
+    ps[threadIdx.x >> 6] = dsum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; w++) {
+      c += pc[w];
+      s += ps[w];
+    }
+    if (c) {
+      atomicAdd(&count[h], c);
+      atomicAdd(&sum[h], s);
+    }
+  }
+}
+
 // guess * source in float32 (IterativeClosestPoint::transformCloud), or a plain copy for an identity guess.
 __global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restrict__ X, int n, Mat12f M, int apply) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;       // k = position in the source's cell-sorted order
@@ -1117,6 +1171,51 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
   if (!guess || !out) return er::fail("er_icp_align: NULL argument");
   return er_icp_align_batch(1, &src, &tgt, guess, max_dist, max_iter, transformation_epsilon, stop_rule, out, iterations, converged,
                             fitness);
+}
+
+int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const float* M, float corr_dist_threshold, int* inliers,
+                            double* fitness) {
+  if (n_hyp < 0 || (n_hyp > 0 && (!M || !inliers))) return er::fail("er_ransac_fitness_batch: bad arguments");
+  if (check_pair(src, tgt, (double)corr_dist_threshold, "er_ransac_fitness_batch")) return 1;
+  if (n_hyp == 0) return 0;
+  WsSet set;
+  if (set.acquire(src->device, 1, 1)) return 1;
+  IcpWs* w = set.ws[0];
+  float* d_hyp = nullptr;
+  int* d_cnt = nullptr;
+  double* d_sum = nullptr;
+  std::vector<double> sums((size_t)n_hyp, 0.0);
+  int rc = 0;
+  const size_t nh = (size_t)n_hyp;
+  if (hipMalloc((void**)&d_hyp, nh * 16 * sizeof(float)) != hipSuccess || hipMalloc((void**)&d_cnt, nh * sizeof(int)) != hipSuccess ||
+      hipMalloc((void**)&d_sum, nh * sizeof(double)) != hipSuccess) {
+    rc = er::fail("er_ransac_fitness_batch: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+  } else if (hipMemcpyAsync(d_hyp, M, nh * 16 * sizeof(float), hipMemcpyHostToDevice, w->stream) != hipSuccess ||
+             hipMemsetAsync(d_cnt, 0, nh * sizeof(int), w->stream) != hipSuccess ||
+             hipMemsetAsync(d_sum, 0, nh * sizeof(double), w->stream) != hipSuccess) {
+    rc = er::fail("er_ransac_fitness_batch: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  } else {
+    if (src->n > 0 && tgt->n > 0) {
+      // few workgroups per hypothesis when there are many hypotheses (the reference's clouds are down-sampled), all of them otherwise
+      const int bx = std::max(1, std::min(nblocks_of(src->n), 4096 / std::min(n_hyp, 4096)));
+      for (int h0 = 0; h0 < n_hyp && rc == 0; h0 += 32768) {
+        const int hn = std::min(32768, n_hyp - h0);
+        hipLaunchKernelGGL(k_ransac_fitness, dim3(bx, hn), dim3(kBlock), 0, w->stream, src->sorted, src->n, d_hyp, h0, grid_of(tgt),
+                           corr_dist_threshold, corr_dist_threshold * corr_dist_threshold, d_cnt, d_sum);
+        if (hipGetLastError() != hipSuccess) rc = er::fail("er_ransac_fitness_batch: launch failed");
+      }
+    }
+    if (rc == 0 && (hipMemcpyAsync(inliers, d_cnt, nh * sizeof(int), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                    hipMemcpyAsync(sums.data(), d_sum, nh * sizeof(double), hipMemcpyDeviceToHost, w->stream) != hipSuccess ||
+                    hipStreamSynchronize(w->stream) != hipSuccess))
+      rc = er::fail("er_ransac_fitness_batch: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (d_hyp) (void)hipFree(d_hyp);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_sum) (void)hipFree(d_sum);
+  if (rc == 0 && fitness)
+    for (int h = 0; h < n_hyp; h++) fitness[h] = inliers[h] > 0 ? sums[(size_t)h] / (double)inliers[h] : (double)FLT_MAX;   // :697-703
+  return rc;
 }
 
 int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist, double normal_cos,

@@ -108,6 +108,17 @@ def icp_align_batch(srcs, tgts, guesses, max_dist=0.03, max_iter=20, eps=1e-6, s
     return out.reshape(n, 4, 4), it, cv.astype(bool), fit
 
 
+def ransac_fitness_batch(src, tgt, Ms, corr_dist_threshold):
+    """RansacCurvature::getFitness (GlobalRegistration/RansacCurvature.h:661-704) for a stack of float32 4x4 hypotheses of one
+    pair.  Returns (inlier counts int32 [n], fitness float64 [n])."""
+    M = np.ascontiguousarray(Ms, np.float32).reshape(-1, 16)
+    n = M.shape[0]
+    cnt, fit = np.zeros(n, np.int32), np.zeros(n, np.float64)
+    _ffi.check(src._lib.er_ransac_fitness_batch(src._h, tgt._h, n, _ffi.ptr(M), C.c_float(corr_dist_threshold), _ffi.ptr(cnt), _ffi.ptr(fit)),
+               "er_ransac_fitness_batch")
+    return cnt, fit
+
+
 _arena = None
 
 

@@ -158,6 +158,15 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
                                  double normal_cos, int* const* pairs_host, const int* capacity, int* n_pairs,
                                  double* info36);
 
+/* SURVEY.md 8f-3, first consumer outside BuildCorrespondence: RansacCurvature::getFitness
+ * (GlobalRegistration/RansacCurvature.h:661-704) for n_hyp pose hypotheses of ONE (source, target) pair in one
+ * launch -- the RANSAC loop calls it once per hypothesis, up to max_iteration = 4 000 000 times per pair.
+ * M: n_hyp row-major FLOAT 4x4 (final_transformation_ candidates).  inliers[h] = #{i : NN sqdist(M_h * src[i], tgt)
+ * < corr_dist_threshold^2} (exact); fitness[h] (nullable) = mean of those squared distances (float64 sum; the
+ * reference adds float32 in point order) or FLT_MAX when there is no inlier. */
+int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const float* M, float corr_dist_threshold,
+                            int* inliers, double* fitness);
+
 /* Frees the pooled ICP workspaces (streams, scratch, pinned blocks).  Optional; call when no ICP call is running. */
 int er_icp_release_workspaces(void);
 

@@ -383,4 +383,38 @@ int icp_find_correspondence(void* src_, void* tgt_, const double* T, double dist
   return m > capacity ? 1 : 0;
 }
 
+// RansacCurvature::getFitness, GlobalRegistration/RansacCurvature.h:661-704: input_transformed =
+// transformPointCloud( *input_, final_transformation_ ) with a Matrix4f ([PCL] float32, per row ((m0*x + m1*y) + m2*z) + m3);
+// inlier iff nn_dists[0] < corr_dist_threshold^2 (float compare, :670,:687); fitness = float32 running sum of the
+// inlier distances in point order / inliers (FLT_MAX when none, :697-703).  Also returns the float64 sum for the
+// order-independent comparison with the parallel implementation.
+int icp_ransac_fitness(void* src_, void* tgt_, const float* M, float corr_dist_threshold, float* fitness_f32, double* sum_f64) {
+  Cloud& src = *static_cast<Cloud*>(src_);
+  Cloud& tgt = *static_cast<Cloud*>(tgt_);
+  std::vector<float> X(src.xyz);
+  transform_float_inplace(X, src.n, M);
+  const float max_range = corr_dist_threshold * corr_dist_threshold;
+  std::vector<float> dd((size_t)src.n);
+  std::vector<char> in((size_t)src.n);
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int k = 0; k < src.n; k++) {
+    float d;
+    const int i = nearest(tgt, &X[3 * (size_t)k], corr_dist_threshold, &d);
+    in[(size_t)k] = i >= 0 && d < max_range;
+    dd[(size_t)k] = d;
+  }
+  int cnt = 0;
+  float f = 0.0f;
+  double s = 0.0;
+  for (int k = 0; k < src.n; k++)
+    if (in[(size_t)k]) {
+      cnt++;
+      f += dd[(size_t)k];
+      s += (double)dd[(size_t)k];
+    }
+  if (fitness_f32) *fitness_f32 = cnt > 0 ? f / (float)cnt : FLT_MAX;
+  if (sum_f64) *sum_f64 = s;
+  return cnt;
+}
+
 }  // extern "C"

@@ -256,6 +256,7 @@ class IcpOracle:
             L.icp_count_inliers.argtypes = [_vp, _vp, _vp, C.c_double]
             L.icp_align.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _vp]
             L.icp_find_correspondence.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int, _vp, _vp]
+            L.icp_ransac_fitness.argtypes = [_vp, _vp, _vp, C.c_float, _vp, _vp]
             cls._lib = L
         return cls._lib
 
@@ -295,6 +296,13 @@ class IcpOracle:
         self.lib().icp_align(self._h, tgt._h, _p(g), float(max_dist), int(max_iter), float(eps), int(stop_rule), _p(out),
                              C.byref(it), C.byref(cv), C.byref(fit) if want_fitness else None)
         return out.reshape(4, 4), it.value, bool(cv.value), (fit.value if want_fitness else None)
+
+    def ransac_fitness(self, tgt, M, corr_dist_threshold):
+        """RansacCurvature::getFitness for one hypothesis: (inliers, float32 fitness as the reference sums it, float64 sum)."""
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        f, s = C.c_float(0), C.c_double(0)
+        cnt = self.lib().icp_ransac_fitness(self._h, tgt._h, _p(Mm), C.c_float(corr_dist_threshold), C.byref(f), C.byref(s))
+        return int(cnt), float(f.value), float(s.value)
 
     def find_correspondence(self, tgt, T, dist, normal_cos=0.8660, want_info=False):
         Tm = np.ascontiguousarray(T, np.float64).reshape(16)

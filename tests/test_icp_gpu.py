@@ -182,3 +182,34 @@ def test_batch_entry_points_equal_single_calls(gpu):
     assert not errs, errs
     for w in range(4):
         assert out[w][0] == [int(c) for c in cb] and out[w][1] == [int(v) for v in itb[:5]]
+
+
+def test_ransac_fitness_batch_matches_oracle(gpu):
+    """SURVEY.md 8f-3: er_ransac_fitness_batch = RansacCurvature::getFitness over a list of hypotheses.  Inlier counts
+    exact; fitness within 1e-9 of the oracle's float64 sum / count and 1e-4 of its float32 running sum (the reference's)."""
+    from elasticreconstruction_amd.icp import ransac_fitness_batch
+    (x0, n0), (x1, n1), P = make_pair(n=30000, rot=3.0, trans=0.03)
+    keep = np.random.default_rng(3).choice(x1.shape[0], 4000, replace=False)      # the reference scores a down-sampled source
+    x1s, n1s = x1[np.sort(keep)], n1[np.sort(keep)]
+    tgt, src = Cloud(x0, n0, 0.05), Cloud(x1s, n1s, 0.05)
+    otgt, osrc = IcpOracle(x0, n0, 0.05), IcpOracle(x1s, n1s, 0.05)
+    hyps = [P.astype(np.float32), np.eye(4, dtype=np.float32), synth.perturbation(1, 60, 2.0).astype(np.float32)]
+    hyps += [(P @ synth.perturbation(100 + k, 0.2 * k, 0.002 * k)).astype(np.float32) for k in range(29)]
+    for thr in (0.05, 0.02):
+        cnt, fit = ransac_fitness_batch(src, tgt, hyps, thr)
+        for h, M in enumerate(hyps):
+            c, f32, s64 = osrc.ransac_fitness(otgt, M, thr)
+            assert int(cnt[h]) == c, "hypothesis %d: %d vs %d inliers" % (h, cnt[h], c)
+            if c:
+                assert fit[h] == pytest.approx(s64 / c, rel=1e-9)
+                assert fit[h] == pytest.approx(f32, rel=1e-4)
+            else:
+                assert fit[h] == float(np.finfo(np.float32).max)
+        assert cnt[0] > 0.3 * len(keep) and cnt[2] == 0
+    # more hypotheses than one launch's grid.y chunk, tiny source
+    tiny = Cloud(x1s[:300], n1s[:300], 0.05)
+    many = np.repeat(np.stack(hyps[:4])[None], 8200, axis=0).reshape(-1, 4, 4)
+    cnt, fit = ransac_fitness_batch(tiny, tgt, many, 0.05)
+    assert cnt.shape[0] == 32800 and np.array_equal(cnt[:4], cnt[-4:]) and np.array_equal(cnt.reshape(-1, 4), np.tile(cnt[:4], (8200, 1)))
+    with pytest.raises(Exception):
+        ransac_fitness_batch(src, tgt, hyps, 0.08)               # radius beyond the target's grid cell

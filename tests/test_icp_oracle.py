@@ -101,3 +101,23 @@ def test_reference_example_files_parse_and_roundtrip(tmp_path):
     p2 = str(tmp_path / "t.info")
     formats.save_info(p2, info[:5])
     assert all(np.allclose(a.info, b.info, atol=1e-8) for a, b in zip(info[:5], formats.load_info(p2)))
+
+
+def test_ransac_fitness_restatement_against_ckdtree():
+    """RansacCurvature::getFitness (GlobalRegistration/RansacCurvature.h:661-704), SURVEY.md 8f-3: inlier count and
+    mean squared NN distance of one hypothesis against an independent exact NN (float64 cKDTree)."""
+    (x0, n0), (x1, n1), P = make_pair(n=20000)
+    tgt, src = IcpOracle(x0, n0, 0.05), IcpOracle(x1, n1, 0.05)
+    for M, thr in ((P.astype(np.float32), 0.05), (np.eye(4, dtype=np.float32), 0.03), (synth.perturbation(5, 60, 2.0).astype(np.float32), 0.05)):
+        cnt, fit32, s64 = src.ransac_fitness(tgt, M, thr)
+        q = ((M[:3, 0] * x1[:, :1] + M[:3, 1] * x1[:, 1:2]) + M[:3, 2] * x1[:, 2:3]) + M[:3, 3]      # float32, same order
+        d, _ = cKDTree(x0.astype(np.float64)).query(q.astype(np.float64))
+        d2 = d * d
+        lim = float(np.float32(thr) * np.float32(thr))
+        clear = np.abs(d2 - lim) > 1e-6 * lim
+        assert abs(cnt - int((d2 < lim).sum())) <= int((~clear).sum())
+        if cnt:
+            assert fit32 == pytest.approx(s64 / cnt, rel=1e-4)
+            assert s64 / cnt == pytest.approx(d2[d2 < lim].mean(), rel=1e-3)
+        else:
+            assert fit32 == np.finfo(np.float32).max
