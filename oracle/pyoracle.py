@@ -312,3 +312,167 @@ class IcpOracle:
         self.lib().icp_find_correspondence(self._h, tgt._h, _p(Tm), float(dist), float(normal_cos), _p(pairs), self.n,
                                            C.byref(m), _p(info) if want_info else None)
         return pairs[:m.value].copy(), (info.reshape(6, 6) if want_info else None)
+
+
+class FoptOracle:
+    """oracle/fopt_oracle.cpp: FragmentOptimizer's point state and Hessian assembly (rigid / SLAC), SURVEY.md 8f-2."""
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = _load("_build/libfopt_oracle.so")
+            L.fopt_create.restype = _vp
+            L.fopt_create.argtypes = [C.c_int, C.c_int, C.c_float]
+            L.fopt_destroy.argtypes = [_vp]
+            L.fopt_set_cloud.argtypes = [_vp, C.c_int, _vp, _vp, C.c_int]
+            L.fopt_cloud_size.argtypes = [_vp, C.c_int]
+            L.fopt_get_points.argtypes = [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+            L.fopt_update_pose.argtypes = [_vp, C.c_int, _vp]
+            L.fopt_update_point_pn.argtypes = [_vp, C.c_int, _vp]
+            L.fopt_clear_pairs.argtypes = [_vp]
+            L.fopt_add_pair.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int]
+            L.fopt_assemble_rigid.argtypes = [_vp, _vp, _vp, _vp]
+            L.fopt_assemble_slac.argtypes = [_vp, _vp, _vp, _vp, _vp]
+            L.fopt_rigid_bucket.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
+            L.fopt_slac_bucket.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, num, resolution=8, length=3.0):
+        self.num, self.resolution, self.length = num, resolution, float(length)
+        self.nper = (resolution + 1) ** 3 * 3
+        self._h = _vp(self.lib().fopt_create(num, resolution, C.c_float(length)))
+
+    def close(self):
+        if self._h:
+            self.lib().fopt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cloud(self, frag, xyz, nrm):
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        return int(self.lib().fopt_set_cloud(self._h, frag, _p(x), _p(n), x.shape[0]))
+
+    def points(self, frag):
+        m = int(self.lib().fopt_cloud_size(self._h, frag))
+        idx0, val, nval = np.zeros(m, np.int32), np.zeros((m, 8), np.float32), np.zeros((m, 8), np.float32)
+        p, n = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+        self.lib().fopt_get_points(self._h, frag, _p(idx0), _p(val), _p(nval), _p(p), _p(n))
+        return dict(idx0=idx0, val=val, nval=nval, p=p, n=n)
+
+    def update_pose(self, frag, M):
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        self.lib().fopt_update_pose(self._h, frag, _p(Mm))
+
+    def update_point_pn(self, frag, ctr_slice):
+        c = np.ascontiguousarray(ctr_slice, np.float64).reshape(-1)
+        assert c.size == self.nper
+        self.lib().fopt_update_point_pn(self._h, frag, _p(c))
+
+    def set_pairs(self, pairs):
+        """pairs: list of (i, j, int32 [m,2] rows (index in i, index in j))."""
+        self.lib().fopt_clear_pairs(self._h)
+        for i, j, pr in pairs:
+            a = np.ascontiguousarray(pr, np.int32).reshape(-1, 2)
+            self.lib().fopt_add_pair(self._h, int(i), int(j), _p(a), a.shape[0])
+
+    def assemble_rigid(self):
+        N = 6 * self.num
+        JJ, Jb, sc = np.zeros((N, N)), np.zeros(N), C.c_double(0)
+        self.lib().fopt_assemble_rigid(self._h, _p(JJ), _p(Jb), C.byref(sc))
+        return JJ, Jb, sc.value
+
+    def assemble_slac(self, pose_rot_t):
+        N = 6 * self.num + self.nper
+        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num, 9)
+        JJ, Jb, sc = np.zeros((N, N)), np.zeros(N), C.c_double(0)
+        self.lib().fopt_assemble_slac(self._h, _p(R), _p(JJ), _p(Jb), C.byref(sc))
+        return JJ, Jb, sc.value
+
+    def rigid_bucket(self, i, ii, j, jj):
+        val, b = np.zeros(12), C.c_double(0)
+        self.lib().fopt_rigid_bucket(self._h, i, ii, j, jj, _p(val), C.byref(b))
+        return val, b.value
+
+    def slac_bucket(self, i, ii, j, jj, pose_rot_t):
+        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num, 9)
+        idx, val, b = np.zeros(60, np.int32), np.zeros(60), C.c_double(0)
+        self.lib().fopt_slac_bucket(self._h, i, ii, j, jj, _p(R), _p(idx), _p(val), C.byref(b))
+        return idx, val, b.value
+
+
+class RefFopt:
+    """oracle/_ref/libref_fopt.so: the reference's own PointCloud.h (compiled in place) + OptApp.cpp's bucket expressions
+    on the vendored Eigen.  Only available where /root/reference was present at build time."""
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(os.path.join(HERE, "_ref", "libref_fopt.so"))
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = _load("_ref/libref_fopt.so")
+            L.rfopt_cloud_create.restype = _vp
+            L.rfopt_cloud_create.argtypes = [C.c_int, C.c_int, C.c_float]
+            L.rfopt_cloud_destroy.argtypes = [_vp]
+            L.rfopt_cloud_load.argtypes = [_vp, _vp, _vp, C.c_int]
+            L.rfopt_get_points.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+            L.rfopt_update_pose.argtypes = [_vp, _vp]
+            L.rfopt_update_point_pn.argtypes = [_vp, _vp, C.c_int]
+            L.rfopt_rigid_bucket.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp]
+            L.rfopt_slac_bucket.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, num, resolution=8, length=3.0):
+        self.num, self.resolution = num, resolution
+        self.nper = (resolution + 1) ** 3 * 3
+        self.clouds = [_vp(self.lib().rfopt_cloud_create(i, resolution, C.c_float(length))) for i in range(num)]
+        self.sizes = [0] * num
+
+    def close(self):
+        for c in self.clouds:
+            self.lib().rfopt_cloud_destroy(c)
+        self.clouds = []
+
+    def set_cloud(self, frag, xyz, nrm):
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        r = int(self.lib().rfopt_cloud_load(self.clouds[frag], _p(x), _p(n), x.shape[0]))
+        self.sizes[frag] = x.shape[0] if r < 0 else r + 1
+        return r
+
+    def points(self, frag):
+        m = self.sizes[frag]
+        idx0, val, nval = np.zeros(m, np.int32), np.zeros((m, 8), np.float32), np.zeros((m, 8), np.float32)
+        p, n = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+        self.lib().rfopt_get_points(self.clouds[frag], _p(idx0), _p(val), _p(nval), _p(p), _p(n))
+        return dict(idx0=idx0, val=val, nval=nval, p=p, n=n)
+
+    def update_pose(self, frag, M):
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        self.lib().rfopt_update_pose(self.clouds[frag], _p(Mm))
+
+    def update_point_pn(self, frag, ctr_full):
+        c = np.ascontiguousarray(ctr_full, np.float64).reshape(-1)
+        self.lib().rfopt_update_point_pn(self.clouds[frag], _p(c), c.size)
+
+    def rigid_bucket(self, i, ii, j, jj):
+        val, b = np.zeros(12), C.c_double(0)
+        self.lib().rfopt_rigid_bucket(self.clouds[i], ii, self.clouds[j], jj, _p(val), C.byref(b))
+        return val, b.value
+
+    def slac_bucket(self, i, ii, j, jj, pose_rot_t):
+        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num, 9)
+        idx, val, b = np.zeros(60, np.int32), np.zeros(60), C.c_double(0)
+        self.lib().rfopt_slac_bucket(self.clouds[i], ii, i, self.clouds[j], jj, j, self.num, _p(R[i]), _p(R[j]), _p(idx), _p(val), C.byref(b))
+        return idx, val, b.value

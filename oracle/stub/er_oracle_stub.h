@@ -36,6 +36,9 @@
 #define PCL_INFO(...)  do { if (!::er_stub::quiet()) { fprintf(stdout, __VA_ARGS__); } } while (0)
 #define PCL_WARN(...)  do { if (!::er_stub::quiet()) { fprintf(stdout, __VA_ARGS__); } } while (0)
 #define PCL_ERROR(...) do { fprintf(stderr, __VA_ARGS__); } while (0)
+#ifndef _isnan
+#define _isnan(x) std::isnan(x)                       /* MSVC spelling, FragmentOptimizer/PointCloud.cpp:29 */
+#endif
 
 namespace er_stub {
 inline bool quiet() { static int q = getenv("ER_ORACLE_QUIET") ? 1 : 0; return q != 0; }
@@ -185,6 +188,8 @@ inline int parse_argument(int argc, char** argv, const char* name, double& v) {
 }  // namespace console
 
 struct PointXYZI { float x, y, z, intensity; };
+// FragmentOptimizer/PointCloud.cpp:22-40 (LoadFromPCDFile); the oracle feeds points through the XYZN path, so loading is a stub.
+struct PointXYZRGBNormal { float x, y, z, normal_x, normal_y, normal_z, rgb, curvature; };
 
 template <class PointT> class PointCloud {
  public:
@@ -195,6 +200,7 @@ template <class PointT> class PointCloud {
 };
 
 namespace io {
+template <class PointT> inline int loadPCDFile(const char*, PointCloud<PointT>&) { return -1; }   // not needed by the checkers
 // Binary PCD v0.7 writer for x/y/z/intensity clouds (the only cloud type the Integrate program saves).
 inline int savePCDFile(const std::string& name, const PointCloud<PointXYZI>& c, bool /*binary*/) {
   FILE* f = fopen(name.c_str(), "wb");
