@@ -21,6 +21,8 @@ SYMBOLS = [
     "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_ransac_fitness_batch",
+    "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
+    "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_group_count", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
 ]
 
 
@@ -92,6 +94,18 @@ def lib():
         L.er_find_correspondence_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
         L.er_icp_release_workspaces.argtypes = []
         L.er_ransac_fitness_batch.argtypes = [vp, vp, C.c_int, vp, C.c_float, vp, vp]
+    if hasattr(L, "er_fopt_create"):
+        L.er_fopt_create.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(vp)]
+        L.er_fopt_destroy.argtypes = [vp]
+        L.er_fopt_set_cloud.argtypes = [vp, C.c_int, vp, vp, C.c_int, ip]
+        L.er_fopt_cloud_size.argtypes = [vp, C.c_int]
+        L.er_fopt_get_points.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+        L.er_fopt_update_pose.argtypes = [vp, C.c_int, vp]
+        L.er_fopt_update_point_pn.argtypes = [vp, C.c_int, vp]
+        L.er_fopt_set_correspondences.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.er_fopt_group_count.argtypes = [vp]
+        L.er_fopt_assemble_rigid.argtypes = [vp, vp, vp, vp]
+        L.er_fopt_assemble_slac.argtypes = [vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -1,0 +1,531 @@
+// er_fopt.hip -- SURVEY.md 8f-2: the data-parallel half of the reference's FragmentOptimizer on MI355X (gfx950):
+// per-point state (PointCloud.h:6-176), UpdatePose / UpdateAllPointPN, and the Hessian assembly of OptimizeRigid
+// (OptApp.cpp:312-375) and OptimizeSLAC (OptApp.cpp:473-560).  The CHOLMOD solve and the lattice regularizer (a few
+// thousand vertices) stay with the host, as in the reference.
+//
+// Assembly = grouped Gram matrices on the FP64 matrix cores.  Every correspondence contributes v v^T (+ b v, b^2) where
+// v is a "bucket" of 12 (rigid) or 60 (SLAC: 12 pose + 24 + 24 lattice) values whose matrix indices depend only on the
+// fragment pair and on the two control-lattice cells the points fall in.  Correspondences are therefore sorted ONCE
+// (they and the cells never change during the optimisation) by (pair, cell of p_i, cell of p_j); one wave per group
+// chunk accumulates G = sum_k [v_k; b_k][v_k; b_k]^T with v_mfma_f64_16x16x4_f64 -- lane (r, q) computes entry
+// 16*blk + r of the bucket of correspondence k0 + q, and that register is at once the A operand of block row blk and
+// the B operand of block column blk, so the 61-vector never touches LDS -- and then adds the upper triangle of G into
+// the dense matrix with float64 atomics, folding coinciding lattice indices exactly like OptApp.cpp:537-548.
+// This is the one GEMM-shaped loop of the pipeline; the reference runs it as scalar double loops under OpenMP.
+#include "er_common.h"
+
+#include "../../include/er_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunkMax = 512;        // correspondences per wave task
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+struct FragPtr {
+  const int* idx0;
+  const float* val;
+  float* p;
+  float* nrm;
+};
+
+struct Chunk {
+  int fi, fj;        // fragments (corres_.idx0_, idx1_)
+  int ci, cj;        // idx_[0] of the lattice cell of p_i / p_j (vertex index * 3)
+  int start, count;  // range in the sorted correspondence arrays
+};
+
+// vertex offsets of idx_[0..7] relative to idx_[0], PointCloud.h:113-120 (t = 4*dx + 2*dy + dz)
+__host__ __device__ inline int vertex_offset(int t, int res) {
+  const int n1 = res + 1;
+  return (((t >> 2) & 1) + ((t >> 1) & 1) * n1 + (t & 1) * n1 * n1) * 3;
+}
+
+// PointCloud::UpdatePose, PointCloud.h:71-83
+__global__ void k_fopt_update_pose(float* __restrict__ p, float* __restrict__ nrm, int n, const float* __restrict__ M) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
+  const float a = nrm[3 * k], b = nrm[3 * k + 1], c = nrm[3 * k + 2];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    p[3 * k + r] = ((M[4 * r] * x + M[4 * r + 1] * y) + M[4 * r + 2] * z) + M[4 * r + 3] * 1.0f;
+    nrm[3 * k + r] = ((M[4 * r] * a + M[4 * r + 1] * b) + M[4 * r + 2] * c) + M[4 * r + 3] * 0.0f;
+  }
+}
+
+// PointCloud::UpdateAllPointPN, PointCloud.h:44-52 (UpdateNormal :58-69, UpdatePoint :85-94); ctr = the fragment's slice
+__global__ void k_fopt_update_pn(const int* __restrict__ idx0, const float* __restrict__ val, const float* __restrict__ nval,
+                                 float* __restrict__ p, float* __restrict__ nrm, int n, const double* __restrict__ ctr, int res) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int base = idx0[k];
+  float c[8][3];
+#pragma unroll
+  for (int t = 0; t < 8; t++) {
+    const int o = base + vertex_offset(t, res);
+#pragma unroll
+    for (int i = 0; i < 3; i++) c[t][i] = (float)ctr[o + i];
+  }
+  float nn[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; t++) s += nval[8 * k + t] * c[t][i];
+    nn[i] = s;
+  }
+  const float len = sqrtf(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) nrm[3 * k + i] = nn[i] / len;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    double pos = 0.0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) pos += (double)(val[8 * k + t] * c[t][i]);
+    p[3 * k + i] = (float)pos;
+  }
+}
+
+// MODE 0 = rigid (12 entries + b at 12, one 16x16 tile), MODE 1 = SLAC (60 entries + b at 60, 4x4 blocks, upper 10 tiles)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_fopt_gram(const Chunk* __restrict__ chunks, int n_chunks, const FragPtr* __restrict__ frags,
+                                                      const int* __restrict__ first, const int* __restrict__ second,
+                                                      const double* __restrict__ rot_t, int num, int res, int N,
+                                                      double* __restrict__ JJ, double* __restrict__ Jb, double* __restrict__ score) {
+  constexpr int NB = MODE ? 4 : 1;                 // 16-entry blocks of the bucket
+  constexpr int NT = MODE ? 10 : 1;                // upper-triangular tile pairs
+  constexpr int BPOS = MODE ? 60 : 12;             // where b sits
+  const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+  if (wave >= n_chunks) return;
+  const Chunk ch = chunks[wave];
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const FragPtr Fi = frags[ch.fi], Fj = frags[ch.fj];
+  double Ri[9], Rj[9];
+  if (MODE) {
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      Ri[t] = rot_t[9 * ch.fi + t];
+      Rj[t] = rot_t[9 * ch.fj + t];
+    }
+  }
+  double4_t acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) acc[t] = double4_t{0.0, 0.0, 0.0, 0.0};
+
+  for (int k0 = 0; k0 < ch.count; k0 += 4) {
+    const int k = k0 + q;
+    double a[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) a[b] = 0.0;
+    if (k < ch.count) {
+      const int ii = first[ch.start + k], jj = second[ch.start + k];
+      const double ppi[3] = {Fi.p[3 * ii], Fi.p[3 * ii + 1], Fi.p[3 * ii + 2]};
+      const double ppj[3] = {Fj.p[3 * jj], Fj.p[3 * jj + 1], Fj.p[3 * jj + 2]};
+      const double npi[3] = {Fi.nrm[3 * ii], Fi.nrm[3 * ii + 1], Fi.nrm[3 * ii + 2]};
+      const double d[3] = {ppi[0] - ppj[0], ppi[1] - ppj[1], ppi[2] - ppj[2]};
+      const double bval = (d[0] * npi[0] + d[1] * npi[1]) + d[2] * npi[2];          // OptApp.cpp:346 / :493
+      if (MODE == 0) {                                                              // OptApp.cpp:363-374
+        double v;
+        if (r == 0) v = (-ppi[2] * npi[1] + ppi[1] * npi[2]) + (-npi[2] * d[1] + npi[1] * d[2]);
+        else if (r == 1) v = (ppi[2] * npi[0] - ppi[0] * npi[2]) + (npi[2] * d[0] - npi[0] * d[2]);
+        else if (r == 2) v = (-ppi[1] * npi[0] + ppi[0] * npi[1]) + (-npi[1] * d[0] + npi[0] * d[1]);
+        else if (r < 6) v = npi[r - 3];
+        else if (r == 6) v = -(-ppj[2] * npi[1] + ppj[1] * npi[2]);
+        else if (r == 7) v = -(ppj[2] * npi[0] - ppj[0] * npi[2]);
+        else if (r == 8) v = -(-ppj[1] * npi[0] + ppj[0] * npi[1]);
+        else if (r < 12) v = -npi[r - 9];
+        else if (r == 12) v = bval;
+        else v = 0.0;
+        a[0] = v;
+      } else {                                                                      // OptApp.cpp:509-535
+        const double t[3] = {ppj[1] * npi[2] - ppj[2] * npi[1], ppj[2] * npi[0] - ppj[0] * npi[2], ppj[0] * npi[1] - ppj[1] * npi[0]};
+        double dTi[3], dTj[3];
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+          dTi[x] = (Ri[3 * x] * npi[0] + Ri[3 * x + 1] * npi[1]) + Ri[3 * x + 2] * npi[2];
+          dTj[x] = -((Rj[3 * x] * npi[0] + Rj[3 * x + 1] * npi[1]) + Rj[3 * x + 2] * npi[2]);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const int e = b * 16 + r;
+          double v;
+          if (e < 12) {
+            const int x = e % 3;
+            const double base = (e % 6) < 3 ? (x == 0 ? t[0] : (x == 1 ? t[1] : t[2])) : (x == 0 ? npi[0] : (x == 1 ? npi[1] : npi[2]));
+            v = e < 6 ? base : -base;
+          } else if (e < 36) {
+            const int ll = (e - 12) / 3, x = (e - 12) % 3;
+            v = (double)Fi.val[8 * ii + ll] * (x == 0 ? dTi[0] : (x == 1 ? dTi[1] : dTi[2]));
+          } else if (e < 60) {
+            const int ll = (e - 36) / 3, x = (e - 36) % 3;
+            v = (double)Fj.val[8 * jj + ll] * (x == 0 ? dTj[0] : (x == 1 ? dTj[1] : dTj[2]));
+          } else {
+            v = e == 60 ? bval : 0.0;
+          }
+          a[b] = v;
+        }
+      }
+    }
+    // G += [v;b][v;b]^T : tile (bi, bj) uses a[bi] as A (A[i = lane%16][k = lane/16]) and a[bj] as B (B[k][j = lane%16])
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+      for (int bj = bi; bj < NB; bj++) {
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[bi], a[bj], acc[t], 0, 0, 0);
+        t++;
+      }
+  }
+
+  // scatter: D[i = q + 4 v][j = r] of tile (bi, bj) is G[16 bi + i][16 bj + j]  (layout probed: scripts/ubench/mfma_f64_layout.hip)
+  const int lat = 6 * num;
+  auto index_of = [&](int g) -> int {
+    if (g < 6) return ch.fi * 6 + g;
+    if (g < 12) return ch.fj * 6 + (g - 6);
+    if (g < 36) return lat + ch.ci + vertex_offset((g - 12) / 3, res) + (g - 12) % 3;
+    return lat + ch.cj + vertex_offset((g - 36) / 3, res) + (g - 36) % 3;
+  };
+  int t = 0;
+#pragma unroll
+  for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+    for (int bj = bi; bj < NB; bj++) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const int gi = bi * 16 + q + 4 * v, gj = bj * 16 + r;
+        const double G = acc[t][v];
+        if (gi > gj || gj > BPOS || G == 0.0) continue;          // lower half of a diagonal tile, padding, nothing to add
+        if (gj == BPOS) {
+          if (gi == BPOS) atomicAdd(score, G);                                       // sum b^2
+          else atomicAdd(&Jb[index_of(gi)], G);                                      // sum b v  (:549 / AddJb)
+          continue;
+        }
+        const int ia = index_of(gi), ic = index_of(gj);
+        if (MODE == 0) {                                                             // AddHessian: both triangles
+          atomicAdd(&JJ[(size_t)ia * N + ic], G);
+          if (gi != gj) atomicAdd(&JJ[(size_t)ic * N + ia], G);
+        } else if (gi == gj) {
+          atomicAdd(&JJ[(size_t)ia * N + ia], G);                                    // :538
+        } else if (ia == ic) {
+          atomicAdd(&JJ[(size_t)ia * N + ia], 2.0 * G);                              // :540-541
+        } else if (ia < ic) {
+          atomicAdd(&JJ[(size_t)ia * N + ic], G);                                    // :542-543
+        } else {
+          atomicAdd(&JJ[(size_t)ic * N + ia], G);                                    // :544-545
+        }
+      }
+      t++;
+    }
+}
+
+}  // namespace
+
+struct er_fopt_s {
+  int device = 0, num = 0, res = 8, nper = 0;
+  float length = 3.0f, ul = 0.375f;
+  hipStream_t stream = nullptr;
+  struct Frag {
+    int n = 0;
+    int* idx0 = nullptr;
+    float *val = nullptr, *nval = nullptr, *p = nullptr, *nrm = nullptr;
+    std::vector<int> h_idx0;
+  };
+  std::vector<Frag> frag;
+  FragPtr* d_frags = nullptr;
+  int n_pairs = 0, n_chunks = 0;
+  long n_corr = 0;
+  int *d_first = nullptr, *d_second = nullptr;
+  Chunk* d_chunks = nullptr;
+  double *d_JJ = nullptr, *d_Jb = nullptr, *d_rot = nullptr, *d_ctr = nullptr;
+  float* d_M = nullptr;
+  size_t jj_cap = 0;
+};
+
+namespace {
+
+void free_frag(er_fopt_s::Frag& f) {
+  void* ptrs[] = {f.idx0, f.val, f.nval, f.p, f.nrm};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  f = er_fopt_s::Frag();
+}
+
+// PointCloud::GetCoordinate, PointCloud.h:92-176, on the host (once per point at load time; float32 like the reference)
+bool get_coordinate(int res, float ul, const float* in6, int& idx0, float val[8], float nval[8], float nrm[3]) {
+  float pt[6];
+  memcpy(pt, in6, sizeof pt);
+  const int corner[3] = {(int)floor(pt[0] / ul), (int)floor(pt[1] / ul), (int)floor(pt[2] / ul)};
+  if (corner[0] < 0 || corner[0] >= res || corner[1] < 0 || corner[1] >= res || corner[2] < 0 || corner[2] >= res) return false;
+  const float r[3] = {pt[0] / ul - corner[0], pt[1] / ul - corner[1], pt[2] / ul - corner[2]};
+  idx0 = (corner[0] + corner[1] * (res + 1) + corner[2] * (res + 1) * (res + 1)) * 3;
+  val[0] = (1 - r[0]) * (1 - r[1]) * (1 - r[2]);
+  val[1] = (1 - r[0]) * (1 - r[1]) * (r[2]);
+  val[2] = (1 - r[0]) * (r[1]) * (1 - r[2]);
+  val[3] = (1 - r[0]) * (r[1]) * (r[2]);
+  val[4] = (r[0]) * (1 - r[1]) * (1 - r[2]);
+  val[5] = (r[0]) * (1 - r[1]) * (r[2]);
+  val[6] = (r[0]) * (r[1]) * (1 - r[2]);
+  val[7] = (r[0]) * (r[1]) * (r[2]);
+  pt[3] /= ul;
+  pt[4] /= ul;
+  pt[5] /= ul;
+  nval[0] = -pt[3] * (1 - r[1]) * (1 - r[2]) - pt[4] * (1 - r[0]) * (1 - r[2]) - pt[5] * (1 - r[0]) * (1 - r[1]);
+  nval[1] = -pt[3] * (1 - r[1]) * (r[2]) - pt[4] * (1 - r[0]) * (r[2]) + pt[5] * (1 - r[0]) * (1 - r[1]);
+  nval[2] = -pt[3] * (r[1]) * (1 - r[2]) + pt[4] * (1 - r[0]) * (1 - r[2]) - pt[5] * (1 - r[0]) * (r[1]);
+  nval[3] = -pt[3] * (r[1]) * (r[2]) + pt[4] * (1 - r[0]) * (r[2]) + pt[5] * (1 - r[0]) * (r[1]);
+  nval[4] = pt[3] * (1 - r[1]) * (1 - r[2]) - pt[4] * (r[0]) * (1 - r[2]) - pt[5] * (r[0]) * (1 - r[1]);
+  nval[5] = pt[3] * (1 - r[1]) * (r[2]) - pt[4] * (r[0]) * (r[2]) + pt[5] * (r[0]) * (1 - r[1]);
+  nval[6] = pt[3] * (r[1]) * (1 - r[2]) + pt[4] * (r[0]) * (1 - r[2]) - pt[5] * (r[0]) * (r[1]);
+  nval[7] = pt[3] * (r[1]) * (r[2]) + pt[4] * (r[0]) * (r[2]) + pt[5] * (r[0]) * (r[1]);
+  nrm[0] = pt[3];
+  nrm[1] = pt[4];
+  nrm[2] = pt[5];
+  return true;
+}
+
+int upload_frag_table(er_fopt_t h) {
+  std::vector<FragPtr> t((size_t)h->num);
+  for (int f = 0; f < h->num; f++) t[(size_t)f] = FragPtr{h->frag[(size_t)f].idx0, h->frag[(size_t)f].val, h->frag[(size_t)f].p, h->frag[(size_t)f].nrm};
+  ER_HIP_TRY(hipMemcpy(h->d_frags, t.data(), t.size() * sizeof(FragPtr), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int ensure_matrix(er_fopt_t h, size_t N) {
+  if (N * N <= h->jj_cap) return 0;
+  if (h->d_JJ) (void)hipFree(h->d_JJ);
+  if (h->d_Jb) (void)hipFree(h->d_Jb);
+  h->d_JJ = h->d_Jb = nullptr;
+  h->jj_cap = 0;
+  ER_HIP_TRY(hipMalloc((void**)&h->d_JJ, N * N * sizeof(double)));
+  ER_HIP_TRY(hipMalloc((void**)&h->d_Jb, (N + 1) * sizeof(double)));
+  h->jj_cap = N * N;
+  return 0;
+}
+
+template <int MODE>
+int assemble(er_fopt_t h, const double* pose_rot_t, double* JJ, double* Jb, double* score) {
+  if (!JJ || !Jb || !score) return er::fail("er_fopt_assemble: NULL output");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  const size_t N = MODE ? (size_t)(6 * h->num + h->nper) : (size_t)(6 * h->num);
+  if (ensure_matrix(h, N)) return 1;
+  ER_HIP_TRY(hipMemsetAsync(h->d_JJ, 0, N * N * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_Jb, 0, (N + 1) * sizeof(double), h->stream));
+  if (MODE) {
+    if (!pose_rot_t) return er::fail("er_fopt_assemble_slac: pose_rot_t is NULL");
+    ER_HIP_TRY(hipMemcpyAsync(h->d_rot, pose_rot_t, (size_t)h->num * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  if (h->n_chunks > 0) {
+    const int blocks = (h->n_chunks * 64 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_fopt_gram<MODE>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks, h->d_frags, h->d_first, h->d_second,
+                       h->d_rot, h->num, h->res, (int)N, h->d_JJ, h->d_Jb, h->d_Jb + N);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  ER_HIP_TRY(hipMemcpyAsync(JJ, h->d_JJ, N * N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(Jb, h->d_Jb, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(score, h->d_Jb + N, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (MODE == 0)
+    for (int k = 0; k < 6 && k < (int)N; k++) JJ[(size_t)k * N + k] += (double)h->n_pairs;     // mat_adder.Add( k, k, 1 ) per pair, OptApp.cpp:322-324
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int er_fopt_create(int num, int resolution, float length, int device, er_fopt_t* out) {
+  if (!out) return er::fail("er_fopt_create: out is NULL");
+  *out = nullptr;
+  if (num <= 0 || resolution <= 0 || !(length > 0.f)) return er::fail("er_fopt_create: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return er::fail("er_fopt_create: no HIP device available (liber_hip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return er::fail("er_fopt_create: device %d out of range [0,%d)", device, ndev);
+  ER_HIP_TRY(hipSetDevice(device));
+  er_fopt_t h = new er_fopt_s();
+  h->device = device;
+  h->num = num;
+  h->res = resolution;
+  h->length = length;
+  h->ul = length / resolution;                                  // PointCloud.cpp:10
+  h->nper = (resolution + 1) * (resolution + 1) * (resolution + 1) * 3;
+  h->frag.resize((size_t)num);
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&h->d_frags, (size_t)num * sizeof(FragPtr)) != hipSuccess ||
+      hipMalloc((void**)&h->d_rot, (size_t)num * 9 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void**)&h->d_ctr, (size_t)h->nper * sizeof(double)) != hipSuccess || hipMalloc((void**)&h->d_M, 16 * sizeof(float)) != hipSuccess) {
+    er_fopt_destroy(h);
+    return er::fail("er_fopt_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (upload_frag_table(h)) {
+    er_fopt_destroy(h);
+    return 1;
+  }
+  *out = h;
+  return 0;
+}
+
+int er_fopt_destroy(er_fopt_t h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& f : h->frag) free_frag(f);
+  void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int er_fopt_set_cloud(er_fopt_t h, int frag, const float* xyz, const float* nrm, int n, int* first_out_of_bound) {
+  if (!h || frag < 0 || frag >= h->num || n < 0 || (n > 0 && (!xyz || !nrm))) return er::fail("er_fopt_set_cloud: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (first_out_of_bound) *first_out_of_bound = -1;
+  std::vector<int> idx0((size_t)n);
+  std::vector<float> val((size_t)n * 8), nval((size_t)n * 8), p((size_t)n * 3), nn((size_t)n * 3);
+  int m = n;
+  for (int k = 0; k < n; k++) {
+    const float x[6] = {xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2], nrm[3 * k], nrm[3 * k + 1], nrm[3 * k + 2]};
+    memcpy(&p[(size_t)k * 3], x, 3 * sizeof(float));
+    if (!get_coordinate(h->res, h->ul, x, idx0[(size_t)k], &val[(size_t)k * 8], &nval[(size_t)k * 8], &nn[(size_t)k * 3])) {
+      if (first_out_of_bound) *first_out_of_bound = k;          // "Error!! Point out of bound!!" -- loading stops here (PointCloud.cpp:57-60)
+      m = k;
+      break;
+    }
+  }
+  er_fopt_s::Frag& f = h->frag[(size_t)frag];
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  free_frag(f);
+  f.n = m;
+  f.h_idx0.assign(idx0.begin(), idx0.begin() + m);
+  const size_t mm = (size_t)std::max(m, 1);
+  ER_HIP_TRY(hipMalloc((void**)&f.idx0, mm * sizeof(int)));
+  ER_HIP_TRY(hipMalloc((void**)&f.val, mm * 8 * sizeof(float)));
+  ER_HIP_TRY(hipMalloc((void**)&f.nval, mm * 8 * sizeof(float)));
+  ER_HIP_TRY(hipMalloc((void**)&f.p, mm * 3 * sizeof(float)));
+  ER_HIP_TRY(hipMalloc((void**)&f.nrm, mm * 3 * sizeof(float)));
+  if (m > 0) {
+    ER_HIP_TRY(hipMemcpy(f.idx0, idx0.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(f.val, val.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(f.nval, nval.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(f.p, p.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(f.nrm, nn.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return upload_frag_table(h);
+}
+
+int er_fopt_cloud_size(er_fopt_t h, int frag) { return (h && frag >= 0 && frag < h->num) ? h->frag[(size_t)frag].n : -1; }
+
+int er_fopt_get_points(er_fopt_t h, int frag, int* idx0, float* val, float* nval, float* p, float* nrm) {
+  if (!h || frag < 0 || frag >= h->num) return er::fail("er_fopt_get_points: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  const er_fopt_s::Frag& f = h->frag[(size_t)frag];
+  const size_t m = (size_t)f.n;
+  if (m == 0) return 0;
+  if (idx0) ER_HIP_TRY(hipMemcpy(idx0, f.idx0, m * sizeof(int), hipMemcpyDeviceToHost));
+  if (val) ER_HIP_TRY(hipMemcpy(val, f.val, m * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  if (nval) ER_HIP_TRY(hipMemcpy(nval, f.nval, m * 8 * sizeof(float), hipMemcpyDeviceToHost));
+  if (p) ER_HIP_TRY(hipMemcpy(p, f.p, m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  if (nrm) ER_HIP_TRY(hipMemcpy(nrm, f.nrm, m * 3 * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int er_fopt_update_pose(er_fopt_t h, int frag, const float M[16]) {
+  if (!h || frag < 0 || frag >= h->num || !M) return er::fail("er_fopt_update_pose: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  er_fopt_s::Frag& f = h->frag[(size_t)frag];
+  if (f.n == 0) return 0;
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));                   // d_M is reused call after call
+  ER_HIP_TRY(hipMemcpyAsync(h->d_M, M, 16 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_fopt_update_pose, dim3((f.n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, f.p, f.nrm, f.n, h->d_M);
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice) {
+  if (!h || frag < 0 || frag >= h->num || !ctr_slice) return er::fail("er_fopt_update_point_pn: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  er_fopt_s::Frag& f = h->frag[(size_t)frag];
+  if (f.n == 0) return 0;
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));                   // d_ctr is reused call after call
+  ER_HIP_TRY(hipMemcpyAsync(h->d_ctr, ctr_slice, (size_t)h->nper * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_fopt_update_pn, dim3((f.n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, f.idx0, f.val, f.nval, f.p, f.nrm, f.n,
+                     h->d_ctr, h->res);
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs, const int* counts) {
+  if (!h || n_pairs < 0 || (n_pairs > 0 && (!frag_i || !frag_j || !pairs || !counts))) return er::fail("er_fopt_set_correspondences: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<int> first, second;
+  std::vector<Chunk> chunks;
+  for (int l = 0; l < n_pairs; l++) {
+    const int i = frag_i[l], j = frag_j[l], m = counts[l];
+    if (i < 0 || i >= h->num || j < 0 || j >= h->num || m < 0 || (m > 0 && !pairs[l])) return er::fail("er_fopt_set_correspondences: bad pair %d", l);
+    const std::vector<int>& ci = h->frag[(size_t)i].h_idx0;
+    const std::vector<int>& cj = h->frag[(size_t)j].h_idx0;
+    std::vector<long long> key((size_t)m);
+    std::vector<int> order((size_t)m);
+    for (int k = 0; k < m; k++) {
+      const int a = pairs[l][2 * k], b = pairs[l][2 * k + 1];
+      if (a < 0 || a >= (int)ci.size() || b < 0 || b >= (int)cj.size())
+        return er::fail("er_fopt_set_correspondences: pair %d row %d (%d, %d) out of range (%zu, %zu points)", l, k, a, b, ci.size(), cj.size());
+      key[(size_t)k] = (long long)ci[(size_t)a] * (1LL << 32) + cj[(size_t)b];
+      order[(size_t)k] = k;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key[(size_t)x] < key[(size_t)y]; });
+    int g0 = 0;
+    while (g0 < m) {
+      int g1 = g0;
+      while (g1 < m && key[(size_t)order[(size_t)g1]] == key[(size_t)order[(size_t)g0]]) g1++;
+      const int a0 = pairs[l][2 * order[(size_t)g0]], b0 = pairs[l][2 * order[(size_t)g0] + 1];
+      for (int s = g0; s < g1; s += kChunkMax)
+        chunks.push_back(Chunk{i, j, ci[(size_t)a0], cj[(size_t)b0], (int)first.size() + (s - g0), std::min(kChunkMax, g1 - s)});
+      for (int s = g0; s < g1; s++) {
+        first.push_back(pairs[l][2 * order[(size_t)s]]);
+        second.push_back(pairs[l][2 * order[(size_t)s] + 1]);
+      }
+      g0 = g1;
+    }
+  }
+  void* old[] = {h->d_first, h->d_second, h->d_chunks};
+  for (void* p : old)
+    if (p) (void)hipFree(p);
+  h->d_first = h->d_second = nullptr;
+  h->d_chunks = nullptr;
+  h->n_pairs = n_pairs;
+  h->n_chunks = (int)chunks.size();
+  h->n_corr = (long)first.size();
+  if (!first.empty()) {
+    ER_HIP_TRY(hipMalloc((void**)&h->d_first, first.size() * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&h->d_second, second.size() * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&h->d_chunks, chunks.size() * sizeof(Chunk)));
+    ER_HIP_TRY(hipMemcpy(h->d_first, first.data(), first.size() * sizeof(int), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(h->d_second, second.data(), second.size() * sizeof(int), hipMemcpyHostToDevice));
+    ER_HIP_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+
+int er_fopt_group_count(er_fopt_t h) { return h ? h->n_chunks : -1; }
+
+int er_fopt_assemble_rigid(er_fopt_t h, double* JJ, double* Jb, double* score) {
+  if (!h) return er::fail("er_fopt_assemble_rigid: NULL handle");
+  return assemble<0>(h, nullptr, JJ, Jb, score);
+}
+
+int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, double* Jb, double* score) {
+  if (!h) return er::fail("er_fopt_assemble_slac: NULL handle");
+  return assemble<1>(h, pose_rot_t, JJ, Jb, score);
+}
+
+}  // extern "C"

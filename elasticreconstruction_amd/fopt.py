@@ -1,0 +1,113 @@
+"""Host-side mirror of the data-parallel half of the reference's FragmentOptimizer over the C ABI.
+
+  FragmentOptimizer  <->  COptApp's point clouds + correspondences (FragmentOptimizer/OptApp.h:39-124, PointCloud.h):
+      InitPointClouds / InitCorrespondences / UpdatePose / UpdateAllPointPN and the Hessian assembly of OptimizeRigid
+      (OptApp.cpp:312-375) and OptimizeSLAC (OptApp.cpp:473-560) run in the HIP kernels of liber_hip.so (er_fopt.hip).
+      The sparse solve (CHOLMOD in the reference) and the lattice regularizer stay on the host; OptimizeRigid below
+      closes the loop with a dense numpy solve so the tests can check convergence end to end.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+
+
+class FragmentOptimizer:
+    def __init__(self, num, resolution=8, length=3.0, device=0):
+        self._lib = _ffi.lib()
+        self.num_, self.resolution_, self.length_ = int(num), int(resolution), float(length)
+        self.nper_ = (resolution + 1) ** 3 * 3
+        h = C.c_void_p()
+        _ffi.check(self._lib.er_fopt_create(self.num_, self.resolution_, C.c_float(length), int(device), C.byref(h)), "er_fopt_create")
+        self._h = h
+        self.n_pairs = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.er_fopt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- COptApp::InitPointClouds, OptApp.cpp:74-98 ------------------------------------------------
+    def SetCloud(self, frag, xyz, normals):
+        """Returns -1, or the index of the first point outside the cube (loading stops there, PointCloud.cpp:57-60)."""
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        bad = C.c_int(-1)
+        _ffi.check(self._lib.er_fopt_set_cloud(self._h, int(frag), _ffi.ptr(x), _ffi.ptr(n), x.shape[0], C.byref(bad)), "er_fopt_set_cloud")
+        return bad.value
+
+    def points(self, frag):
+        m = self._lib.er_fopt_cloud_size(self._h, int(frag))
+        idx0, val, nval = np.zeros(m, np.int32), np.zeros((m, 8), np.float32), np.zeros((m, 8), np.float32)
+        p, n = np.zeros((m, 3), np.float32), np.zeros((m, 3), np.float32)
+        _ffi.check(self._lib.er_fopt_get_points(self._h, int(frag), _ffi.ptr(idx0), _ffi.ptr(val), _ffi.ptr(nval), _ffi.ptr(p), _ffi.ptr(n)),
+                   "er_fopt_get_points")
+        return dict(idx0=idx0, val=val, nval=nval, p=p, n=n)
+
+    # ---- PointCloud::UpdatePose / UpdateAllPointPN ------------------------------------------------------
+    def UpdatePose(self, frag, M):
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        _ffi.check(self._lib.er_fopt_update_pose(self._h, int(frag), _ffi.ptr(Mm)), "er_fopt_update_pose")
+
+    def UpdateAllPointPN(self, expand_ctr):
+        c = np.ascontiguousarray(expand_ctr, np.float64).reshape(self.num_, self.nper_)
+        for f in range(self.num_):
+            row = np.ascontiguousarray(c[f])
+            _ffi.check(self._lib.er_fopt_update_point_pn(self._h, f, _ffi.ptr(row)), "er_fopt_update_point_pn")
+
+    # ---- COptApp::InitCorrespondences, OptApp.cpp:100-118 ---------------------------------------------
+    def SetCorrespondences(self, pairs):
+        """pairs: list of (i, j, int32 [m,2] rows (index in fragment i, index in fragment j))."""
+        n = len(pairs)
+        fi = np.array([p[0] for p in pairs], np.int32)
+        fj = np.array([p[1] for p in pairs], np.int32)
+        arrs = [np.ascontiguousarray(p[2], np.int32).reshape(-1, 2) for p in pairs]
+        ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+        cnt = np.array([a.shape[0] for a in arrs], np.int32)
+        _ffi.check(self._lib.er_fopt_set_correspondences(self._h, n, _ffi.ptr(fi), _ffi.ptr(fj), ptrs, _ffi.ptr(cnt)), "er_fopt_set_correspondences")
+        self.n_pairs = n
+        return self._lib.er_fopt_group_count(self._h)
+
+    # ---- Hessian assembly ---------------------------------------------------------------------------------
+    def AssembleRigid(self):
+        N = 6 * self.num_
+        JJ, Jb, sc = np.zeros((N, N)), np.zeros(N), C.c_double(0)
+        _ffi.check(self._lib.er_fopt_assemble_rigid(self._h, _ffi.ptr(JJ), _ffi.ptr(Jb), C.byref(sc)), "er_fopt_assemble_rigid")
+        return JJ, Jb, sc.value
+
+    def AssembleSLAC(self, pose_rot_t):
+        N = 6 * self.num_ + self.nper_
+        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num_, 9)
+        JJ, Jb, sc = np.zeros((N, N)), np.zeros(N), C.c_double(0)
+        _ffi.check(self._lib.er_fopt_assemble_slac(self._h, _ffi.ptr(R), _ffi.ptr(JJ), _ffi.ptr(Jb), C.byref(sc)), "er_fopt_assemble_slac")
+        return JJ, Jb, sc.value
+
+    # ---- COptApp::OptimizeRigid, OptApp.cpp:282-412 (dense numpy solve in place of CHOLMOD) ----------------
+    def OptimizeRigid(self, ipose, max_iteration=5):
+        """ipose: list of float64 4x4 initial poses.  Returns (poses, scores per iteration)."""
+        pose = [np.array(P, np.float64) for P in ipose]
+        for l in range(self.num_):
+            self.UpdatePose(l, pose[l].astype(np.float32))                       # :296
+        scores = []
+        for _ in range(max_iteration):
+            JJ, Jb, score = self.AssembleRigid()
+            scores.append(score)
+            result = -np.linalg.solve(JJ, Jb)                                        # solver.solve( thisJb ), :389-393
+            for l in range(self.num_):
+                a, b, g = result[l * 6:l * 6 + 3]
+                Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+                Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+                Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+                aff = np.eye(4)
+                aff[:3, :3] = Rz @ Ry @ Rx                                           # AngleAxis Z * Y * X, :396-399
+                aff[:3, 3] = result[l * 6 + 3:l * 6 + 6]
+                pose[l] = aff @ pose[l]                                              # :401
+                self.UpdatePose(l, aff.astype(np.float32))                           # :402
+        return pose, scores

@@ -170,6 +170,41 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
 /* Frees the pooled ICP workspaces (streams, scratch, pinned blocks).  Optional; call when no ICP call is running. */
 int er_icp_release_workspaces(void);
 
+/* ------------------------------------------ next consumer: FragmentOptimizer ---- */
+typedef struct er_fopt_s* er_fopt_t;
+
+/* COptApp's point clouds (FragmentOptimizer/OptApp.cpp:74-98, PointCloud.h): num fragments over a control lattice of
+ * (resolution+1)^3 vertices, cube edge `length`. */
+int er_fopt_create(int num, int resolution, float length, int device, er_fopt_t* out);
+int er_fopt_destroy(er_fopt_t h);
+
+/* PointCloud::LoadFromXYZNFile / LoadFromPCDFile body (PointCloud.cpp:22-63): n points (xyz, normals; NaN-normal points
+ * already dropped) through GetCoordinate (PointCloud.h:92-176).  Like the reference, loading stops at the first point
+ * outside the cube; *first_out_of_bound (nullable) receives its index or -1. */
+int er_fopt_set_cloud(er_fopt_t h, int frag, const float* xyz_host, const float* normal_host, int n, int* first_out_of_bound);
+int er_fopt_cloud_size(er_fopt_t h, int frag);
+/* Point state read-back (any pointer may be NULL): idx_[0], val_[8], nval_[8], p_[3], n_[3] per point. */
+int er_fopt_get_points(er_fopt_t h, int frag, int* idx0, float* val, float* nval, float* p, float* n);
+
+/* PointCloud::UpdatePose (PointCloud.h:71-83): p_, n_ <- M * (p_,1), M * (n_,0); M row-major FLOAT 4x4. */
+int er_fopt_update_pose(er_fopt_t h, int frag, const float M[16]);
+/* PointCloud::UpdateAllPointPN (PointCloud.h:44-52): p_, n_ from the fragment's slice of expand_ctr (nper doubles). */
+int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice_host);
+
+/* COptApp::InitCorrespondences (OptApp.cpp:100-118): n_pairs lists of (index in fragment frag_i, index in frag_j) rows =
+ * the lines of corres_<i>_<j>.txt.  Sorted once by lattice cell pair for the assembly kernels. */
+int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs_host,
+                                const int* counts);
+int er_fopt_group_count(er_fopt_t h);
+
+/* Hessian assembly of OptimizeRigid (OptApp.cpp:312-375): JJ = (6 num)^2 row-major FULL symmetric matrix including the
+ * "+1" every pair puts on the first six diagonal entries, Jb (6 num), score = sum b^2.  Host output buffers. */
+int er_fopt_assemble_rigid(er_fopt_t h, double* JJ, double* Jb, double* score);
+/* Data term of OptimizeSLAC (OptApp.cpp:473-560): JJ = (6 num + nper)^2 row-major, UPPER triangle as the reference
+ * accumulates it (before baseJJ and the gauge "+1"s), Jb, score.  pose_rot_t: num * 9 doubles, row-major
+ * pose_[l].block<3,3>(0,0).transpose(). */
+int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, double* Jb, double* score);
+
 #ifdef __cplusplus
 }
 #endif
