@@ -219,6 +219,66 @@ def icp_section(n_pairs, device, with_cpu=True):
     return res
 
 
+def fopt_section(device):
+    """SURVEY.md 8f-2 figure: Hessian assembly of the reference's FragmentOptimizer (SLAC and rigid modes) for 4 fragments
+    of ~250 k points / 6 pairs with exact correspondence lists, GPU (er_fopt_assemble_*) vs the sequential oracle."""
+    import numpy as np
+    from elasticreconstruction_amd import synth
+    from elasticreconstruction_amd.fopt import FragmentOptimizer
+    from elasticreconstruction_amd.icp import Cloud, find_correspondence_batch
+    num, length = 4, 3.0
+    base = synth.look_at((1.5, 1.5, 1.5), (0, 0, 1)) @ np.linalg.inv(synth.basepose())
+    frags, poses = [], []
+    for f in range(num):
+        P = base @ (synth.perturbation(70 + 10 * f, 4.0, 0.06) if f else np.eye(4))
+        x, n = synth.sample_fragment(P, 600000, seed=70 + f)
+        ok = ((x > 1e-3) & (x < length - 1e-3)).all(1)
+        frags.append((x[ok].astype(np.float32), n[ok].astype(np.float32)))
+        poses.append(P)
+    clouds = [Cloud(x, n, 0.03, device) for x, n in frags]
+    ij = [(i, j) for i in range(num) for j in range(i + 1, num)]
+    lists, _ = find_correspondence_batch([clouds[j] for i, j in ij], [clouds[i] for i, j in ij],
+                                         [np.linalg.inv(poses[i]) @ poses[j] for i, j in ij], 0.015, 0.866)
+    pairs = [(i, j, l) for (i, j), l in zip(ij, lists)]
+    ncorr = int(sum(l.shape[0] for l in lists))
+    g = FragmentOptimizer(num, 8, length, device)
+    for f, (x, n) in enumerate(frags):
+        g.SetCloud(f, x, n)
+        g.UpdatePose(f, poses[f].astype(np.float32))
+    groups = g.SetCorrespondences(pairs)
+    Rt = np.stack([P[:3, :3].T.reshape(9) for P in poses])
+    g.AssembleSLAC(Rt)
+    g.AssembleRigid()
+    ts, tr = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        JJ, _, _ = g.AssembleSLAC(Rt)
+        ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        g.AssembleRigid()
+        tr.append(time.perf_counter() - t0)
+    res = {"correspondences": ncorr, "pairs": len(pairs), "group_chunks": int(groups), "slac_matrix_dim": int(JJ.shape[0]),
+           "slac_assembly_ms": 1e3 * sorted(ts)[2], "rigid_assembly_ms": 1e3 * sorted(tr)[2],
+           "slac_correspondences_per_s": ncorr / sorted(ts)[2],
+           "what": "er_fopt_assemble_slac / _rigid = OptimizeSLAC / OptimizeRigid Hessian assembly (OptApp.cpp:473-560, 312-375), dense matrix copied to the host included"}
+    try:
+        from oracle.pyoracle import FoptOracle
+        o = FoptOracle(num, 8, length)
+        for f, (x, n) in enumerate(frags):
+            o.set_cloud(f, x, n)
+            o.update_pose(f, poses[f].astype(np.float32))
+        sub = [(i, j, l[:20000]) for i, j, l in pairs]
+        o.set_pairs(sub)
+        t0 = time.perf_counter()
+        o.assemble_slac(Rt)
+        nsub = sum(l.shape[0] for _, _, l in sub)
+        res["cpu_port_slac_correspondences_per_s"] = nsub / (time.perf_counter() - t0)
+        res["cpu_port_note"] = "oracle/fopt_oracle.cpp, 1 thread, %d correspondences (the reference runs the same loop on 8 OpenMP threads)" % nsub
+    except Exception as ex:
+        res["cpu_port_note"] = "oracle not available: %s" % ex
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,6 +461,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sc, host, ns)
         if icp is not None:
             out["icp"] = icp
+            if world == 1:
+                out["fragment_optimizer"] = fopt_section(local)
         print(json.dumps(out), flush=True)
     vol.close()
     if use_dist:

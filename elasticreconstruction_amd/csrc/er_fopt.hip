@@ -24,7 +24,13 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kChunkMax = 512;        // correspondences per wave task
+#ifndef ER_FOPT_CHUNK
+#define ER_FOPT_CHUNK 512
+#endif
+#ifndef ER_FOPT_MINBLOCKS
+#define ER_FOPT_MINBLOCKS 2
+#endif
+constexpr int kChunkMax = ER_FOPT_CHUNK;   // correspondences per wave task
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -95,7 +101,7 @@ __global__ void k_fopt_update_pn(const int* __restrict__ idx0, const float* __re
 
 // MODE 0 = rigid (12 entries + b at 12, one 16x16 tile), MODE 1 = SLAC (60 entries + b at 60, 4x4 blocks, upper 10 tiles)
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_fopt_gram(const Chunk* __restrict__ chunks, int n_chunks, const FragPtr* __restrict__ frags,
+__global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const Chunk* __restrict__ chunks, int n_chunks, const FragPtr* __restrict__ frags,
                                                       const int* __restrict__ first, const int* __restrict__ second,
                                                       const double* __restrict__ rot_t, int num, int res, int N,
                                                       double* __restrict__ JJ, double* __restrict__ Jb, double* __restrict__ score) {
