@@ -249,7 +249,8 @@ def fopt_section(device):
     Rt = np.stack([P[:3, :3].T.reshape(9) for P in poses])
     g.AssembleSLAC(Rt)
     g.AssembleRigid()
-    ts, tr = [], []
+    g.AssembleNonrigid(1.0)
+    ts, tr, tn = [], [], []
     for _ in range(5):
         t0 = time.perf_counter()
         JJ, _, _ = g.AssembleSLAC(Rt)
@@ -257,10 +258,13 @@ def fopt_section(device):
         t0 = time.perf_counter()
         g.AssembleRigid()
         tr.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        g.AssembleNonrigid(1.0)
+        tn.append(time.perf_counter() - t0)
     res = {"correspondences": ncorr, "pairs": len(pairs), "group_chunks": int(groups), "slac_matrix_dim": int(JJ.shape[0]),
-           "slac_assembly_ms": 1e3 * sorted(ts)[2], "rigid_assembly_ms": 1e3 * sorted(tr)[2],
+           "slac_assembly_ms": 1e3 * sorted(ts)[2], "rigid_assembly_ms": 1e3 * sorted(tr)[2], "nonrigid_assembly_ms": 1e3 * sorted(tn)[2],
            "slac_correspondences_per_s": ncorr / sorted(ts)[2],
-           "what": "er_fopt_assemble_slac / _rigid = OptimizeSLAC / OptimizeRigid Hessian assembly (OptApp.cpp:473-560, 312-375), dense matrix copied to the host included"}
+           "what": "er_fopt_assemble_slac / _rigid / _nonrigid = Hessian assembly of OptimizeSLAC / OptimizeRigid / OptimizeNonrigid (OptApp.cpp:473-560, 312-375, 159-206), result copied to the host included"}
     try:
         from oracle.pyoracle import FoptOracle
         o = FoptOracle(num, 8, length)

@@ -45,6 +45,7 @@ struct Chunk {
   int fi, fj;        // fragments (corres_.idx0_, idx1_)
   int ci, cj;        // idx_[0] of the lattice cell of p_i / p_j (vertex index * 3)
   int start, count;  // range in the sorted correspondence arrays
+  int group;         // index of the (pair, cell, cell) group this chunk belongs to
 };
 
 // vertex offsets of idx_[0..7] relative to idx_[0], PointCloud.h:113-120 (t = 4*dx + 2*dy + dz)
@@ -67,8 +68,10 @@ __global__ void k_fopt_update_pose(float* __restrict__ p, float* __restrict__ nr
 }
 
 // PointCloud::UpdateAllPointPN, PointCloud.h:44-52 (UpdateNormal :58-69, UpdatePoint :85-94); ctr = the fragment's slice
+// normals_only = 1: PointCloud::UpdateAllNormal (PointCloud.h:32-36), the non-rigid mode's per-iteration update (OptApp.cpp:151-153)
 __global__ void k_fopt_update_pn(const int* __restrict__ idx0, const float* __restrict__ val, const float* __restrict__ nval,
-                                 float* __restrict__ p, float* __restrict__ nrm, int n, const double* __restrict__ ctr, int res) {
+                                 float* __restrict__ p, float* __restrict__ nrm, int n, const double* __restrict__ ctr, int res,
+                                 int normals_only) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int base = idx0[k];
@@ -90,6 +93,7 @@ __global__ void k_fopt_update_pn(const int* __restrict__ idx0, const float* __re
   const float len = sqrtf(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
 #pragma unroll
   for (int i = 0; i < 3; i++) nrm[3 * k + i] = nn[i] / len;
+  if (normals_only) return;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     double pos = 0.0;
@@ -99,22 +103,25 @@ __global__ void k_fopt_update_pn(const int* __restrict__ idx0, const float* __re
   }
 }
 
-// MODE 0 = rigid (12 entries + b at 12, one 16x16 tile), MODE 1 = SLAC (60 entries + b at 60, 4x4 blocks, upper 10 tiles)
+// MODE 0 = rigid (12 entries + b at 12, one 16x16 tile), MODE 1 = SLAC (60 entries + b at 60, 4x4 blocks, upper 10 tiles),
+// MODE 2 = non-rigid (OptApp.cpp:159-206: val1 (24) | val2 (24), 3x3 blocks, upper 6 tiles; no right-hand side: Ab comes from
+// the regularizer only).  MODE 2 writes block-sparse output: G11 / G22 into the per-fragment, per-cell 24x24 blocks `JJ`
+// ([fragment][corner vertex][24][24], both triangles like AddHessian) and G12 into `Jb` = one 24x24 block per group.
 template <int MODE>
 __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const Chunk* __restrict__ chunks, int n_chunks, const FragPtr* __restrict__ frags,
                                                       const int* __restrict__ first, const int* __restrict__ second,
                                                       const double* __restrict__ rot_t, int num, int res, int N,
                                                       double* __restrict__ JJ, double* __restrict__ Jb, double* __restrict__ score) {
-  constexpr int NB = MODE ? 4 : 1;                 // 16-entry blocks of the bucket
-  constexpr int NT = MODE ? 10 : 1;                // upper-triangular tile pairs
-  constexpr int BPOS = MODE ? 60 : 12;             // where b sits
+  constexpr int NB = MODE == 0 ? 1 : (MODE == 1 ? 4 : 3);      // 16-entry blocks of the bucket
+  constexpr int NT = NB * (NB + 1) / 2;                        // upper-triangular tile pairs
+  constexpr int BPOS = MODE == 0 ? 12 : (MODE == 1 ? 60 : 48); // where b sits (MODE 2: nothing there)
   const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
   if (wave >= n_chunks) return;
   const Chunk ch = chunks[wave];
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const FragPtr Fi = frags[ch.fi], Fj = frags[ch.fj];
   double Ri[9], Rj[9];
-  if (MODE) {
+  if (MODE == 1) {
 #pragma unroll
     for (int t = 0; t < 9; t++) {
       Ri[t] = rot_t[9 * ch.fi + t];
@@ -150,6 +157,15 @@ __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const C
         else if (r == 12) v = bval;
         else v = 0.0;
         a[0] = v;
+      } else if (MODE == 2) {                                                       // OptApp.cpp:176-190, entry c*8 + t
+        const double weight = rot_t[0];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          const int e = b * 16 + r, h = e < 24 ? e : e - 24, c = h >> 3, tt = h & 7;
+          const double nc = c == 0 ? npi[0] : (c == 1 ? npi[1] : npi[2]);
+          const double w = e < 24 ? (double)Fi.val[8 * ii + tt] : -(double)Fj.val[8 * jj + tt];
+          a[b] = (w * weight) * nc;
+        }
       } else {                                                                      // OptApp.cpp:509-535
         const double t[3] = {ppj[1] * npi[2] - ppj[2] * npi[1], ppj[2] * npi[0] - ppj[0] * npi[2], ppj[0] * npi[1] - ppj[1] * npi[0]};
         double dTi[3], dTj[3];
@@ -191,6 +207,35 @@ __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const C
   }
 
   // scatter: D[i = q + 4 v][j = r] of tile (bi, bj) is G[16 bi + i][16 bj + j]  (layout probed: scripts/ubench/mfma_f64_layout.hip)
+  if (MODE == 2) {
+    const int nv = (res + 1) * (res + 1) * (res + 1);
+    double* Di = JJ + ((size_t)ch.fi * nv + ch.ci / 3) * 576;
+    double* Dj = JJ + ((size_t)ch.fj * nv + ch.cj / 3) * 576;
+    double* Oij = Jb + (size_t)ch.group * 576;
+    int t = 0;
+#pragma unroll
+    for (int bi = 0; bi < NB; bi++)
+#pragma unroll
+      for (int bj = bi; bj < NB; bj++) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          const int gi = bi * 16 + q + 4 * v, gj = bj * 16 + r;
+          const double G = acc[t][v];
+          if (gi > gj || G == 0.0) continue;
+          if (gj < 24) {                                        // mati.AddHessian( idx1, val1, 24 ): both triangles
+            atomicAdd(&Di[gi * 24 + gj], G);
+            if (gi != gj) atomicAdd(&Di[gj * 24 + gi], G);
+          } else if (gi >= 24) {                                // matj.AddHessian( idx2, val2, 24 )
+            atomicAdd(&Dj[(gi - 24) * 24 + (gj - 24)], G);
+            if (gi != gj) atomicAdd(&Dj[(gj - 24) * 24 + (gi - 24)], G);
+          } else {                                              // matij.AddHessian( idx1, val1, 24, idx2, val2, 24 )
+            atomicAdd(&Oij[gi * 24 + (gj - 24)], G);
+          }
+        }
+        t++;
+      }
+    return;
+  }
   const int lat = 6 * num;
   auto index_of = [&](int g) -> int {
     if (g < 6) return ch.fi * 6 + g;
@@ -245,7 +290,10 @@ struct er_fopt_s {
   };
   std::vector<Frag> frag;
   FragPtr* d_frags = nullptr;
-  int n_pairs = 0, n_chunks = 0;
+  int n_pairs = 0, n_chunks = 0, n_groups = 0;
+  std::vector<int> group_info;   // 4 per group: fragment i, fragment j, idx_[0] of the cell of p_i, of p_j
+  double *d_diag = nullptr, *d_off = nullptr;
+  size_t diag_cap = 0, off_cap = 0;
   long n_corr = 0;
   int *d_first = nullptr, *d_second = nullptr;
   Chunk* d_chunks = nullptr;
@@ -381,7 +429,7 @@ int er_fopt_destroy(er_fopt_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& f : h->frag) free_frag(f);
-  void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M};
+  void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M, h->d_diag, h->d_off};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -455,24 +503,27 @@ int er_fopt_update_pose(er_fopt_t h, int frag, const float M[16]) {
   return 0;
 }
 
-int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice) {
-  if (!h || frag < 0 || frag >= h->num || !ctr_slice) return er::fail("er_fopt_update_point_pn: bad arguments");
+static int update_from_ctr(er_fopt_t h, int frag, const double* ctr_slice, int normals_only) {
+  if (!h || frag < 0 || frag >= h->num || !ctr_slice) return er::fail("er_fopt_update_point_pn / update_normals: bad arguments");
   ER_HIP_TRY(hipSetDevice(h->device));
   er_fopt_s::Frag& f = h->frag[(size_t)frag];
   if (f.n == 0) return 0;
   ER_HIP_TRY(hipStreamSynchronize(h->stream));                   // d_ctr is reused call after call
   ER_HIP_TRY(hipMemcpyAsync(h->d_ctr, ctr_slice, (size_t)h->nper * sizeof(double), hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_fopt_update_pn, dim3((f.n + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, f.idx0, f.val, f.nval, f.p, f.nrm, f.n,
-                     h->d_ctr, h->res);
+                     h->d_ctr, h->res, normals_only);
   ER_HIP_TRY(hipGetLastError());
   return 0;
 }
+
+int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice) { return update_from_ctr(h, frag, ctr_slice, 0); }
+int er_fopt_update_normals(er_fopt_t h, int frag, const double* ctr_slice) { return update_from_ctr(h, frag, ctr_slice, 1); }
 
 int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs, const int* counts) {
   if (!h || n_pairs < 0 || (n_pairs > 0 && (!frag_i || !frag_j || !pairs || !counts))) return er::fail("er_fopt_set_correspondences: bad arguments");
   ER_HIP_TRY(hipSetDevice(h->device));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
-  std::vector<int> first, second;
+  std::vector<int> first, second, ginfo;
   std::vector<Chunk> chunks;
   for (int l = 0; l < n_pairs; l++) {
     const int i = frag_i[l], j = frag_j[l], m = counts[l];
@@ -494,8 +545,10 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
       int g1 = g0;
       while (g1 < m && key[(size_t)order[(size_t)g1]] == key[(size_t)order[(size_t)g0]]) g1++;
       const int a0 = pairs[l][2 * order[(size_t)g0]], b0 = pairs[l][2 * order[(size_t)g0] + 1];
+      const int gid = (int)ginfo.size() / 4;
+      ginfo.insert(ginfo.end(), {i, j, ci[(size_t)a0], cj[(size_t)b0]});
       for (int s = g0; s < g1; s += kChunkMax)
-        chunks.push_back(Chunk{i, j, ci[(size_t)a0], cj[(size_t)b0], (int)first.size() + (s - g0), std::min(kChunkMax, g1 - s)});
+        chunks.push_back(Chunk{i, j, ci[(size_t)a0], cj[(size_t)b0], (int)first.size() + (s - g0), std::min(kChunkMax, g1 - s), gid});
       for (int s = g0; s < g1; s++) {
         first.push_back(pairs[l][2 * order[(size_t)s]]);
         second.push_back(pairs[l][2 * order[(size_t)s] + 1]);
@@ -510,6 +563,8 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
   h->d_chunks = nullptr;
   h->n_pairs = n_pairs;
   h->n_chunks = (int)chunks.size();
+  h->n_groups = (int)ginfo.size() / 4;
+  h->group_info.swap(ginfo);
   h->n_corr = (long)first.size();
   if (!first.empty()) {
     ER_HIP_TRY(hipMalloc((void**)&h->d_first, first.size() * sizeof(int)));
@@ -522,7 +577,13 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
   return 0;
 }
 
-int er_fopt_group_count(er_fopt_t h) { return h ? h->n_chunks : -1; }
+int er_fopt_group_count(er_fopt_t h) { return h ? h->n_groups : -1; }
+
+int er_fopt_group_info(er_fopt_t h, int* info4) {
+  if (!h || !info4) return er::fail("er_fopt_group_info: bad arguments");
+  if (!h->group_info.empty()) memcpy(info4, h->group_info.data(), h->group_info.size() * sizeof(int));
+  return 0;
+}
 
 int er_fopt_assemble_rigid(er_fopt_t h, double* JJ, double* Jb, double* score) {
   if (!h) return er::fail("er_fopt_assemble_rigid: NULL handle");
@@ -532,6 +593,40 @@ int er_fopt_assemble_rigid(er_fopt_t h, double* JJ, double* Jb, double* score) {
 int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, double* Jb, double* score) {
   if (!h) return er::fail("er_fopt_assemble_slac: NULL handle");
   return assemble<1>(h, pose_rot_t, JJ, Jb, score);
+}
+
+int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* offdiag) {
+  if (!h || !diag || (h->n_groups > 0 && !offdiag)) return er::fail("er_fopt_assemble_nonrigid: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  const size_t nv = (size_t)(h->res + 1) * (h->res + 1) * (h->res + 1);
+  const size_t nd = (size_t)h->num * nv * 576, no = (size_t)std::max(h->n_groups, 1) * 576;
+  if (nd > h->diag_cap) {
+    if (h->d_diag) (void)hipFree(h->d_diag);
+    h->d_diag = nullptr;
+    h->diag_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->d_diag, nd * sizeof(double)));
+    h->diag_cap = nd;
+  }
+  if (no > h->off_cap) {
+    if (h->d_off) (void)hipFree(h->d_off);
+    h->d_off = nullptr;
+    h->off_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->d_off, no * sizeof(double)));
+    h->off_cap = no;
+  }
+  ER_HIP_TRY(hipMemsetAsync(h->d_diag, 0, nd * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_off, 0, no * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->d_rot, &weight, sizeof(double), hipMemcpyHostToDevice, h->stream));     // MODE 2 reads the weight from rot_t[0]
+  if (h->n_chunks > 0) {
+    const int blocks = (h->n_chunks * 64 + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_fopt_gram<2>, dim3(blocks), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks, h->d_frags, h->d_first, h->d_second,
+                       h->d_rot, h->num, h->res, 0, h->d_diag, h->d_off, (double*)nullptr);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  ER_HIP_TRY(hipMemcpyAsync(diag, h->d_diag, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (h->n_groups > 0) ER_HIP_TRY(hipMemcpyAsync(offdiag, h->d_off, (size_t)h->n_groups * 576 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 }  // extern "C"

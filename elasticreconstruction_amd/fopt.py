@@ -62,6 +62,13 @@ class FragmentOptimizer:
             row = np.ascontiguousarray(c[f])
             _ffi.check(self._lib.er_fopt_update_point_pn(self._h, f, _ffi.ptr(row)), "er_fopt_update_point_pn")
 
+    def UpdateAllNormal(self, ctr):
+        """pointclouds_[l].UpdateAllNormal(ctr) for every fragment (non-rigid mode, OptApp.cpp:151-153); ctr has num * nper entries."""
+        c = np.ascontiguousarray(ctr, np.float64).reshape(self.num_, self.nper_)
+        for f in range(self.num_):
+            row = np.ascontiguousarray(c[f])
+            _ffi.check(self._lib.er_fopt_update_normals(self._h, f, _ffi.ptr(row)), "er_fopt_update_normals")
+
     # ---- COptApp::InitCorrespondences, OptApp.cpp:100-118 ---------------------------------------------
     def SetCorrespondences(self, pairs):
         """pairs: list of (i, j, int32 [m,2] rows (index in fragment i, index in fragment j))."""
@@ -88,6 +95,49 @@ class FragmentOptimizer:
         JJ, Jb, sc = np.zeros((N, N)), np.zeros(N), C.c_double(0)
         _ffi.check(self._lib.er_fopt_assemble_slac(self._h, _ffi.ptr(R), _ffi.ptr(JJ), _ffi.ptr(Jb), C.byref(sc)), "er_fopt_assemble_slac")
         return JJ, Jb, sc.value
+
+    def AssembleNonrigid(self, weight):
+        """Data term of OptimizeNonrigid (OptApp.cpp:159-206) as block-sparse arrays:
+        diag [num, (res+1)^3, 24, 24], offdiag [groups, 24, 24], info [groups, 4] = (frag_i, frag_j, idx0_i, idx0_j)."""
+        nv = (self.resolution_ + 1) ** 3
+        ng = self._lib.er_fopt_group_count(self._h)
+        diag = np.zeros((self.num_, nv, 24, 24))
+        off = np.zeros((max(ng, 1), 24, 24))
+        info = np.zeros((max(ng, 1), 4), np.int32)
+        _ffi.check(self._lib.er_fopt_group_info(self._h, _ffi.ptr(info)), "er_fopt_group_info")
+        _ffi.check(self._lib.er_fopt_assemble_nonrigid(self._h, float(weight), _ffi.ptr(diag), _ffi.ptr(off)), "er_fopt_assemble_nonrigid")
+        return diag, off[:ng], info[:ng]
+
+    def local_to_lattice(self):
+        """Lattice offset of local bucket entry c*8 + t relative to idx_[0]: vertex_offset(t) + c (PointCloud.h:113-120)."""
+        n1 = self.resolution_ + 1
+        t = np.arange(8)
+        voff = (((t >> 2) & 1) + ((t >> 1) & 1) * n1 + (t & 1) * n1 * n1) * 3
+        return (voff[None, :] + np.arange(3)[:, None]).reshape(24)
+
+    def NonrigidTriplets(self, weight):
+        """thisAA - baseAA as merged COO triplets (rows, cols, vals) with global indices fragment * nper + lattice index --
+        what the reference hands to CHOLMOD after adding baseAA."""
+        diag, off, info = self.AssembleNonrigid(weight)
+        loc = self.local_to_lattice()
+        M = self.nper_ * self.num_
+        f, v = np.nonzero(np.abs(diag).reshape(self.num_, diag.shape[1], -1).max(-1) > 0)
+        base = f * self.nper_ + v * 3
+        r = (base[:, None] + loc[None, :])
+        keys = [(r[:, :, None] * M + r[:, None, :]).reshape(-1)]
+        vals = [diag[f, v].reshape(-1)]
+        if off.shape[0]:
+            ri = info[:, 0].astype(np.int64) * self.nper_ + info[:, 2]
+            rj = info[:, 1].astype(np.int64) * self.nper_ + info[:, 3]
+            a = ri[:, None] + loc[None, :]
+            b = rj[:, None] + loc[None, :]
+            keys.append((a[:, :, None] * M + b[:, None, :]).reshape(-1))
+            vals.append(off.reshape(-1))
+        keys, vals = np.concatenate(keys), np.concatenate(vals)
+        uk, inv = np.unique(keys, return_inverse=True)
+        out = np.zeros(uk.size)
+        np.add.at(out, inv, vals)
+        return uk // M, uk % M, out
 
     # ---- COptApp::OptimizeRigid, OptApp.cpp:282-412 (dense numpy solve in place of CHOLMOD) ----------------
     def OptimizeRigid(self, ipose, max_iteration=5):

@@ -195,7 +195,10 @@ int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice_host)
  * the lines of corres_<i>_<j>.txt.  Sorted once by lattice cell pair for the assembly kernels. */
 int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs_host,
                                 const int* counts);
-int er_fopt_group_count(er_fopt_t h);
+int er_fopt_group_count(er_fopt_t h);          /* groups = distinct (pair, lattice cell of p_i, lattice cell of p_j) */
+int er_fopt_group_info(er_fopt_t h, int* info4);   /* 4 ints per group: frag_i, frag_j, idx_[0] of p_i's cell, of p_j's cell */
+/* PointCloud::UpdateAllNormal (PointCloud.h:32-36): n_ only, from the fragment's slice of ctr (non-rigid mode, OptApp.cpp:151-153). */
+int er_fopt_update_normals(er_fopt_t h, int frag, const double* ctr_slice_host);
 
 /* Hessian assembly of OptimizeRigid (OptApp.cpp:312-375): JJ = (6 num)^2 row-major FULL symmetric matrix including the
  * "+1" every pair puts on the first six diagonal entries, Jb (6 num), score = sum b^2.  Host output buffers. */
@@ -204,6 +207,14 @@ int er_fopt_assemble_rigid(er_fopt_t h, double* JJ, double* Jb, double* score);
  * accumulates it (before baseJJ and the gauge "+1"s), Jb, score.  pose_rot_t: num * 9 doubles, row-major
  * pose_[l].block<3,3>(0,0).transpose(). */
 int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, double* Jb, double* score);
+
+/* Data term of OptimizeNonrigid (OptApp.cpp:159-206), block-sparse as it is born:
+ *   diag    [num][(resolution+1)^3][24][24]  sum of mati / matj blocks per fragment and lattice cell (cell = its corner vertex
+ *           idx_[0]/3); local index c*8 + t  <->  lattice index idx_[t] + c (t = vertex 4dx+2dy+dz, c = x,y,z); both triangles
+ *   offdiag [groups][24][24]                 matij block of each group (rows: fragment i's cell, columns: fragment j's cell)
+ * thisAA - baseAA is the sum of these blocks at their global positions (fragment * nper + lattice index); the host merges
+ * blocks that share lattice vertices when it builds the sparse matrix for the solver. */
+int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* offdiag);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <vector>
 
 namespace {
@@ -114,6 +115,31 @@ void update_point_pn(Cloud& c, const double* ctr) {
       q.p[i] = (float)pos;
     }
   }
+}
+
+// PointCloud::UpdateAllNormal, PointCloud.h:32-36 (UpdateNormal :58-69): normals only (non-rigid mode, OptApp.cpp:151-153)
+void update_normals(Cloud& c, const double* ctr) {
+  for (Point& q : c.pts) {
+    for (int i = 0; i < 3; i++) {
+      q.n[i] = 0.0f;
+      for (int j = 0; j < 8; j++) q.n[i] += q.nval[j] * (float)ctr[q.idx[j] + i];
+    }
+    const float len = (float)sqrt((double)(q.n[0] * q.n[0] + q.n[1] * q.n[1] + q.n[2] * q.n[2]));
+    q.n[0] /= len;
+    q.n[1] /= len;
+    q.n[2] /= len;
+  }
+}
+
+// The two 24-entry buckets of the non-rigid mode, OptApp.cpp:176-190: entry c*8 + t  (c = x,y,z component, t = vertex)
+void nonrigid_bucket(const Point& pi, const Point& pj, double weight, int idx1[24], double val1[24], int idx2[24], double val2[24]) {
+  for (int t = 0; t < 8; t++)
+    for (int c = 0; c < 3; c++) {
+      idx1[c * 8 + t] = pi.idx[t] + c;
+      val1[c * 8 + t] = pi.val[t] * weight * pi.n[c];
+      idx2[c * 8 + t] = pj.idx[t] + c;
+      val2[c * 8 + t] = -pj.val[t] * weight * pi.n[c];
+    }
 }
 
 // The 12 pose entries of the rigid bucket and b, OptApp.cpp:337-365 (Vector4d dots written out; zero terms kept out).
@@ -290,6 +316,50 @@ void fopt_assemble_slac(void* h, const double* pose_rot_t, double* JJ, double* J
     total += sc;
   }
   *score = total;
+}
+
+void fopt_update_normals(void* h, int frag, const double* ctr_slice) { update_normals(static_cast<Fopt*>(h)->clouds[(size_t)frag], ctr_slice); }
+
+// OptimizeNonrigid's data term, OptApp.cpp:159-206: thisAA - baseAA as merged triplets (row, col, value), rows/cols global
+// (fragment * nper + lattice index).  mati / matj add full 24x24 blocks on the diagonal fragment blocks, matij the (i, j)
+// block only (HashSparseMatrix.cpp:42-66).  Call with rows == NULL to get the count.
+static std::map<long long, double>* g_tri = nullptr;
+long fopt_assemble_nonrigid(void* h, double weight, long long* keys, double* vals) {
+  Fopt& f = *static_cast<Fopt*>(h);
+  if (!keys) {
+    delete g_tri;
+    g_tri = new std::map<long long, double>();
+    const long long M = (long long)f.nper * f.num;
+    for (const Pair& pr : f.pairs) {
+      const long long oi = (long long)pr.i * f.nper, oj = (long long)pr.j * f.nper;
+      for (size_t k = 0; k < pr.first.size(); k++) {
+        const Point& pi = f.clouds[(size_t)pr.i].pts[(size_t)pr.first[k]];
+        const Point& pj = f.clouds[(size_t)pr.j].pts[(size_t)pr.second[k]];
+        int idx1[24], idx2[24];
+        double val1[24], val2[24];
+        nonrigid_bucket(pi, pj, weight, idx1, val1, idx2, val2);
+        for (int a = 0; a < 24; a++)
+          for (int c = 0; c < 24; c++) {
+            (*g_tri)[(oi + idx1[a]) * M + (oi + idx1[c])] += val1[a] * val1[c];
+            (*g_tri)[(oj + idx2[a]) * M + (oj + idx2[c])] += val2[a] * val2[c];
+            (*g_tri)[(oi + idx1[a]) * M + (oj + idx2[c])] += val1[a] * val2[c];
+          }
+      }
+    }
+    return (long)g_tri->size();
+  }
+  long n = 0;
+  for (const auto& kv : *g_tri) {
+    keys[n] = kv.first;
+    vals[n] = kv.second;
+    n++;
+  }
+  return n;
+}
+
+void fopt_nonrigid_bucket(void* h, int i, int ii, int j, int jj, double weight, int* idx1, double* val1, int* idx2, double* val2) {
+  Fopt& f = *static_cast<Fopt*>(h);
+  nonrigid_bucket(f.clouds[(size_t)i].pts[(size_t)ii], f.clouds[(size_t)j].pts[(size_t)jj], weight, idx1, val1, idx2, val2);
 }
 
 // single-correspondence buckets for the pin test

@@ -336,6 +336,10 @@ class FoptOracle:
             L.fopt_assemble_slac.argtypes = [_vp, _vp, _vp, _vp, _vp]
             L.fopt_rigid_bucket.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]
             L.fopt_slac_bucket.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]
+            L.fopt_update_normals.argtypes = [_vp, C.c_int, _vp]
+            L.fopt_assemble_nonrigid.restype = C.c_long
+            L.fopt_assemble_nonrigid.argtypes = [_vp, C.c_double, _vp, _vp]
+            L.fopt_nonrigid_bucket.argtypes = [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _vp, _vp, _vp, _vp]
             cls._lib = L
         return cls._lib
 
@@ -396,6 +400,24 @@ class FoptOracle:
         self.lib().fopt_assemble_slac(self._h, _p(R), _p(JJ), _p(Jb), C.byref(sc))
         return JJ, Jb, sc.value
 
+    def update_normals(self, frag, ctr_slice):
+        c = np.ascontiguousarray(ctr_slice, np.float64).reshape(-1)
+        assert c.size == self.nper
+        self.lib().fopt_update_normals(self._h, frag, _p(c))
+
+    def assemble_nonrigid(self, weight):
+        """OptimizeNonrigid's data term as merged triplets: (rows, cols, vals), global indices fragment * nper + lattice index."""
+        n = int(self.lib().fopt_assemble_nonrigid(self._h, float(weight), None, None))
+        keys, vals = np.zeros(n, np.int64), np.zeros(n, np.float64)
+        self.lib().fopt_assemble_nonrigid(self._h, float(weight), _p(keys), _p(vals))
+        M = self.nper * self.num
+        return keys // M, keys % M, vals
+
+    def nonrigid_bucket(self, i, ii, j, jj, weight):
+        i1, v1, i2, v2 = np.zeros(24, np.int32), np.zeros(24), np.zeros(24, np.int32), np.zeros(24)
+        self.lib().fopt_nonrigid_bucket(self._h, i, ii, j, jj, float(weight), _p(i1), _p(v1), _p(i2), _p(v2))
+        return i1, v1, i2, v2
+
     def rigid_bucket(self, i, ii, j, jj):
         val, b = np.zeros(12), C.c_double(0)
         self.lib().fopt_rigid_bucket(self._h, i, ii, j, jj, _p(val), C.byref(b))
@@ -430,6 +452,8 @@ class RefFopt:
             L.rfopt_update_point_pn.argtypes = [_vp, _vp, C.c_int]
             L.rfopt_rigid_bucket.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp]
             L.rfopt_slac_bucket.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+            L.rfopt_update_normals.argtypes = [_vp, _vp, C.c_int]
+            L.rfopt_nonrigid_bucket.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp]
             cls._lib = L
         return cls._lib
 
@@ -465,6 +489,15 @@ class RefFopt:
     def update_point_pn(self, frag, ctr_full):
         c = np.ascontiguousarray(ctr_full, np.float64).reshape(-1)
         self.lib().rfopt_update_point_pn(self.clouds[frag], _p(c), c.size)
+
+    def update_normals(self, frag, ctr_full):
+        c = np.ascontiguousarray(ctr_full, np.float64).reshape(-1)
+        self.lib().rfopt_update_normals(self.clouds[frag], _p(c), c.size)
+
+    def nonrigid_bucket(self, i, ii, j, jj, weight):
+        i1, v1, i2, v2 = np.zeros(24, np.int32), np.zeros(24), np.zeros(24, np.int32), np.zeros(24)
+        self.lib().rfopt_nonrigid_bucket(self.clouds[i], ii, self.clouds[j], jj, float(weight), _p(i1), _p(v1), _p(i2), _p(v2))
+        return i1, v1, i2, v2
 
     def rigid_bucket(self, i, ii, j, jj):
         val, b = np.zeros(12), C.c_double(0)

@@ -51,6 +51,32 @@ void rfopt_update_point_pn(void* c_, const double* ctr_full, int size) {
   static_cast<PointCloud*>(c_)->UpdateAllPointPN(ctr);
 }
 
+void rfopt_update_normals(void* c_, const double* ctr_full, int size) {
+  Eigen::VectorXd ctr(size);
+  for (int i = 0; i < size; i++) ctr(i) = ctr_full[i];
+  static_cast<PointCloud*>(c_)->UpdateAllNormal(ctr);
+}
+
+// OptApp.cpp:176-190 verbatim expressions (non-rigid buckets)
+void rfopt_nonrigid_bucket(void* ci_, int ii, void* cj_, int jj, double weight_, int* idx1, double* val1, int* idx2, double* val2) {
+  Point& pi = static_cast<PointCloud*>(ci_)->points_[ii];
+  Point& pj = static_cast<PointCloud*>(cj_)->points_[jj];
+  for (int t = 0; t < 8; t++) {
+    idx1[t] = pi.idx_[t];
+    val1[t] = pi.val_[t] * weight_ * pi.n_[0];
+    idx1[8 + t] = pi.idx_[t] + 1;
+    val1[8 + t] = pi.val_[t] * weight_ * pi.n_[1];
+    idx1[16 + t] = pi.idx_[t] + 2;
+    val1[16 + t] = pi.val_[t] * weight_ * pi.n_[2];
+    idx2[t] = pj.idx_[t];
+    val2[t] = -pj.val_[t] * weight_ * pi.n_[0];
+    idx2[8 + t] = pj.idx_[t] + 1;
+    val2[8 + t] = -pj.val_[t] * weight_ * pi.n_[1];
+    idx2[16 + t] = pj.idx_[t] + 2;
+    val2[16 + t] = -pj.val_[t] * weight_ * pi.n_[2];
+  }
+}
+
 // OptApp.cpp:337-365 verbatim expressions (rigid bucket)
 void rfopt_rigid_bucket(void* ci_, int ii, void* cj_, int jj, double* val, double* b_out) {
   Point& pi = static_cast<PointCloud*>(ci_)->points_[ii];

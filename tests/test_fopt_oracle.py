@@ -98,3 +98,39 @@ def test_dense_assembly_equals_bucket_sums():
             s2 += b * b
     assert np.allclose(JJ, np.triu(J2), rtol=1e-11, atol=1e-13) and np.allclose(Jb, b2, rtol=1e-11, atol=1e-13)
     assert score == pytest.approx(s2, rel=1e-12) and np.count_nonzero(np.tril(JJ, -1)) == 0
+
+
+@pytest.mark.skipif(not RefFopt.available(), reason="oracle/_ref/libref_fopt.so needs /root/reference at build time")
+def test_nonrigid_normals_and_buckets_against_reference_header():
+    """Non-rigid mode (OptApp.cpp:120-206): UpdateAllNormal bit for bit, the two 24-entry buckets exactly (they are plain
+    products, no Eigen reductions), and the merged triplets against a numpy construction from the buckets."""
+    sc = make_scene(num=3, n=5000, res=4)
+    own, ref = _load(sc, FoptOracle), _load(sc, RefFopt)
+    ctr = lattice_ctr(sc["num"], sc["res"], sc["length"], [np.eye(4)] * sc["num"], 0.004, np.random.default_rng(2))
+    for f in range(sc["num"]):
+        own.update_normals(f, ctr[f * own.nper:(f + 1) * own.nper])
+        ref.update_normals(f, ctr)
+        a, b = own.points(f), ref.points(f)
+        assert np.array_equal(a["n"].view(np.uint32), b["n"].view(np.uint32)) and np.array_equal(a["p"], b["p"])
+    rng = np.random.default_rng(8)
+    for i, j, pr in sc["pairs"]:
+        for k in rng.choice(pr.shape[0], 100, replace=False):
+            A = own.nonrigid_bucket(i, int(pr[k, 0]), j, int(pr[k, 1]), 1.7)
+            B = ref.nonrigid_bucket(i, int(pr[k, 0]), j, int(pr[k, 1]), 1.7)
+            for x, y in zip(A, B):
+                assert np.array_equal(x, y)
+    sub = [(i, j, pr[:150]) for i, j, pr in sc["pairs"]]
+    own.set_pairs(sub)
+    rows, cols, vals = own.assemble_nonrigid(1.7)
+    M = own.nper * sc["num"]
+    D = np.zeros((M, M))
+    for i, j, pr in sub:
+        for a, c in pr:
+            i1, v1, i2, v2 = own.nonrigid_bucket(i, int(a), j, int(c), 1.7)
+            r1, r2 = i * own.nper + i1, j * own.nper + i2
+            np.add.at(D, (r1[:, None], r1[None, :]), np.outer(v1, v1))
+            np.add.at(D, (r2[:, None], r2[None, :]), np.outer(v2, v2))
+            np.add.at(D, (r1[:, None], r2[None, :]), np.outer(v1, v2))
+    S = np.zeros((M, M))
+    S[rows, cols] = vals
+    assert np.allclose(S, D, rtol=1e-11, atol=1e-13) and rows.size == np.count_nonzero(D) + int((D[rows, cols] == 0).sum())
