@@ -368,9 +368,19 @@ __global__ __launch_bounds__(kBlock) void k_integrate(
       m &= m - 1;
       const FrameXform fx = frames[f];
       const float* __restrict__ sc = scaled + (size_t)f * pixels;
+      // phase 1: project every row and issue its depth gather; phase 2: the arithmetic that needs the sample (the gathers'
+      // L2 latency overlaps the other rows' work: k_integrate 0.418 -> 0.390 ms, profiles/r01_ab_variants.txt run 11)
+      bool ok[kRows];
+      float dp[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
-        const bool upd = voxel_update(S[r], W[r], g0, g1[r], g2, fx, cam, cols, rows, sc);
+        unsigned pixel;
+        ok[r] = voxel_project(g0, g1[r], g2, fx, cam, cols, rows, pixel);
+        dp[r] = ok[r] ? sc[pixel] : 0.0f;
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        const bool upd = ok[r] && voxel_finish(S[r], W[r], dp[r], g0, g1[r], g2, fx);
 #ifdef ER_STATS
         const unsigned long long b = __ballot(upd);
         if (lane == 0) {

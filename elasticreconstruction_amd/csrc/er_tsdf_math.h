@@ -188,8 +188,12 @@ ER_HD bool pixel_index(float x, float lim_m_half, int& p) {
 // regions instead of 6.  Measured A/B on MI355X (same box, interleaved, profiles/r01_ab_variants.txt):
 // folded predicates 0.565 ms per 50-frame launch vs 0.600 ms test by test; extra-branch "shortcuts"
 // (skipping the update division when S == 1, guarded multiply for the band division) were slower.
-ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
-                        int cols, int rows, const float* __restrict__ scaled) {
+//
+// Split in two so that a thread can issue the depth gathers of all its rows before it needs the first one
+// (k_integrate keeps kRows voxels per thread; the gather's L2 latency then overlaps the other rows' arithmetic):
+//   voxel_project  :76-80   the pixel under the voxel, or false
+//   voxel_finish   :81-94   everything that depends on the depth sample
+ER_HD bool voxel_project(float g0, float g1, float g2, const FrameXform& f, const Camera& c, int cols, int rows, unsigned& pixel) {
   const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
   const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
   const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
@@ -207,9 +211,11 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
   // :78-80  round( float expr ) and the image-range test, see pixel_index.
   int px, py;
   const bool vx = pixel_index(qu + c.cx, (float)cols - 0.5f, px), vy = pixel_index(qv + c.cy, (float)rows - 0.5f, py);
-  const bool valid = (t2 > 0.0f) & vx & vy;                              // :77,:80
-  if (!valid) return false;
-  const float dp = scaled[(unsigned)(py * cols + px)];                     // :81
+  pixel = (unsigned)(py * cols + px);
+  return (t2 > 0.0f) & vx & vy;                                          // :77,:80
+}
+
+ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float g2, const FrameXform& f) {
   const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
   const float d2 = (rx * rx + ry * ry) + rz * rz;
   // No range guard: for d2 < 2^-96 (voxel within 4e-15 m of the camera centre; hipcc's sqrtf would rescale)
@@ -237,6 +243,13 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
   S = div_inrange(S * W + tsdf, W + 1.0f);
   W = W + 1.0f;                                                          // :94
   return true;
+}
+
+ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
+                        int cols, int rows, const float* __restrict__ scaled) {
+  unsigned pixel;
+  if (!voxel_project(g0, g1, g2, f, c, cols, rows, pixel)) return false;
+  return voxel_finish(S, W, scaled[pixel], g0, g1, g2, f);               // :81
 }
 
 // ---- exact culling of (voxel patch, frame) pairs -------------------------------------------------
