@@ -14,7 +14,7 @@
 //   zbuf      uint32[64][rows*cols]           Reproject's z-buffer (atomicMin; 0xFFFFFFFF = empty)
 //
 // Launch sequence for a batch of <= 64 frames (er_tsdf_integrate_frames):
-//   [k_reproject_scatter -> k_reproject_fix{1,2,3}]   per SOURCE pixel: warp + scatter-min   (A6/A7)
+//   [k_reproject_scatter -> k_reproject_fix]          per SOURCE pixel: warp + scatter-min   (A6/A7)
 //   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
 //                  allocates the unit on first ever touch, appends it to the batch list
 //   k_plan         sorts the batch's units by cost (frames in the mask) for a balanced static deal
@@ -83,61 +83,79 @@ __global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* _
 // grid and scattered into the frame's z-buffer.  The reference's sequential "write if empty or
 // closer" is an order-independent min for dd != 0; a write of dd == 0 RESETS the cell (0 means
 // empty), which is order dependent, so such writes only record their source index and raise a flag;
-// k_reproject_fix* then replay the affected cells exactly (practically never taken).
-__global__ void k_reproject_scatter(const uint16_t* __restrict__ depth, int n_frames, int cols, int rows, Camera cam, CameraInv cami,
-                                    const double* __restrict__ seg12, const double* __restrict__ madj12,
-                                    const int* __restrict__ grid_index, const float* __restrict__ ctr, int res,
-                                    float grid_ul, int floats_per_grid, uint32_t* __restrict__ zbuf,
-                                    uint32_t* __restrict__ lastzero, int* __restrict__ counters, int replay) {
-  // 64 x 4 pixel tiles per 256-thread workgroup, frame = blockIdx.z: no integer divisions for the indices.
-  // A workgroup strides over tiles so the (normally idle) replay pass can be launched with a small grid.
-  const int pixels = cols * rows;
-  if (replay && counters[C_ZERO_WRITE] == 0) return;
-  const int f = blockIdx.z;
-  for (int ty = blockIdx.y; ty * 4 < rows; ty += gridDim.y) {
-    for (int tx = blockIdx.x; tx * 64 < cols; tx += gridDim.x) {
-      const int u = tx * 64 + (threadIdx.x & 63);
-      const int v = ty * 4 + (threadIdx.x >> 6);
-      if (u >= cols || v >= rows) continue;
-      const int p = v * cols + u;
-      const uint16_t d = depth[(size_t)f * pixels + p];
-      if (d == 0) continue;                                             // UVD2XYZ false
-      int cell;
-      uint16_t dd;
-      if (!reproject_px(u, v, d, cam, cami, cols, rows, seg12 + f * 16, madj12 + f * 12,
-                        ctr + (size_t)grid_index[f] * floats_per_grid, res, grid_ul, cell, dd))
-        continue;
-      const size_t o = (size_t)f * pixels + cell;
-      if (!replay) {
-        if (dd != 0) {
-          atomicMin(&zbuf[o], (uint32_t)dd);
-        } else {
-          atomicMax(&lastzero[o], (uint32_t)p + 1u);
-          atomicOr(&counters[C_ZERO_WRITE], 1);
-        }
-      } else {
-        const uint32_t lz = lastzero[o];
-        if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&zbuf[o], (uint32_t)dd);
-      }
+// k_reproject_fix then replays the affected cells exactly (practically never taken).
+struct ReprojArgs {
+  const uint16_t* depth;
+  int n_frames, cols, rows;
+  Camera cam;
+  CameraInv cami;
+  const double* seg12;
+  const double* madj12;
+  const int* grid_index;
+  const float* ctr;
+  int res;
+  float grid_ul;
+  int floats_per_grid;
+  uint32_t* zbuf;
+  uint32_t* lastzero;
+  int* counters;
+};
+
+// One source pixel (u, v) of frame f: warp, then scatter (replay = 0) or re-scatter under the replay rule (replay = 1).
+__device__ __forceinline__ void reproject_scatter_px(const ReprojArgs& A, int f, int u, int v, int replay) {
+  const int pixels = A.cols * A.rows;
+  const int p = v * A.cols + u;
+  const uint16_t d = A.depth[(size_t)f * pixels + p];
+  if (d == 0) return;                                                   // UVD2XYZ false
+  int cell;
+  uint16_t dd;
+  if (!reproject_px(u, v, d, A.cam, A.cami, A.cols, A.rows, A.seg12 + f * 16, A.madj12 + f * 12,
+                    A.ctr + (size_t)A.grid_index[f] * A.floats_per_grid, A.res, A.grid_ul, cell, dd))
+    return;
+  const size_t o = (size_t)f * pixels + cell;
+  if (!replay) {
+    if (dd != 0) {
+      atomicMin(&A.zbuf[o], (uint32_t)dd);
+    } else {
+      atomicMax(&A.lastzero[o], (uint32_t)p + 1u);
+      atomicOr(&A.counters[C_ZERO_WRITE], 1);
     }
+  } else {
+    const uint32_t lz = A.lastzero[o];
+    if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&A.zbuf[o], (uint32_t)dd);
   }
 }
 
-// Replay step 1: cells that saw a zero write forget everything (step 2 = scatter with replay = 1).
-__global__ void k_reproject_fix_clear(uint32_t* __restrict__ zbuf, const uint32_t* __restrict__ lastzero, long total,
-                                      const int* __restrict__ counters) {
-  if (counters[C_ZERO_WRITE] == 0) return;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x)
-    if (lastzero[t] > 0) zbuf[t] = kZEmpty;
+__global__ void k_reproject_scatter(ReprojArgs A) {
+  // 64 x 4 pixel tiles per 256-thread workgroup, frame = blockIdx.z: no integer divisions for the indices.
+  const int f = blockIdx.z;
+  const int u = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (u >= A.cols || v >= A.rows) return;
+  reproject_scatter_px(A, f, u, v, 0);
 }
 
-// Replay step 3: re-arm (lastzero back to all zero, flag down).
-__global__ void k_reproject_fix_rearm(uint32_t* __restrict__ lastzero, long total, int* __restrict__ counters) {
-  if (counters[C_ZERO_WRITE] == 0) return;
-  for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x)
-    lastzero[t] = 0;
+// The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch that
+// returns at once unless a zero write was flagged -- it practically never is (a warped depth below 0.5 mm) -- and
+// otherwise lets a single workgroup run the three passes in order: cells that saw a zero write forget everything;
+// every source pixel is scattered again under the replay rule (only writes that come after the cell's last zero
+// write count); lastzero and the flag are re-armed.  Slow (one workgroup) by design: keeping it to one launch saves
+// three idle launches per batch on the pre-pass stream.
+__global__ __launch_bounds__(1024) void k_reproject_fix(ReprojArgs A) {
+  if (A.counters[C_ZERO_WRITE] == 0) return;
+  const long total = (long)A.n_frames * A.cols * A.rows;
+  for (long t = threadIdx.x; t < total; t += blockDim.x)
+    if (A.lastzero[t] > 0) A.zbuf[t] = kZEmpty;
+  __threadfence();
+  __syncthreads();
+  for (int f = 0; f < A.n_frames; f++)
+    for (int p = threadIdx.x; p < A.cols * A.rows; p += blockDim.x) reproject_scatter_px(A, f, p % A.cols, p / A.cols, 1);
+  __threadfence();
+  __syncthreads();
+  for (long t = threadIdx.x; t < total; t += blockDim.x) A.lastzero[t] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) A.counters[C_ZERO_WRITE] = 0;
 }
-__global__ void k_reproject_fix_flag(int* __restrict__ counters) { counters[C_ZERO_WRITE] = 0; }
 
 __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -541,7 +559,8 @@ struct er_tsdf_s {
   int* batch[2] = {nullptr, nullptr};
   unsigned long long* ht_mask[2] = {nullptr, nullptr};
   float *scaled[2] = {nullptr, nullptr}, *tile_max[2] = {nullptr, nullptr};
-  er::FrameXform* frames[2] = {nullptr, nullptr};
+  er::FrameXform* frames[2] = {nullptr, nullptr};   // = &dstage[q]->fx
+  void* dstage[2] = {nullptr, nullptr};             // device twin of the pinned per-batch constants (struct Staging)
   hipEvent_t pre_done[2] = {nullptr, nullptr}, int_done[2] = {nullptr, nullptr};
   void* pinned[2] = {nullptr, nullptr};                   // host staging of the per-batch constants
   int ht_cap = 0, ht_shift = 0;
@@ -670,12 +689,14 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   }
   hipStream_t X = h->aux_stream, S = h->stream;
   int* nbatch = h->counters + (p ? C_NBATCH1 : C_NBATCH);
-  ER_HIP_TRY(hipMemcpyAsync(h->frames[p], st->fx, (size_t)n * sizeof(er::FrameXform), hipMemcpyHostToDevice, X));
-  ER_HIP_TRY(hipMemcpyAsync(h->T12, st->t12, (size_t)n * 12 * sizeof(double), hipMemcpyHostToDevice, X));
 
-  const long total = (long)n * h->pixels;
   const int wide_grid = h->n_cu * 8;
   uint32_t* zsrc = nullptr;
+  char* dst = static_cast<char*>(h->dstage[p]);
+  const double* dev_t12 = reinterpret_cast<const double*>(dst + offsetof(Staging, t12));
+  const double* dev_seg = reinterpret_cast<const double*>(dst + offsetof(Staging, seg));
+  const double* dev_madj = reinterpret_cast<const double*>(dst + offsetof(Staging, madj));
+  const int* dev_gi = reinterpret_cast<const int*>(dst + offsetof(Staging, gi));
   if (warp) {
     for (int f = 0; f < n; f++) {
       for (int q = 0; q < 12; q++) {
@@ -688,26 +709,23 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
       if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
       st->gi[f] = g;
     }
-    ER_HIP_TRY(hipMemcpyAsync(h->seg12, st->seg, (size_t)n * 16 * sizeof(double), hipMemcpyHostToDevice, X));
-    ER_HIP_TRY(hipMemcpyAsync(h->madj12, st->madj, (size_t)n * 12 * sizeof(double), hipMemcpyHostToDevice, X));
-    ER_HIP_TRY(hipMemcpyAsync(h->grid_index, st->gi, (size_t)n * sizeof(int), hipMemcpyHostToDevice, X));
+  }
+  // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
+  ER_HIP_TRY(hipMemcpyAsync(h->dstage[p], st, sizeof(Staging), hipMemcpyHostToDevice, X));
+  if (warp) {
     // zbuf is all-empty here: filled at create, re-armed by its consumer (k_prepare / k_zbuf_to_depth)
     const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
-    for (int replay = 0; replay < 2; replay++) {
-      if (replay) hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, X, h->zbuf, h->lastzero, total, h->counters);
-      hipLaunchKernelGGL(k_reproject_scatter, replay ? dim3(4, 8, n) : dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n),
-                         dim3(kBlock), 0, X, depth_dev, n, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12,
-                         h->grid_index, h->ctr, warp->resolution, grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
-    }
-    hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, X, h->lastzero, total, h->counters);
-    hipLaunchKernelGGL(k_reproject_fix_flag, dim3(1), dim3(1), 0, X, h->counters);
+    const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
+                        verts * 3, h->zbuf, h->lastzero, h->counters};
+    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
+    hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, X, RA);
     ER_HIP_TRY(hipGetLastError());
     zsrc = h->zbuf;
   }
 
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
-                     depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, h->T12, h->scaled[p], h->ht_key, h->ht_slot,
+                     depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch[p], nbatch, h->counters,
                      h->tile_max[p]);
   ER_HIP_TRY(hipGetLastError());
@@ -806,7 +824,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->depth_stage, B * px * sizeof(uint16_t));
   ER_ALLOC(h->zbuf, B * px * sizeof(uint32_t));
   ER_ALLOC(h->lastzero, B * px * sizeof(uint32_t));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->frames[q], B * sizeof(er::FrameXform));
+  for (int q = 0; q < 2; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
+  for (int q = 0; q < 2; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
   ER_ALLOC(h->seg12, B * 16 * sizeof(double));
   ER_ALLOC(h->madj12, B * 12 * sizeof(double));
@@ -848,8 +867,8 @@ int er_tsdf_destroy(er_tsdf_t h) {
   }
   if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask[0], h->ht_mask[1], h->unit_key, h->counters, h->stats, h->batch[0],
-                  h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage, h->zbuf, h->lastzero, h->frames[0],
-                  h->frames[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch,
+                  h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage, h->zbuf, h->lastzero, h->dstage[0],
+                  h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch,
                   h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1]};
   for (int q = 0; q < 2; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
@@ -924,16 +943,10 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   ER_HIP_TRY(hipMemcpyAsync(h->grid_index, &gi, sizeof(int), hipMemcpyHostToDevice, h->stream));
   const float grid_ul = length / (float)resolution;
   const long total = (long)px;
-  const int wide_grid = h->n_cu * 8;
-  for (int replay = 0; replay < 2; replay++) {
-    if (replay)
-      hipLaunchKernelGGL(k_reproject_fix_clear, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->zbuf, h->lastzero, total, h->counters);
-    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, 1), dim3(kBlock), 0, h->stream,
-                       h->depth_stage, 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution,
-                       grid_ul, verts * 3, h->zbuf, h->lastzero, h->counters, replay);
-  }
-  hipLaunchKernelGGL(k_reproject_fix_rearm, dim3(wide_grid), dim3(kBlock), 0, h->stream, h->lastzero, total, h->counters);
-  hipLaunchKernelGGL(k_reproject_fix_flag, dim3(1), dim3(1), 0, h->stream, h->counters);
+  const ReprojArgs RA{h->depth_stage, 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
+                      verts * 3, h->zbuf, h->lastzero, h->counters};
+  hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, 1), dim3(kBlock), 0, h->stream, RA);
+  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, h->stream, RA);
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
                      h->depth_stage, total);
   ER_HIP_TRY(hipGetLastError());
