@@ -341,7 +341,10 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFull));
 }
 
-__global__ __launch_bounds__(kBlock) void k_integrate(
+#ifndef ER_INT_MINBLOCKS
+#define ER_INT_MINBLOCKS 1
+#endif
+__global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, const Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
@@ -690,7 +693,10 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipStream_t X = h->aux_stream, S = h->stream;
   int* nbatch = h->counters + (p ? C_NBATCH1 : C_NBATCH);
 
-  const int wide_grid = h->n_cu * 8;
+#ifndef ER_INT_BLOCKS_PER_CU
+#define ER_INT_BLOCKS_PER_CU 8
+#endif
+  const int wide_grid = h->n_cu * ER_INT_BLOCKS_PER_CU;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);
   const double* dev_t12 = reinterpret_cast<const double*>(dst + offsetof(Staging, t12));
@@ -757,6 +763,16 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 
 }  // namespace
 
+static hipError_t aux_create(hipStream_t* s) {
+#ifdef ER_AUX_PRIO
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, ER_AUX_PRIO > 0 ? hi : lo);
+#else
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+#endif
+}
+
 extern "C" {
 
 int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int device, er_tsdf_t* out) {
@@ -798,7 +814,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
     }                                                                                                \
   } while (0)
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+      aux_create(&h->aux_stream) != hipSuccess) {
     delete h;
     return er::fail("er_tsdf_create: hipStreamCreate failed");
   }
