@@ -154,6 +154,27 @@ ER_HD float div_inrange(float n, float d) {
 #endif
 }
 
+// Three quotients by one denominator (ControlGrid::GetCoordinate's pt / unit_length_, ControlGrid.h:46-48).
+ER_HD void div3_inrange(float n0, float n1, float n2, float d, float& q0, float& q1, float& q2) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  float r = __builtin_amdgcn_rcpf(d);
+  r = fmaf(fmaf(-d, r, 1.0f), r, r);
+  float m = n0 * r;
+  m = fmaf(fmaf(-d, m, n0), r, m);
+  q0 = fmaf(fmaf(-d, m, n0), r, m);
+  m = n1 * r;
+  m = fmaf(fmaf(-d, m, n1), r, m);
+  q1 = fmaf(fmaf(-d, m, n1), r, m);
+  m = n2 * r;
+  m = fmaf(fmaf(-d, m, n2), r, m);
+  q2 = fmaf(fmaf(-d, m, n2), r, m);
+#else
+  q0 = n0 / d;
+  q1 = n1 / d;
+  q2 = n2 / d;
+#endif
+}
+
 ER_HD float sqrt_inrange(float x) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
   float s = __builtin_amdgcn_sqrtf(x);                       // <= 1 ulp
@@ -369,7 +390,17 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   float pt[3];
   cube_coords(u, v, d, c, ci, seg, pt);
   // ControlGrid::GetCoordinate, ControlGrid.h:44-81 (float32)
-  float a0 = pt[0] / grid_ul, a1 = pt[1] / grid_ul, a2 = pt[2] / grid_ul;
+  // pt / unit_length_ with ONE reciprocal: for a lattice spacing in [2^-30, 2^30] the core can differ from '/' only when
+  // |pt| < 2^-100 (both quotients are then below 2^-69: corner 0 or -1 alike, and a residual that vanishes in 1 - r and
+  // in the weighted sums) or |pt / unit_length_| >= 2^95 (both far outside the lattice, or NaN, and rejected below).
+  float a0, a1, a2;
+  if ((grid_ul >= 0x1p-30f) & (grid_ul <= 0x1p30f)) {
+    div3_inrange(pt[0], pt[1], pt[2], grid_ul, a0, a1, a2);
+  } else {
+    a0 = pt[0] / grid_ul;
+    a1 = pt[1] / grid_ul;
+    a2 = pt[2] / grid_ul;
+  }
   float f0 = floorf(a0), f1 = floorf(a1), f2 = floorf(a2);
   float fres = (float)res;
   if (!(f0 >= 0.0f && f0 < fres && f1 >= 0.0f && f1 < fres && f2 >= 0.0f && f2 < fres)) return false;
