@@ -443,11 +443,19 @@ def main():
             bytes_total = 16.0 * sum_w + FRAME_BYTES_FIXED * n_frames + (2 * FRAME_BYTES_RAW * n_frames if warp_on else 0)
             per_launch = bytes_total / launches
             ach = per_launch / (ms_launch * 1e-3) / 1e9
-            traffic = None
+            traffic, valu = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("k_integrate_hbm_bytes_per_launch")   # measured on a 50-frame launch
+                    pj = json.load(open(pmc))
+                    traffic = pj.get("k_integrate_hbm_bytes_per_launch")                     # measured on a 50-frame launch
+                    wi = pj.get("k_integrate_valu_wave_instructions_per_launch")
+                    if wi and I == 50:
+                        # the limiter that actually binds: VALU issue.  peak = SIMDs x clock / 4 cycles per wave64 instruction
+                        peak = torch.cuda.get_device_properties(local).multi_processor_count * 4 * 2.4e9 / 4.0
+                        valu = {"wave_instructions_per_launch": wi, "achieved": wi / (ms_launch * 1e-3), "peak": peak,
+                                "unit": "wave-instructions/s", "frac": wi / (ms_launch * 1e-3) / peak,
+                                "note": "SQ_INSTS_VALU (profiles/pmc_latest.json) over the live launch time; peak = 1024 SIMDs x 2.4 GHz / 4"}
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -455,7 +463,7 @@ def main():
                                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms_launch, "launches": launches,
                                "voxel_updates": sum_w, "unit_visits": prof["unit_visits"],
                                "note": "rank 0 kernel; voxel updates = job total / ranks" if world > 1 else "",
-                               "whole_job_frac": bytes_total / dt / 1e9 / HBM_PEAK_GBS}
+                               "whole_job_frac": bytes_total / dt / 1e9 / HBM_PEAK_GBS, "valu_issue": valu}
         else:
             out["roofline"] = {"bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "avg_launch_ms": ms_launch, "launches": launches}
