@@ -307,3 +307,56 @@ def test_exact_arithmetic_cores_exhaustive(gpu):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l.split() for l in r.stdout.strip().splitlines()]
     assert len(lines) == 5 and all(int(l[2]) > 10 ** 9 and int(l[4]) == 0 for l in lines), r.stdout
+
+
+def test_randomised_configurations_bit_exact(gpu):
+    """Seeded fuzz over what the kernels' exactness arguments depend on: image size (not tile multiples), intrinsics
+    (principal point off-centre / zero, anisotropic focal lengths), camera poses anywhere around and inside the room
+    (voxels behind the camera, grazing views, the camera inside a unit), depth images with holes, salt noise and values
+    beyond integration_trunc, and a warp through randomly deformed control grids.  Every configuration must give the
+    oracle's unit set and bit patterns."""
+    rng = np.random.default_rng(20240919)
+    for case in range(10):
+        warped = case % 2 == 1                                # odd cases go through Reproject, whose XYZ2UVD bounds are the
+        if warped:                                            # literal 640 x 480 (TSDFVolume.h:55): full-size images only
+            cols, rows = 640, 480
+            fx, fy = float(rng.uniform(400, 650)), float(rng.uniform(400, 650))
+        else:
+            cols, rows = int(rng.integers(48, 200)), int(rng.integers(40, 160))
+            fx, fy = float(rng.uniform(60, 260)), float(rng.uniform(60, 260))
+        cx = 0.0 if case == 3 else float(rng.uniform(0.2, 0.8) * cols)
+        cy = float(rng.uniform(0.2, 0.8) * rows)
+        cam = np.array([fx, fy, cx, cy, 2.5, float(rng.uniform(1.0, 3.5))], np.float32)
+        n = 3 if warped else int(rng.integers(3, 9))
+        poses = []
+        for _ in range(n):
+            eye = rng.uniform(0.3, 2.7, 3)
+            tgt = rng.uniform(0.0, 3.0, 3)
+            P = synth.look_at(tuple(eye), tuple(tgt))
+            poses.append(P @ synth.perturbation(int(rng.integers(1 << 30)), 20.0, 0.0))     # roll / off-axis views
+        poses = np.stack(poses)
+        depth = synth.to_numpy_u16(synth.render_depth(poses, cols=cols, rows=rows, cam=tuple(float(c) for c in cam[:4]))).copy()
+        holes = rng.random(depth.shape) < 0.05
+        depth[holes] = 0
+        salt = rng.random(depth.shape) < 0.01
+        depth[salt] = rng.integers(1, 12000, int(salt.sum()), dtype=np.uint16)       # up to 12 m: beyond integration_trunc, units still touched
+        vol, ora = TSDFVolume(cols, rows, cam, max_units=4096), OracleVolume(cols, rows, cam)
+        warp = None
+        if warped:
+            res, length = 8, 3.0
+            k, j, i = np.meshgrid(np.arange(res + 1), np.arange(res + 1), np.arange(res + 1), indexing="ij")
+            base = np.stack([i.ravel(), j.ravel(), k.ravel()], 1) * (length / res)
+            grid = (base + rng.normal(0, 0.01, base.shape)).astype(np.float32)
+            seg = np.stack([np.linalg.inv(poses[0]) @ P for P in poses])      # camera poses in the first frame's fragment cube
+            cube = synth.basepose()
+            seg = np.stack([cube @ S for S in seg])
+            madj = np.stack([np.linalg.inv(poses[f]) @ poses[0] @ np.linalg.inv(seg[0]) for f in range(n)])
+            warp = dict(ctr=grid[None], resolution=res, length=np.float32(length), grid_index=np.zeros(n, np.int32), seg=seg, madj=madj)
+        vol.IntegrateFrames(depth, poses, warp)
+        for f in range(n):
+            d = depth[f]
+            if warp is not None:
+                d = ora.Reproject(d, warp["ctr"][0], warp["resolution"], warp["length"], warp["seg"][f], warp["madj"][f])
+            ora.Integrate(d, poses[f])
+        helpers.assert_volumes_identical(vol, ora, "fuzz case %d (%dx%d)" % (case, cols, rows))
+        vol.close()
