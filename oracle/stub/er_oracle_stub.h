@@ -164,6 +164,9 @@ class ScopeTime : public StopWatch {
 };
 
 namespace console {
+// FragmentOptimizer.cpp:44-45
+enum VERBOSITY_LEVEL { L_ALWAYS, L_ERROR, L_WARN, L_INFO, L_DEBUG, L_VERBOSE };
+inline void setVerbosityLevel(VERBOSITY_LEVEL) {}
 inline int find_argument(int argc, char** argv, const char* name) {
   for (int i = 1; i < argc; ++i)
     if (strcmp(argv[i], name) == 0) return i;
@@ -197,6 +200,11 @@ template <class PointT> class PointCloud {
   std::vector<PointT> points;
   void push_back(const PointT& p) { points.push_back(p); }
   size_t size() const { return points.size(); }
+};
+
+// FragmentOptimizer/OptApp.cpp:921-922 (SavePoints, only with --write_xyzn_sample): not needed by the checkers.
+struct PCDWriter {
+  template <class CloudT> int writeBinaryCompressed(const std::string&, const CloudT&) { return -1; }
 };
 
 namespace io {
