@@ -139,6 +139,165 @@ class FragmentOptimizer:
         np.add.at(out, inv, vals)
         return uk // M, uk % M, out
 
+    # ---- host-side pieces of COptApp (a few thousand lattice vertices: numpy) ------------------------------------
+    def GetIndex(self, i, j, k):
+        n1 = self.resolution_ + 1
+        return i + j * n1 + k * n1 * n1
+
+    def _lattice_edges(self):
+        """(vertex, neighbour) pairs in the order of the reference's six `if` blocks (OptApp.cpp:227-245, 576-611, 773-798)."""
+        r, out = self.resolution_, []
+        for i in range(r + 1):
+            for j in range(r + 1):
+                for k in range(r + 1):
+                    nb = []
+                    if i > 0: nb.append(self.GetIndex(i - 1, j, k))
+                    if i < r: nb.append(self.GetIndex(i + 1, j, k))
+                    if j > 0: nb.append(self.GetIndex(i, j - 1, k))
+                    if j < r: nb.append(self.GetIndex(i, j + 1, k))
+                    if k > 0: nb.append(self.GetIndex(i, j, k - 1))
+                    if k < r: nb.append(self.GetIndex(i, j, k + 1))
+                    out.append((self.GetIndex(i, j, k), nb, (i, j, k)))
+        return out
+
+    def _laplacian(self):
+        """Sum over (vertex, neighbour) of AddHessian2( {v, nb}, {1, -1} ): [[1, -1], [-1, 1]] per xyz component
+        (HashSparseMatrix.cpp:50-58) -- every undirected edge is visited from both ends.  Dense nper x nper."""
+        L = np.zeros((self.nper_, self.nper_))
+        for v, nb, _ in self._lattice_edges():
+            for w in nb:
+                for c in range(3):
+                    a, b = v * 3 + c, w * 3 + c
+                    L[a, a] += 1.0
+                    L[b, b] += 1.0
+                    L[a, b] -= 1.0
+                    L[b, a] -= 1.0
+        return L
+
+    @staticmethod
+    def GetRotation(dif, diff):
+        """COptApp::GetRotation, OptApp.cpp:850-871: C = sum dif^T diff over the neighbours, R = V U^T (det fixed)."""
+        Cm = dif.T @ diff
+        U, _, Vt = np.linalg.svd(Cm)
+        V = Vt.T
+        R = V @ U.T
+        if np.linalg.det(R) < 0:
+            U = U.copy()
+            U[:, 2] *= -1
+            R = V @ U.T
+        return R
+
+    @staticmethod
+    def _increment(x6):
+        """AngleAxis(z) * AngleAxis(y) * AngleAxis(x) and the translation of one 6-vector of the solution (OptApp.cpp:395-400, 645-651)."""
+        a, b, g = x6[:3]
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+        aff = np.eye(4)
+        aff[:3, :3] = Rz @ Ry @ Rx
+        aff[:3, 3] = x6[3:6]
+        return aff
+
+    def _canonical_lattice(self):
+        """(i, j, k) * unit_length_ per vertex, xyz interleaved (InitCtrSLAC, OptApp.cpp:723-733)."""
+        ul = self.length_ / self.resolution_
+        out = np.zeros(self.nper_)
+        for v, _, (i, j, k) in self._lattice_edges():
+            out[v * 3:v * 3 + 3] = (i * ul, j * ul, k * ul)
+        return out
+
+    @staticmethod
+    def _apply(P, xyz):
+        """Matrix4d * (x, y, z, 1), row by row ((m0 x + m1 y) + m2 z) + m3."""
+        return ((P[:3, 0] * xyz[:, :1] + P[:3, 1] * xyz[:, 1:2]) + P[:3, 2] * xyz[:, 2:3]) + P[:3, 3]
+
+    # ---- COptApp::OptimizeSLAC, OptApp.cpp:414-680 ----------------------------------------------------------------
+    def OptimizeSLAC(self, ipose, weight=1.0, max_iteration=5):
+        """Returns (poses, expand_ctr [num * nper], data scores).  The data term comes from er_fopt_assemble_slac; base term,
+        regularizer, dense solve (CHOLMOD in the reference) and the pose / lattice updates follow the reference line by line."""
+        num, nper = self.num_, self.nper_
+        N = 6 * num + nper
+        default_weight = num * weight                                                # :416
+        pose = [np.array(P, np.float64) for P in ipose]
+        ictr = self._canonical_lattice()
+        thisCtr = ictr.copy()
+        for l in range(num):
+            self.UpdatePose(l, pose[l].astype(np.float32))                           # :443
+        base = np.zeros((N, N))
+        base[6 * num:, 6 * num:] = self._laplacian()
+        anchor = 6 * num + self.GetIndex(self.resolution_ // 2, self.resolution_ // 2, 0) * 3
+        for c in range(3):
+            base[anchor + c, anchor + c] += 1.0                                      # :839-843
+        base *= default_weight                                                       # :452
+        edges = self._lattice_edges()
+        scores = []
+        for _ in range(max_iteration):
+            Rt = np.stack([P[:3, :3].T.reshape(9) for P in pose])
+            JJ, dataJb, score = self.AssembleSLAC(Rt)
+            scores.append(score)
+            thisJJ = np.triu(base) + JJ                                              # :456 (Upper view) + data term
+            thisJJ[np.arange(6), np.arange(6)] += 1.0                                # :459-464
+            full = thisJJ + np.triu(thisJJ, 1).T
+            baseJb = np.zeros(N)
+            cur, ini = thisCtr.reshape(-1, 3), ictr.reshape(-1, 3)
+            for v, nb, ijk in edges:                                                 # regularizer, :570-631
+                dif = ini[v] - ini[nb]
+                diff = cur[v] - cur[nb]
+                R = np.eye(3) if ijk == (self.resolution_ // 2, self.resolution_ // 2, 0) else self.GetRotation(dif, diff)
+                bx = (diff - dif @ R.T) * default_weight
+                baseJb[6 * num + v * 3:6 * num + v * 3 + 3] += bx.sum(0)
+                for t, w in enumerate(nb):
+                    baseJb[6 * num + w * 3:6 * num + w * 3 + 3] -= bx[t]
+            result = -np.linalg.solve(full, dataJb + baseJb)                         # :632-638
+            thisCtr = thisCtr + result[6 * num:]                                     # :644-646
+            for l in range(num):
+                pose[l] = self._increment(result[l * 6:l * 6 + 6]) @ pose[l]         # :648-658
+            expand = np.concatenate([self._apply(pose[l], thisCtr.reshape(-1, 3)).reshape(-1) for l in range(num)])   # ExpandCtr, :752-763
+            self.UpdateAllPointPN(expand)                                            # :660-663
+        expand = np.concatenate([self._apply(pose[l], thisCtr.reshape(-1, 3)).reshape(-1) for l in range(num)])
+        return pose, expand, scores
+
+    # ---- COptApp::OptimizeNonrigid, OptApp.cpp:120-278 ------------------------------------------------------------
+    def OptimizeNonrigid(self, ipose, weight=1.0, max_iteration=5, max_inner_iteration=10):
+        """Returns (ctr [num * nper], inner-iteration scores).  Data term from er_fopt_assemble_nonrigid; regularizer, dense
+        solve and control flow as in the reference."""
+        num, nper = self.num_, self.nper_
+        M = num * nper
+        lat = self._canonical_lattice().reshape(-1, 3)
+        ctr = np.concatenate([self._apply(np.array(P, np.float64), lat).reshape(-1) for P in ipose])    # InitCtr, :709-721
+        ictr = ctr.copy()
+        baseAA = np.zeros((M, M))
+        Lp = self._laplacian()
+        for l in range(num):
+            baseAA[l * nper:(l + 1) * nper, l * nper:(l + 1) * nper] = Lp
+        for c in range(3):
+            baseAA[c, c] += 1.0                                                      # :803-807
+        edges = self._lattice_edges()
+        scores = []
+        for _ in range(max_iteration):
+            self.UpdateAllNormal(ctr)                                                # :151-153
+            r, c, v = self.NonrigidTriplets(weight)
+            thisAA = baseAA.copy()
+            np.add.at(thisAA, (r, c), v)
+            thisAA = np.triu(thisAA) + np.triu(thisAA, 1).T                          # the solver reads the Upper triangle
+            for _m in range(max_inner_iteration):
+                Ab = np.zeros(M)
+                for l in range(num):
+                    cur = ctr[l * nper:(l + 1) * nper].reshape(-1, 3)
+                    ini = ictr[l * nper:(l + 1) * nper].reshape(-1, 3)
+                    for vv, nb, _ in edges:                                          # :221-260
+                        dif = ini[vv] - ini[nb]
+                        R = self.GetRotation(dif, cur[vv] - cur[nb])
+                        bx = dif @ R.T
+                        Ab[l * nper + vv * 3:l * nper + vv * 3 + 3] += bx.sum(0)
+                        for t, w in enumerate(nb):
+                            Ab[l * nper + w * 3:l * nper + w * 3 + 3] -= bx[t]
+                old = ctr
+                ctr = np.linalg.solve(thisAA, Ab)                                    # :263
+                scores.append(float(np.linalg.norm(old - ctr)))
+        return ctr, scores
+
     # ---- COptApp::OptimizeRigid, OptApp.cpp:282-412 (dense numpy solve in place of CHOLMOD) ----------------
     def OptimizeRigid(self, ipose, max_iteration=5):
         """ipose: list of float64 4x4 initial poses.  Returns (poses, scores per iteration)."""

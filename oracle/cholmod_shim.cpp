@@ -114,9 +114,10 @@ int cholmod_factorize(cholmod_sparse* A, cholmod_factor* Lf, cholmod_common* c) 
     }
     const double s = sqrt(piv);
     M[(size_t)k * n + k] = s;
-#pragma omp parallel for schedule(static)
     for (long i = k + 1; i < n; i++) M[(size_t)i * n + k] /= s;
-#pragma omp parallel for schedule(dynamic, 16)
+    // 8 threads like the reference's own loops: hosts that expose hundreds of hardware threads under a CPU quota make wide
+    // OpenMP barriers (one per column here) pathologically slow
+#pragma omp parallel for schedule(dynamic, 16) num_threads(8) if (n - k > 256)
     for (long i = k + 1; i < n; i++) {
       const double lik = M[(size_t)i * n + k];
       if (lik == 0.0) continue;

@@ -125,3 +125,65 @@ def test_nonrigid_assembly_matches_oracle(gpu):
     assert ng > 50
     diag, off, info = g.AssembleNonrigid(1.0)
     assert off.shape == (ng, 24, 24) and info.shape == (ng, 4) and np.allclose(diag, diag.transpose(0, 1, 3, 2), rtol=1e-12, atol=1e-12 * np.abs(diag).max())
+
+
+# ---- end to end against the reference PROGRAM ---------------------------------------------------------------------
+import os
+
+from test_fopt_oracle import REF_BIN, _run_ref, _write_dataset
+
+
+def _read_ctr(fn):
+    return np.loadtxt(fn).reshape(-1)
+
+
+def _read_log(fn):
+    rows = [l.split() for l in open(fn) if l.strip()]
+    return [np.array(rows[k + 1:k + 5], np.float64) for k in range(0, len(rows), 5)]
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/FragmentOptimizer_ref is built where /root/reference exists")
+def test_optimisation_loops_match_the_reference_program(gpu, tmp_path):
+    """fopt.FragmentOptimizer (GPU assembly + host regularizer / dense solve) against the reference's own FragmentOptimizer
+    program (oracle/_ref, CHOLMOD replaced by the dense shim) on the same files: output.ctr and pose.log after two outer
+    iterations of --rigid and --slac and one of the default non-rigid mode.  Tolerances are those of two different
+    Cholesky solvers iterated twice (1e-7 absolute on metre-scale coordinates; the files carry 8-10 decimals)."""
+    d = str(tmp_path)
+    sc = make_scene(num=3, n=3000)
+    poses = _write_dataset(sc, d)
+    num = sc["num"]
+
+    def fresh(s):
+        g = FragmentOptimizer(s["num"], s["res"], s["length"])
+        for f, (x, n) in enumerate(s["frags"]):
+            assert g.SetCloud(f, x, n) == -1
+        g.SetCorrespondences(s["pairs"])
+        return g
+
+    args = ["--num", str(num), "--resolution", "8", "--length", "3.0", "--iteration", "2"]
+    # rigid
+    _run_ref(d, "rigid", "reg_output.log", args)
+    ref_pose, ref_ctr = _read_log(os.path.join(d, "pose.log")), _read_ctr(os.path.join(d, "out_rigid.ctr"))
+    g = fresh(sc)
+    pose, _ = g.OptimizeRigid(poses, max_iteration=2)
+    assert max(np.abs(a - b).max() for a, b in zip(pose, ref_pose)) < 1e-7
+    lat = g._canonical_lattice().reshape(-1, 3)
+    ctr = np.concatenate([g._apply(P, lat).reshape(-1) for P in pose])           # Pose2Ctr, OptApp.cpp:735-750
+    assert np.abs(ctr - ref_ctr).max() < 1e-7
+    # SLAC
+    _run_ref(d, "slac", "reg_output.log", args)
+    ref_pose, ref_ctr = _read_log(os.path.join(d, "pose.log")), _read_ctr(os.path.join(d, "out_slac.ctr"))
+    g = fresh(sc)
+    pose, expand, _ = g.OptimizeSLAC(poses, weight=1.0, max_iteration=2)
+    assert max(np.abs(a - b).max() for a, b in zip(pose, ref_pose)) < 1e-7
+    assert np.abs(expand - ref_ctr).max() < 1e-7
+    # non-rigid (default mode), resolution 4 keeps the dense solves quick
+    sc4 = make_scene(num=3, n=3000, res=4)
+    d4 = os.path.join(d, "r4")
+    os.makedirs(d4)
+    poses4 = _write_dataset(sc4, d4)
+    _run_ref(d4, "nonrigid", "reg_output.log", ["--num", str(num), "--resolution", "4", "--length", "3.0", "--weight", "1.7", "--inner_iteration", "2"])
+    ref_ctr = _read_ctr(os.path.join(d4, "out_nonrigid.ctr"))
+    g = fresh(sc4)
+    ctr, _ = g.OptimizeNonrigid(poses4, weight=1.7, max_iteration=1, max_inner_iteration=2)
+    assert np.abs(ctr - ref_ctr).max() < 1e-6

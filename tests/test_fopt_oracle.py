@@ -178,12 +178,14 @@ def _write_dataset(sc, d):
 
 
 def _run_ref(d, mode, reg, extra=()):
-    env = dict(os.environ, ER_CHOLMOD_DUMP=os.path.join(d, "dump_" + mode + "_" + reg.split(".")[0]), ER_ORACLE_QUIET="1")
-    cmd = [REF_BIN, "--registration", os.path.join(d, reg), "--dir", d + "/", "--rgbdslam", os.path.join(d, "rgbd.log"), "--interval", "1",
-           "--blacklistpair", "0", "--iteration", "1", "--inner_iteration", "1", "--save_to", os.path.join(d, "out_%s.ctr" % mode)] + list(extra)
+    env = dict(os.environ, ER_CHOLMOD_DUMP=os.path.join(d, "dump_" + mode + "_" + reg.split(".")[0]), ER_ORACLE_QUIET="1", OMP_NUM_THREADS="8",
+               OMP_WAIT_POLICY="passive")
+    cmd = [REF_BIN] + list(extra) + ["--registration", os.path.join(d, reg), "--dir", d + "/", "--rgbdslam", os.path.join(d, "rgbd.log"),
+                                     "--interval", "1", "--blacklistpair", "0", "--iteration", "1", "--inner_iteration", "1",
+                                     "--save_to", os.path.join(d, "out_%s.ctr" % mode)]      # the first occurrence of a flag wins
     if mode != "nonrigid":
         cmd.append("--" + mode)
-    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, timeout=600)
+    subprocess.run(cmd, check=True, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env, timeout=180)
     return env["ER_CHOLMOD_DUMP"]
 
 
