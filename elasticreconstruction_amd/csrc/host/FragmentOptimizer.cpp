@@ -1,0 +1,641 @@
+// FragmentOptimizer -- drop-in for the reference's FragmentOptimizer program (FragmentOptimizer/FragmentOptimizer.cpp,
+// OptApp.{h,cpp}) on MI355X: same flags, same input files (rgbdslam / registration .log, cloud_bin_<i>.pcd or
+// cloud_bin_xyzn_<i>.xyzn, corres_<i>_<j>.txt), same output files (--save_to .ctr, pose.log).
+// The data-parallel half -- point set-up, UpdatePose / UpdateAllPointPN / UpdateAllNormal and the Hessian assembly of the
+// three modes -- runs in liber_hip.so (er_fopt_*, csrc/er_fopt.hip).  The host keeps what the reference keeps on the host:
+// the lattice regularizer, gauge terms, the pose / lattice updates and the linear solve.  The reference solves with CHOLMOD
+// (sparse supernodal LL^T); here the system is solved by a dense Cholesky, which is exact for the same matrix and fast for
+// the SLAC and rigid systems (6 num + 2187 unknowns).  The non-rigid mode's system has num * 2187 unknowns: the dense solve
+// is accepted up to --dense_limit unknowns (default 12000) and refused beyond with a clear message.
+#include <omp.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../../include/er_hip.h"
+#include "er_formats.h"
+
+namespace {
+
+using erfmt::FramedTransformation;
+
+typedef std::vector<double> Vec;
+
+void mat4_mul(const double* A, const double* B, double* C) {
+  double t[16];
+  for (int r = 0; r < 4; r++)
+    for (int c = 0; c < 4; c++) t[r * 4 + c] = ((A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c]) + A[r * 4 + 2] * B[8 + c]) + A[r * 4 + 3] * B[12 + c];
+  memcpy(C, t, sizeof t);
+}
+
+bool mat4_inverse(const double* m, double* inv) {      // cofactor expansion
+  double a[16];
+  a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+  if (det == 0.0 || !std::isfinite(det)) return false;
+  for (int i = 0; i < 16; i++) inv[i] = a[i] / det;
+  return true;
+}
+
+// Symmetric dense solve A x = b by Cholesky (A: n x n row-major, only the LOWER triangle is read; destroyed).  Returns
+// false when A is not positive definite.
+bool cholesky_solve(std::vector<double>& A, long n, Vec& b) {
+  for (long k = 0; k < n; k++) {
+    const double piv = A[(size_t)k * n + k];
+    if (!(piv > 0.0)) return false;
+    const double s = std::sqrt(piv);
+    A[(size_t)k * n + k] = s;
+    for (long i = k + 1; i < n; i++) A[(size_t)i * n + k] /= s;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(8) if (n - k > 256)
+    for (long i = k + 1; i < n; i++) {
+      const double lik = A[(size_t)i * n + k];
+      if (lik == 0.0) continue;
+      double* Ai = &A[(size_t)i * n];
+      for (long j = k + 1; j <= i; j++) Ai[j] -= lik * A[(size_t)j * n + k];
+    }
+  }
+  for (long i = 0; i < n; i++) {
+    double s = b[(size_t)i];
+    for (long j = 0; j < i; j++) s -= A[(size_t)i * n + j] * b[(size_t)j];
+    b[(size_t)i] = s / A[(size_t)i * n + i];
+  }
+  for (long i = n - 1; i >= 0; i--) {
+    double s = b[(size_t)i];
+    for (long j = i + 1; j < n; j++) s -= A[(size_t)j * n + i] * b[(size_t)j];
+    b[(size_t)i] = s / A[(size_t)i * n + i];
+  }
+  return true;
+}
+
+// COptApp::GetRotation, OptApp.cpp:850-871: C = sum dif^T diff, R = V U^T of its SVD (last column of U flipped when det < 0)
+// = the proper rotation maximising trace(R C).  Computed from the symmetric 4x4 matrix of Horn's closed form with Jacobi
+// eigen-iterations (no SVD library here); equal to the SVD construction wherever that one is well defined.
+void best_rotation(const double C[9], double R[9]) {
+  // R maximises sum_i diff_i . (R dif_i)  with C = sum dif_i^T diff_i  (C[a][b] = sum dif[a] * diff[b])
+  const double Sxx = C[0], Sxy = C[1], Sxz = C[2], Syx = C[3], Syy = C[4], Syz = C[5], Szx = C[6], Szy = C[7], Szz = C[8];
+  double N[4][4] = {{Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx},
+                    {Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz},
+                    {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
+                    {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = 0.0;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) off += N[p][q] * N[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 4; p++)
+      for (int q = p + 1; q < 4; q++) {
+        if (N[p][q] == 0.0) continue;
+        const double theta = (N[q][q] - N[p][p]) / (2.0 * N[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; k++) {
+          const double a = N[k][p], b = N[k][q];
+          N[k][p] = c * a - s * b;
+          N[k][q] = s * a + c * b;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double a = N[p][k], b = N[q][k];
+          N[p][k] = c * a - s * b;
+          N[q][k] = s * a + c * b;
+        }
+        for (int k = 0; k < 4; k++) {
+          const double a = V[k][p], b = V[k][q];
+          V[k][p] = c * a - s * b;
+          V[k][q] = s * a + c * b;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; k++)
+    if (N[k][k] > N[best][best]) best = k;
+  double q0 = V[0][best], qx = V[1][best], qy = V[2][best], qz = V[3][best];
+  const double nn = std::sqrt(q0 * q0 + qx * qx + qy * qy + qz * qz);
+  q0 /= nn; qx /= nn; qy /= nn; qz /= nn;
+  R[0] = q0 * q0 + qx * qx - qy * qy - qz * qz; R[1] = 2 * (qx * qy - q0 * qz); R[2] = 2 * (qx * qz + q0 * qy);
+  R[3] = 2 * (qy * qx + q0 * qz); R[4] = q0 * q0 - qx * qx + qy * qy - qz * qz; R[5] = 2 * (qy * qz - q0 * qx);
+  R[6] = 2 * (qz * qx - q0 * qy); R[7] = 2 * (qz * qy + q0 * qx); R[8] = q0 * q0 - qx * qx - qy * qy + qz * qz;
+}
+
+class COptApp {                                     // OptApp.h:39-124
+ public:
+  std::vector<FramedTransformation> rgbd_traj_, reg_traj_;
+  int resolution_ = 8, interval_ = 50, num_ = 0;
+  double weight_ = 1.0, length_ = 3.0;
+  int max_iteration_ = 5, max_inner_iteration_ = 10;
+  std::string dir_prefix_, ctr_filename_ = "output.ctr", pose_filename_ = "pose.log", init_ctr_file_;
+  int sample_num_ = -1, blacklist_pair_num_ = 10000, device_ = 0;
+  long dense_limit_ = 12000;
+  std::set<int> blacklist_;
+  std::vector<int> absolute2relative_map_, relative2absolute_map_;
+  std::vector<std::vector<double>> ipose_, pose_;    // 16 doubles each, row-major
+  er_fopt_t fo_ = nullptr;
+  int nper_ = 0, nv_ = 0;
+  double unit_length_ = 0;
+  struct Edge { int v; std::vector<int> nb; int i, j, k; };
+  std::vector<Edge> edges_;
+
+  ~COptApp() { if (fo_) er_fopt_destroy(fo_); }
+
+  int GetIndex(int i, int j, int k) const { return i + j * (resolution_ + 1) + k * (resolution_ + 1) * (resolution_ + 1); }
+
+  void Blacklist(const std::string& fn) {           // OptApp.cpp:925-941
+    blacklist_.clear();
+    if (FILE* f = fopen(fn.c_str(), "r")) {
+      char buf[1024];
+      int id;
+      while (fgets(buf, 1024, f))
+        if (strlen(buf) > 0 && buf[0] != '#' && sscanf(buf, "%d", &id) == 1) blacklist_.insert(id);
+      fclose(f);
+    }
+  }
+
+  void IPoseFromFile(const std::string& fn) {       // OptApp.h:91-98
+    std::vector<FramedTransformation> ip;
+    erfmt::load_log(fn, ip);
+    ipose_.clear();
+    for (const auto& t : ip) ipose_.emplace_back(t.T, t.T + 16);
+  }
+
+  void InitMap() {                                  // OptApp.cpp:31-47
+    absolute2relative_map_.assign((size_t)num_, -1);
+    relative2absolute_map_.clear();
+    for (int i = 0; i < num_; i++)
+      if (!blacklist_.count(i)) {
+        absolute2relative_map_[(size_t)i] = (int)relative2absolute_map_.size();
+        relative2absolute_map_.push_back(i);
+      }
+    if (num_ != (int)relative2absolute_map_.size())
+      printf("Blacklisted fragments, number reduced from %d to %d.\n", num_, (int)relative2absolute_map_.size());
+    num_ = (int)relative2absolute_map_.size();
+  }
+
+  bool InitIPose() {                                // OptApp.cpp:49-72 (pose_ is sized in every case; the reference forgets to with --ipose)
+    pose_.assign((size_t)num_, std::vector<double>(16, 0.0));
+    if (!ipose_.empty()) {
+      if ((int)ipose_.size() < num_) { fprintf(stderr, "FragmentOptimizer: --ipose holds %zu poses, %d needed\n", ipose_.size(), num_); return false; }
+      return true;
+    }
+    double base[16] = {1, 0, 0, length_ / 2.0, 0, 1, 0, length_ / 2.0, 0, 0, 1, -0.3, 0, 0, 0, 1}, binv[16], r0inv[16], left[16];
+    if (rgbd_traj_.empty()) { fprintf(stderr, "FragmentOptimizer: no --rgbdslam / --ipose trajectory\n"); return false; }
+    mat4_inverse(base, binv);
+    if (!mat4_inverse(rgbd_traj_[0].T, r0inv)) return false;
+    mat4_mul(base, r0inv, left);
+    ipose_.assign((size_t)num_, std::vector<double>(16));
+    for (int i = 0; i < num_; i++) {
+      const size_t k = (size_t)relative2absolute_map_[(size_t)i] * (size_t)interval_;
+      if (k >= rgbd_traj_.size()) { fprintf(stderr, "FragmentOptimizer: trajectory too short for fragment %d\n", i); return false; }
+      double t[16];
+      mat4_mul(left, rgbd_traj_[k].T, t);
+      mat4_mul(t, binv, ipose_[(size_t)i].data());
+    }
+    printf("IPose initialized.\n");
+    return true;
+  }
+
+  bool InitPointClouds() {                          // OptApp.cpp:74-98
+    if (er_fopt_create(num_, resolution_, (float)length_, device_, &fo_)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+    for (int i = 0; i < num_; i++) {
+      const int ii = relative2absolute_map_[(size_t)i];
+      char fn[1024];
+      std::vector<float> xyz, nrm;
+      snprintf(fn, sizeof fn, "%scloud_bin_%d.pcd", dir_prefix_.c_str(), ii);
+      if (erfmt::file_exists(fn)) {
+        std::vector<std::vector<float>> cols;
+        size_t n = 0;
+        if (!erfmt::load_pcd_fields(fn, {"x", "y", "z", "normal_x", "normal_y", "normal_z"}, cols, n)) { fprintf(stderr, "Error loading file.\n"); return false; }
+        for (size_t k = 0; k < n; k++)
+          if (!std::isnan(cols[3][k])) {              // PointCloud.cpp:29
+            xyz.insert(xyz.end(), {cols[0][k], cols[1][k], cols[2][k]});
+            nrm.insert(nrm.end(), {cols[3][k], cols[4][k], cols[5][k]});
+          }
+      } else {
+        snprintf(fn, sizeof fn, "%scloud_bin_xyzn_%d.xyzn", dir_prefix_.c_str(), ii);
+        FILE* f = fopen(fn, "r");
+        if (!f) { fprintf(stderr, "File not found ... Check dir and num parameters.\n"); return false; }
+        char buf[1024];
+        float x[6];
+        while (fgets(buf, 1024, f))
+          if (strlen(buf) > 0 && buf[0] != '#') {     // PointCloud.cpp:49-52
+            sscanf(buf, "%f %f %f %f %f %f", &x[0], &x[1], &x[2], &x[3], &x[4], &x[5]);
+            xyz.insert(xyz.end(), {x[0], x[1], x[2]});
+            nrm.insert(nrm.end(), {x[3], x[4], x[5]});
+          }
+        fclose(f);
+      }
+      int bad = -1;
+      if (er_fopt_set_cloud(fo_, i, xyz.data(), nrm.data(), (int)(xyz.size() / 3), &bad)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      if (bad >= 0) fprintf(stderr, "Error!! Point out of bound!!\n");
+      printf("Read %s ... get %d points.\n", fn, er_fopt_cloud_size(fo_, i));
+    }
+    return true;
+  }
+
+  bool InitCorrespondences() {                      // OptApp.cpp:100-118
+    std::vector<int> fi, fj, counts;
+    std::vector<std::vector<int>> rows;
+    for (const auto& t : reg_traj_) {
+      if (blacklist_.count(t.id1) || blacklist_.count(t.id2) || t.id1 >= (int)absolute2relative_map_.size() || t.id2 >= (int)absolute2relative_map_.size()) continue;
+      if (t.frame != -1 && t.frame >= blacklist_pair_num_) {
+        char fn[1024];
+        snprintf(fn, sizeof fn, "%scorres_%d_%d.txt", dir_prefix_.c_str(), t.id1, t.id2);
+        std::vector<int> r;
+        if (FILE* f = fopen(fn, "r")) {
+          char buf[1024];
+          int a, b;
+          while (fgets(buf, 1024, f))
+            if (strlen(buf) > 0 && buf[0] != '#' && sscanf(buf, "%d %d", &a, &b) == 2) { r.push_back(a); r.push_back(b); }
+          fclose(f);
+        }
+        printf("Read %s, get %d correspondences.\n", fn, (int)r.size() / 2);
+        fi.push_back(absolute2relative_map_[(size_t)t.id1]);
+        fj.push_back(absolute2relative_map_[(size_t)t.id2]);
+        counts.push_back((int)r.size() / 2);
+        rows.push_back(std::move(r));
+      }
+    }
+    std::vector<const int*> ptrs;
+    for (auto& r : rows) ptrs.push_back(r.data());
+    if (er_fopt_set_correspondences(fo_, (int)fi.size(), fi.data(), fj.data(), ptrs.data(), counts.data())) {
+      fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error());
+      return false;
+    }
+    return true;
+  }
+
+  void InitLattice() {
+    unit_length_ = length_ / resolution_;
+    nv_ = (resolution_ + 1) * (resolution_ + 1) * (resolution_ + 1);
+    nper_ = nv_ * 3;
+    edges_.clear();
+    const int r = resolution_;
+    for (int i = 0; i <= r; i++)
+      for (int j = 0; j <= r; j++)
+        for (int k = 0; k <= r; k++) {                // the reference's six `if` blocks, in order
+          Edge e;
+          e.v = GetIndex(i, j, k); e.i = i; e.j = j; e.k = k;
+          if (i > 0) e.nb.push_back(GetIndex(i - 1, j, k));
+          if (i < r) e.nb.push_back(GetIndex(i + 1, j, k));
+          if (j > 0) e.nb.push_back(GetIndex(i, j - 1, k));
+          if (j < r) e.nb.push_back(GetIndex(i, j + 1, k));
+          if (k > 0) e.nb.push_back(GetIndex(i, j, k - 1));
+          if (k < r) e.nb.push_back(GetIndex(i, j, k + 1));
+          edges_.push_back(e);
+        }
+  }
+
+  // AddHessian2( {v, nb}, {1, -1} ) for every (vertex, neighbour): [[1,-1],[-1,1]] per component, added at offset `off`
+  void add_laplacian(std::vector<double>& A, long n, long off, double scale) const {
+    for (const Edge& e : edges_)
+      for (int w : e.nb)
+        for (int c = 0; c < 3; c++) {
+          const long a = off + e.v * 3 + c, b = off + w * 3 + c;
+          A[(size_t)a * n + a] += scale;
+          A[(size_t)b * n + b] += scale;
+          A[(size_t)a * n + b] -= scale;
+          A[(size_t)b * n + a] -= scale;
+        }
+  }
+
+  void rotation_of(const double* ini, const double* cur, const Edge& e, double R[9]) const {
+    double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w : e.nb)
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) C[a * 3 + b] += (ini[e.v * 3 + a] - ini[w * 3 + a]) * (cur[e.v * 3 + b] - cur[w * 3 + b]);
+    best_rotation(C, R);
+  }
+
+  static void increment(const double* x6, double* aff) {   // AngleAxis(z) * AngleAxis(y) * AngleAxis(x), OptApp.cpp:395-400
+    const double a = x6[0], b = x6[1], g = x6[2];
+    const double Rx[9] = {1, 0, 0, 0, cos(a), -sin(a), 0, sin(a), cos(a)}, Ry[9] = {cos(b), 0, sin(b), 0, 1, 0, -sin(b), 0, cos(b)},
+                 Rz[9] = {cos(g), -sin(g), 0, sin(g), cos(g), 0, 0, 0, 1};
+    double zy[9], R[9];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) zy[r * 3 + c] = (Rz[r * 3] * Ry[c] + Rz[r * 3 + 1] * Ry[3 + c]) + Rz[r * 3 + 2] * Ry[6 + c];
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) R[r * 3 + c] = (zy[r * 3] * Rx[c] + zy[r * 3 + 1] * Rx[3 + c]) + zy[r * 3 + 2] * Rx[6 + c];
+    for (int i = 0; i < 16; i++) aff[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) aff[r * 4 + c] = R[r * 3 + c];
+      aff[r * 4 + 3] = x6[3 + r];
+    }
+  }
+
+  bool update_pose_gpu(int l, const double* M) {
+    float Mf[16];
+    for (int i = 0; i < 16; i++) Mf[i] = (float)M[i];
+    if (er_fopt_update_pose(fo_, l, Mf)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+    return true;
+  }
+
+  void canonical_lattice(Vec& out) const {           // InitCtrSLAC, OptApp.cpp:723-733
+    out.assign((size_t)nper_, 0.0);
+    for (const Edge& e : edges_) {
+      out[(size_t)e.v * 3] = e.i * unit_length_;
+      out[(size_t)e.v * 3 + 1] = e.j * unit_length_;
+      out[(size_t)e.v * 3 + 2] = e.k * unit_length_;
+    }
+  }
+
+  static void apply(const double* P, const double* xyz, double* out) {
+    for (int r = 0; r < 3; r++) out[r] = ((P[r * 4] * xyz[0] + P[r * 4 + 1] * xyz[1]) + P[r * 4 + 2] * xyz[2]) + P[r * 4 + 3] * 1.0;
+  }
+
+  void expand(const Vec& lattice, Vec& out) const {  // Pose2Ctr / ExpandCtr, OptApp.cpp:735-763
+    out.assign((size_t)num_ * nper_, 0.0);
+    for (int l = 0; l < num_; l++)
+      for (int v = 0; v < nv_; v++) apply(pose_[(size_t)l].data(), &lattice[(size_t)v * 3], &out[(size_t)l * nper_ + (size_t)v * 3]);
+  }
+
+  void SaveCtr(const Vec& ctr, const std::string& fn) const {   // OptApp.cpp:873-884
+    printf("Save ctr to file %s ... ", fn.c_str());
+    if (FILE* f = fopen(fn.c_str(), "w")) {
+      for (size_t i = 0; i < ctr.size() / 3; i++) fprintf(f, "%.10f %.10f %.10f\n", ctr[i * 3], ctr[i * 3 + 1], ctr[i * 3 + 2]);
+      fclose(f);
+    }
+    printf("Done.\n");
+  }
+
+  void SavePoses() const {
+    std::vector<FramedTransformation> out;
+    for (int i = 0; i < num_; i++) {
+      FramedTransformation t;
+      t.id1 = i; t.id2 = i; t.frame = i + 1;
+      memcpy(t.T, pose_[(size_t)i].data(), sizeof t.T);
+      out.push_back(t);
+    }
+    erfmt::save_log(pose_filename_, out);
+  }
+
+  bool Prepare() {
+    InitMap();
+    InitLattice();
+    return InitIPose() && InitPointClouds() && InitCorrespondences();
+  }
+
+  // ---- OptimizeRigid, OptApp.cpp:282-417 ------------------------------------------------------------------
+  bool OptimizeRigid() {
+    printf("Rigid optimization.\nParameters: resolution %d, piece number %d, max iteration %d\n", resolution_, num_, max_iteration_);
+    if (!Prepare()) return false;
+    const long N = 6L * num_;
+    for (int i = 0; i < num_; i++) {
+      pose_[(size_t)i] = ipose_[(size_t)i];
+      if (!update_pose_gpu(i, pose_[(size_t)i].data())) return false;
+    }
+    std::vector<double> JJ((size_t)N * N);
+    Vec Jb((size_t)N);
+    for (int itr = 0; itr < max_iteration_; itr++) {
+      double score = 0;
+      if (er_fopt_assemble_rigid(fo_, JJ.data(), Jb.data(), &score)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      printf("Error score is : %.2f\n", score);
+      if (!cholesky_solve(JJ, N, Jb)) { fprintf(stderr, "FragmentOptimizer: the rigid system is not positive definite\n"); return false; }
+      for (int l = 0; l < num_; l++) {
+        double x6[6], aff[16], np[16];
+        for (int q = 0; q < 6; q++) x6[q] = -Jb[(size_t)l * 6 + q];           // result = - solver.solve( thisJb )
+        increment(x6, aff);
+        mat4_mul(aff, pose_[(size_t)l].data(), np);
+        pose_[(size_t)l].assign(np, np + 16);
+        if (!update_pose_gpu(l, aff)) return false;
+      }
+    }
+    SavePoses();
+    Vec lat, ctr;
+    canonical_lattice(lat);
+    expand(lat, ctr);
+    SaveCtr(ctr, ctr_filename_);
+    return true;
+  }
+
+  // ---- OptimizeSLAC, OptApp.cpp:419-680 ---------------------------------------------------------------------
+  bool OptimizeSLAC() {
+    printf("SLAC optimization.\nParameters: weight %.5f, resolution %d, piece number %d, max iteration %d\n", weight_, resolution_, num_, max_iteration_);
+    const double default_weight = num_ * weight_;      // note: num_ BEFORE InitMap, like the reference (:421 precedes :425)
+    if (!Prepare()) return false;
+    const long N = 6L * num_ + nper_, L0 = 6L * num_;
+    Vec ictr, thisCtr, expand_ctr;
+    canonical_lattice(ictr);
+    thisCtr = ictr;
+    for (int i = 0; i < num_; i++) {
+      pose_[(size_t)i] = ipose_[(size_t)i];
+      if (!update_pose_gpu(i, pose_[(size_t)i].data())) return false;
+    }
+    std::vector<double> JJ((size_t)N * N), A((size_t)N * N);
+    Vec Jb((size_t)N), rot((size_t)num_ * 9);
+    const long anchor = L0 + (long)GetIndex(resolution_ / 2, resolution_ / 2, 0) * 3;
+    for (int itr = 0; itr < max_iteration_; itr++) {
+      for (int l = 0; l < num_; l++)
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) rot[(size_t)l * 9 + r * 3 + c] = pose_[(size_t)l][(size_t)c * 4 + r];     // pose_rot_t_ = R^T
+      double score = 0;
+      if (er_fopt_assemble_slac(fo_, rot.data(), JJ.data(), Jb.data(), &score)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      printf("Data error score is : %.2f\n", score);
+      // thisJJ = Upper( baseJJ * default_weight ) + gauge + data term; the solver reads the upper triangle: mirror it down
+      std::fill(A.begin(), A.end(), 0.0);
+      add_laplacian(A, N, L0, default_weight);
+      for (int c = 0; c < 3; c++) A[(size_t)(anchor + c) * N + anchor + c] += default_weight;
+      for (long r = 0; r < N; r++)
+        for (long c = r; c < N; c++) {
+          const double v = A[(size_t)r * N + c] + JJ[(size_t)r * N + c] + ((r == c && r < 6) ? 1.0 : 0.0);
+          A[(size_t)c * N + r] = v;                   // lower triangle for cholesky_solve
+        }
+      // regularizer right-hand side, OptApp.cpp:570-631
+      Vec b(Jb);
+      double regscore = 0;
+      for (const Edge& e : edges_) {
+        double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (!(e.i == resolution_ / 2 && e.j == resolution_ / 2 && e.k == 0)) rotation_of(ictr.data(), thisCtr.data(), e, R);
+        for (int w : e.nb) {
+          double bx[3];
+          for (int a = 0; a < 3; a++) {
+            double rd = 0;
+            for (int c = 0; c < 3; c++) rd += R[a * 3 + c] * (ictr[(size_t)e.v * 3 + c] - ictr[(size_t)w * 3 + c]);
+            bx[a] = (thisCtr[(size_t)e.v * 3 + a] - thisCtr[(size_t)w * 3 + a]) - rd;
+            regscore += default_weight * bx[a] * bx[a];
+            b[(size_t)(L0 + e.v * 3 + a)] += bx[a] * default_weight;
+            b[(size_t)(L0 + w * 3 + a)] -= bx[a] * default_weight;
+          }
+        }
+      }
+      printf("Regularization error score is : %.2f\n", regscore);
+      if (!cholesky_solve(A, N, b)) { fprintf(stderr, "FragmentOptimizer: the SLAC system is not positive definite\n"); return false; }
+      for (int q = 0; q < nper_; q++) thisCtr[(size_t)q] += -b[(size_t)(L0 + q)];
+      for (int l = 0; l < num_; l++) {
+        double x6[6], aff[16], np[16];
+        for (int q = 0; q < 6; q++) x6[q] = -b[(size_t)l * 6 + q];
+        increment(x6, aff);
+        mat4_mul(aff, pose_[(size_t)l].data(), np);
+        pose_[(size_t)l].assign(np, np + 16);
+      }
+      expand(thisCtr, expand_ctr);
+      for (int l = 0; l < num_; l++)
+        if (er_fopt_update_point_pn(fo_, l, &expand_ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+    }
+    SavePoses();
+    expand(thisCtr, expand_ctr);
+    SaveCtr(expand_ctr, ctr_filename_);
+    return true;
+  }
+
+  // ---- OptimizeNonrigid, OptApp.cpp:120-278 -------------------------------------------------------------------
+  bool OptimizeNonrigid() {
+    printf("Nonrigid optimization.\nParameters: weight %.5f, resolution %d, piece number %d, max iteration %d\n", weight_, resolution_, num_, max_iteration_);
+    if (!Prepare()) return false;
+    const long M = (long)num_ * nper_;
+    if (M > dense_limit_) {
+      fprintf(stderr, "FragmentOptimizer: the non-rigid system has %ld unknowns; this build solves it densely up to --dense_limit %ld "
+                      "(use --slac or --rigid, or fewer fragments)\n", M, dense_limit_);
+      return false;
+    }
+    Vec lat, ctr, ictr;
+    canonical_lattice(lat);
+    for (int i = 0; i < num_; i++) pose_[(size_t)i] = ipose_[(size_t)i];
+    expand(lat, ctr);                                 // InitCtr, :709-721
+    ictr = ctr;
+    const int ng = er_fopt_group_count(fo_);
+    std::vector<int> info((size_t)std::max(ng, 1) * 4);
+    er_fopt_group_info(fo_, info.data());
+    std::vector<double> diag((size_t)num_ * nv_ * 576), off((size_t)std::max(ng, 1) * 576), A((size_t)M * M);
+    int loc[24];                                      // local bucket entry c*8 + t -> lattice offset from idx_[0]
+    for (int c = 0; c < 3; c++)
+      for (int t = 0; t < 8; t++) {
+        const int n1 = resolution_ + 1;
+        loc[c * 8 + t] = (((t >> 2) & 1) + ((t >> 1) & 1) * n1 + (t & 1) * n1 * n1) * 3 + c;
+      }
+    for (int itr = 0; itr < max_iteration_; itr++) {
+      for (int l = 0; l < num_; l++)
+        if (er_fopt_update_normals(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      if (er_fopt_assemble_nonrigid(fo_, weight_, diag.data(), off.data())) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      // thisAA = baseAA + blocks; assembled as a full symmetric matrix from the entries the reference stores at (row <= col)
+      std::fill(A.begin(), A.end(), 0.0);
+      for (int l = 0; l < num_; l++) add_laplacian(A, M, (long)l * nper_, 1.0);
+      for (int c = 0; c < 3; c++) A[(size_t)c * M + c] += 1.0;                 // :803-807
+      for (int l = 0; l < num_; l++)
+        for (int v = 0; v < nv_; v++) {
+          const double* B = &diag[((size_t)l * nv_ + v) * 576];
+          const long base = (long)l * nper_ + (long)v * 3;
+          for (int a = 0; a < 24; a++)
+            for (int c = 0; c < 24; c++)
+              if (B[a * 24 + c] != 0.0) A[(size_t)(base + loc[a]) * M + base + loc[c]] += B[a * 24 + c];
+        }
+      for (int g = 0; g < ng; g++) {
+        const long bi = (long)info[(size_t)g * 4] * nper_ + info[(size_t)g * 4 + 2], bj = (long)info[(size_t)g * 4 + 1] * nper_ + info[(size_t)g * 4 + 3];
+        const double* B = &off[(size_t)g * 576];
+        for (int a = 0; a < 24; a++)
+          for (int c = 0; c < 24; c++) {
+            const double v = B[a * 24 + c];
+            if (v == 0.0) continue;
+            const long r = bi + loc[a], q = bj + loc[c];
+            A[(size_t)r * M + q] += v;                // the (i, j) block; the solver reads the upper triangle and mirrors it
+            A[(size_t)q * M + r] += v;
+          }
+      }
+      std::vector<double> F;
+      for (int m = 0; m < max_inner_iteration_; m++) {
+        Vec Ab((size_t)M, 0.0);
+        for (int l = 0; l < num_; l++) {
+          const double* ini = &ictr[(size_t)l * nper_];
+          const double* cur = &ctr[(size_t)l * nper_];
+          for (const Edge& e : edges_) {              // :221-260
+            double R[9];
+            rotation_of(ini, cur, e, R);
+            for (int w : e.nb)
+              for (int a = 0; a < 3; a++) {
+                double bx = 0;
+                for (int c = 0; c < 3; c++) bx += R[a * 3 + c] * (ini[e.v * 3 + c] - ini[w * 3 + c]);
+                Ab[(size_t)l * nper_ + (size_t)e.v * 3 + a] += bx;
+                Ab[(size_t)l * nper_ + (size_t)w * 3 + a] -= bx;
+              }
+          }
+        }
+        F = A;                                        // (factorised anew per inner iteration: simple, and small next to the assembly of real runs)
+        if (!cholesky_solve(F, M, Ab)) { fprintf(stderr, "FragmentOptimizer: the non-rigid system is not positive definite\n"); return false; }
+        double sc = 0;
+        for (long q = 0; q < M; q++) sc += (ctr[(size_t)q] - Ab[(size_t)q]) * (ctr[(size_t)q] - Ab[(size_t)q]);
+        ctr = Ab;
+        printf("Iteration #%d:%d (%d:%d) : score is %.4f\n", itr + 1, m + 1, max_iteration_, max_inner_iteration_, std::sqrt(sc));
+      }
+    }
+    SaveCtr(ctr, ctr_filename_);
+    return true;
+  }
+};
+
+int print_help() {
+  printf("\nApplication parameters:\n"
+         "    --help, -h                      : print this message\n"
+         "    --rgbdslam <log_file>           : rgbdslam.log/opt_output.log file, get ipose\n"
+         "    --registration <log_file>       : reg_output.log, invalid pair when frame_ == -1\n"
+         "    --dir <dir_prefix>              : dir prefix, place to loopup .xyzn files\n"
+         "    --num <number>                  : number of pieces, important parameter\n"
+         "    --weight <weight>               : 1.0 for nonrigid, 10000.0 for rigid\n"
+         "    --resolution <resolution>       : default - 8\n"
+         "    --length <length>               : default - 3.0\n"
+         "    --interval <interval>           : default - 50\n"
+         "    --iteration <max_number>        : default - 5\n"
+         "    --inner_iteration <max_number>  : default - 10\n"
+         "    --save_to <ctr_file>            : default - output.ctr\n"
+         "    --blasklist <blacklist_file>    : each line is the block we want to blacklist\n"
+         "    --blacklistpair <threshold>     : threshold of accepting pairwise registration, default - 10000\n"
+         "    --ipose <log_file>              : get ipose from log file\n"
+         "    --device <id>, --dense_limit <n>: (new) HIP device; largest system solved densely in the non-rigid mode\n"
+         "Optimization options:\n"
+         "    --nonrigid                      : default, nonrigid alignment published in ICCV 2013\n"
+         "    --rigid                         : dense rigid optimization\n"
+         "    --slac                          : simultaneous localization and calibration, published in CVPR 2014\n");
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {                     // FragmentOptimizer.cpp:40-93
+  using namespace erfmt;
+  if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
+  COptApp app;
+  std::string s, blacklist_file, ipose_file;
+  if (parse_argument(argc, argv, "--rgbdslam", s) > 0) load_log(s, app.rgbd_traj_);
+  if (parse_argument(argc, argv, "--registration", s) > 0) load_log(s, app.reg_traj_);
+  parse_argument(argc, argv, "--dir", app.dir_prefix_);
+  parse_argument(argc, argv, "--init_ctr", app.init_ctr_file_);
+  parse_argument(argc, argv, "--num", app.num_);
+  parse_argument(argc, argv, "--weight", app.weight_);
+  parse_argument(argc, argv, "--resolution", app.resolution_);
+  parse_argument(argc, argv, "--length", app.length_);
+  parse_argument(argc, argv, "--interval", app.interval_);
+  parse_argument(argc, argv, "--iteration", app.max_iteration_);
+  parse_argument(argc, argv, "--inner_iteration", app.max_inner_iteration_);
+  parse_argument(argc, argv, "--save_to", app.ctr_filename_);
+  parse_argument(argc, argv, "--write_xyzn_sample", app.sample_num_);
+  parse_argument(argc, argv, "--blacklistpair", app.blacklist_pair_num_);
+  parse_argument(argc, argv, "--device", app.device_);
+  double dl = (double)app.dense_limit_;
+  if (parse_argument(argc, argv, "--dense_limit", dl) > 0) app.dense_limit_ = (long)dl;
+  if (parse_argument(argc, argv, "--blacklist", blacklist_file) > 0) app.Blacklist(blacklist_file);
+  if (parse_argument(argc, argv, "--ipose", ipose_file) > 0) app.IPoseFromFile(ipose_file);
+  if (!app.init_ctr_file_.empty()) fprintf(stderr, "FragmentOptimizer: --init_ctr is not supported by this build (ignored)\n");
+  if (app.sample_num_ > 0) fprintf(stderr, "FragmentOptimizer: --write_xyzn_sample is not supported by this build (ignored)\n");
+  bool ok;
+  if (find_switch(argc, argv, "--slac")) ok = app.OptimizeSLAC();
+  else if (find_switch(argc, argv, "--rigid")) ok = app.OptimizeRigid();
+  else ok = app.OptimizeNonrigid();
+  return ok ? 0 : 1;
+}

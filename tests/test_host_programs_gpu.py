@@ -142,3 +142,56 @@ def test_build_correspondence_program(gpu, tmp_path):
     out = formats.load_log(d + "reg_output.log")
     assert [t.frame == -1 for t in out] == [False, True, False]
     assert np.abs(out[0].T - truth[1]).max() < 2e-3 and np.abs(out[2].T - np.linalg.inv(truth[1]) @ truth[2]).max() < 2e-3
+
+
+def test_fragment_optimizer_program_equals_reference_program(gpu, tmp_path):
+    """bin/FragmentOptimizer (GPU assembly, host regularizer + dense Cholesky) against the reference's own FragmentOptimizer
+    program (oracle/_ref/FragmentOptimizer_ref: reference sources compiled in place, CHOLMOD replaced by the dense shim) on
+    the same files and flags: output.ctr and pose.log of --rigid, --slac and the default non-rigid mode."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fopt_helpers import make_scene
+    from test_fopt_oracle import REF_BIN, _run_ref, _write_dataset
+    if not os.path.exists(REF_BIN):
+        pytest.skip("oracle/_ref/FragmentOptimizer_ref is built where /root/reference exists")
+
+    def run_ours(d, mode, extra, out):
+        cmd = [os.path.join(BIN, "FragmentOptimizer")] + extra + ["--registration", os.path.join(d, "reg_output.log"), "--dir", d + "/",
+                                                               "--rgbdslam", os.path.join(d, "rgbd.log"), "--interval", "1", "--blacklistpair", "0",
+                                                               "--save_to", os.path.join(d, out)]
+        if mode != "nonrigid":
+            cmd.append("--" + mode)
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+
+    def read_log(fn):
+        return [t.T for t in formats.load_log(fn)]
+
+    d = str(tmp_path)
+    sc = make_scene(num=3, n=3000)
+    _write_dataset(sc, d)
+    args = ["--num", "3", "--resolution", "8", "--length", "3.0", "--iteration", "2"]
+    for mode in ("rigid", "slac"):
+        _run_ref(d, mode, "reg_output.log", args)
+        ref_pose, ref_ctr = read_log(os.path.join(d, "pose.log")), np.loadtxt(os.path.join(d, "out_%s.ctr" % mode))
+        os.rename(os.path.join(d, "pose.log"), os.path.join(d, "pose_ref_%s.log" % mode))
+        out = run_ours(d, mode, args, "ours_%s.ctr" % mode)
+        assert "Read " in out and "correspondences" in out
+        pose, ctr = read_log(os.path.join(d, "pose.log")), np.loadtxt(os.path.join(d, "ours_%s.ctr" % mode))
+        assert max(np.abs(a - b).max() for a, b in zip(pose, ref_pose)) < 1e-7, mode
+        assert np.abs(ctr - ref_ctr).max() < 1e-7, mode
+    sc4 = make_scene(num=3, n=3000, res=4)
+    d4 = os.path.join(d, "r4")
+    os.makedirs(d4)
+    _write_dataset(sc4, d4)
+    args4 = ["--num", "3", "--resolution", "4", "--length", "3.0", "--weight", "1.7", "--inner_iteration", "2", "--iteration", "1"]
+    _run_ref(d4, "nonrigid", "reg_output.log", args4)
+    ref_ctr = np.loadtxt(os.path.join(d4, "out_nonrigid.ctr"))
+    run_ours(d4, "nonrigid", args4, "ours.ctr")
+    assert np.abs(np.loadtxt(os.path.join(d4, "ours.ctr")) - ref_ctr).max() < 1e-6
+    # the dense limit of the non-rigid mode is enforced with a message, not a crash
+    r = subprocess.run([os.path.join(BIN, "FragmentOptimizer"), "--num", "3", "--resolution", "4", "--dense_limit", "100", "--registration",
+                        os.path.join(d4, "reg_output.log"), "--dir", d4 + "/", "--rgbdslam", os.path.join(d4, "rgbd.log"), "--interval", "1",
+                        "--blacklistpair", "0"], cwd=d4, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "dense_limit" in r.stderr
