@@ -23,7 +23,7 @@ SYMBOLS = [
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_ransac_fitness_batch",
     "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
     "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_group_count", "er_fopt_group_info", "er_fopt_update_normals", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
-    "er_fopt_assemble_nonrigid",
+    "er_fopt_assemble_nonrigid", "er_fopt_factor_slac", "er_fopt_factor_nonrigid", "er_fopt_solve",
 ]
 
 
@@ -110,6 +110,9 @@ def lib():
         L.er_fopt_group_info.argtypes = [vp, vp]
         L.er_fopt_update_normals.argtypes = [vp, C.c_int, vp]
         L.er_fopt_assemble_nonrigid.argtypes = [vp, C.c_double, vp, vp]
+        L.er_fopt_factor_slac.argtypes = [vp, vp, C.c_double, vp, vp]
+        L.er_fopt_factor_nonrigid.argtypes = [vp, C.c_double]
+        L.er_fopt_solve.argtypes = [vp, vp, C.c_int, vp]
     _lib = L
     return L
 

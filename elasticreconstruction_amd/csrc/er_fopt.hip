@@ -16,8 +16,12 @@
 
 #include "../../include/er_hip.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -276,6 +280,101 @@ __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const C
     }
 }
 
+// ---- the linear systems, kept and solved on the device -----------------------------------------------------------
+// Row-major UPPER triangle throughout (= column-major lower triangle for rocSOLVER).
+// AddHessian2( {v, w}, {1, -1} ) for every (vertex, neighbour) ordered pair of the lattice (OptApp.cpp:765-800, 811-836):
+// +scale on both diagonals, -scale on the coupling, per xyz component.
+__global__ void k_fopt_add_laplacian(double* __restrict__ A, long ld, long off, int res, double scale) {
+  const int n1 = res + 1, nv = n1 * n1 * n1;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv * 6) return;
+  const int v = t / 6, dir = t % 6;
+  const int i = v % n1, j = (v / n1) % n1, k = v / (n1 * n1);
+  int w = -1;
+  if (dir == 0 && i > 0) w = v - 1;
+  if (dir == 1 && i < res) w = v + 1;
+  if (dir == 2 && j > 0) w = v - n1;
+  if (dir == 3 && j < res) w = v + n1;
+  if (dir == 4 && k > 0) w = v - n1 * n1;
+  if (dir == 5 && k < res) w = v + n1 * n1;
+  if (w < 0) return;
+  for (int c = 0; c < 3; c++) {
+    const long a = off + (long)v * 3 + c, b = off + (long)w * 3 + c;
+    atomicAdd(&A[a * ld + a], scale);
+    atomicAdd(&A[b * ld + b], scale);
+    atomicAdd(&A[(a < b ? a : b) * ld + (a < b ? b : a)], -scale);
+  }
+}
+
+__global__ void k_fopt_add_diag(double* __restrict__ A, long ld, long first, int count, double value) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) atomicAdd(&A[(first + t) * ld + first + t], value);
+}
+
+// non-rigid: the 24x24 blocks of er_fopt_assemble_nonrigid scattered into the dense upper triangle
+__global__ void k_fopt_scatter_blocks(const double* __restrict__ blocks, long n_blocks, const int* __restrict__ info, int diag_mode, int nv,
+                                      int res, long nper, double* __restrict__ A, long ld) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_blocks * 576) return;
+  const double v = blocks[t];
+  if (v == 0.0) return;
+  const long blk = t / 576;
+  const int a = (int)(t % 576) / 24, c = (int)(t % 24);
+  long bi, bj;
+  if (diag_mode) {
+    const long l = blk / nv, vert = blk % nv;
+    bi = bj = l * nper + vert * 3;
+  } else {
+    bi = (long)info[blk * 4] * nper + info[blk * 4 + 2];
+    bj = (long)info[blk * 4 + 1] * nper + info[blk * 4 + 3];
+  }
+  const long r = bi + vertex_offset(a & 7, res) + (a >> 3), q = bj + vertex_offset(c & 7, res) + (c >> 3);
+  if (diag_mode) {
+    if (r <= q) atomicAdd(&A[r * ld + q], v);                 // both triangles are present in the block: keep the upper one
+  } else {
+    atomicAdd(&A[(r < q ? r : q) * ld + (r < q ? q : r)], v);
+  }
+}
+
+__global__ void k_fopt_axpy(double* __restrict__ y, const double* __restrict__ x, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) y[t] += x[t];
+}
+
+// rocSOLVER / rocBLAS are loaded on first use (the TSDF and ICP paths never pay for them).  Caveat met on this ROCm: when
+// the host PROGRAM reached HIP through its start-up dependencies (liber_hip.so as DT_NEEDED), a later dlopen of librocsolver
+// hangs in its static initialisation; such programs link librocsolver / librocblas themselves (bin/FragmentOptimizer does),
+// after which the dlopen below only finds the libraries already loaded.  From Python (ctypes) the lazy load works as is.
+struct RocSolver {
+  void *blas = nullptr, *solver = nullptr, *handle = nullptr;
+  int (*create_handle)(void**) = nullptr;
+  int (*destroy_handle)(void*) = nullptr;
+  int (*set_stream)(void*, hipStream_t) = nullptr;
+  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
+  int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+};
+constexpr int kFillLower = 122;                                 // rocblas_fill_lower
+
+int rocsolver_load(RocSolver& R, hipStream_t stream) {
+  if (R.handle) return 0;
+  R.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!R.blas) R.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+  R.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!R.solver) R.solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!R.blas || !R.solver) return er::fail("the on-device solve needs librocblas.so and librocsolver.so: %s", dlerror());
+  R.create_handle = reinterpret_cast<int (*)(void**)>(dlsym(R.blas, "rocblas_create_handle"));
+  R.destroy_handle = reinterpret_cast<int (*)(void*)>(dlsym(R.blas, "rocblas_destroy_handle"));
+  R.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(R.blas, "rocblas_set_stream"));
+  R.dpotrf = reinterpret_cast<int (*)(void*, int, int, double*, int, int*)>(dlsym(R.solver, "rocsolver_dpotrf"));
+  R.dpotrs = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, int)>(dlsym(R.solver, "rocsolver_dpotrs"));
+  if (!R.create_handle || !R.destroy_handle || !R.set_stream || !R.dpotrf || !R.dpotrs) return er::fail("rocSOLVER symbols not found");
+  if (R.create_handle(&R.handle) != 0 || R.set_stream(R.handle, stream) != 0) {
+    R.handle = nullptr;
+    return er::fail("rocblas_create_handle failed");
+  }
+  return 0;
+}
+
 }  // namespace
 
 struct er_fopt_s {
@@ -294,6 +393,15 @@ struct er_fopt_s {
   std::vector<int> group_info;   // 4 per group: fragment i, fragment j, idx_[0] of the cell of p_i, of p_j
   double *d_diag = nullptr, *d_off = nullptr;
   size_t diag_cap = 0, off_cap = 0;
+  // the system kept on the device for er_fopt_solve
+  RocSolver roc;
+  double *d_sys = nullptr, *d_rhs = nullptr;       // d_sys aliases d_JJ in the SLAC mode, own allocation in the non-rigid mode
+  double* d_big = nullptr;
+  size_t big_cap = 0;
+  long sys_n = 0;
+  int* d_info = nullptr;
+  int* d_ginfo = nullptr;
+  bool factored = false;
   long n_corr = 0;
   int *d_first = nullptr, *d_second = nullptr;
   Chunk* d_chunks = nullptr;
@@ -429,7 +537,9 @@ int er_fopt_destroy(er_fopt_t h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& f : h->frag) free_frag(f);
-  void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M, h->d_diag, h->d_off};
+  if (h->roc.handle && h->roc.destroy_handle) (void)h->roc.destroy_handle(h->roc.handle);
+  void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M, h->d_diag, h->d_off,
+                  h->d_big, h->d_rhs, h->d_info, h->d_ginfo};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -565,6 +675,11 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
   h->n_chunks = (int)chunks.size();
   h->n_groups = (int)ginfo.size() / 4;
   h->group_info.swap(ginfo);
+  if (h->d_ginfo) {
+    (void)hipFree(h->d_ginfo);
+    h->d_ginfo = nullptr;
+  }
+  h->factored = false;
   h->n_corr = (long)first.size();
   if (!first.empty()) {
     ER_HIP_TRY(hipMalloc((void**)&h->d_first, first.size() * sizeof(int)));
@@ -625,6 +740,122 @@ int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* 
   }
   ER_HIP_TRY(hipMemcpyAsync(diag, h->d_diag, nd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   if (h->n_groups > 0) ER_HIP_TRY(hipMemcpyAsync(offdiag, h->d_off, (size_t)h->n_groups * 576 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// ---- on-device solve -------------------------------------------------------------------------------------------------
+static int factor_common(er_fopt_t h, double* A, long n) {
+  if (rocsolver_load(h->roc, h->stream)) return 1;
+  if (!h->d_info) ER_HIP_TRY(hipMalloc((void**)&h->d_info, sizeof(int)));
+  if (h->d_rhs) {
+    (void)hipFree(h->d_rhs);
+    h->d_rhs = nullptr;
+  }
+  ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)n * sizeof(double)));
+  if (n > 2147483647L) return er::fail("system too large for rocSOLVER (%ld unknowns)", n);
+  if (h->roc.dpotrf(h->roc.handle, kFillLower, (int)n, A, (int)n, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed");
+  int info = 0;
+  ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (info != 0) return er::fail("the assembled system is not positive definite (rocsolver_dpotrf info = %d)", info);
+  h->d_sys = A;
+  h->sys_n = n;
+  h->factored = true;
+  return 0;
+}
+
+int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score) {
+  if (!h || !pose_rot_t) return er::fail("er_fopt_factor_slac: bad arguments");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  h->factored = false;
+  const size_t N = (size_t)(6 * h->num + h->nper);
+  if (ensure_matrix(h, N)) return 1;
+  ER_HIP_TRY(hipMemsetAsync(h->d_JJ, 0, N * N * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_Jb, 0, (N + 1) * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->d_rot, pose_rot_t, (size_t)h->num * 9 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->n_chunks > 0) {
+    hipLaunchKernelGGL(k_fopt_gram<1>, dim3((h->n_chunks * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks,
+                       h->d_frags, h->d_first, h->d_second, h->d_rot, h->num, h->res, (int)N, h->d_JJ, h->d_Jb, h->d_Jb + N);
+  }
+  // + default_weight * ( lattice Laplacian + anchor ) + the gauge "+1" on the first six unknowns (OptApp.cpp:452-464, 839-843)
+  const int nv = h->nper / 3;
+  const long L0 = 6L * h->num;
+  hipLaunchKernelGGL(k_fopt_add_laplacian, dim3((nv * 6 + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_JJ, (long)N, L0, h->res, default_weight);
+  const long anchor = L0 + ((long)(h->res / 2) + (long)(h->res / 2) * (h->res + 1)) * 3;
+  hipLaunchKernelGGL(k_fopt_add_diag, dim3(1), dim3(64), 0, h->stream, h->d_JJ, (long)N, anchor, 3, default_weight);
+  hipLaunchKernelGGL(k_fopt_add_diag, dim3(1), dim3(64), 0, h->stream, h->d_JJ, (long)N, 0L, 6, 1.0);
+  ER_HIP_TRY(hipGetLastError());
+  if (dataJb_host) ER_HIP_TRY(hipMemcpyAsync(dataJb_host, h->d_Jb, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (score) ER_HIP_TRY(hipMemcpyAsync(score, h->d_Jb + N, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  return factor_common(h, h->d_JJ, (long)N);
+}
+
+int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
+  if (!h) return er::fail("er_fopt_factor_nonrigid: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  h->factored = false;
+  const size_t nv = (size_t)h->nper / 3, M = (size_t)h->num * h->nper;
+  const size_t nd = (size_t)h->num * nv * 576, no = (size_t)std::max(h->n_groups, 1) * 576;
+  if (nd > h->diag_cap) {
+    if (h->d_diag) (void)hipFree(h->d_diag);
+    h->d_diag = nullptr;
+    h->diag_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->d_diag, nd * sizeof(double)));
+    h->diag_cap = nd;
+  }
+  if (no > h->off_cap) {
+    if (h->d_off) (void)hipFree(h->d_off);
+    h->d_off = nullptr;
+    h->off_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->d_off, no * sizeof(double)));
+    h->off_cap = no;
+  }
+  if (M * M > h->big_cap) {
+    if (h->d_big) (void)hipFree(h->d_big);
+    h->d_big = nullptr;
+    h->big_cap = 0;
+    hipError_t e = hipMalloc((void**)&h->d_big, M * M * sizeof(double));
+    if (e != hipSuccess) return er::fail("er_fopt_factor_nonrigid: %zu x %zu float64 system (%.1f GB) does not fit: %s", M, M, (double)(M * M * 8) / 1e9, hipGetErrorString(e));
+    h->big_cap = M * M;
+  }
+  if (!h->d_ginfo && h->n_groups > 0) {
+    ER_HIP_TRY(hipMalloc((void**)&h->d_ginfo, (size_t)h->n_groups * 4 * sizeof(int)));
+    ER_HIP_TRY(hipMemcpyAsync(h->d_ginfo, h->group_info.data(), (size_t)h->n_groups * 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  ER_HIP_TRY(hipMemsetAsync(h->d_diag, 0, nd * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_off, 0, no * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_big, 0, M * M * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->d_rot, &weight, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->n_chunks > 0)
+    hipLaunchKernelGGL(k_fopt_gram<2>, dim3((h->n_chunks * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks,
+                       h->d_frags, h->d_first, h->d_second, h->d_rot, h->num, h->res, 0, h->d_diag, h->d_off, (double*)nullptr);
+  hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)((nd + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_diag, (long)(nd / 576),
+                     (const int*)nullptr, 1, (int)nv, h->res, (long)h->nper, h->d_big, (long)M);
+  if (h->n_groups > 0)
+    hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)(((size_t)h->n_groups * 576 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_off,
+                       (long)h->n_groups, h->d_ginfo, 0, (int)nv, h->res, (long)h->nper, h->d_big, (long)M);
+  for (int l = 0; l < h->num; l++)                                            // baseAA, OptApp.cpp:765-810
+    hipLaunchKernelGGL(k_fopt_add_laplacian, dim3((unsigned)((nv * 6 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_big, (long)M,
+                       (long)l * h->nper, h->res, 1.0);
+  hipLaunchKernelGGL(k_fopt_add_diag, dim3(1), dim3(64), 0, h->stream, h->d_big, (long)M, 0L, 3, 1.0);
+  ER_HIP_TRY(hipGetLastError());
+  return factor_common(h, h->d_big, (long)M);
+}
+
+int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* x_host) {
+  if (!h || !rhs_host || !x_host) return er::fail("er_fopt_solve: bad arguments");
+  if (!h->factored) return er::fail("er_fopt_solve: no factored system (call er_fopt_factor_slac / er_fopt_factor_nonrigid first)");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  const long n = h->sys_n;
+  ER_HIP_TRY(hipMemcpyAsync(h->d_rhs, rhs_host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (add_data_jb) {
+    if (h->d_sys != h->d_JJ) return er::fail("er_fopt_solve: add_data_jb is only meaningful after er_fopt_factor_slac");
+    hipLaunchKernelGGL(k_fopt_axpy, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_rhs, h->d_Jb, n);
+    ER_HIP_TRY(hipGetLastError());
+  }
+  if (h->roc.dpotrs(h->roc.handle, kFillLower, (int)n, 1, h->d_sys, (int)n, h->d_rhs, (int)n) != 0) return er::fail("rocsolver_dpotrs failed");
+  ER_HIP_TRY(hipMemcpyAsync(x_host, h->d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }

@@ -4,9 +4,10 @@
 // The data-parallel half -- point set-up, UpdatePose / UpdateAllPointPN / UpdateAllNormal and the Hessian assembly of the
 // three modes -- runs in liber_hip.so (er_fopt_*, csrc/er_fopt.hip).  The host keeps what the reference keeps on the host:
 // the lattice regularizer, gauge terms, the pose / lattice updates and the linear solve.  The reference solves with CHOLMOD
-// (sparse supernodal LL^T); here the system is solved by a dense Cholesky, which is exact for the same matrix and fast for
-// the SLAC and rigid systems (6 num + 2187 unknowns).  The non-rigid mode's system has num * 2187 unknowns: the dense solve
-// is accepted up to --dense_limit unknowns (default 12000) and refused beyond with a clear message.
+// (sparse supernodal LL^T); here the SLAC and non-rigid systems are assembled, factored and solved in HBM by a dense Cholesky
+// (er_fopt_factor_* / er_fopt_solve, rocSOLVER), the small rigid system (6 num unknowns) by a dense Cholesky on the host.  The non-rigid mode's system has num * 2187 unknowns: it is
+// assembled as a dense matrix in HBM (288 GB hold ~180 k unknowns = 82 fragments) and refused beyond --dense_limit unknowns
+// (default 200000) or when the allocation fails, with a clear message.
 #include <omp.h>
 
 #include <algorithm>
@@ -145,7 +146,7 @@ class COptApp {                                     // OptApp.h:39-124
   int max_iteration_ = 5, max_inner_iteration_ = 10;
   std::string dir_prefix_, ctr_filename_ = "output.ctr", pose_filename_ = "pose.log", init_ctr_file_;
   int sample_num_ = -1, blacklist_pair_num_ = 10000, device_ = 0;
-  long dense_limit_ = 12000;
+  long dense_limit_ = 200000;
   std::set<int> blacklist_;
   std::vector<int> absolute2relative_map_, relative2absolute_map_;
   std::vector<std::vector<double>> ipose_, pose_;    // 16 doubles each, row-major
@@ -439,25 +440,15 @@ class COptApp {                                     // OptApp.h:39-124
       pose_[(size_t)i] = ipose_[(size_t)i];
       if (!update_pose_gpu(i, pose_[(size_t)i].data())) return false;
     }
-    std::vector<double> JJ((size_t)N * N), A((size_t)N * N);
     Vec Jb((size_t)N), rot((size_t)num_ * 9);
-    const long anchor = L0 + (long)GetIndex(resolution_ / 2, resolution_ / 2, 0) * 3;
     for (int itr = 0; itr < max_iteration_; itr++) {
       for (int l = 0; l < num_; l++)
         for (int r = 0; r < 3; r++)
           for (int c = 0; c < 3; c++) rot[(size_t)l * 9 + r * 3 + c] = pose_[(size_t)l][(size_t)c * 4 + r];     // pose_rot_t_ = R^T
       double score = 0;
-      if (er_fopt_assemble_slac(fo_, rot.data(), JJ.data(), Jb.data(), &score)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      // thisJJ = Upper( baseJJ * default_weight ) + gauge + data term: assembled AND factored in HBM (dense Cholesky, rocSOLVER)
+      if (er_fopt_factor_slac(fo_, rot.data(), default_weight, Jb.data(), &score)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       printf("Data error score is : %.2f\n", score);
-      // thisJJ = Upper( baseJJ * default_weight ) + gauge + data term; the solver reads the upper triangle: mirror it down
-      std::fill(A.begin(), A.end(), 0.0);
-      add_laplacian(A, N, L0, default_weight);
-      for (int c = 0; c < 3; c++) A[(size_t)(anchor + c) * N + anchor + c] += default_weight;
-      for (long r = 0; r < N; r++)
-        for (long c = r; c < N; c++) {
-          const double v = A[(size_t)r * N + c] + JJ[(size_t)r * N + c] + ((r == c && r < 6) ? 1.0 : 0.0);
-          A[(size_t)c * N + r] = v;                   // lower triangle for cholesky_solve
-        }
       // regularizer right-hand side, OptApp.cpp:570-631
       Vec b(Jb);
       double regscore = 0;
@@ -477,7 +468,11 @@ class COptApp {                                     // OptApp.h:39-124
         }
       }
       printf("Regularization error score is : %.2f\n", regscore);
-      if (!cholesky_solve(A, N, b)) { fprintf(stderr, "FragmentOptimizer: the SLAC system is not positive definite\n"); return false; }
+      {
+        Vec x((size_t)N);
+        if (er_fopt_solve(fo_, b.data(), 0, x.data())) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+        b.swap(x);
+      }
       for (int q = 0; q < nper_; q++) thisCtr[(size_t)q] += -b[(size_t)(L0 + q)];
       for (int l = 0; l < num_; l++) {
         double x6[6], aff[16], np[16];
@@ -511,45 +506,11 @@ class COptApp {                                     // OptApp.h:39-124
     for (int i = 0; i < num_; i++) pose_[(size_t)i] = ipose_[(size_t)i];
     expand(lat, ctr);                                 // InitCtr, :709-721
     ictr = ctr;
-    const int ng = er_fopt_group_count(fo_);
-    std::vector<int> info((size_t)std::max(ng, 1) * 4);
-    er_fopt_group_info(fo_, info.data());
-    std::vector<double> diag((size_t)num_ * nv_ * 576), off((size_t)std::max(ng, 1) * 576), A((size_t)M * M);
-    int loc[24];                                      // local bucket entry c*8 + t -> lattice offset from idx_[0]
-    for (int c = 0; c < 3; c++)
-      for (int t = 0; t < 8; t++) {
-        const int n1 = resolution_ + 1;
-        loc[c * 8 + t] = (((t >> 2) & 1) + ((t >> 1) & 1) * n1 + (t & 1) * n1 * n1) * 3 + c;
-      }
     for (int itr = 0; itr < max_iteration_; itr++) {
       for (int l = 0; l < num_; l++)
         if (er_fopt_update_normals(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
-      if (er_fopt_assemble_nonrigid(fo_, weight_, diag.data(), off.data())) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
-      // thisAA = baseAA + blocks; assembled as a full symmetric matrix from the entries the reference stores at (row <= col)
-      std::fill(A.begin(), A.end(), 0.0);
-      for (int l = 0; l < num_; l++) add_laplacian(A, M, (long)l * nper_, 1.0);
-      for (int c = 0; c < 3; c++) A[(size_t)c * M + c] += 1.0;                 // :803-807
-      for (int l = 0; l < num_; l++)
-        for (int v = 0; v < nv_; v++) {
-          const double* B = &diag[((size_t)l * nv_ + v) * 576];
-          const long base = (long)l * nper_ + (long)v * 3;
-          for (int a = 0; a < 24; a++)
-            for (int c = 0; c < 24; c++)
-              if (B[a * 24 + c] != 0.0) A[(size_t)(base + loc[a]) * M + base + loc[c]] += B[a * 24 + c];
-        }
-      for (int g = 0; g < ng; g++) {
-        const long bi = (long)info[(size_t)g * 4] * nper_ + info[(size_t)g * 4 + 2], bj = (long)info[(size_t)g * 4 + 1] * nper_ + info[(size_t)g * 4 + 3];
-        const double* B = &off[(size_t)g * 576];
-        for (int a = 0; a < 24; a++)
-          for (int c = 0; c < 24; c++) {
-            const double v = B[a * 24 + c];
-            if (v == 0.0) continue;
-            const long r = bi + loc[a], q = bj + loc[c];
-            A[(size_t)r * M + q] += v;                // the (i, j) block; the solver reads the upper triangle and mirrors it
-            A[(size_t)q * M + r] += v;
-          }
-      }
-      std::vector<double> F;
+      // thisAA = baseAA + data blocks: scattered into a dense matrix and factored in HBM (dense Cholesky, rocSOLVER)
+      if (er_fopt_factor_nonrigid(fo_, weight_)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       for (int m = 0; m < max_inner_iteration_; m++) {
         Vec Ab((size_t)M, 0.0);
         for (int l = 0; l < num_; l++) {
@@ -567,8 +528,11 @@ class COptApp {                                     // OptApp.h:39-124
               }
           }
         }
-        F = A;                                        // (factorised anew per inner iteration: simple, and small next to the assembly of real runs)
-        if (!cholesky_solve(F, M, Ab)) { fprintf(stderr, "FragmentOptimizer: the non-rigid system is not positive definite\n"); return false; }
+        {
+          Vec x((size_t)M);
+          if (er_fopt_solve(fo_, Ab.data(), 0, x.data())) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+          Ab.swap(x);
+        }
         double sc = 0;
         for (long q = 0; q < M; q++) sc += (ctr[(size_t)q] - Ab[(size_t)q]) * (ctr[(size_t)q] - Ab[(size_t)q]);
         ctr = Ab;

@@ -139,6 +139,24 @@ class FragmentOptimizer:
         np.add.at(out, inv, vals)
         return uk // M, uk % M, out
 
+    # ---- systems kept and solved on the device (dense Cholesky in HBM, rocSOLVER) ---------------------------------
+    def FactorSLAC(self, pose_rot_t, default_weight):
+        """thisJJ of one OptimizeSLAC iteration assembled and factored on the device.  Returns (dataJb, data score)."""
+        N = 6 * self.num_ + self.nper_
+        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num_, 9)
+        Jb, sc = np.zeros(N), C.c_double(0)
+        _ffi.check(self._lib.er_fopt_factor_slac(self._h, _ffi.ptr(R), float(default_weight), _ffi.ptr(Jb), C.byref(sc)), "er_fopt_factor_slac")
+        return Jb, sc.value
+
+    def FactorNonrigid(self, weight):
+        _ffi.check(self._lib.er_fopt_factor_nonrigid(self._h, float(weight)), "er_fopt_factor_nonrigid")
+
+    def Solve(self, rhs, add_data_jb=False):
+        b = np.ascontiguousarray(rhs, np.float64).reshape(-1)
+        x = np.zeros_like(b)
+        _ffi.check(self._lib.er_fopt_solve(self._h, _ffi.ptr(b), 1 if add_data_jb else 0, _ffi.ptr(x)), "er_fopt_solve")
+        return x
+
     # ---- host-side pieces of COptApp (a few thousand lattice vertices: numpy) ------------------------------------
     def GetIndex(self, i, j, k):
         n1 = self.resolution_ + 1
@@ -213,7 +231,7 @@ class FragmentOptimizer:
         return ((P[:3, 0] * xyz[:, :1] + P[:3, 1] * xyz[:, 1:2]) + P[:3, 2] * xyz[:, 2:3]) + P[:3, 3]
 
     # ---- COptApp::OptimizeSLAC, OptApp.cpp:414-680 ----------------------------------------------------------------
-    def OptimizeSLAC(self, ipose, weight=1.0, max_iteration=5):
+    def OptimizeSLAC(self, ipose, weight=1.0, max_iteration=5, solver="device"):
         """Returns (poses, expand_ctr [num * nper], data scores).  The data term comes from er_fopt_assemble_slac; base term,
         regularizer, dense solve (CHOLMOD in the reference) and the pose / lattice updates follow the reference line by line."""
         num, nper = self.num_, self.nper_
@@ -234,11 +252,14 @@ class FragmentOptimizer:
         scores = []
         for _ in range(max_iteration):
             Rt = np.stack([P[:3, :3].T.reshape(9) for P in pose])
-            JJ, dataJb, score = self.AssembleSLAC(Rt)
+            if solver == "device":                                                   # system assembled, factored and solved in HBM
+                dataJb, score = self.FactorSLAC(Rt, default_weight)
+            else:
+                JJ, dataJb, score = self.AssembleSLAC(Rt)
+                thisJJ = np.triu(base) + JJ                                          # :456 (Upper view) + data term
+                thisJJ[np.arange(6), np.arange(6)] += 1.0                            # :459-464
+                full = thisJJ + np.triu(thisJJ, 1).T
             scores.append(score)
-            thisJJ = np.triu(base) + JJ                                              # :456 (Upper view) + data term
-            thisJJ[np.arange(6), np.arange(6)] += 1.0                                # :459-464
-            full = thisJJ + np.triu(thisJJ, 1).T
             baseJb = np.zeros(N)
             cur, ini = thisCtr.reshape(-1, 3), ictr.reshape(-1, 3)
             for v, nb, ijk in edges:                                                 # regularizer, :570-631
@@ -249,7 +270,7 @@ class FragmentOptimizer:
                 baseJb[6 * num + v * 3:6 * num + v * 3 + 3] += bx.sum(0)
                 for t, w in enumerate(nb):
                     baseJb[6 * num + w * 3:6 * num + w * 3 + 3] -= bx[t]
-            result = -np.linalg.solve(full, dataJb + baseJb)                         # :632-638
+            result = -(self.Solve(dataJb + baseJb) if solver == "device" else np.linalg.solve(full, dataJb + baseJb))   # :632-638
             thisCtr = thisCtr + result[6 * num:]                                     # :644-646
             for l in range(num):
                 pose[l] = self._increment(result[l * 6:l * 6 + 6]) @ pose[l]         # :648-658
@@ -259,7 +280,7 @@ class FragmentOptimizer:
         return pose, expand, scores
 
     # ---- COptApp::OptimizeNonrigid, OptApp.cpp:120-278 ------------------------------------------------------------
-    def OptimizeNonrigid(self, ipose, weight=1.0, max_iteration=5, max_inner_iteration=10):
+    def OptimizeNonrigid(self, ipose, weight=1.0, max_iteration=5, max_inner_iteration=10, solver="device"):
         """Returns (ctr [num * nper], inner-iteration scores).  Data term from er_fopt_assemble_nonrigid; regularizer, dense
         solve and control flow as in the reference."""
         num, nper = self.num_, self.nper_
@@ -267,20 +288,24 @@ class FragmentOptimizer:
         lat = self._canonical_lattice().reshape(-1, 3)
         ctr = np.concatenate([self._apply(np.array(P, np.float64), lat).reshape(-1) for P in ipose])    # InitCtr, :709-721
         ictr = ctr.copy()
-        baseAA = np.zeros((M, M))
-        Lp = self._laplacian()
-        for l in range(num):
-            baseAA[l * nper:(l + 1) * nper, l * nper:(l + 1) * nper] = Lp
-        for c in range(3):
-            baseAA[c, c] += 1.0                                                      # :803-807
+        if solver != "device":
+            baseAA = np.zeros((M, M))
+            Lp = self._laplacian()
+            for l in range(num):
+                baseAA[l * nper:(l + 1) * nper, l * nper:(l + 1) * nper] = Lp
+            for c in range(3):
+                baseAA[c, c] += 1.0                                                  # :803-807
         edges = self._lattice_edges()
         scores = []
         for _ in range(max_iteration):
             self.UpdateAllNormal(ctr)                                                # :151-153
-            r, c, v = self.NonrigidTriplets(weight)
-            thisAA = baseAA.copy()
-            np.add.at(thisAA, (r, c), v)
-            thisAA = np.triu(thisAA) + np.triu(thisAA, 1).T                          # the solver reads the Upper triangle
+            if solver == "device":
+                self.FactorNonrigid(weight)
+            else:
+                r, c, v = self.NonrigidTriplets(weight)
+                thisAA = baseAA.copy()
+                np.add.at(thisAA, (r, c), v)
+                thisAA = np.triu(thisAA) + np.triu(thisAA, 1).T                      # the solver reads the Upper triangle
             for _m in range(max_inner_iteration):
                 Ab = np.zeros(M)
                 for l in range(num):
@@ -294,7 +319,7 @@ class FragmentOptimizer:
                         for t, w in enumerate(nb):
                             Ab[l * nper + w * 3:l * nper + w * 3 + 3] -= bx[t]
                 old = ctr
-                ctr = np.linalg.solve(thisAA, Ab)                                    # :263
+                ctr = self.Solve(Ab) if solver == "device" else np.linalg.solve(thisAA, Ab)   # :263
                 scores.append(float(np.linalg.norm(old - ctr)))
         return ctr, scores
 

@@ -216,6 +216,18 @@ int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, dou
  * blocks that share lattice vertices when it builds the sparse matrix for the solver. */
 int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* offdiag);
 
+/* The systems can stay where they are assembled and be solved there: dense Cholesky in HBM (rocSOLVER potrf / potrs, loaded
+ * on first use) instead of the reference's sparse CHOLMOD factorisation on the host.  288 GB hold the non-rigid mode's dense
+ * system up to ~180 k unknowns (82 fragments at resolution 8).
+ *   er_fopt_factor_slac      thisJJ of one OptimizeSLAC iteration: data term + default_weight * (lattice Laplacian + anchor) +
+ *                            the gauge "+1"s (OptApp.cpp:449-560, 811-846), factored.  dataJb_host (nullable, 6 num + nper) and
+ *                            score (nullable) return the data term's right-hand side and error.
+ *   er_fopt_factor_nonrigid  thisAA of one OptimizeNonrigid iteration: baseAA + data term (OptApp.cpp:155-211, 765-810), factored.
+ *   er_fopt_solve            x = A^-1 rhs with the factor kept on the device (rhs + the device's dataJb when add_data_jb != 0). */
+int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score);
+int er_fopt_factor_nonrigid(er_fopt_t h, double weight);
+int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* x_host);
+
 #ifdef __cplusplus
 }
 #endif

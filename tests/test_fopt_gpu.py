@@ -173,10 +173,11 @@ def test_optimisation_loops_match_the_reference_program(gpu, tmp_path):
     # SLAC
     _run_ref(d, "slac", "reg_output.log", args)
     ref_pose, ref_ctr = _read_log(os.path.join(d, "pose.log")), _read_ctr(os.path.join(d, "out_slac.ctr"))
-    g = fresh(sc)
-    pose, expand, _ = g.OptimizeSLAC(poses, weight=1.0, max_iteration=2)
-    assert max(np.abs(a - b).max() for a, b in zip(pose, ref_pose)) < 1e-7
-    assert np.abs(expand - ref_ctr).max() < 1e-7
+    for solver in ("device", "host"):                                        # dense Cholesky in HBM (rocSOLVER) / numpy on the host
+        g = fresh(sc)
+        pose, expand, _ = g.OptimizeSLAC(poses, weight=1.0, max_iteration=2, solver=solver)
+        assert max(np.abs(a - b).max() for a, b in zip(pose, ref_pose)) < 1e-7, solver
+        assert np.abs(expand - ref_ctr).max() < 1e-7, solver
     # non-rigid (default mode), resolution 4 keeps the dense solves quick
     sc4 = make_scene(num=3, n=3000, res=4)
     d4 = os.path.join(d, "r4")
@@ -184,6 +185,7 @@ def test_optimisation_loops_match_the_reference_program(gpu, tmp_path):
     poses4 = _write_dataset(sc4, d4)
     _run_ref(d4, "nonrigid", "reg_output.log", ["--num", str(num), "--resolution", "4", "--length", "3.0", "--weight", "1.7", "--inner_iteration", "2"])
     ref_ctr = _read_ctr(os.path.join(d4, "out_nonrigid.ctr"))
-    g = fresh(sc4)
-    ctr, _ = g.OptimizeNonrigid(poses4, weight=1.7, max_iteration=1, max_inner_iteration=2)
-    assert np.abs(ctr - ref_ctr).max() < 1e-6
+    for solver in ("device", "host"):
+        g = fresh(sc4)
+        ctr, _ = g.OptimizeNonrigid(poses4, weight=1.7, max_iteration=1, max_inner_iteration=2, solver=solver)
+        assert np.abs(ctr - ref_ctr).max() < 1e-6, solver
