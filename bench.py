@@ -250,6 +250,14 @@ def fopt_section(device):
     g.AssembleSLAC(Rt)
     g.AssembleRigid()
     g.AssembleNonrigid(1.0)
+    Jb0, _ = g.FactorSLAC(Rt, 4.0)
+    g.Solve(Jb0)
+    tf = []
+    for _ in range(5):                                       # the whole linear step on the device: assemble + base terms + Cholesky + solve
+        t0 = time.perf_counter()
+        Jb0, _ = g.FactorSLAC(Rt, 4.0)
+        g.Solve(Jb0)
+        tf.append(time.perf_counter() - t0)
     ts, tr, tn = [], [], []
     for _ in range(5):
         t0 = time.perf_counter()
@@ -263,7 +271,7 @@ def fopt_section(device):
         tn.append(time.perf_counter() - t0)
     res = {"correspondences": ncorr, "pairs": len(pairs), "group_chunks": int(groups), "slac_matrix_dim": int(JJ.shape[0]),
            "slac_assembly_ms": 1e3 * sorted(ts)[2], "rigid_assembly_ms": 1e3 * sorted(tr)[2], "nonrigid_assembly_ms": 1e3 * sorted(tn)[2],
-           "slac_correspondences_per_s": ncorr / sorted(ts)[2],
+           "slac_correspondences_per_s": ncorr / sorted(ts)[2], "slac_assemble_factor_solve_on_device_ms": 1e3 * sorted(tf)[2],
            "what": "er_fopt_assemble_slac / _rigid / _nonrigid = Hessian assembly of OptimizeSLAC / OptimizeRigid / OptimizeNonrigid (OptApp.cpp:473-560, 312-375, 159-206), result copied to the host included"}
     try:
         from oracle.pyoracle import FoptOracle
