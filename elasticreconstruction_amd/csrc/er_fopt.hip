@@ -566,6 +566,10 @@ int er_fopt_set_cloud(er_fopt_t h, int frag, const float* xyz, const float* nrm,
   er_fopt_s::Frag& f = h->frag[(size_t)frag];
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   free_frag(f);
+  // correspondence lists index into the clouds: a new cloud invalidates them (set them again) and any factored system
+  h->n_pairs = h->n_chunks = h->n_groups = 0;
+  h->group_info.clear();
+  h->factored = false;
   f.n = m;
   f.h_idx0.assign(idx0.begin(), idx0.begin() + m);
   const size_t mm = (size_t)std::max(m, 1);

@@ -180,7 +180,7 @@ int er_fopt_destroy(er_fopt_t h);
 
 /* PointCloud::LoadFromXYZNFile / LoadFromPCDFile body (PointCloud.cpp:22-63): n points (xyz, normals; NaN-normal points
  * already dropped) through GetCoordinate (PointCloud.h:92-176).  Like the reference, loading stops at the first point
- * outside the cube; *first_out_of_bound (nullable) receives its index or -1. */
+ * outside the cube; *first_out_of_bound (nullable) receives its index or -1.  Replacing a cloud drops the correspondence lists. */
 int er_fopt_set_cloud(er_fopt_t h, int frag, const float* xyz_host, const float* normal_host, int n, int* first_out_of_bound);
 int er_fopt_cloud_size(er_fopt_t h, int frag);
 /* Point state read-back (any pointer may be NULL): idx_[0], val_[8], nval_[8], p_[3], n_[3] per point. */
