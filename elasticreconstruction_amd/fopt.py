@@ -13,11 +13,93 @@ import numpy as np
 from . import _ffi
 
 
+class Lattice:
+    """The control lattice of COptApp and the host-side pieces defined on it (a few thousand vertices: plain numpy, no GPU):
+    vertex indexing, the regularizer's edge list and Laplacian, the local rotation fit, pose increments."""
+
+    def __init__(self, resolution=8, length=3.0):
+        self.resolution_, self.length_ = int(resolution), float(length)
+        self.nper_ = (self.resolution_ + 1) ** 3 * 3
+
+    def GetIndex(self, i, j, k):
+        n1 = self.resolution_ + 1
+        return i + j * n1 + k * n1 * n1
+
+    def edges(self):
+        """(vertex, neighbour) pairs in the order of the reference's six `if` blocks (OptApp.cpp:227-245, 576-611, 773-798)."""
+        r, out = self.resolution_, []
+        for i in range(r + 1):
+            for j in range(r + 1):
+                for k in range(r + 1):
+                    nb = []
+                    if i > 0: nb.append(self.GetIndex(i - 1, j, k))
+                    if i < r: nb.append(self.GetIndex(i + 1, j, k))
+                    if j > 0: nb.append(self.GetIndex(i, j - 1, k))
+                    if j < r: nb.append(self.GetIndex(i, j + 1, k))
+                    if k > 0: nb.append(self.GetIndex(i, j, k - 1))
+                    if k < r: nb.append(self.GetIndex(i, j, k + 1))
+                    out.append((self.GetIndex(i, j, k), nb, (i, j, k)))
+        return out
+
+    def laplacian(self):
+        """Sum over (vertex, neighbour) of AddHessian2( {v, nb}, {1, -1} ): [[1, -1], [-1, 1]] per xyz component
+        (HashSparseMatrix.cpp:50-58) -- every undirected edge is visited from both ends.  Dense nper x nper."""
+        L = np.zeros((self.nper_, self.nper_))
+        for v, nb, _ in self.edges():
+            for w in nb:
+                for c in range(3):
+                    a, b = v * 3 + c, w * 3 + c
+                    L[a, a] += 1.0
+                    L[b, b] += 1.0
+                    L[a, b] -= 1.0
+                    L[b, a] -= 1.0
+        return L
+
+    @staticmethod
+    def GetRotation(dif, diff):
+        """COptApp::GetRotation, OptApp.cpp:850-871: C = sum dif^T diff over the neighbours, R = V U^T (det fixed)."""
+        Cm = dif.T @ diff
+        U, _, Vt = np.linalg.svd(Cm)
+        V = Vt.T
+        R = V @ U.T
+        if np.linalg.det(R) < 0:
+            U = U.copy()
+            U[:, 2] *= -1
+            R = V @ U.T
+        return R
+
+    @staticmethod
+    def increment(x6):
+        """AngleAxis(z) * AngleAxis(y) * AngleAxis(x) and the translation of one 6-vector of the solution (OptApp.cpp:395-400, 645-651)."""
+        a, b, g = x6[:3]
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+        aff = np.eye(4)
+        aff[:3, :3] = Rz @ Ry @ Rx
+        aff[:3, 3] = x6[3:6]
+        return aff
+
+    def canonical(self):
+        """(i, j, k) * unit_length_ per vertex, xyz interleaved (InitCtrSLAC, OptApp.cpp:723-733)."""
+        ul = self.length_ / self.resolution_
+        out = np.zeros(self.nper_)
+        for v, _, (i, j, k) in self.edges():
+            out[v * 3:v * 3 + 3] = (i * ul, j * ul, k * ul)
+        return out
+
+    @staticmethod
+    def apply(P, xyz):
+        """Matrix4d * (x, y, z, 1), row by row ((m0 x + m1 y) + m2 z) + m3."""
+        return ((P[:3, 0] * xyz[:, :1] + P[:3, 1] * xyz[:, 1:2]) + P[:3, 2] * xyz[:, 2:3]) + P[:3, 3]
+
+
 class FragmentOptimizer:
     def __init__(self, num, resolution=8, length=3.0, device=0):
         self._lib = _ffi.lib()
         self.num_, self.resolution_, self.length_ = int(num), int(resolution), float(length)
         self.nper_ = (resolution + 1) ** 3 * 3
+        self.lattice = Lattice(resolution, length)
         h = C.c_void_p()
         _ffi.check(self._lib.er_fopt_create(self.num_, self.resolution_, C.c_float(length), int(device), C.byref(h)), "er_fopt_create")
         self._h = h
@@ -157,78 +239,22 @@ class FragmentOptimizer:
         _ffi.check(self._lib.er_fopt_solve(self._h, _ffi.ptr(b), 1 if add_data_jb else 0, _ffi.ptr(x)), "er_fopt_solve")
         return x
 
-    # ---- host-side pieces of COptApp (a few thousand lattice vertices: numpy) ------------------------------------
+    # ---- host-side pieces of COptApp: see class Lattice ----------------------------------------------------------
     def GetIndex(self, i, j, k):
-        n1 = self.resolution_ + 1
-        return i + j * n1 + k * n1 * n1
+        return self.lattice.GetIndex(i, j, k)
 
     def _lattice_edges(self):
-        """(vertex, neighbour) pairs in the order of the reference's six `if` blocks (OptApp.cpp:227-245, 576-611, 773-798)."""
-        r, out = self.resolution_, []
-        for i in range(r + 1):
-            for j in range(r + 1):
-                for k in range(r + 1):
-                    nb = []
-                    if i > 0: nb.append(self.GetIndex(i - 1, j, k))
-                    if i < r: nb.append(self.GetIndex(i + 1, j, k))
-                    if j > 0: nb.append(self.GetIndex(i, j - 1, k))
-                    if j < r: nb.append(self.GetIndex(i, j + 1, k))
-                    if k > 0: nb.append(self.GetIndex(i, j, k - 1))
-                    if k < r: nb.append(self.GetIndex(i, j, k + 1))
-                    out.append((self.GetIndex(i, j, k), nb, (i, j, k)))
-        return out
+        return self.lattice.edges()
 
     def _laplacian(self):
-        """Sum over (vertex, neighbour) of AddHessian2( {v, nb}, {1, -1} ): [[1, -1], [-1, 1]] per xyz component
-        (HashSparseMatrix.cpp:50-58) -- every undirected edge is visited from both ends.  Dense nper x nper."""
-        L = np.zeros((self.nper_, self.nper_))
-        for v, nb, _ in self._lattice_edges():
-            for w in nb:
-                for c in range(3):
-                    a, b = v * 3 + c, w * 3 + c
-                    L[a, a] += 1.0
-                    L[b, b] += 1.0
-                    L[a, b] -= 1.0
-                    L[b, a] -= 1.0
-        return L
-
-    @staticmethod
-    def GetRotation(dif, diff):
-        """COptApp::GetRotation, OptApp.cpp:850-871: C = sum dif^T diff over the neighbours, R = V U^T (det fixed)."""
-        Cm = dif.T @ diff
-        U, _, Vt = np.linalg.svd(Cm)
-        V = Vt.T
-        R = V @ U.T
-        if np.linalg.det(R) < 0:
-            U = U.copy()
-            U[:, 2] *= -1
-            R = V @ U.T
-        return R
-
-    @staticmethod
-    def _increment(x6):
-        """AngleAxis(z) * AngleAxis(y) * AngleAxis(x) and the translation of one 6-vector of the solution (OptApp.cpp:395-400, 645-651)."""
-        a, b, g = x6[:3]
-        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
-        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
-        Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
-        aff = np.eye(4)
-        aff[:3, :3] = Rz @ Ry @ Rx
-        aff[:3, 3] = x6[3:6]
-        return aff
+        return self.lattice.laplacian()
 
     def _canonical_lattice(self):
-        """(i, j, k) * unit_length_ per vertex, xyz interleaved (InitCtrSLAC, OptApp.cpp:723-733)."""
-        ul = self.length_ / self.resolution_
-        out = np.zeros(self.nper_)
-        for v, _, (i, j, k) in self._lattice_edges():
-            out[v * 3:v * 3 + 3] = (i * ul, j * ul, k * ul)
-        return out
+        return self.lattice.canonical()
 
-    @staticmethod
-    def _apply(P, xyz):
-        """Matrix4d * (x, y, z, 1), row by row ((m0 x + m1 y) + m2 z) + m3."""
-        return ((P[:3, 0] * xyz[:, :1] + P[:3, 1] * xyz[:, 1:2]) + P[:3, 2] * xyz[:, 2:3]) + P[:3, 3]
+    GetRotation = staticmethod(lambda dif, diff: Lattice.GetRotation(dif, diff))
+    _increment = staticmethod(lambda x6: Lattice.increment(x6))
+    _apply = staticmethod(lambda P, xyz: Lattice.apply(P, xyz))
 
     # ---- COptApp::OptimizeSLAC, OptApp.cpp:414-680 ----------------------------------------------------------------
     def OptimizeSLAC(self, ipose, weight=1.0, max_iteration=5, solver="device"):

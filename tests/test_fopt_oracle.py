@@ -266,3 +266,55 @@ def test_assembly_pinned_to_the_reference_program(tmp_path):
     S[r, c] = v
     D = np.triu(A) - np.triu(A0)
     assert np.abs(D - np.triu(S)).max() <= 1e-9 * np.abs(S).max()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/FragmentOptimizer_ref needs /root/reference at build time")
+def test_host_side_lattice_pieces_against_the_reference_program(tmp_path):
+    """fopt.Lattice (pure numpy, what the Python mirror and -- restated in C++ -- bin/FragmentOptimizer keep on the host) against
+    the systems the reference program assembles when every pair is invalid: baseJJ * default_weight + gauge (SLAC, InitBaseJJ
+    OptApp.cpp:811-846) and baseAA (non-rigid, InitBaseAA :765-810); and the regularizer right-hand side of the non-rigid mode's
+    first inner iteration (GetRotation :850-871 on an undeformed lattice gives the identity, so Ab = Laplacian * ctr)."""
+    from elasticreconstruction_amd.fopt import Lattice
+    d = str(tmp_path)
+    sc = make_scene(num=3, n=800, res=4)
+    poses = _write_dataset(sc, d)
+    num = 3
+    args = ["--num", "3", "--resolution", "4", "--length", "3.0", "--weight", "2.5"]
+    L = Lattice(4, 3.0)
+    lap = L.laplacian()
+    # SLAC base system
+    A0 = _load_A(_run_ref(d, "slac", "reg_empty.log", args))
+    N = 6 * num + L.nper_
+    B = np.zeros((N, N))
+    B[6 * num:, 6 * num:] = lap
+    anchor = 6 * num + L.GetIndex(2, 2, 0) * 3
+    B[anchor:anchor + 3, anchor:anchor + 3] += np.eye(3)
+    B *= num * 2.5                                             # default_weight = num_ * weight_, :421,:452
+    B[np.arange(6), np.arange(6)] += 1.0                       # :459-464
+    assert np.abs(np.triu(A0) - np.triu(B)).max() <= 1e-12 * np.abs(B).max()
+    # non-rigid base system and first right-hand side
+    pre = _run_ref(d, "nonrigid", "reg_empty.log", args)
+    A0, b0 = _load_A(pre), _load_b(pre)
+    M = num * L.nper_
+    B = np.zeros((M, M))
+    for l in range(num):
+        B[l * L.nper_:(l + 1) * L.nper_, l * L.nper_:(l + 1) * L.nper_] = lap
+    B[np.arange(3), np.arange(3)] += 1.0                       # :803-807
+    assert np.abs(np.triu(A0) - np.triu(B)).max() <= 1e-12
+    ctr = np.concatenate([Lattice.apply(P, L.canonical().reshape(-1, 3)).reshape(-1) for P in poses])
+    Ab = np.zeros(M)
+    for l in range(num):
+        cur = ctr[l * L.nper_:(l + 1) * L.nper_].reshape(-1, 3)
+        for v, nb, _ in L.edges():
+            dif = cur[v] - cur[nb]
+            R = Lattice.GetRotation(dif, dif)
+            assert np.abs(R - np.eye(3)).max() < 1e-9
+            bx = dif @ R.T
+            Ab[l * L.nper_ + v * 3:l * L.nper_ + v * 3 + 3] += bx.sum(0)
+            for t, w in enumerate(nb):
+                Ab[l * L.nper_ + w * 3:l * L.nper_ + w * 3 + 3] -= bx[t]
+    assert np.abs(Ab - b0).max() <= 1e-9 * max(np.abs(b0).max(), 1.0)
+    # pose increments: AngleAxis(z) * AngleAxis(y) * AngleAxis(x) (:395-400)
+    inc = Lattice.increment(np.array([0.1, -0.2, 0.3, 1.0, 2.0, 3.0]))
+    assert np.allclose(inc[:3, :3] @ inc[:3, :3].T, np.eye(3), atol=1e-14) and np.allclose(inc[:3, 3], [1, 2, 3])
+    assert inc[2, 0] == pytest.approx(-np.sin(-0.2)) and inc[1, 0] == pytest.approx(np.sin(0.3) * np.cos(-0.2))
