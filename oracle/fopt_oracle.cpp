@@ -7,11 +7,11 @@
 //                                                                                  HashSparseMatrix.cpp:16-48
 //   SLAC assembly (12 + 24 + 24 bucket into a dense upper-triangular matrix)       FragmentOptimizer/OptApp.cpp:473-560
 //
-// Plain scalar C++ (no Eigen), sequential sums in the reference's loop order.  Pinned by
-// tests/test_fopt_oracle.py against oracle/_ref/libref_fopt.so, which compiles the reference's own PointCloud.h and
-// the same bucket expressions on the vendored Eigen: float32 point state bit for bit, float64 bucket values to
-// 1e-15 relative (Eigen's fixed-size dot products add in a different order).  The CHOLMOD solve and the
-// regularizer (a few thousand lattice vertices) stay on the host and are not restated.
+// Plain scalar C++ (no Eigen), sequential sums in the reference's loop order.  Pinned by tests/test_fopt_oracle.py: the
+// float32 point state bit for bit against oracle/_ref/libref_fopt.so (the reference's own PointCloud.{h,cpp} compiled in
+// place), the assembled systems against what the reference PROGRAM (oracle/_ref/FragmentOptimizer_ref) hands to its solver
+// (1e-12 rigid, 1e-10 SLAC, 1e-9 non-rigid: Eigen's fixed-size dot products add in another order).  The CHOLMOD solve and
+// the regularizer (a few thousand lattice vertices) stay on the host and are not restated here.
 #include <cmath>
 #include <cstdint>
 #include <cstring>

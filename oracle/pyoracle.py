@@ -431,8 +431,8 @@ class FoptOracle:
 
 
 class RefFopt:
-    """oracle/_ref/libref_fopt.so: the reference's own PointCloud.h (compiled in place) + OptApp.cpp's bucket expressions
-    on the vendored Eigen.  Only available where /root/reference was present at build time."""
+    """oracle/_ref/libref_fopt.so: the reference's own PointCloud.{h,cpp} compiled in place (point state only).
+    Only available where /root/reference was present at build time."""
     _lib = None
 
     @classmethod
@@ -450,10 +450,7 @@ class RefFopt:
             L.rfopt_get_points.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
             L.rfopt_update_pose.argtypes = [_vp, _vp]
             L.rfopt_update_point_pn.argtypes = [_vp, _vp, C.c_int]
-            L.rfopt_rigid_bucket.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp]
-            L.rfopt_slac_bucket.argtypes = [_vp, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
             L.rfopt_update_normals.argtypes = [_vp, _vp, C.c_int]
-            L.rfopt_nonrigid_bucket.argtypes = [_vp, C.c_int, _vp, C.c_int, C.c_double, _vp, _vp, _vp, _vp]
             cls._lib = L
         return cls._lib
 
@@ -493,19 +490,3 @@ class RefFopt:
     def update_normals(self, frag, ctr_full):
         c = np.ascontiguousarray(ctr_full, np.float64).reshape(-1)
         self.lib().rfopt_update_normals(self.clouds[frag], _p(c), c.size)
-
-    def nonrigid_bucket(self, i, ii, j, jj, weight):
-        i1, v1, i2, v2 = np.zeros(24, np.int32), np.zeros(24), np.zeros(24, np.int32), np.zeros(24)
-        self.lib().rfopt_nonrigid_bucket(self.clouds[i], ii, self.clouds[j], jj, float(weight), _p(i1), _p(v1), _p(i2), _p(v2))
-        return i1, v1, i2, v2
-
-    def rigid_bucket(self, i, ii, j, jj):
-        val, b = np.zeros(12), C.c_double(0)
-        self.lib().rfopt_rigid_bucket(self.clouds[i], ii, self.clouds[j], jj, _p(val), C.byref(b))
-        return val, b.value
-
-    def slac_bucket(self, i, ii, j, jj, pose_rot_t):
-        R = np.ascontiguousarray(pose_rot_t, np.float64).reshape(self.num, 9)
-        idx, val, b = np.zeros(60, np.int32), np.zeros(60), C.c_double(0)
-        self.lib().rfopt_slac_bucket(self.clouds[i], ii, i, self.clouds[j], jj, j, self.num, _p(R[i]), _p(R[j]), _p(idx), _p(val), C.byref(b))
-        return idx, val, b.value
