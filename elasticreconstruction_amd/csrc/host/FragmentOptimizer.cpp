@@ -368,6 +368,19 @@ class COptApp {                                     // OptApp.h:39-124
       for (int v = 0; v < nv_; v++) apply(pose_[(size_t)l].data(), &lattice[(size_t)v * 3], &out[(size_t)l * nper_ + (size_t)v * 3]);
   }
 
+  // --init_ctr: `count` lines "%lf %lf %lf" into out[offset ...] (InitCtr :693-707, InitCtrSLAC :734-745)
+  bool LoadInitCtr(Vec& out, size_t offset, size_t count) const {
+    FILE* f = fopen(init_ctr_file_.c_str(), "r");
+    if (!f) return false;                               // the reference silently keeps its default too
+    char buf[1024];
+    for (size_t i = 0; i < count; i++) {
+      if (!fgets(buf, 1024, f)) break;
+      sscanf(buf, "%lf %lf %lf", &out[offset + i * 3], &out[offset + i * 3 + 1], &out[offset + i * 3 + 2]);
+    }
+    fclose(f);
+    return true;
+  }
+
   void SaveCtr(const Vec& ctr, const std::string& fn) const {   // OptApp.cpp:873-884
     printf("Save ctr to file %s ... ", fn.c_str());
     if (FILE* f = fopen(fn.c_str(), "w")) {
@@ -436,6 +449,7 @@ class COptApp {                                     // OptApp.h:39-124
     Vec ictr, thisCtr, expand_ctr;
     canonical_lattice(ictr);
     thisCtr = ictr;
+    if (init_ctr_file_.length() > 1) LoadInitCtr(thisCtr, 0, (size_t)nv_);
     for (int i = 0; i < num_; i++) {
       pose_[(size_t)i] = ipose_[(size_t)i];
       if (!update_pose_gpu(i, pose_[(size_t)i].data())) return false;
@@ -505,6 +519,7 @@ class COptApp {                                     // OptApp.h:39-124
     canonical_lattice(lat);
     for (int i = 0; i < num_; i++) pose_[(size_t)i] = ipose_[(size_t)i];
     expand(lat, ctr);                                 // InitCtr, :709-721
+    if (init_ctr_file_.length() > 1) LoadInitCtr(ctr, 0, (size_t)num_ * nv_);
     ictr = ctr;
     for (int itr = 0; itr < max_iteration_; itr++) {
       for (int l = 0; l < num_; l++)
@@ -558,6 +573,7 @@ int print_help() {
          "    --iteration <max_number>        : default - 5\n"
          "    --inner_iteration <max_number>  : default - 10\n"
          "    --save_to <ctr_file>            : default - output.ctr\n"
+         "    --init_ctr <ctr_file>           : initial control lattice(s)\n"
          "    --blasklist <blacklist_file>    : each line is the block we want to blacklist\n"
          "    --blacklistpair <threshold>     : threshold of accepting pairwise registration, default - 10000\n"
          "    --ipose <log_file>              : get ipose from log file\n"
@@ -595,7 +611,6 @@ int main(int argc, char* argv[]) {                     // FragmentOptimizer.cpp:
   if (parse_argument(argc, argv, "--dense_limit", dl) > 0) app.dense_limit_ = (long)dl;
   if (parse_argument(argc, argv, "--blacklist", blacklist_file) > 0) app.Blacklist(blacklist_file);
   if (parse_argument(argc, argv, "--ipose", ipose_file) > 0) app.IPoseFromFile(ipose_file);
-  if (!app.init_ctr_file_.empty()) fprintf(stderr, "FragmentOptimizer: --init_ctr is not supported by this build (ignored)\n");
   if (app.sample_num_ > 0) fprintf(stderr, "FragmentOptimizer: --write_xyzn_sample is not supported by this build (ignored)\n");
   bool ok;
   if (find_switch(argc, argv, "--slac")) ok = app.OptimizeSLAC();

@@ -190,6 +190,19 @@ def test_fragment_optimizer_program_equals_reference_program(gpu, tmp_path):
     ref_ctr = np.loadtxt(os.path.join(d4, "out_nonrigid.ctr"))
     run_ours(d4, "nonrigid", args4, "ours.ctr")
     assert np.abs(np.loadtxt(os.path.join(d4, "ours.ctr")) - ref_ctr).max() < 1e-6
+    # --init_ctr: the non-rigid mode restarted from the lattices just written, SLAC from a jittered canonical lattice
+    os.replace(os.path.join(d4, "out_nonrigid.ctr"), os.path.join(d4, "start.ctr"))
+    _run_ref(d4, "nonrigid", "reg_output.log", ["--init_ctr", os.path.join(d4, "start.ctr")] + args4)
+    ref_ctr = np.loadtxt(os.path.join(d4, "out_nonrigid.ctr"))
+    run_ours(d4, "nonrigid", ["--init_ctr", os.path.join(d4, "start.ctr")] + args4, "ours2.ctr")
+    assert np.abs(np.loadtxt(os.path.join(d4, "ours2.ctr")) - ref_ctr).max() < 1e-6
+    k, j, i = np.meshgrid(np.arange(9), np.arange(9), np.arange(9), indexing="ij")
+    lat = np.stack([i.ravel(), j.ravel(), k.ravel()], 1) * (3.0 / 8) + np.random.default_rng(1).normal(0, 0.002, (729, 3))
+    np.savetxt(os.path.join(d, "lat.ctr"), lat, fmt="%.10f")
+    _run_ref(d, "slac", "reg_output.log", ["--init_ctr", os.path.join(d, "lat.ctr")] + args)
+    ref_ctr = np.loadtxt(os.path.join(d, "out_slac.ctr"))
+    run_ours(d, "slac", ["--init_ctr", os.path.join(d, "lat.ctr")] + args, "ours_slac2.ctr")
+    assert np.abs(np.loadtxt(os.path.join(d, "ours_slac2.ctr")) - ref_ctr).max() < 1e-7
     # the dense limit of the non-rigid mode is enforced with a message, not a crash
     r = subprocess.run([os.path.join(BIN, "FragmentOptimizer"), "--num", "3", "--resolution", "4", "--dense_limit", "100", "--registration",
                         os.path.join(d4, "reg_output.log"), "--dir", d4 + "/", "--rgbdslam", os.path.join(d4, "rgbd.log"), "--interval", "1",
