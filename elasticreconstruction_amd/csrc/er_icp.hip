@@ -268,6 +268,53 @@ __global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restr
   }
 }
 
+// The accepted hypothesis once more, this time keeping the lists (RansacCurvature.h:661-704: `inliers`, `inliers_target`):
+// match[original source index] = NN index if d < threshold^2, else -1; acc[20] += d over the inliers.
+__global__ __launch_bounds__(kBlock) void k_ransac_match(const float4* __restrict__ src_sorted, int n, Mat12f M, Grid g, float radius,
+                                                         float max_range, int* __restrict__ match, double* __restrict__ acc) {
+  __shared__ NnShared sh;
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  float qx = 0.f, qy = 0.f, qz = 0.f, d;
+  int k = 0;
+  if (q < n) {
+    const float4 s = src_sorted[q];
+    k = __float_as_int(s.w);
+    qx = ((M.m[0] * s.x + M.m[1] * s.y) + M.m[2] * s.z) + M.m[3];
+    qy = ((M.m[4] * s.x + M.m[5] * s.y) + M.m[6] * s.z) + M.m[7];
+    qz = ((M.m[8] * s.x + M.m[9] * s.y) + M.m[10] * s.z) + M.m[11];
+  }
+  const int i = nn_block(sh, g, q < n, qx, qy, qz, radius * radius, d);
+  const bool hit = q < n && i >= 0 && d < max_range;
+  if (q < n) match[k] = hit ? i : -1;
+  double v[1] = {hit ? (double)d : 0.0};
+  __syncthreads();
+  block_reduce_atomic<1>(v, acc + 20);
+}
+
+// getInformation's target half (RansacCurvature.h:723-731): the ten distinct terms of sum A^T A (see k_count_blocks) over the
+// matched TARGET points.
+__global__ __launch_bounds__(kBlock) void k_info_matched(const int* __restrict__ match, const float* __restrict__ tgt_xyz, int n,
+                                                         double* __restrict__ info) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) v[i] = 0.0;
+  const int m = k < n ? match[k] : -1;
+  if (m >= 0) {
+    const float tx = tgt_xyz[3 * m], ty = tgt_xyz[3 * m + 1], tz = tgt_xyz[3 * m + 2];
+    const double ax = (double)(2 * tx), ay = (double)(2 * ty), az = (double)(2 * tz);
+    v[0] = ax; v[1] = ay; v[2] = az;
+    v[3] = az * az + ay * ay;
+    v[4] = az * az + ax * ax;
+    v[5] = ay * ay + ax * ax;
+    v[6] = ay * (-ax);
+    v[7] = (-az) * ax;
+    v[8] = az * (-ay);
+    v[9] = 1.0;
+  }
+  block_reduce_atomic<10>(v, info);
+}
+
 // guess * source in float32 (IterativeClosestPoint::transformCloud), or a plain copy for an identity guess.
 __global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restrict__ X, int n, Mat12f M, int apply) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;       // k = position in the source's cell-sorted order
@@ -901,6 +948,26 @@ bool is_pinned_host(const void* p) {
   return at.type == hipMemoryTypeHost;
 }
 
+// sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203,
+// RansacCurvature.h:717-721) from its ten distinct terms (k_count_blocks / k_info_matched).
+void expand_information(const double* acc, double* I) {
+  memset(I, 0, 36 * sizeof(double));
+  const double N = acc[9];
+  I[0 * 6 + 0] = I[1 * 6 + 1] = I[2 * 6 + 2] = N;
+  I[0 * 6 + 4] = I[4 * 6 + 0] = acc[2];      //  sum 2sz
+  I[0 * 6 + 5] = I[5 * 6 + 0] = -acc[1];     // -sum 2sy
+  I[1 * 6 + 3] = I[3 * 6 + 1] = -acc[2];
+  I[1 * 6 + 5] = I[5 * 6 + 1] = acc[0];      //  sum 2sx
+  I[2 * 6 + 3] = I[3 * 6 + 2] = acc[1];
+  I[2 * 6 + 4] = I[4 * 6 + 2] = -acc[0];
+  I[3 * 6 + 3] = acc[3];
+  I[4 * 6 + 4] = acc[4];
+  I[5 * 6 + 5] = acc[5];
+  I[3 * 6 + 4] = I[4 * 6 + 3] = acc[6];
+  I[3 * 6 + 5] = I[5 * 6 + 3] = acc[7];
+  I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
+}
+
 // (Letting k_compact store the list straight into page-locked host memory -- zero-copy -- was tried: one stage
 // fewer, but 3.5 instead of 2.9 ms per 40 pairs.)
 // Stage 2 of a pair (after the lane's kernel event): the pair count is known; start the copy of exactly that many
@@ -928,26 +995,7 @@ int corr_start_copy(IcpWs* w, int* pairs_host, int capacity, int* n_pairs, doubl
     ER_HIP_TRY(hipMemcpyAsync(dst, w->pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, w->stream));
     ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
   }
-  if (info36) {
-    // sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203)
-    const double* acc = w->host->acc;
-    double* I = info36;
-    memset(I, 0, 36 * sizeof(double));
-    const double N = acc[9];
-    I[0 * 6 + 0] = I[1 * 6 + 1] = I[2 * 6 + 2] = N;
-    I[0 * 6 + 4] = I[4 * 6 + 0] = acc[2];      //  sum 2sz
-    I[0 * 6 + 5] = I[5 * 6 + 0] = -acc[1];     // -sum 2sy
-    I[1 * 6 + 3] = I[3 * 6 + 1] = -acc[2];
-    I[1 * 6 + 5] = I[5 * 6 + 1] = acc[0];      //  sum 2sx
-    I[2 * 6 + 3] = I[3 * 6 + 2] = acc[1];
-    I[2 * 6 + 4] = I[4 * 6 + 2] = -acc[0];
-    I[3 * 6 + 3] = acc[3];
-    I[4 * 6 + 4] = acc[4];
-    I[5 * 6 + 5] = acc[5];
-    I[3 * 6 + 4] = I[4 * 6 + 3] = acc[6];
-    I[3 * 6 + 5] = I[5 * 6 + 3] = acc[7];
-    I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
-  }
+  if (info36) expand_information(w->host->acc, info36);
   return 0;
 }
 
@@ -1216,6 +1264,39 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
   if (rc == 0 && fitness)
     for (int h = 0; h < n_hyp; h++) fitness[h] = inliers[h] > 0 ? sums[(size_t)h] / (double)inliers[h] : (double)FLT_MAX;   // :697-703
   return rc;
+}
+
+int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float corr_dist_threshold, int* pairs_host, int capacity,
+                      int* n_inliers, double* fitness, double* info_source36, double* info_target36) {
+  if (!M16 || !n_inliers || capacity < 0 || (capacity > 0 && !pairs_host)) return er::fail("er_ransac_inliers: bad arguments");
+  if (check_pair(src, tgt, (double)corr_dist_threshold, "er_ransac_inliers")) return 1;
+  *n_inliers = 0;
+  if (fitness) *fitness = (double)FLT_MAX;
+  if (info_source36) memset(info_source36, 0, 36 * sizeof(double));
+  if (info_target36) memset(info_target36, 0, 36 * sizeof(double));
+  if (src->n == 0 || tgt->n == 0) return 0;
+  WsSet set;
+  if (set.acquire(src->device, (size_t)src->n, 1)) return 1;
+  IcpWs* w = set.ws[0];
+  const int n = src->n, nb = nblocks_of(n);
+  Mat12f M;
+  for (int q = 0; q < 12; q++) M.m[q] = M16[q];
+  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
+  hipLaunchKernelGGL(k_ransac_match, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, src->sorted, n, M, grid_of(tgt), corr_dist_threshold,
+                     corr_dist_threshold * corr_dist_threshold, w->match, w->acc);
+  hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kBlock), 0, w->stream, w->match, src->xyz, n, w->block_count, w->acc, info_source36 ? 1 : 0);
+  if (info_target36) hipLaunchKernelGGL(k_info_matched, dim3(nb), dim3(kBlock), 0, w->stream, w->match, tgt->xyz, n, w->acc + 10);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, w->stream, w->block_count, w->block_offset, nb, w->icount + 1);
+  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kBlock), 0, w->stream, w->match, n, w->block_offset, w->pairs, n);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[1], w->icount + 1, sizeof(int), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  bool staged = false;
+  if (corr_start_copy(w, pairs_host, capacity, n_inliers, info_source36, &staged)) return 1;
+  if (info_target36) expand_information(w->host->acc + 10, info_target36);
+  if (fitness && *n_inliers > 0) *fitness = w->host->acc[20] / (double)*n_inliers;                  // :697-703
+  return corr_finish(w, pairs_host, capacity, *n_inliers, staged);
 }
 
 int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist, double normal_cos,

@@ -144,7 +144,7 @@ class COptApp {                                     // OptApp.h:39-124
   int resolution_ = 8, interval_ = 50, num_ = 0;
   double weight_ = 1.0, length_ = 3.0;
   int max_iteration_ = 5, max_inner_iteration_ = 10;
-  std::string dir_prefix_, ctr_filename_ = "output.ctr", pose_filename_ = "pose.log", init_ctr_file_;
+  std::string dir_prefix_, ctr_filename_ = "output.ctr", pose_filename_ = "pose.log", init_ctr_file_, sample_filename_ = "sample.pcd";
   int sample_num_ = -1, blacklist_pair_num_ = 10000, device_ = 0;
   long dense_limit_ = 200000;
   std::set<int> blacklist_;
@@ -390,6 +390,37 @@ class COptApp {                                     // OptApp.h:39-124
     printf("Done.\n");
   }
 
+  // SavePoints, OptApp.cpp:897-923: every sample_num_-th point of every fragment, moved by its lattice (UpdateAllNormal +
+  // UpdatePoint = the device's UpdateAllPointPN), normal re-normalised in float64, written as sample.pcd.
+  bool SavePoints(const Vec& ctr) {
+    if (sample_num_ <= 0) return true;
+    std::vector<float> col[8];
+    std::vector<float> p, nrm;
+    for (int l = 0; l < num_; l++) {
+      if (er_fopt_update_point_pn(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      const int n = er_fopt_cloud_size(fo_, l);
+      p.resize((size_t)n * 3);
+      nrm.resize((size_t)n * 3);
+      if (n && er_fopt_get_points(fo_, l, nullptr, nullptr, nullptr, p.data(), nrm.data())) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      for (int i = 0; i < n; i += sample_num_) {
+        double v[3] = {nrm[(size_t)i * 3], nrm[(size_t)i * 3 + 1], nrm[(size_t)i * 3 + 2]};
+        const double inv = 1.0 / std::sqrt(v[0] * v[0] + (v[1] * v[1] + v[2] * v[2]));   // Eigen's normalize(): v *= 1 / norm()
+        for (int c = 0; c < 3; c++) {
+          col[c].push_back(p[(size_t)i * 3 + c]);
+          col[3 + c].push_back((float)(v[c] * inv));
+        }
+        col[6].push_back(0.0f);
+        col[7].push_back(0.0f);
+      }
+    }
+    printf("Save sample pcd into %s ... ", sample_filename_.c_str());
+    std::vector<const float*> cols;
+    for (auto& c : col) cols.push_back(c.data());
+    const bool ok = erfmt::save_pcd_compressed(sample_filename_, {"x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb", "curvature"}, cols, col[0].size());
+    printf("Done.\n");
+    return ok;
+  }
+
   void SavePoses() const {
     std::vector<FramedTransformation> out;
     for (int i = 0; i < num_; i++) {
@@ -437,7 +468,7 @@ class COptApp {                                     // OptApp.h:39-124
     canonical_lattice(lat);
     expand(lat, ctr);
     SaveCtr(ctr, ctr_filename_);
-    return true;
+    return SavePoints(ctr);
   }
 
   // ---- OptimizeSLAC, OptApp.cpp:419-680 ---------------------------------------------------------------------
@@ -502,7 +533,7 @@ class COptApp {                                     // OptApp.h:39-124
     SavePoses();
     expand(thisCtr, expand_ctr);
     SaveCtr(expand_ctr, ctr_filename_);
-    return true;
+    return SavePoints(expand_ctr);
   }
 
   // ---- OptimizeNonrigid, OptApp.cpp:120-278 -------------------------------------------------------------------
@@ -526,6 +557,7 @@ class COptApp {                                     // OptApp.h:39-124
         if (er_fopt_update_normals(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       // thisAA = baseAA + data blocks: scattered into a dense matrix and factored in HBM (dense Cholesky, rocSOLVER)
       if (er_fopt_factor_nonrigid(fo_, weight_)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
+      if (sample_num_ > 0) SaveCtr(ctr, "itr" + std::to_string(itr) + ".ctr");              // :213-218
       for (int m = 0; m < max_inner_iteration_; m++) {
         Vec Ab((size_t)M, 0.0);
         for (int l = 0; l < num_; l++) {
@@ -552,10 +584,11 @@ class COptApp {                                     // OptApp.h:39-124
         for (long q = 0; q < M; q++) sc += (ctr[(size_t)q] - Ab[(size_t)q]) * (ctr[(size_t)q] - Ab[(size_t)q]);
         ctr = Ab;
         printf("Iteration #%d:%d (%d:%d) : score is %.4f\n", itr + 1, m + 1, max_iteration_, max_inner_iteration_, std::sqrt(sc));
+        if (sample_num_ > 0) SaveCtr(ctr, "itr" + std::to_string(itr) + "_inner" + std::to_string(m) + "_out.ctr");   // :267-272
       }
     }
     SaveCtr(ctr, ctr_filename_);
-    return true;
+    return SavePoints(ctr);
   }
 };
 
@@ -611,7 +644,6 @@ int main(int argc, char* argv[]) {                     // FragmentOptimizer.cpp:
   if (parse_argument(argc, argv, "--dense_limit", dl) > 0) app.dense_limit_ = (long)dl;
   if (parse_argument(argc, argv, "--blacklist", blacklist_file) > 0) app.Blacklist(blacklist_file);
   if (parse_argument(argc, argv, "--ipose", ipose_file) > 0) app.IPoseFromFile(ipose_file);
-  if (app.sample_num_ > 0) fprintf(stderr, "FragmentOptimizer: --write_xyzn_sample is not supported by this build (ignored)\n");
   bool ok;
   if (find_switch(argc, argv, "--slac")) ok = app.OptimizeSLAC();
   else if (find_switch(argc, argv, "--rigid")) ok = app.OptimizeRigid();

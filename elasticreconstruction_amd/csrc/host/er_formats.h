@@ -16,6 +16,8 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -270,6 +272,69 @@ inline bool save_pcd_xyzi(const std::string& path, const float* xyzi, size_t n) 
           "COUNT 1 1 1 1\nWIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary\n",
           n, n);
   if (n) fwrite(xyzi, sizeof(float) * 4, n, f);
+  fclose(f);
+  return true;
+}
+
+// LZF stream writer (the format lzf_decompress above reads; liblzf's published container-less format as PCL's
+// "DATA binary_compressed" uses it): greedy matcher over a hash of 3-byte strings, back references of 3..264 bytes
+// up to 8192 bytes back, literal runs of up to 32 bytes.
+inline void lzf_compress(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+  out.clear();
+  out.reserve(n + n / 32 + 8);
+  std::vector<int64_t> last((size_t)1 << 16, -1);
+  size_t lit = 0;
+  auto flush = [&](size_t end) {
+    while (lit < end) {
+      size_t run = std::min<size_t>(32, end - lit);
+      out.push_back((uint8_t)(run - 1));
+      out.insert(out.end(), in + lit, in + lit + run);
+      lit += run;
+    }
+  };
+  auto slot = [&](size_t i) { return (size_t)((((uint32_t)in[i] << 16 | (uint32_t)in[i + 1] << 8 | in[i + 2]) * 2654435761u) >> 16); };
+  size_t i = 0;
+  while (i + 2 < n) {
+    const size_t h = slot(i);
+    const int64_t ref = last[h];
+    last[h] = (int64_t)i;
+    if (ref >= 0 && i - (size_t)ref <= 8192 && in[ref] == in[i] && in[ref + 1] == in[i + 1] && in[ref + 2] == in[i + 2]) {
+      const size_t cap = std::min<size_t>(n - i, 264);
+      size_t len = 3;
+      while (len < cap && in[(size_t)ref + len] == in[i + len]) len++;
+      flush(i);
+      const size_t back = i - (size_t)ref - 1, l = len - 2;
+      if (l < 7) out.push_back((uint8_t)((l << 5) | (back >> 8)));
+      else { out.push_back((uint8_t)((7u << 5) | (back >> 8))); out.push_back((uint8_t)(l - 7)); }
+      out.push_back((uint8_t)(back & 0xFF));
+      for (size_t k = i + 1; k < i + len && k + 2 < n; k++) last[slot(k)] = (int64_t)k;
+      i += len;
+      lit = i;
+    } else {
+      i++;
+    }
+  }
+  flush(n);
+}
+
+// pcl::PCDWriter::writeBinaryCompressed( name, PointCloud<PointXYZRGBNormal> ) (OptApp.cpp:921-922): the templated writer's
+// packed field list (padding dropped), fields stored one after another (all x, all y, ...), the block LZF-compressed and
+// preceded by its compressed and uncompressed sizes.  cols[c] points at n floats of field c.
+inline bool save_pcd_compressed(const std::string& path, const std::vector<std::string>& names, const std::vector<const float*>& cols, size_t n) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  std::string fields, sizes, types, counts;
+  for (const std::string& nm : names) { fields += " " + nm; sizes += " 4"; types += " F"; counts += " 1"; }
+  fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS%s\nSIZE%s\nTYPE%s\nCOUNT%s\nWIDTH %zu\nHEIGHT 1\n"
+             "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA binary_compressed\n",
+          fields.c_str(), sizes.c_str(), types.c_str(), counts.c_str(), n, n);
+  std::vector<uint8_t> raw(names.size() * n * 4), packed;
+  for (size_t c = 0; c < names.size(); c++)
+    if (n) memcpy(&raw[c * n * 4], cols[c], n * 4);
+  lzf_compress(raw.data(), raw.size(), packed);
+  const uint32_t hdr[2] = {(uint32_t)packed.size(), (uint32_t)raw.size()};
+  fwrite(hdr, 4, 2, f);
+  if (!packed.empty()) fwrite(packed.data(), 1, packed.size(), f);
   fclose(f);
   return true;
 }

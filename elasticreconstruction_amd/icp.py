@@ -119,6 +119,20 @@ def ransac_fitness_batch(src, tgt, Ms, corr_dist_threshold):
     return cnt, fit
 
 
+def ransac_inliers(src, tgt, M, corr_dist_threshold):
+    """getFitness's inlier lists for one hypothesis + getInformation (GlobalRegistration/RansacCurvature.h:661-733).
+    Returns (inliers int32 [m], inliers_target int32 [m], fitness, information_source [6,6], information_target [6,6])."""
+    Mf = np.ascontiguousarray(M, np.float32).reshape(16)
+    pairs = np.zeros((max(src.n, 1), 2), np.int32)
+    m = C.c_int(0)
+    fit = C.c_double(0.0)
+    info_s, info_t = np.zeros((6, 6)), np.zeros((6, 6))
+    _ffi.check(src._lib.er_ransac_inliers(src._h, tgt._h, _ffi.ptr(Mf), C.c_float(corr_dist_threshold), _ffi.ptr(pairs), src.n, C.byref(m),
+                                          C.byref(fit), _ffi.ptr(info_s), _ffi.ptr(info_t)), "er_ransac_inliers")
+    pairs = pairs[:m.value]
+    return pairs[:, 1].copy(), pairs[:, 0].copy(), fit.value, info_s, info_t      # pairs are (target, source) like corres_*.txt
+
+
 _arena = None
 
 

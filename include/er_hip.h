@@ -167,6 +167,14 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
 int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const float* M, float corr_dist_threshold,
                             int* inliers, double* fitness);
 
+/* The accepted hypothesis, with the lists: getFitness's `inliers` / `inliers_target` (RansacCurvature.h:661-704) and
+ * getInformation (:707-733) in one call.  pairs_host receives min(*n_inliers, capacity) (target index, source index)
+ * pairs -- the layout of er_find_correspondence -- in ascending source index, the reference's push_back order;
+ * *fitness (nullable) as above; info_source36 / info_target36 (nullable, row-major 6x6) = sum A^T A over the inlier
+ * source points / their matched target points. */
+int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float corr_dist_threshold, int* pairs_host, int capacity,
+                      int* n_inliers, double* fitness, double* info_source36, double* info_target36);
+
 /* Frees the pooled ICP workspaces (streams, scratch, pinned blocks).  Optional; call when no ICP call is running. */
 int er_icp_release_workspaces(void);
 

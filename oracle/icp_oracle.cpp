@@ -417,4 +417,42 @@ int icp_ransac_fitness(void* src_, void* tgt_, const float* M, float corr_dist_t
   return cnt;
 }
 
+// RansacCurvature::getFitness's lists (GlobalRegistration/RansacCurvature.h:680-695: inliers.push_back( i ),
+// inliers_target.push_back( nn_indices[ 0 ] ) in point order) followed by getInformation (:707-733): for every inlier the
+// 3x6 matrix A = [ I | 0 2z -2y ; -2z 0 2x ; 2y -2x 0 ] built from the FLOAT coordinates (2 * sz is a float product) widened
+// to double, information += A^T A, once over the source inliers and once over their target matches.
+// pairs (2 ints per inlier) must hold src.n entries.  Returns the inlier count.
+int icp_ransac_inliers(void* src_, void* tgt_, const float* M, float corr_dist_threshold, int* pairs, double* info_source36,
+                       double* info_target36) {
+  Cloud& src = *static_cast<Cloud*>(src_);
+  Cloud& tgt = *static_cast<Cloud*>(tgt_);
+  std::vector<float> X(src.xyz);
+  transform_float_inplace(X, src.n, M);
+  const float max_range = corr_dist_threshold * corr_dist_threshold;
+  std::vector<int> nn((size_t)src.n);
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (int k = 0; k < src.n; k++) {
+    float d;
+    const int i = nearest(tgt, &X[3 * (size_t)k], corr_dist_threshold, &d);
+    nn[(size_t)k] = (i >= 0 && d < max_range) ? i : -1;
+  }
+  int cnt = 0;
+  for (int q = 0; q < 36; q++) info_source36[q] = info_target36[q] = 0.0;
+  for (int k = 0; k < src.n; k++) {
+    if (nn[(size_t)k] < 0) continue;
+    pairs[2 * cnt] = k;
+    pairs[2 * cnt + 1] = nn[(size_t)k];
+    cnt++;
+    for (int side = 0; side < 2; side++) {
+      const float* p = side == 0 ? &src.xyz[3 * (size_t)k] : &tgt.xyz[3 * (size_t)nn[(size_t)k]];
+      const float x2 = 2 * p[0], y2 = 2 * p[1], z2 = 2 * p[2];
+      const double A[3][6] = {{1, 0, 0, 0, (double)z2, (double)-y2}, {0, 1, 0, (double)-z2, 0, (double)x2}, {0, 0, 1, (double)y2, (double)-x2, 0}};
+      double* I = side == 0 ? info_source36 : info_target36;
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) I[r * 6 + c] += (A[0][r] * A[0][c] + A[1][r] * A[1][c]) + A[2][r] * A[2][c];
+    }
+  }
+  return cnt;
+}
+
 }  // extern "C"

@@ -257,6 +257,7 @@ class IcpOracle:
             L.icp_align.argtypes = [_vp, _vp, _vp, C.c_double, C.c_int, C.c_double, C.c_int, _vp, _vp, _vp, _vp]
             L.icp_find_correspondence.argtypes = [_vp, _vp, _vp, C.c_double, C.c_double, _vp, C.c_int, _vp, _vp]
             L.icp_ransac_fitness.argtypes = [_vp, _vp, _vp, C.c_float, _vp, _vp]
+            L.icp_ransac_inliers.argtypes = [_vp, _vp, _vp, C.c_float, _vp, _vp, _vp]
             cls._lib = L
         return cls._lib
 
@@ -303,6 +304,14 @@ class IcpOracle:
         f, s = C.c_float(0), C.c_double(0)
         cnt = self.lib().icp_ransac_fitness(self._h, tgt._h, _p(Mm), C.c_float(corr_dist_threshold), C.byref(f), C.byref(s))
         return int(cnt), float(f.value), float(s.value)
+
+    def ransac_inliers(self, tgt, M, corr_dist_threshold):
+        """getFitness's inlier lists + getInformation: (inliers, inliers_target, information_source, information_target)."""
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        pairs = np.empty((max(self.n, 1), 2), np.int32)
+        i_s, i_t = np.zeros(36), np.zeros(36)
+        m = self.lib().icp_ransac_inliers(self._h, tgt._h, _p(Mm), C.c_float(corr_dist_threshold), _p(pairs), _p(i_s), _p(i_t))
+        return pairs[:m, 0].copy(), pairs[:m, 1].copy(), i_s.reshape(6, 6), i_t.reshape(6, 6)
 
     def find_correspondence(self, tgt, T, dist, normal_cos=0.8660, want_info=False):
         Tm = np.ascontiguousarray(T, np.float64).reshape(16)

@@ -192,7 +192,10 @@ inline int parse_argument(int argc, char** argv, const char* name, double& v) {
 
 struct PointXYZI { float x, y, z, intensity; };
 // FragmentOptimizer/PointCloud.cpp:22-40 (LoadFromPCDFile); the oracle feeds points through the XYZN path, so loading is a stub.
-struct PointXYZRGBNormal { float x, y, z, normal_x, normal_y, normal_z, rgb, curvature; };
+struct PointXYZRGBNormal {
+  float x, y, z, normal_x, normal_y, normal_z, rgb, curvature;
+  PointXYZRGBNormal() : x(0), y(0), z(0), normal_x(0), normal_y(0), normal_z(0), rgb(0), curvature(0) {}   // PCL 1.7 zero-initialises
+};
 
 template <class PointT> class PointCloud {
  public:
@@ -202,9 +205,21 @@ template <class PointT> class PointCloud {
   size_t size() const { return points.size(); }
 };
 
-// FragmentOptimizer/OptApp.cpp:921-922 (SavePoints, only with --write_xyzn_sample): not needed by the checkers.
+// FragmentOptimizer/OptApp.cpp:921-922 (SavePoints, only with --write_xyzn_sample).  The stand-in stores the same records
+// uncompressed ("DATA binary", the packed field list PCL's templated writer emits) -- the checker compares values, not bytes.
 struct PCDWriter {
-  template <class CloudT> int writeBinaryCompressed(const std::string&, const CloudT&) { return -1; }
+  int writeBinaryCompressed(const std::string& name, const PointCloud<PointXYZRGBNormal>& c) {
+    FILE* f = fopen(name.c_str(), "wb");
+    if (!f) return -1;
+    fprintf(f,
+            "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z normal_x normal_y normal_z rgb curvature\n"
+            "SIZE 4 4 4 4 4 4 4 4\nTYPE F F F F F F F F\nCOUNT 1 1 1 1 1 1 1 1\nWIDTH %zu\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\n"
+            "POINTS %zu\nDATA binary\n",
+            c.size(), c.size());
+    if (c.size()) fwrite(c.points.data(), sizeof(PointXYZRGBNormal), c.size(), f);
+    fclose(f);
+    return 0;
+  }
 };
 
 namespace io {

@@ -1,0 +1,36 @@
+// Test helper (CPU only): writes the float32 columns of a raw file as a binary_compressed PCD with the host programs' writer,
+// and round-trips a byte file through lzf_compress / lzf_decompress.
+//   pcd_compressed_check pcd <raw_f32> <n_points> <out.pcd> <field> [<field> ...]
+//   pcd_compressed_check lzf <in_bytes> <out_bytes>      (prints the compressed size)
+#include "../../elasticreconstruction_amd/csrc/host/er_formats.h"
+
+int main(int argc, char** argv) {
+  if (argc >= 6 && std::string(argv[1]) == "pcd") {
+    const size_t n = (size_t)atol(argv[3]);
+    std::vector<std::string> names(argv + 5, argv + argc);
+    std::vector<float> raw(names.size() * n);
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(raw.data(), 4, raw.size(), f) != raw.size()) return 2;
+    fclose(f);
+    std::vector<const float*> cols;
+    for (size_t c = 0; c < names.size(); c++) cols.push_back(raw.data() + c * n);
+    return erfmt::save_pcd_compressed(argv[4], names, cols, n) ? 0 : 3;
+  }
+  if (argc == 4 && std::string(argv[1]) == "lzf") {
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> in, packed, back;
+    uint8_t buf[65536];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) in.insert(in.end(), buf, buf + got);
+    fclose(f);
+    erfmt::lzf_compress(in.data(), in.size(), packed);
+    if (!erfmt::lzf_decompress(packed.data(), packed.size(), back, in.size())) return 4;
+    f = fopen(argv[3], "wb");
+    if (!back.empty()) fwrite(back.data(), 1, back.size(), f);
+    fclose(f);
+    printf("%zu\n", packed.size());
+    return 0;
+  }
+  return 1;
+}

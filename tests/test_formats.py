@@ -64,3 +64,42 @@ def test_pcd_binary_ascii_compressed(tmp_path):
     assert np.array_equal(d["y"], xyz[:, 1])
     # back-reference decoding
     assert formats.lzf_decompress(bytes([2, 97, 98, 99, (1 << 5) | 0, 2]), 6) == b"abcabc"
+
+
+def test_host_program_compressed_pcd_writer(tmp_path):
+    """`save_pcd_compressed` / `lzf_compress` of csrc/host/er_formats.h (sample.pcd of bin/FragmentOptimizer, OptApp.cpp:921-922)
+    against this package's independent PCD reader; the stream must really use back references on compressible data."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pcc")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(here, "cpp", "pcd_compressed_check.cpp"), "-lz", "-o", exe], check=True)
+    rng = np.random.RandomState(11)
+    names = ["x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb", "curvature"]
+    for n in (0, 1, 7, 5000):
+        cols = rng.randn(len(names), n).astype(np.float32)
+        cols[6:] = 0.0                                       # rgb / curvature are constant zero in sample.pcd
+        if n > 100:
+            cols[0, 50:90] = cols[0, 10:50]                  # an overlapping-distance repeat inside the 8 KiB window
+        raw = str(tmp_path / "raw.bin")
+        cols.tofile(raw)
+        out = str(tmp_path / ("s%d.pcd" % n))
+        subprocess.run([exe, "pcd", raw, str(n), out] + names, check=True)
+        d = formats.load_pcd(out)
+        for c, nm in enumerate(names):
+            assert np.array_equal(d[nm], cols[c]), (n, nm)
+        if n == 5000:
+            assert os.path.getsize(out) < 0.8 * cols.nbytes   # the two zero columns (25 %) collapse
+    # byte-level round trips: empty, tiny, long runs (len > 264 per reference, overlapping copies), random, text
+    cases = [b"", b"a", b"ab", b"abc", b"a" * 1000, b"abcabcabc" * 500, rng.bytes(70000), (b"lattice %d\n" * 3000) % tuple(range(3000)),
+             bytes(9000) + b"tail"]
+    for k, blob in enumerate(cases):
+        src, dst = str(tmp_path / ("b%d" % k)), str(tmp_path / ("r%d" % k))
+        with open(src, "wb") as f:
+            f.write(blob)
+        r = subprocess.run([exe, "lzf", src, dst], check=True, capture_output=True, text=True)
+        assert open(dst, "rb").read() == blob
+        packed = int(r.stdout)
+        assert packed <= len(blob) + len(blob) // 32 + 1
+        if k in (4, 5, 8):
+            assert packed < len(blob) // 10

@@ -203,6 +203,31 @@ def test_fragment_optimizer_program_equals_reference_program(gpu, tmp_path):
     ref_ctr = np.loadtxt(os.path.join(d, "out_slac.ctr"))
     run_ours(d, "slac", ["--init_ctr", os.path.join(d, "lat.ctr")] + args, "ours_slac2.ctr")
     assert np.abs(np.loadtxt(os.path.join(d, "ours_slac2.ctr")) - ref_ctr).max() < 1e-7
+    # --write_xyzn_sample: sample.pcd (SavePoints, OptApp.cpp:897-923; ours is binary_compressed like PCL's, the reference
+    # build's stand-in writer stores the same records uncompressed) and the per-iteration lattices of the non-rigid mode
+    def sample(dirname):
+        c = formats.load_pcd(os.path.join(dirname, "sample.pcd"))
+        return np.stack([c[k] for k in ("x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb", "curvature")], 1)
+
+    sargs = ["--write_xyzn_sample", "7", "--init_ctr", os.path.join(d, "lat.ctr")] + args
+    _run_ref(d, "slac", "reg_output.log", sargs)
+    ref_s = sample(d)
+    os.remove(os.path.join(d, "sample.pcd"))
+    run_ours(d, "slac", sargs, "ours_slac3.ctr")
+    assert b"DATA binary_compressed" in open(os.path.join(d, "sample.pcd"), "rb").read(400)
+    s = sample(d)
+    assert s.shape == ref_s.shape and len(s) > 300 and np.abs(s - ref_s).max() < 2e-6
+    _run_ref(d4, "nonrigid", "reg_output.log", ["--write_xyzn_sample", "5"] + args4)
+    ref_s = sample(d4)
+    dumps = ["itr0.ctr", "itr0_inner0_out.ctr", "itr0_inner1_out.ctr"]
+    ref_d = [np.loadtxt(os.path.join(d4, f)) for f in dumps]
+    for f in dumps + ["sample.pcd"]:
+        os.remove(os.path.join(d4, f))
+    run_ours(d4, "nonrigid", ["--write_xyzn_sample", "5"] + args4, "ours3.ctr")
+    s = sample(d4)
+    assert s.shape == ref_s.shape and np.abs(s - ref_s).max() < 5e-6
+    for f, r in zip(dumps, ref_d):
+        assert np.abs(np.loadtxt(os.path.join(d4, f)) - r).max() < 1e-6, f
     # the dense limit of the non-rigid mode is enforced with a message, not a crash
     r = subprocess.run([os.path.join(BIN, "FragmentOptimizer"), "--num", "3", "--resolution", "4", "--dense_limit", "100", "--registration",
                         os.path.join(d4, "reg_output.log"), "--dir", d4 + "/", "--rgbdslam", os.path.join(d4, "rgbd.log"), "--interval", "1",

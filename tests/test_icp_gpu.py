@@ -206,6 +206,15 @@ def test_ransac_fitness_batch_matches_oracle(gpu):
             else:
                 assert fit[h] == float(np.finfo(np.float32).max)
         assert cnt[0] > 0.3 * len(keep) and cnt[2] == 0
+    # the accepted hypothesis with its lists: getFitness's inliers / inliers_target + getInformation (RansacCurvature.h:661-733)
+    from elasticreconstruction_amd.icp import ransac_inliers
+    for M, thr in ((hyps[0], 0.05), (hyps[7], 0.02), (hyps[2], 0.05)):
+        ins, int_, f, info_s, info_t = ransac_inliers(src, tgt, M, thr)
+        o_ins, o_int, o_is, o_it = osrc.ransac_inliers(otgt, M, thr)
+        c, f32, s64 = osrc.ransac_fitness(otgt, M, thr)
+        assert np.array_equal(ins, o_ins) and np.array_equal(int_, o_int)                 # same lists, same order
+        assert np.allclose(info_s, o_is, rtol=1e-12, atol=1e-9) and np.allclose(info_t, o_it, rtol=1e-12, atol=1e-9)
+        assert f == (pytest.approx(s64 / c, rel=1e-9) if c else float(np.finfo(np.float32).max))
     # more hypotheses than one launch's grid.y chunk, tiny source
     tiny = Cloud(x1s[:300], n1s[:300], 0.05)
     many = np.repeat(np.stack(hyps[:4])[None], 8200, axis=0).reshape(-1, 4, 4)

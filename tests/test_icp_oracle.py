@@ -121,3 +121,36 @@ def test_ransac_fitness_restatement_against_ckdtree():
             assert s64 / cnt == pytest.approx(d2[d2 < lim].mean(), rel=1e-3)
         else:
             assert fit32 == np.finfo(np.float32).max
+
+
+def test_ransac_inlier_lists_and_information_restatement():
+    """getFitness's `inliers` / `inliers_target` and getInformation (RansacCurvature.h:680-695, :707-733) against an
+    independent statement: cKDTree matches and sum A^T A built with numpy from the float32 coordinates."""
+    (x0, n0), (x1, n1), P = make_pair(n=20000)
+    tgt, src = IcpOracle(x0, n0, 0.05), IcpOracle(x1, n1, 0.05)
+
+    def information(p):
+        A = np.zeros((len(p), 3, 6))
+        A[:, 0, 0] = A[:, 1, 1] = A[:, 2, 2] = 1.0
+        two = (np.float32(2) * p).astype(np.float64)                     # 2 * sz is a float product in the reference
+        A[:, 0, 4], A[:, 0, 5] = two[:, 2], -two[:, 1]
+        A[:, 1, 3], A[:, 1, 5] = -two[:, 2], two[:, 0]
+        A[:, 2, 3], A[:, 2, 4] = two[:, 1], -two[:, 0]
+        return np.einsum("nki,nkj->ij", A, A)
+
+    for M, thr in ((P.astype(np.float32), 0.05), (np.eye(4, dtype=np.float32), 0.02)):
+        ins, int_, info_s, info_t = src.ransac_inliers(tgt, M, thr)
+        cnt, _, _ = src.ransac_fitness(tgt, M, thr)
+        assert len(ins) == cnt and np.all(np.diff(ins) > 0)
+        q = ((M[:3, 0] * x1[:, :1] + M[:3, 1] * x1[:, 1:2]) + M[:3, 2] * x1[:, 2:3]) + M[:3, 3]
+        d, nn = cKDTree(x0.astype(np.float64)).query(q.astype(np.float64))
+        lim = float(np.float32(thr) * np.float32(thr))
+        sure = np.abs(d * d - lim) > 1e-6 * lim
+        mine = np.zeros(len(x1), bool)
+        mine[ins] = True
+        assert np.array_equal(mine[sure], (d * d < lim)[sure])
+        dd = np.linalg.norm(q[ins].astype(np.float64) - x0[int_].astype(np.float64), axis=1)
+        assert np.all(dd <= d[ins] * (1 + 1e-5) + 1e-7)                   # the listed target IS a nearest neighbour
+        assert np.allclose(info_s, information(x1[ins]), rtol=1e-12, atol=1e-9)
+        assert np.allclose(info_t, information(x0[int_]), rtol=1e-12, atol=1e-9)
+        assert info_s[0, 0] == cnt and np.allclose(info_s, info_s.T)
