@@ -460,6 +460,7 @@ int upload_frag_table(er_fopt_t h) {
 }
 
 int ensure_matrix(er_fopt_t h, size_t N) {
+  if (h->d_sys == h->d_JJ) h->factored = false;                  // the caller is about to overwrite a SLAC factor kept in d_JJ
   if (N * N <= h->jj_cap) return 0;
   if (h->d_JJ) (void)hipFree(h->d_JJ);
   if (h->d_Jb) (void)hipFree(h->d_Jb);
@@ -521,8 +522,9 @@ int er_fopt_create(int num, int resolution, float length, int device, er_fopt_t*
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&h->d_frags, (size_t)num * sizeof(FragPtr)) != hipSuccess ||
       hipMalloc((void**)&h->d_rot, (size_t)num * 9 * sizeof(double)) != hipSuccess ||
       hipMalloc((void**)&h->d_ctr, (size_t)h->nper * sizeof(double)) != hipSuccess || hipMalloc((void**)&h->d_M, 16 * sizeof(float)) != hipSuccess) {
+    const hipError_t e = hipGetLastError();
     er_fopt_destroy(h);
-    return er::fail("er_fopt_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    return er::fail("er_fopt_create: allocation failed: %s", hipGetErrorString(e));
   }
   if (upload_frag_table(h)) {
     er_fopt_destroy(h);
@@ -570,21 +572,23 @@ int er_fopt_set_cloud(er_fopt_t h, int frag, const float* xyz, const float* nrm,
   h->n_pairs = h->n_chunks = h->n_groups = 0;
   h->group_info.clear();
   h->factored = false;
+  const size_t mm = (size_t)std::max(m, 1);
+  const bool ok = hipMalloc((void**)&f.idx0, mm * sizeof(int)) == hipSuccess && hipMalloc((void**)&f.val, mm * 8 * sizeof(float)) == hipSuccess &&
+                  hipMalloc((void**)&f.nval, mm * 8 * sizeof(float)) == hipSuccess && hipMalloc((void**)&f.p, mm * 3 * sizeof(float)) == hipSuccess &&
+                  hipMalloc((void**)&f.nrm, mm * 3 * sizeof(float)) == hipSuccess &&
+                  (m == 0 || (hipMemcpy(f.idx0, idx0.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+                              hipMemcpy(f.val, val.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+                              hipMemcpy(f.nval, nval.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+                              hipMemcpy(f.p, p.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
+                              hipMemcpy(f.nrm, nn.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess));
+  if (!ok) {                                                     // leave an empty fragment behind, never a half-built one
+    const hipError_t e = hipGetLastError();
+    free_frag(f);
+    (void)upload_frag_table(h);
+    return er::fail("er_fopt_set_cloud: fragment %d (%d points): %s", frag, m, hipGetErrorString(e));
+  }
   f.n = m;
   f.h_idx0.assign(idx0.begin(), idx0.begin() + m);
-  const size_t mm = (size_t)std::max(m, 1);
-  ER_HIP_TRY(hipMalloc((void**)&f.idx0, mm * sizeof(int)));
-  ER_HIP_TRY(hipMalloc((void**)&f.val, mm * 8 * sizeof(float)));
-  ER_HIP_TRY(hipMalloc((void**)&f.nval, mm * 8 * sizeof(float)));
-  ER_HIP_TRY(hipMalloc((void**)&f.p, mm * 3 * sizeof(float)));
-  ER_HIP_TRY(hipMalloc((void**)&f.nrm, mm * 3 * sizeof(float)));
-  if (m > 0) {
-    ER_HIP_TRY(hipMemcpy(f.idx0, idx0.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice));
-    ER_HIP_TRY(hipMemcpy(f.val, val.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice));
-    ER_HIP_TRY(hipMemcpy(f.nval, nval.data(), (size_t)m * 8 * sizeof(float), hipMemcpyHostToDevice));
-    ER_HIP_TRY(hipMemcpy(f.p, p.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
-    ER_HIP_TRY(hipMemcpy(f.nrm, nn.data(), (size_t)m * 3 * sizeof(float), hipMemcpyHostToDevice));
-  }
   return upload_frag_table(h);
 }
 
@@ -675,16 +679,14 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
     if (p) (void)hipFree(p);
   h->d_first = h->d_second = nullptr;
   h->d_chunks = nullptr;
-  h->n_pairs = n_pairs;
-  h->n_chunks = (int)chunks.size();
-  h->n_groups = (int)ginfo.size() / 4;
-  h->group_info.swap(ginfo);
+  h->n_pairs = h->n_chunks = h->n_groups = 0;                    // an upload failure below leaves "no correspondences", not dangling lists
+  h->n_corr = 0;
+  h->group_info.clear();
   if (h->d_ginfo) {
     (void)hipFree(h->d_ginfo);
     h->d_ginfo = nullptr;
   }
   h->factored = false;
-  h->n_corr = (long)first.size();
   if (!first.empty()) {
     ER_HIP_TRY(hipMalloc((void**)&h->d_first, first.size() * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&h->d_second, second.size() * sizeof(int)));
@@ -693,6 +695,11 @@ int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, con
     ER_HIP_TRY(hipMemcpy(h->d_second, second.data(), second.size() * sizeof(int), hipMemcpyHostToDevice));
     ER_HIP_TRY(hipMemcpy(h->d_chunks, chunks.data(), chunks.size() * sizeof(Chunk), hipMemcpyHostToDevice));
   }
+  h->n_pairs = n_pairs;
+  h->n_chunks = (int)chunks.size();
+  h->n_groups = (int)ginfo.size() / 4;
+  h->group_info.swap(ginfo);
+  h->n_corr = (long)first.size();
   return 0;
 }
 
@@ -756,8 +763,8 @@ static int factor_common(er_fopt_t h, double* A, long n) {
     (void)hipFree(h->d_rhs);
     h->d_rhs = nullptr;
   }
-  ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)n * sizeof(double)));
   if (n > 2147483647L) return er::fail("system too large for rocSOLVER (%ld unknowns)", n);
+  ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)n * sizeof(double)));
   if (h->roc.dpotrf(h->roc.handle, kFillLower, (int)n, A, (int)n, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed");
   int info = 0;
   ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -85,6 +85,18 @@ def test_rigid_and_slac_assembly_match_oracle(gpu):
     _close(JJ, J0, "SLAC JJ (2)"); _close(Jb, b0, "SLAC Jb (2)")
     with pytest.raises(Exception):
         g.SetCorrespondences([(0, 1, np.array([[10 ** 8, 0]], np.int32))])
+    # the factor of er_fopt_factor_slac lives in the matrix the assembly calls fill: a later assembly must invalidate it
+    g.FactorSLAC(Rt, 1000.0)
+    x = g.Solve(np.ones(6 * sc["num"] + g.nper_))
+    assert np.all(np.isfinite(x))
+    g.AssembleSLAC(Rt)
+    with pytest.raises(Exception, match="no factored system"):
+        g.Solve(np.ones(6 * sc["num"] + g.nper_))
+    g.FactorSLAC(Rt, 1000.0)
+    assert np.allclose(g.Solve(np.ones(6 * sc["num"] + g.nper_)), x, rtol=1e-9, atol=1e-12)
+    g.AssembleRigid()
+    with pytest.raises(Exception, match="no factored system"):
+        g.Solve(np.ones(6 * sc["num"] + g.nper_))
 
 
 def test_rigid_optimisation_recovers_poses(gpu):
