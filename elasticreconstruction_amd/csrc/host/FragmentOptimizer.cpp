@@ -235,7 +235,7 @@ class COptApp {                                     // OptApp.h:39-124
         FILE* f = fopen(fn, "r");
         if (!f) { fprintf(stderr, "File not found ... Check dir and num parameters.\n"); return false; }
         char buf[1024];
-        float x[6];
+        float x[6] = {0, 0, 0, 0, 0, 0};
         while (fgets(buf, 1024, f))
           if (strlen(buf) > 0 && buf[0] != '#') {     // PointCloud.cpp:49-52
             sscanf(buf, "%f %f %f %f %f %f", &x[0], &x[1], &x[2], &x[3], &x[4], &x[5]);
@@ -256,7 +256,9 @@ class COptApp {                                     // OptApp.h:39-124
     std::vector<int> fi, fj, counts;
     std::vector<std::vector<int>> rows;
     for (const auto& t : reg_traj_) {
-      if (blacklist_.count(t.id1) || blacklist_.count(t.id2) || t.id1 >= (int)absolute2relative_map_.size() || t.id2 >= (int)absolute2relative_map_.size()) continue;
+      if (t.id1 < 0 || t.id2 < 0 || blacklist_.count(t.id1) || blacklist_.count(t.id2) || t.id1 >= (int)absolute2relative_map_.size() ||
+          t.id2 >= (int)absolute2relative_map_.size())
+        continue;
       if (t.frame != -1 && t.frame >= blacklist_pair_num_) {
         char fn[1024];
         snprintf(fn, sizeof fn, "%scorres_%d_%d.txt", dir_prefix_.c_str(), t.id1, t.id2);
@@ -610,6 +612,7 @@ int print_help() {
          "    --blasklist <blacklist_file>    : each line is the block we want to blacklist\n"
          "    --blacklistpair <threshold>     : threshold of accepting pairwise registration, default - 10000\n"
          "    --ipose <log_file>              : get ipose from log file\n"
+         "    --write_xyzn_sample <sample_num>: per <sample_num> write a point into sample.pcd\n"
          "    --device <id>, --dense_limit <n>: (new) HIP device; largest system solved densely in the non-rigid mode\n"
          "Optimization options:\n"
          "    --nonrigid                      : default, nonrigid alignment published in ICCV 2013\n"
