@@ -51,8 +51,25 @@ ER_HD float scale_lambda(int x, int y, const Camera& c) {
   return sqrtf((xl * xl + yl * yl) + 1.0f);
 }
 
+// x / 1000.f (TSDFVolume.cpp:30) as q + (x - 1000 q) r, r = RN(1/1000) -- 3 full-rate operations instead of the 11 of the
+// IEEE sequence with its half-rate v_rcp_f32 (see band_quotient_core below for the float64 twin).  x = (float)d * lambda with
+// an integer d in [0, 65535] and lambda = sqrtf( .. + 1.0f ) >= 1 (or inf / NaN for a degenerate camera), so x is +0, >= 1,
+// +inf or NaN; tests/test_hostcheck.py compares core and '/' for EVERY such float: identical bits, given the +inf patch
+// (q*1000 - inf is NaN).  Below 1 the core may differ (the residual underflows) -- unreachable, see above.
+ER_HD float div1000_core(float x) {
+  const float r = 1.0f / 1000.0f;                            // folded, correctly rounded
+  const float q = x * r;
+  const float e = fmaf(-q, 1000.0f, x);
+  const float q2 = fmaf(e, r, q);
+  return x == __builtin_inff() ? x : q2;
+}
+
 ER_HD float scale_depth_px(uint16_t d, float lambda, float integration_trunc) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  float res = div1000_core((float)d * lambda);
+#else
   float res = ((float)d * lambda) / 1000.f;
+#endif
   return (res > integration_trunc) ? 0.0f : res;
 }
 
@@ -188,6 +205,28 @@ ER_HD float sqrt_inrange(float x) {
 #endif
 }
 
+// (double)sdf / tsdf_trunc_ (TSDFVolume.cpp:88) without the IEEE division sequence (v_div_scale x2, v_rcp_f64 -- quarter
+// rate --, 5 fma, v_div_fmas, v_div_fixup): with r = RN(1/c), q = RN(x*r), e = x - q*c (exact in one fma) the value
+// RN(q + e*r) is the correctly rounded quotient (Markstein's correction step; q is within 1 ulp of x/c).  The theorem's
+// side conditions are not argued here but CHECKED: tests/test_hostcheck.py evaluates core and '/' for every float in
+// [-0.03f, 0.03f] -- the only arguments voxel_finish passes -- and they agree bit for bit as DOUBLES for all of them except
+// x = -0 (core +0, '/' -0), which "dp - dist" with dp > 0.001 cannot produce (x - x is +0 in round-to-nearest).
+ER_HD double band_quotient_core(float sdf) {
+  const double x = (double)sdf;
+  const double r = 1.0 / kTsdfTrunc;                         // folded at compile time, correctly rounded
+  const double q = x * r;
+  const double e = fma(-q, kTsdfTrunc, x);
+  return fma(e, r, q);
+}
+
+ER_HD double band_quotient(float sdf) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+  return band_quotient_core(sdf);
+#else
+  return (double)sdf / kTsdfTrunc;
+#endif
+}
+
 // TSDFVolume::round (TSDFVolume.h:70-72) of a float expression plus the image-range test of :80, in float32:
 //   p = floor( (double)x + 0.5 ),  0 <= p < lim    <=>    -0.5 <= x < lim - 0.5
 // (x + 0.5 is exact in float64 and both bounds are floats, so the two float compares decide exactly; NaN fails).
@@ -236,6 +275,20 @@ ER_HD bool voxel_project(float g0, float g1, float g2, const FrameXform& f, cons
   return (t2 > 0.0f) & vx & vy;                                          // :77,:80
 }
 
+// voxel_project for a voxel of a patch that patch_may_update has proven "inside" (below): t2 lies in the division core's
+// domain and both image-range tests are true, so only the pixel is computed -- by the very same operations.
+ER_HD unsigned voxel_project_inside(float g0, float g1, float g2, const FrameXform& f, const Camera& c, int cols, int rows) {
+  const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
+  const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
+  const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
+  float qu, qv;
+  div2_inrange(t0 * c.fx, t1 * c.fy, t2, qu, qv);
+  int px, py;
+  (void)pixel_index(qu + c.cx, (float)cols - 0.5f, px);
+  (void)pixel_index(qv + c.cy, (float)rows - 0.5f, py);
+  return (unsigned)(py * cols + px);
+}
+
 ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float g2, const FrameXform& f) {
   const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
   const float d2 = (rx * rx + ry * ry) + rz * rz;
@@ -255,7 +308,7 @@ ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float 
   // the value is identical either way.
   float tsdf = 1.0f;
   if (sdf <= 0.03f) {
-    const float q = (float)((double)sdf / kTsdfTrunc);
+    const float q = (float)band_quotient(sdf);
     tsdf = q < 1.0f ? q : 1.0f;
   }
   // :93  (w == 1.0f, w * tsdf == tsdf).  W + 1 is an integer-valued float in [1, 2^25]; the numerator is 0 or at
@@ -286,8 +339,26 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 //   * M = max of the scaled depth over the 32x32-pixel tiles under the box is <= 0.001 -> :82 fails everywhere
 //   * M - (distance from the camera centre to the rectangle) < -trunc - 1e-4          -> :87 fails everywhere
 // tile_max: per frame, tiles_x * tiles_y floats written by k_prepare.  Returns false only if provably dead.
+//
+// *inside (second verdict, for the frames that stay): true only if EVERY voxel of the patch provably passes the tests of
+// voxel_project -- t2 > 0, t2 inside [2^-30, 2^30], -0.5 <= u < cols - 0.5, -0.5 <= v < rows - 0.5 -- so that k_integrate may
+// run voxel_project_inside for the patch.  Proof sketch (u = 2^-24; T_k the exact affine forms, t_k their float values):
+//   * |t_k - T_k| <= gamma_4 A_k with A_k = sum of the magnitudes of the four terms over the patch; e_k = 2^-21 A_k (= 8u A_k,
+//     evaluated in float) bounds it, at the corners and at every voxel alike.  Hence every voxel's t2 lies in
+//     [tau, t2max + 2 e2], tau = t2min - 2 e2 (corner values), and the test demands 2^-20 <= tau, t2max + 2 e2 <= 2^20.
+//   * With P = T0 fx / T2 (true u - cx):  |fl(fl(t0 fx) / t2) - P| <= (fx e0 + |P| e2) / tau * (1 + 2.01u) + 2.2u |P|  when
+//     e2 / tau <= 2^-12 (demanded), and adding cx costs another u (|P| + |cx|): every computed u, corner or voxel, is within
+//     s_u = 1.0625 (fx e0 + ua e2) / tau + 2^-20 (ua + |cx| + 1) of its true value, where ua = 1.001 Q + 1 >= max |P| and Q is
+//     the largest computed |u_corner - cx| (P is projective-linear on the rectangle, so its extremes are at corners; the
+//     corner errors are absorbed by the 1.001 and the + 1 because s_u <= 1/8 is demanded).
+//   * A planar rectangle in front of the camera projects into the convex hull of its corners, so every voxel's computed u
+//     lies in [umin - 2 s_u, umax + 2 s_u] of the computed corner values; with s_u <= 1/8 the demand 0.5 <= umin and
+//     umax <= cols - 1.5 puts it inside [0.25, cols - 1.25].  Same for v.
+// NaNs anywhere make a comparison false and the verdict false.  tests/hostcheck cross-checks every "inside" voxel of the golden
+// and fuzz scenes against voxel_project itself.
 ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
-                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y) {
+                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
+  *inside = false;
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
   for (int a = 0; a < 2; a++) {
     const float g1 = a ? g1hi : g1lo;
@@ -322,6 +393,19 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
   const float dz = f.tz < g2lo ? g2lo - f.tz : (f.tz > g2hi ? f.tz - g2hi : 0.0f);
   const float dmin = sqrtf((dx * dx + dy * dy) + dz * dz);
   if (dmax_tile - dmin < -(float)kTsdfTrunc - 1e-4f) return false;   // every voxel is behind the surface by more than trunc
+  {
+    const float a0 = fabsf(g0), G1 = fmaxf(fabsf(g1lo), fabsf(g1hi)), G2 = fmaxf(fabsf(g2lo), fabsf(g2hi));
+    const float e0 = 0x1p-21f * (((fabsf(f.mi[0]) * a0 + fabsf(f.mi[1]) * G1) + fabsf(f.mi[2]) * G2) + fabsf(f.mi[3]));
+    const float e1 = 0x1p-21f * (((fabsf(f.mi[4]) * a0 + fabsf(f.mi[5]) * G1) + fabsf(f.mi[6]) * G2) + fabsf(f.mi[7]));
+    const float e2 = 0x1p-21f * (((fabsf(f.mi[8]) * a0 + fabsf(f.mi[9]) * G1) + fabsf(f.mi[10]) * G2) + fabsf(f.mi[11]));
+    const float tau = t2min - 2.0f * e2;
+    const float ua = 1.001f * fmaxf(fabsf(umin - c.cx), fabsf(umax - c.cx)) + 1.0f;
+    const float va = 1.001f * fmaxf(fabsf(vmin - c.cy), fabsf(vmax - c.cy)) + 1.0f;
+    const float su = 1.0625f * (fabsf(c.fx) * e0 + ua * e2) / tau + 0x1p-20f * ((ua + fabsf(c.cx)) + 1.0f);
+    const float sv = 1.0625f * (fabsf(c.fy) * e1 + va * e2) / tau + 0x1p-20f * ((va + fabsf(c.cy)) + 1.0f);
+    *inside = (tau >= 0x1p-20f) & (t2max + 2.0f * e2 <= 0x1p20f) & (e2 * 4096.0f <= tau) & (su <= 0.125f) & (sv <= 0.125f) &
+              (umin >= 0.5f) & (umax <= (float)cols - 1.5f) & (vmin >= 0.5f) & (vmax <= (float)rows - 1.5f);
+  }
   return true;
 }
 

@@ -1,5 +1,5 @@
 // GPU check of the exact arithmetic cores used by the voxel update (er_tsdf_math.h) against hipcc's IEEE
-// operators, EXHAUSTIVELY where the domain is one float (sqrt, pixel rounding) and on 2^31 hashed operand
+// operators, EXHAUSTIVELY where the domain is one float (sqrt, pixel rounding, the two constant divisions) and on 2^31 hashed operand
 // triples per division scenario.  Test infrastructure: built by tests/conftest.py, run by tests/test_tsdf_gpu.py.
 // Prints one line per check "name tested mismatches" and exits non-zero on any mismatch.
 #include <hip/hip_runtime.h>
@@ -50,6 +50,29 @@ __global__ void k_pixel_all() {
     }
   }
   atomicAdd(&g_bad[1], bad); atomicAdd(&g_cnt[1], cnt);
+}
+
+// band_quotient_core vs the float64 '/' for every float in [-0.03f, 0.03f] except -0 (unreachable, see er_tsdf_math.h);
+// div1000_core vs '/' for +0 and every float >= 1 including +inf (NaN in, NaN out).
+__global__ void k_const_div_all() {
+  unsigned long long bad5 = 0, cnt5 = 0, bad6 = 0, cnt6 = 0;
+  const uint32_t top = __float_as_uint(0.03f);
+  for (uint64_t b = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < (1ull << 32); b += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t u = (uint32_t)b;
+    const float x = __uint_as_float(u);
+    if ((u & 0x7fffffffu) <= top && u != 0x80000000u) {
+      const double got = band_quotient_core(x), ref = (double)x / kTsdfTrunc;
+      ++cnt5;
+      bad5 += __double_as_longlong(got) != __double_as_longlong(ref);
+    }
+    if (u == 0u || (u >= 0x3f800000u && u <= 0x7fffffffu)) {
+      const float got = div1000_core(x), ref = x / 1000.f;
+      ++cnt6;
+      bad6 += (ref != ref) ? !(got != got) : (__float_as_uint(got) != __float_as_uint(ref));
+    }
+  }
+  atomicAdd(&g_bad[5], bad5); atomicAdd(&g_cnt[5], cnt5);
+  atomicAdd(&g_bad[6], bad6); atomicAdd(&g_cnt[6], cnt6);
 }
 
 // Hashed operand triples.
@@ -111,6 +134,7 @@ int main() {
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_nex), zu, sizeof zu);
   hipLaunchKernelGGL(k_sqrt_all, dim3(4096), dim3(256), 0, 0);
   hipLaunchKernelGGL(k_pixel_all, dim3(4096), dim3(256), 0, 0);
+  hipLaunchKernelGGL(k_const_div_all, dim3(4096), dim3(256), 0, 0);
   for (int m = 0; m < 3; ++m) hipLaunchKernelGGL(k_div, dim3(4096), dim3(256), 0, 0, m, 1ull << 31);
   if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failure\n"); return 2; }
   unsigned long long bad[8], cnt[8];
@@ -119,9 +143,9 @@ int main() {
   float ex[8][4][4]; unsigned nex[8];
   (void)hipMemcpyFromSymbol(ex, HIP_SYMBOL(g_ex), sizeof ex);
   (void)hipMemcpyFromSymbol(nex, HIP_SYMBOL(g_nex), sizeof nex);
-  const char* names[5] = {"sqrt_inrange", "pixel_index", "div_projection", "div_weight", "div_camera"};
+  const char* names[7] = {"sqrt_inrange", "pixel_index", "div_projection", "div_weight", "div_camera", "band_quotient", "div1000"};
   int rc = 0;
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < 7; ++i) {
     printf("%s tested %llu mismatches %llu\n", names[i], cnt[i], bad[i]);
     for (unsigned k = 0; k < nex[i] && k < 4; ++k)
       fprintf(stderr, "  %s: n=%a d=%a core=%a operator=%a\n", names[i], ex[i][k][0], ex[i][k][1], ex[i][k][2], ex[i][k][3]);

@@ -14,7 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
-struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -96,11 +96,15 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
       for (int j0 = 0; j0 < 64; j0 += 4) {
         // the same (4 rows x 64 voxels, frame) culling k_integrate applies before its frame loop
         std::vector<int> frames;
+        std::vector<char> in;
         for (int f : u.frames) {
+          bool inside = false;
           if (patch_may_update(grid_coord(i, xs), grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs),
-                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y)) {
+                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside)) {
             frames.push_back(f);
+            in.push_back(inside);
             kept++;
+            v->inside += inside;
           } else {
             culled++;
           }
@@ -109,8 +113,22 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           for (int k = 0; k < 64; k++) {
             const int l = (i * 64 + j) * 64 + k;
             float S = u.sdf[l], W = u.w[l];
-            for (int f : frames)
-              voxel_update(S, W, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), fx[f], v->cam, v->cols, v->rows, scaled[f].data());
+            const float g0 = grid_coord(i, xs), g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
+            for (size_t q = 0; q < frames.size(); q++) {
+              const int f = frames[q];
+              if (in[q]) {                                  // k_integrate's shortcut, cross-checked against the full test
+                const unsigned pixel = voxel_project_inside(g0, g1, g2, fx[f], v->cam, v->cols, v->rows);
+                unsigned ref_pixel = 0;
+                const float t2 = ((fx[f].mi[8] * g0 + fx[f].mi[9] * g1) + fx[f].mi[10] * g2) + fx[f].mi[11];
+                if (!voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, ref_pixel) || ref_pixel != pixel ||
+                    !(t2 >= 0x1p-30f && t2 <= 0x1p30f) || pixel >= (unsigned)px)
+                  v->inside_violations++;
+                else
+                  voxel_finish(S, W, scaled[f][pixel], g0, g1, g2, fx[f]);
+              } else {
+                voxel_update(S, W, g0, g1, g2, fx[f], v->cam, v->cols, v->rows, scaled[f].data());
+              }
+            }
             u.sdf[l] = S; u.w[l] = W;
           }
       }
@@ -121,6 +139,8 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
 }
 
 long hc_culled(void* h) { return static_cast<HcVolume*>(h)->culled; }
+long hc_inside(void* h) { return static_cast<HcVolume*>(h)->inside; }
+long hc_inside_violations(void* h) { return static_cast<HcVolume*>(h)->inside_violations; }
 long hc_kept(void* h) { return static_cast<HcVolume*>(h)->kept; }
 int hc_unit_count(void* h) { return (int)static_cast<HcVolume*>(h)->units.size(); }
 void hc_unit_keys(void* h, int* keys) { int n = 0; for (auto& kv : static_cast<HcVolume*>(h)->units) keys[n++] = kv.first; }
@@ -131,6 +151,35 @@ int hc_read_unit(void* h, int key, float* sdf, float* w) {
   memcpy(sdf, it->second.sdf.data(), kUnitVox * sizeof(float));
   memcpy(w, it->second.w.data(), kUnitVox * sizeof(float));
   return 0;
+}
+
+// band_quotient_core against the IEEE division it replaces on the device, for every float whose magnitude bits lie in
+// [lo, hi], both signs, compared as float64 bit patterns.  Returns the number of mismatches, the first one in *first.
+long hc_band_quotient_check(unsigned lo, unsigned hi, unsigned* first) {
+  long bad = 0;
+  for (unsigned long long u = lo; u <= hi; u++)
+    for (unsigned s = 0; s < 2; s++) {
+      const unsigned bits = (unsigned)u | (s << 31);
+      float x;
+      memcpy(&x, &bits, 4);
+      const double a = (double)x / kTsdfTrunc, b = band_quotient_core(x);
+      if (memcmp(&a, &b, 8) != 0 && bad++ == 0 && first) *first = bits;
+    }
+  return bad;
+}
+
+// div1000_core against x / 1000.f for every float with bits in [lo, hi] (positive floats, +inf and the positive NaNs).
+long hc_div1000_check(unsigned lo, unsigned hi, unsigned* first) {
+  long bad = 0;
+  for (unsigned long long u = lo; u <= hi; u++) {
+    const unsigned bits = (unsigned)u;
+    float x;
+    memcpy(&x, &bits, 4);
+    const float a = x / 1000.f, b = div1000_core(x);
+    const bool same = (a != a) ? (b != b) : memcmp(&a, &b, 4) == 0;       // any NaN equals any NaN ("res > trunc" is false for all)
+    if (!same && bad++ == 0 && first) *first = bits;
+  }
+  return bad;
 }
 
 }  // extern "C"

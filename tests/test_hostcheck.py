@@ -38,16 +38,20 @@ def hc():
     L.hc_culled.argtypes = [vp]
     L.hc_kept.restype = C.c_long
     L.hc_kept.argtypes = [vp]
+    L.hc_inside.restype = C.c_long
+    L.hc_inside.argtypes = [vp]
+    L.hc_inside_violations.restype = C.c_long
+    L.hc_inside_violations.argtypes = [vp]
     L.hc_unit_keys.argtypes = [vp, vp]
     L.hc_read_unit.argtypes = [vp, C.c_int, vp, vp]
     return L
 
 
 class HcVolume:
-    def __init__(self, L, cam=None):
+    def __init__(self, L, cam=None, cols=640, rows=480):
         self.L = L
         self.cam = np.array([525.0, 525.0, 319.5, 239.5, 2.5, 2.5], np.float32) if cam is None else np.asarray(cam, np.float32)
-        self.h = vp(L.hc_create(640, 480, self.cam.ctypes.data_as(vp)))
+        self.h = vp(L.hc_create(cols, rows, self.cam.ctypes.data_as(vp)))
 
     def integrate(self, depth, T):
         depth = np.ascontiguousarray(depth, np.uint16)
@@ -92,6 +96,11 @@ def test_device_math_rigid_matches_golden(hc):
     # the exact (patch, frame) culling must both fire and change nothing
     culled, kept = hc.hc_culled(v.h), hc.hc_kept(v.h)
     assert culled > 0.15 * (culled + kept), "patch culling removed only %d of %d patch-frames" % (culled, culled + kept)
+    # ... and so must the "whole patch inside the image" verdict that lets k_integrate skip the per-voxel range tests:
+    # every voxel it covers was re-tested with the full voxel_project (same pixel, in range) by the host build
+    inside = hc.hc_inside(v.h)
+    print("patch-frames: %d culled, %d kept, %d of them inside (%.0f %%)" % (culled, kept, inside, 100.0 * inside / kept))
+    assert hc.hc_inside_violations(v.h) == 0 and inside > 0.4 * kept
 
 
 def test_device_math_warp_matches_golden(hc):
@@ -108,6 +117,7 @@ def test_device_math_warp_matches_golden(hc):
     v.integrate(np.stack(rep), sc["traj"])
     d = helpers.volume_digest(v)
     assert d["keys"] == g["keys"] and d["sha256"] == g["sha256"]
+    assert hc.hc_inside_violations(v.h) == 0 and hc.hc_inside(v.h) > 0
 
 
 def test_device_math_custom_camera_vs_oracle(hc):
@@ -119,3 +129,85 @@ def test_device_math_custom_camera_vs_oracle(hc):
     for i in range(3):
         ora.Integrate(depth[i], poses[i])
     helpers.assert_volumes_identical(v, ora, "hostcheck/custom camera")
+    assert hc.hc_inside_violations(v.h) == 0 and hc.hc_inside(v.h) > 0
+
+
+def test_band_quotient_core_equals_division_for_every_band_float(hc):
+    """The device evaluates (double)sdf / tsdf_trunc_ (TSDFVolume.cpp:88) as q + (x - q c) r with r = RN(1/c) (er_tsdf_math.h
+    band_quotient_core).  Checked here for EVERY float voxel_finish can pass, |sdf| <= 0.03f (2 x 1.02e9 values): the float64
+    results are identical except for x = -0, which "dp - dist" cannot produce."""
+    from concurrent.futures import ThreadPoolExecutor
+    hc.hc_band_quotient_check.restype = C.c_long
+    hc.hc_band_quotient_check.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_uint)]
+    top = int(np.float32(0.03).view(np.uint32))
+    assert float(np.float32(0.03)) < 0.03 < float(np.nextafter(np.float32(0.03), np.float32(1)))   # the band test's float bound
+    nchunk = 16
+    edges = np.linspace(0, top + 1, nchunk + 1).astype(np.int64)
+
+    def run(k):
+        first = C.c_uint(0)
+        bad = hc.hc_band_quotient_check(int(edges[k]), int(edges[k + 1] - 1), C.byref(first))
+        return bad, first.value
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(run, range(nchunk)))
+    assert sum(b for b, _ in res) == 1 and res[0] == (1, 0x80000000), res       # only -0
+
+
+def test_div1000_core_equals_division_on_its_whole_domain(hc):
+    """ScaleDepth's x / 1000.f (TSDFVolume.cpp:30) is evaluated on the device as q + (x - 1000 q) r (er_tsdf_math.h div1000_core).
+    x = (float)d * lambda is +0, >= 1, +inf or NaN; every such float is compared here (1.07e9 values)."""
+    from concurrent.futures import ThreadPoolExecutor
+    hc.hc_div1000_check.restype = C.c_long
+    hc.hc_div1000_check.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_uint)]
+    one, last = int(np.float32(1).view(np.uint32)), 0x7FFFFFFF
+    edges = np.linspace(one, last + 1, 17).astype(np.int64)
+
+    def run(k):
+        first = C.c_uint(0)
+        return hc.hc_div1000_check(int(edges[k]), int(edges[k + 1] - 1), C.byref(first)), hex(first.value)
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(run, range(16)))
+    assert all(b == 0 for b, _ in res), res
+    first = C.c_uint(0)
+    assert hc.hc_div1000_check(0, 0, C.byref(first)) == 0                      # +0
+    # and what the domain argument excludes really does differ somewhere below 1 (so the argument is needed)
+    assert hc.hc_div1000_check(1, 1 << 20, C.byref(first)) > 0                   # denormal x: the residual underflows
+
+
+def test_device_math_randomised_configurations_vs_oracle(hc):
+    """CPU twin of tests/test_tsdf_gpu.py::test_randomised_configurations_bit_exact for the per-voxel arithmetic and the two
+    patch verdicts (culling, "inside"): odd image sizes, off-centre / zero principal points, anisotropic and very short focal
+    lengths, cameras anywhere in and around the room (voxels behind and next to the camera plane), holes and salt noise, and a
+    scene pushed 40 m away from the origin (large coordinates = large rounding slop in the projection).  Bit-exact against
+    the oracle, and every voxel covered by an "inside" verdict re-tested with the full projection."""
+    rng = np.random.default_rng(77)
+    total_inside = 0
+    for case in range(6):
+        cols, rows = int(rng.integers(48, 160)), int(rng.integers(40, 120))
+        fx, fy = (float(rng.uniform(20, 45)), float(rng.uniform(20, 45))) if case == 4 else (float(rng.uniform(60, 260)), float(rng.uniform(60, 260)))
+        cx = 0.0 if case == 3 else float(rng.uniform(0.2, 0.8) * cols)
+        cam = np.array([fx, fy, cx, float(rng.uniform(0.2, 0.8) * rows), 2.5, float(rng.uniform(1.0, 3.5))], np.float32)
+        n = int(rng.integers(2, 5))
+        poses = []
+        for _ in range(n):
+            P = synth.look_at(tuple(rng.uniform(0.3, 2.7, 3)), tuple(rng.uniform(0.0, 3.0, 3)))
+            poses.append(P @ synth.perturbation(int(rng.integers(1 << 30)), 20.0, 0.0))
+        poses = np.stack(poses)
+        depth = synth.to_numpy_u16(synth.render_depth(poses, cols=cols, rows=rows, cam=tuple(float(c) for c in cam[:4]))).copy()
+        depth[rng.random(depth.shape) < 0.05] = 0
+        salt = rng.random(depth.shape) < 0.01
+        depth[salt] = rng.integers(1, 9000, int(salt.sum()), dtype=np.uint16)
+        if case == 5:                                         # the same views of a room standing 40 m from the origin
+            shift = np.eye(4)
+            shift[:3, 3] = (40.0, -35.0, 38.0)
+            poses = np.stack([shift @ P for P in poses])
+        v, ora = HcVolume(hc, cam, cols, rows), OracleVolume(cols, rows, cam)
+        v.integrate(depth, poses)
+        for f in range(n):
+            ora.Integrate(depth[f], poses[f])
+        helpers.assert_volumes_identical(v, ora, "hostcheck fuzz case %d (%dx%d)" % (case, cols, rows))
+        assert hc.hc_inside_violations(v.h) == 0, case
+        total_inside += hc.hc_inside(v.h)
+    assert total_inside > 0

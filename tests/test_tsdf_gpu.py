@@ -296,7 +296,8 @@ def test_full_config2_batching_invariance(gpu):
 @pytest.mark.gpu
 def test_exact_arithmetic_cores_exhaustive(gpu):
     """The voxel update replaces hipcc's IEEE '/' and sqrtf by their un-wrapped cores and the float64 pixel rounding
-    by a float32 form (er_tsdf_math.h: div2_inrange, div_inrange, sqrt_inrange, pixel_index).  tests/hip/arith_check
+    by a float32 form, and the two divisions by constants (/ tsdf_trunc_, / 1000.f) by a multiply + Markstein correction
+    (er_tsdf_math.h: div2_inrange, div_inrange, sqrt_inrange, pixel_index, band_quotient_core, div1000_core).  tests/hip/arith_check
     compares them ON THE GPU with the plain operators: every float for sqrt and pixel rounding (two image limits),
     2^31 hashed operand triples per division scenario.  Zero mismatches required."""
     import subprocess
@@ -306,7 +307,7 @@ def test_exact_arithmetic_cores_exhaustive(gpu):
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l.split() for l in r.stdout.strip().splitlines()]
-    assert len(lines) == 5 and all(int(l[2]) > 10 ** 9 and int(l[4]) == 0 for l in lines), r.stdout
+    assert len(lines) == 7 and all(int(l[2]) > 10 ** 9 and int(l[4]) == 0 for l in lines), r.stdout
 
 
 def test_randomised_configurations_bit_exact(gpu):
