@@ -182,14 +182,14 @@ def test_device_math_randomised_configurations_vs_oracle(hc):
     lengths, cameras anywhere in and around the room (voxels behind and next to the camera plane), holes and salt noise, and a
     scene pushed 40 m away from the origin (large coordinates = large rounding slop in the projection).  Bit-exact against
     the oracle, and every voxel covered by an "inside" verdict re-tested with the full projection."""
-    rng = np.random.default_rng(77)
     total_inside = 0
-    for case in range(6):
+    for case in range(6):                                     # 3: cx == 0, 4: very short focal lengths, 5: far from the origin
+        rng = np.random.default_rng(7700 + case)
         cols, rows = int(rng.integers(48, 160)), int(rng.integers(40, 120))
         fx, fy = (float(rng.uniform(20, 45)), float(rng.uniform(20, 45))) if case == 4 else (float(rng.uniform(60, 260)), float(rng.uniform(60, 260)))
         cx = 0.0 if case == 3 else float(rng.uniform(0.2, 0.8) * cols)
         cam = np.array([fx, fy, cx, float(rng.uniform(0.2, 0.8) * rows), 2.5, float(rng.uniform(1.0, 3.5))], np.float32)
-        n = int(rng.integers(2, 5))
+        n = int(rng.integers(2, 4))
         poses = []
         for _ in range(n):
             P = synth.look_at(tuple(rng.uniform(0.3, 2.7, 3)), tuple(rng.uniform(0.0, 3.0, 3)))
@@ -197,7 +197,7 @@ def test_device_math_randomised_configurations_vs_oracle(hc):
         poses = np.stack(poses)
         depth = synth.to_numpy_u16(synth.render_depth(poses, cols=cols, rows=rows, cam=tuple(float(c) for c in cam[:4]))).copy()
         depth[rng.random(depth.shape) < 0.05] = 0
-        salt = rng.random(depth.shape) < 0.01
+        salt = rng.random(depth.shape) < 0.002               # every salt pixel touches a 64^3 unit of its own: keep them few
         depth[salt] = rng.integers(1, 9000, int(salt.sum()), dtype=np.uint16)
         if case == 5:                                         # the same views of a room standing 40 m from the origin
             shift = np.eye(4)
