@@ -65,7 +65,7 @@ ER_HD float div1000_core(float x) {
 }
 
 ER_HD float scale_depth_px(uint16_t d, float lambda, float integration_trunc) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV) && !defined(ER_PLAIN_CONST_DIV)
   float res = div1000_core((float)d * lambda);
 #else
   float res = ((float)d * lambda) / 1000.f;
@@ -220,7 +220,7 @@ ER_HD double band_quotient_core(float sdf) {
 }
 
 ER_HD double band_quotient(float sdf) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV) && !defined(ER_PLAIN_CONST_DIV)
   return band_quotient_core(sdf);
 #else
   return (double)sdf / kTsdfTrunc;
