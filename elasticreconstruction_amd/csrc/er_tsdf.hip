@@ -823,6 +823,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   }
   h->cami.inv_fx = 1.0 / (double)h->cam.fx;
   h->cami.inv_fy = 1.0 / (double)h->cam.fy;
+  h->cami.pp_small = (std::fabs((double)h->cam.cx) < 1e6 && std::fabs((double)h->cam.cy) < 1e6) ? 1 : 0;
+  h->cami.pad = 0;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) h->n_cu = prop.multiProcessorCount;
   int cap = 1024, lg = 10;

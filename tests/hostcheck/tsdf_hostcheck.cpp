@@ -24,6 +24,7 @@ void* hc_create(int cols, int rows, const float* cam6) {
   HcVolume* v = new HcVolume();
   v->cam = Camera{cam6[0], cam6[1], cam6[2], cam6[3], cam6[4], cam6[5]};
   v->cami.inv_fx = 1.0 / (double)v->cam.fx; v->cami.inv_fy = 1.0 / (double)v->cam.fy;
+  v->cami.pp_small = (std::fabs((double)v->cam.cx) < 1e6 && std::fabs((double)v->cam.cy) < 1e6) ? 1 : 0; v->cami.pad = 0;
   v->cols = cols; v->rows = rows;
   return v;
 }
