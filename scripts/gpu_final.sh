@@ -11,7 +11,7 @@ echo "== t=${SECONDS}s bench"
 BT=$((LIMIT - SECONDS - 5)); [ $BT -gt 200 ] && BT=200; [ $BT -lt 20 ] && BT=20
 timeout $BT python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; tail -1 gpurun_out/bench_default_$TAG.json | cut -c1-700
 echo "== t=${SECONDS}s A/B"
-if [ $SECONDS -lt $((LIMIT - 110)) ]; then bash scripts/ab_libs.sh 1 main r01s noinside plainconst > gpurun_out/ab_$TAG.txt 2>&1; cat gpurun_out/ab_$TAG.txt; fi
+if [ $SECONDS -lt $((LIMIT - 110)) ]; then bash scripts/ab_libs.sh ${AB_REPS:-1} ${AB_LIST:-main r01s} > gpurun_out/ab_$TAG.txt 2>&1; cat gpurun_out/ab_$TAG.txt; fi
 echo "== t=${SECONDS}s stats"
 if [ $SECONDS -lt $((LIMIT - 60)) ]; then bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -12; fi
 echo "== t=${SECONDS}s pmc"
