@@ -371,7 +371,14 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
       const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
       const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
       const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
+#if defined(__HIP_DEVICE_COMPILE__) && defined(ER_FAST_CULL)
+      // (experiment, off by default: the 1-ulp hardware reciprocal is enough for tests whose margins are 1.5 px and whose
+      //  "inside" slack budgets 16u where 3.3u + 4u are needed; not measured yet with the pre-pass chain as the critical one)
+      const float rt2 = __builtin_amdgcn_rcpf(t2);
+      const float u = (t0 * c.fx) * rt2 + c.cx, v = (t1 * c.fy) * rt2 + c.cy;
+#else
       const float u = t0 * c.fx / t2 + c.cx, v = t1 * c.fy / t2 + c.cy;
+#endif
       t2min = fminf(t2min, t2);
       t2max = fmaxf(t2max, t2);
       umin = fminf(umin, u); umax = fmaxf(umax, u);
