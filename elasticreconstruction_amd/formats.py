@@ -200,6 +200,70 @@ def lzf_decompress(src, out_len):
     return bytes(out[:op])
 
 
+def lzf_compress(data):
+    """LZF encoder (the stream lzf_decompress / PCL's binary_compressed reader take): greedy matcher over a hash of 3-byte
+    strings, back references of 3..264 bytes up to 8192 bytes back, literal runs of up to 32 bytes.  Pure Python -- meant
+    for the sample-sized clouds this package writes, the C++ programs have their own (csrc/host/er_formats.h)."""
+    src = bytes(data)
+    n = len(src)
+    out = bytearray()
+    last = {}
+    lit = 0
+    i = 0
+
+    def flush(end):
+        nonlocal lit
+        while lit < end:
+            run = min(32, end - lit)
+            out.append(run - 1)
+            out.extend(src[lit:lit + run])
+            lit += run
+
+    while i + 2 < n:
+        key = src[i:i + 3]
+        ref = last.get(key, -1)
+        last[key] = i
+        if ref >= 0 and i - ref <= 8192:
+            cap = min(n - i, 264)
+            ln = 3
+            while ln < cap and src[ref + ln] == src[i + ln]:
+                ln += 1
+            flush(i)
+            back, l = i - ref - 1, ln - 2
+            if l < 7:
+                out.append((l << 5) | (back >> 8))
+            else:
+                out.append((7 << 5) | (back >> 8))
+                out.append(l - 7)
+            out.append(back & 0xFF)
+            for k in range(i + 1, min(i + ln, n - 2)):
+                last[src[k:k + 3]] = k
+            i += ln
+            lit = i
+        else:
+            i += 1
+    flush(n)
+    return bytes(out)
+
+
+def save_pcd_compressed(path, fields):
+    """pcl::PCDWriter::writeBinaryCompressed layout (FragmentOptimizer's sample.pcd, OptApp.cpp:921-922): `fields` is an
+    ordered mapping name -> float32 column; columns are stored one after another, LZF-compressed, behind the two sizes."""
+    names = list(fields)
+    cols = [np.ascontiguousarray(fields[k], np.float32).reshape(-1) for k in names]
+    n = cols[0].shape[0] if cols else 0
+    assert all(c.shape[0] == n for c in cols)
+    raw = b"".join(c.tobytes() for c in cols)
+    packed = lzf_compress(raw)
+    k = len(names)
+    with open(path, "wb") as f:
+        f.write(("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS %s\nSIZE %s\nTYPE %s\nCOUNT %s\nWIDTH %d\nHEIGHT 1\n"
+                 "VIEWPOINT 0 0 0 1 0 0 0\nPOINTS %d\nDATA binary_compressed\n"
+                 % (" ".join(names), " ".join(["4"] * k), " ".join(["F"] * k), " ".join(["1"] * k), n, n)).encode("ascii"))
+        f.write(np.array([len(packed), len(raw)], np.uint32).tobytes())
+        f.write(packed)
+
+
 def load_pcd(path):
     """Reads ascii / binary / binary_compressed PCD v0.7 with an arbitrary field list
     (format per Matlab_Toolbox/External/matpcl/loadpcd.m:33-224).  Returns dict field -> 1-D array."""

@@ -2,6 +2,7 @@
 // and round-trips a byte file through lzf_compress / lzf_decompress.
 //   pcd_compressed_check pcd <raw_f32> <n_points> <out.pcd> <field> [<field> ...]
 //   pcd_compressed_check lzf <in_bytes> <out_bytes>      (prints the compressed size)
+//   pcd_compressed_check read <in.pcd> <out_raw_f32> <field> [<field> ...]   (the programs' PCD reader; prints the point count)
 #include "../../elasticreconstruction_amd/csrc/host/er_formats.h"
 
 int main(int argc, char** argv) {
@@ -15,6 +16,18 @@ int main(int argc, char** argv) {
     std::vector<const float*> cols;
     for (size_t c = 0; c < names.size(); c++) cols.push_back(raw.data() + c * n);
     return erfmt::save_pcd_compressed(argv[4], names, cols, n) ? 0 : 3;
+  }
+  if (argc >= 5 && std::string(argv[1]) == "read") {
+    std::vector<std::string> names(argv + 4, argv + argc);
+    std::vector<std::vector<float>> cols;
+    size_t n = 0;
+    if (!erfmt::load_pcd_fields(argv[2], names, cols, n)) return 5;
+    FILE* f = fopen(argv[3], "wb");
+    for (auto& c : cols)
+      if (n) fwrite(c.data(), 4, n, f);
+    fclose(f);
+    printf("%zu\n", n);
+    return 0;
   }
   if (argc == 4 && std::string(argv[1]) == "lzf") {
     FILE* f = fopen(argv[2], "rb");

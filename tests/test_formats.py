@@ -103,3 +103,32 @@ def test_host_program_compressed_pcd_writer(tmp_path):
         assert packed <= len(blob) + len(blob) // 32 + 1
         if k in (4, 5, 8):
             assert packed < len(blob) // 10
+
+
+def test_python_compressed_pcd_writer_against_the_programs_reader(tmp_path):
+    """formats.lzf_compress / save_pcd_compressed (pure Python) read back by this package's reader AND by the C++ programs'
+    reader (csrc/host/er_formats.h load_pcd_fields); byte-level round trips of the encoder on its edge cases."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pcc")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(here, "cpp", "pcd_compressed_check.cpp"), "-lz", "-o", exe], check=True)
+    rng = np.random.RandomState(5)
+    for blob in (b"", b"a", b"ab", b"abc", b"a" * 1000, b"abcabcabc" * 500, rng.bytes(20000), bytes(9000) + b"tail"):
+        packed = formats.lzf_compress(blob)
+        assert formats.lzf_decompress(packed, len(blob)) == blob
+        assert len(packed) <= len(blob) + len(blob) // 32 + 1
+    names = ["x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb", "curvature"]
+    for n in (0, 1, 2500):
+        cols = {k: rng.randn(n).astype(np.float32) for k in names}
+        cols["rgb"][:] = 0
+        cols["curvature"][:] = 0
+        p = str(tmp_path / ("py%d.pcd" % n))
+        formats.save_pcd_compressed(p, cols)
+        d = formats.load_pcd(p)
+        assert all(np.array_equal(d[k], cols[k]) for k in names)
+        raw = str(tmp_path / "cols.bin")
+        r = subprocess.run([exe, "read", p, raw] + names, check=True, capture_output=True, text=True)
+        assert int(r.stdout) == n
+        back = np.fromfile(raw, np.float32).reshape(len(names), n)
+        assert all(np.array_equal(back[i], cols[k]) for i, k in enumerate(names))
