@@ -37,6 +37,40 @@ def test_no_cpu_fallback():
         TSDFVolume()
 
 
+def test_host_programs_and_every_constructor_refuse_to_run_without_a_gpu(tmp_path):
+    """The three drop-in programs, the clouds and the FragmentOptimizer handle: an error message and a non-zero exit /
+    an exception, never a computation on the host."""
+    import subprocess
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from elasticreconstruction_amd import formats
+    from elasticreconstruction_amd.icp import Cloud
+    from elasticreconstruction_amd.fopt import FragmentOptimizer
+    x = (np.random.default_rng(0).random((100, 3)) * 2 + 0.2).astype(np.float32)
+    n = np.tile(np.array([0, 0, 1], np.float32), (100, 1))
+    with pytest.raises(_ffi.ErError):
+        Cloud(x, n, 0.05)
+    with pytest.raises(_ffi.ErError):
+        FragmentOptimizer(2, 8, 3.0)
+    d = str(tmp_path)
+    eye = np.eye(4)
+    formats.save_log(os.path.join(d, "traj.log"), [formats.FramedTransformation(0, 0, 1, eye), formats.FramedTransformation(1, 1, 2, eye)])
+    formats.save_log(os.path.join(d, "reg.log"), [formats.FramedTransformation(0, 1, 2, eye)])
+    np.zeros((2, 480 * 640), np.uint16).tofile(os.path.join(d, "frames.raw"))
+    for i in range(2):
+        formats.save_pcd_xyzn(os.path.join(d, "cloud_bin_%d.pcd" % i), x, n)
+    bin_ = os.path.join(ROOT, "elasticreconstruction_amd", "bin")
+    for cmd in (["Integrate", "--ref_traj", "traj.log", "-oni", "frames.raw"],
+                ["BuildCorrespondence", "--reg_traj", "reg.log", "--registration"],
+                ["FragmentOptimizer", "--rigid", "--num", "2", "--registration", "reg.log", "--rgbdslam", "traj.log", "--interval", "1", "--dir", "./"]):
+        r = subprocess.run([os.path.join(bin_, cmd[0])] + cmd[1:], cwd=d, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "no HIP device" in r.stderr, (cmd[0], r.returncode, r.stderr)
+        assert not os.path.exists(os.path.join(d, "world.pcd")) and not os.path.exists(os.path.join(d, "reg_output.log")) \
+            and not os.path.exists(os.path.join(d, "pose.log"))
+
+
 def test_product_never_imports_oracle():
     """The product path must not reference oracle/ (only tests/, smoke() and bench.py's cpu_baseline may)."""
     pkg = os.path.join(ROOT, "elasticreconstruction_amd")
