@@ -154,3 +154,33 @@ def test_ransac_inlier_lists_and_information_restatement():
         assert np.allclose(info_s, information(x1[ins]), rtol=1e-12, atol=1e-9)
         assert np.allclose(info_t, information(x0[int_]), rtol=1e-12, atol=1e-9)
         assert info_s[0, 0] == cnt and np.allclose(info_s, info_s.T)
+
+
+def test_single_icp_step_equals_an_independent_point_to_plane_least_squares():
+    """One iteration of the restated ICP (max_iter = 1) against an independent statement of the published step (Low 2004 /
+    PCL's TransformationEstimationPointToPlaneLLS): cKDTree correspondences within max_dist, rows [s x n, n] and right-hand
+    sides n . (d - s), numpy's least-squares solution, and the rotation Rz(gamma) Ry(beta) Rx(alpha) of the six parameters."""
+    (x0, n0), (x1, n1), P = make_pair(n=30000, rot=1.0, trans=0.01)
+    tgt, src = IcpOracle(x0, n0, 0.03), IcpOracle(x1, n1, 0.03)
+    for guess in (np.eye(4), P @ synth.perturbation(3, 0.3, 0.003)):
+        g32 = guess.astype(np.float32)
+        T1, it, conv, _ = src.align(tgt, g32, max_dist=0.03, max_iter=1)
+        assert it == 1
+        s = ((g32[:3, 0] * x1[:, :1] + g32[:3, 1] * x1[:, 1:2]) + g32[:3, 2] * x1[:, 2:3]) + g32[:3, 3] if not np.array_equal(g32, np.eye(4, dtype=np.float32)) else x1
+        s = s.astype(np.float64)
+        d, j = cKDTree(x0.astype(np.float64)).query(s)
+        keep = d <= 0.03 * (1 - 1e-6)
+        s, q, nn = s[keep], x0[j[keep]].astype(np.float64), n0[j[keep]].astype(np.float64)
+        A = np.concatenate([np.cross(s, nn), nn], axis=1)
+        b = np.einsum("ij,ij->i", nn, q - s)
+        x = np.linalg.lstsq(A, b, rcond=None)[0]
+        ca, sa, cb, sb, cg, sg = np.cos(x[0]), np.sin(x[0]), np.cos(x[1]), np.sin(x[1]), np.cos(x[2]), np.sin(x[2])
+        Rx = np.array([[1, 0, 0], [0, ca, -sa], [0, sa, ca]])
+        Ry = np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]])
+        Rz = np.array([[cg, -sg, 0], [sg, cg, 0], [0, 0, 1]])
+        D = np.eye(4)
+        D[:3, :3], D[:3, 3] = Rz @ Ry @ Rx, x[3:]
+        want = D @ guess
+        assert np.abs(T1.astype(np.float64) - want).max() < 2e-6, np.abs(T1 - want).max()
+        # and the step goes the right way
+        assert np.abs((D @ guess)[:3, 3] - P[:3, 3]).max() <= np.abs(guess[:3, 3] - P[:3, 3]).max() + 1e-9
