@@ -3,6 +3,8 @@
 //   pcd_compressed_check pcd <raw_f32> <n_points> <out.pcd> <field> [<field> ...]
 //   pcd_compressed_check lzf <in_bytes> <out_bytes>      (prints the compressed size)
 //   pcd_compressed_check read <in.pcd> <out_raw_f32> <field> [<field> ...]   (the programs' PCD reader; prints the point count)
+//   pcd_compressed_check png <in.png> <out_raw_u16>      (the programs' depth PNG reader; prints "w h")
+//   pcd_compressed_check pngw <in_raw_u16> <w> <h> <out.png>
 #include "../../elasticreconstruction_amd/csrc/host/er_formats.h"
 
 int main(int argc, char** argv) {
@@ -28,6 +30,24 @@ int main(int argc, char** argv) {
     fclose(f);
     printf("%zu\n", n);
     return 0;
+  }
+  if (argc == 4 && std::string(argv[1]) == "png") {
+    int w = 0, h = 0;
+    std::vector<uint16_t> px;
+    if (!erfmt::load_png16(argv[2], w, h, px)) return 6;
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(px.data(), 2, px.size(), f);
+    fclose(f);
+    printf("%d %d\n", w, h);
+    return 0;
+  }
+  if (argc == 6 && std::string(argv[1]) == "pngw") {
+    const int w = atoi(argv[3]), h = atoi(argv[4]);
+    std::vector<uint16_t> px((size_t)w * h);
+    FILE* f = fopen(argv[2], "rb");
+    if (!f || fread(px.data(), 2, px.size(), f) != px.size()) return 2;
+    fclose(f);
+    return erfmt::save_png16(argv[5], w, h, px.data()) ? 0 : 7;
   }
   if (argc == 4 && std::string(argv[1]) == "lzf") {
     FILE* f = fopen(argv[2], "rb");

@@ -132,3 +132,45 @@ def test_python_compressed_pcd_writer_against_the_programs_reader(tmp_path):
         assert int(r.stdout) == n
         back = np.fromfile(raw, np.float32).reshape(len(names), n)
         assert all(np.array_equal(back[i], cols[k]) for i, k in enumerate(names))
+
+
+def test_host_program_depth_png_reader_and_writer(tmp_path):
+    """load_png16 / save_png16 of csrc/host/er_formats.h (Integrate --depth_list) against Pillow: 16-bit and 8-bit grayscale,
+    every PNG filter type (smooth ramps make the encoder pick Sub / Up / Average / Paeth), odd sizes; interlaced and colour
+    files are refused."""
+    import os
+    import subprocess
+    from PIL import Image
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pcc")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(here, "cpp", "pcd_compressed_check.cpp"), "-lz", "-o", exe], check=True)
+    rng = np.random.RandomState(9)
+    yy, xx = np.mgrid[0:61, 0:83]
+    images = [rng.randint(0, 65536, (480, 640)).astype(np.uint16),
+              ((xx * 37 + yy * 101) % 65536).astype(np.uint16),                       # ramps
+              (1000 + 500 * np.sin(xx / 7.0) * np.cos(yy / 5.0)).astype(np.uint16),   # smooth
+              np.zeros((1, 1), np.uint16), np.full((3, 5), 65535, np.uint16)]
+    for k, img in enumerate(images):
+        p = str(tmp_path / ("d%d.png" % k))
+        Image.fromarray(img).save(p, optimize=bool(k % 2))
+        raw = str(tmp_path / "px.bin")
+        r = subprocess.run([exe, "png", p, raw], check=True, capture_output=True, text=True)
+        assert r.stdout.split() == [str(img.shape[1]), str(img.shape[0])]
+        assert np.array_equal(np.fromfile(raw, np.uint16).reshape(img.shape), img), k
+        # the writer, read back by Pillow
+        img.tofile(raw)
+        q = str(tmp_path / ("w%d.png" % k))
+        subprocess.run([exe, "pngw", raw, str(img.shape[1]), str(img.shape[0]), q], check=True)
+        assert np.array_equal(np.asarray(Image.open(q)).astype(np.uint16), img), k
+    p8 = str(tmp_path / "g8.png")
+    g8 = rng.randint(0, 256, (20, 31)).astype(np.uint8)
+    Image.fromarray(g8).save(p8)
+    raw = str(tmp_path / "px8.bin")
+    subprocess.run([exe, "png", p8, raw], check=True, capture_output=True)
+    assert np.array_equal(np.fromfile(raw, np.uint16).reshape(g8.shape), g8.astype(np.uint16))
+    rgb = str(tmp_path / "rgb.png")
+    Image.fromarray(rng.randint(0, 256, (8, 8, 3)).astype(np.uint8)).save(rgb)
+    assert subprocess.run([exe, "png", rgb, raw], capture_output=True).returncode != 0
+    with open(str(tmp_path / "junk.png"), "wb") as f:
+        f.write(b"not a png at all")
+    assert subprocess.run([exe, "png", str(tmp_path / "junk.png"), raw], capture_output=True).returncode != 0
