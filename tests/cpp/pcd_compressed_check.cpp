@@ -5,6 +5,9 @@
 //   pcd_compressed_check read <in.pcd> <out_raw_f32> <field> [<field> ...]   (the programs' PCD reader; prints the point count)
 //   pcd_compressed_check png <in.png> <out_raw_u16>      (the programs' depth PNG reader; prints "w h")
 //   pcd_compressed_check pngw <in_raw_u16> <w> <h> <out.png>
+//   pcd_compressed_check log <in.log> <out.log>          (load_log -> save_log; prints the entry count)
+//   pcd_compressed_check ctr <in.ctr> <num> <res> <out_raw_f32>
+//   pcd_compressed_check camera <in.txt> <out_raw_f32>   (6 floats)
 #include "../../elasticreconstruction_amd/csrc/host/er_formats.h"
 
 int main(int argc, char** argv) {
@@ -48,6 +51,28 @@ int main(int argc, char** argv) {
     if (!f || fread(px.data(), 2, px.size(), f) != px.size()) return 2;
     fclose(f);
     return erfmt::save_png16(argv[5], w, h, px.data()) ? 0 : 7;
+  }
+  if (argc == 4 && std::string(argv[1]) == "log") {
+    std::vector<erfmt::FramedTransformation> v;
+    if (!erfmt::load_log(argv[2], v) || !erfmt::save_log(argv[3], v)) return 8;
+    printf("%zu\n", v.size());
+    return 0;
+  }
+  if (argc == 6 && std::string(argv[1]) == "ctr") {
+    std::vector<float> g;
+    if (!erfmt::load_ctr(argv[2], atoi(argv[3]), atoi(argv[4]), g)) return 9;
+    FILE* f = fopen(argv[5], "wb");
+    fwrite(g.data(), 4, g.size(), f);
+    fclose(f);
+    return 0;
+  }
+  if (argc == 4 && std::string(argv[1]) == "camera") {
+    float cam[6];
+    erfmt::load_camera(argv[2], cam);
+    FILE* f = fopen(argv[3], "wb");
+    fwrite(cam, 4, 6, f);
+    fclose(f);
+    return 0;
   }
   if (argc == 4 && std::string(argv[1]) == "lzf") {
     FILE* f = fopen(argv[2], "rb");

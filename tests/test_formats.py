@@ -174,3 +174,48 @@ def test_host_program_depth_png_reader_and_writer(tmp_path):
     with open(str(tmp_path / "junk.png"), "wb") as f:
         f.write(b"not a png at all")
     assert subprocess.run([exe, "png", str(tmp_path / "junk.png"), raw], capture_output=True).returncode != 0
+
+
+def test_host_program_text_parsers_agree_with_the_python_mirror(tmp_path):
+    """load_log / save_log / load_ctr / load_camera of csrc/host/er_formats.h against formats.py on the same files, including
+    comment lines, a truncated last entry and a missing camera file (reference defaults, TSDFVolumeUnit.h:69)."""
+    import glob
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "pcc")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(here, "cpp", "pcd_compressed_check.cpp"), "-lz", "-o", exe], check=True)
+    rng = np.random.RandomState(2)
+    traj = [formats.FramedTransformation(i, i + 1, 10 * i, synth.perturbation(i, 30.0, 1.0)) for i in range(7)]
+    p = str(tmp_path / "t.log")
+    formats.save_log(p, traj)
+    with open(p) as f:
+        body = f.read()
+    with open(p, "w") as f:
+        f.write("# a comment where a header is expected\n" + body + "7\t8\t70\n1 0 0 0\n0 1 0 0\n")     # truncated entry at the end
+    out = str(tmp_path / "t2.log")
+    r = subprocess.run([exe, "log", p, out], check=True, capture_output=True, text=True)
+    assert int(r.stdout) == 7
+    back, mine = formats.load_log(out), formats.load_log(p)
+    assert len(back) == 7 and len(mine) == 7
+    for a, b, c in zip(traj, back, mine):
+        assert (a.id1, a.id2, a.frame) == (b.id1, b.id2, b.frame) == (c.id1, c.id2, c.frame)
+        assert np.abs(a.T - b.T).max() < 2e-8 and np.abs(a.T - c.T).max() < 1e-8
+    for ref_log in sorted(glob.glob("/root/reference/Matlab_Toolbox/Example/Data/**/*.log", recursive=True))[:3]:
+        r = subprocess.run([exe, "log", ref_log, out], check=True, capture_output=True, text=True)
+        mine = formats.load_log(ref_log)
+        back = formats.load_log(out)
+        assert int(r.stdout) == len(mine) == len(back) and all(np.abs(a.T - b.T).max() < 2e-8 for a, b in zip(mine, back))
+    grids = rng.randn(2, 125, 3).astype(np.float32)
+    pc = str(tmp_path / "g.ctr")
+    formats.save_ctr(pc, grids)
+    raw = str(tmp_path / "g.bin")
+    subprocess.run([exe, "ctr", pc, "2", "4", raw], check=True)
+    assert np.array_equal(np.fromfile(raw, np.float32).reshape(2, 125, 3), formats.load_ctr(pc, 2, 4))
+    cam = np.array([517.25, 516.5, 318.625, 255.375, 2.5, 1.75], np.float32)
+    pcam = str(tmp_path / "cam.txt")
+    formats.save_camera(pcam, cam)
+    subprocess.run([exe, "camera", pcam, raw], check=True, capture_output=True)
+    assert np.array_equal(np.fromfile(raw, np.float32), cam) and np.array_equal(formats.load_camera(pcam), cam)
+    subprocess.run([exe, "camera", str(tmp_path / "absent.txt"), raw], check=True, capture_output=True)
+    assert np.array_equal(np.fromfile(raw, np.float32), np.array([525, 525, 319.5, 239.5, 2.5, 2.5], np.float32))
