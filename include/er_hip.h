@@ -3,6 +3,9 @@
  *
  *   path A  TSDF depth integration with control-grid warp   (reference: Integrate/)
  *   path B  pairwise ICP refinement + correspondences       (reference: BuildCorrespondence/)
+ * and, after those two, the first rows of SURVEY.md 8f:
+ *   RansacCurvature::getFitness / getInformation             (reference: GlobalRegistration/RansacCurvature.h)
+ *   COptApp's per-point state, Hessian assembly and solve    (reference: FragmentOptimizer/OptApp.cpp, PointCloud.h)
  *
  * The reference has no FFI; its boundary is "executable + argv + files" (SURVEY.md 8b).  These
  * entry points are the thin C ABI the new host programs (and any cgo/JNI/ctypes caller) bind.
