@@ -211,3 +211,33 @@ def test_device_math_randomised_configurations_vs_oracle(hc):
         assert hc.hc_inside_violations(v.h) == 0, case
         total_inside += hc.hc_inside(v.h)
     assert total_inside > 0
+
+
+def test_device_reproject_randomised_grids_vs_oracle(hc):
+    """CPU twin of the warp half of the GPU fuzz test: CIntegrateApp::Reproject (IntegrateApp.cpp:236-268) through the device
+    header -- division-free cube coordinates, fused pixel rounding, their guards and exact fall-backs -- against the oracle for
+    randomly deformed control grids, off-centre cameras, holes and salt noise, at the 640 x 480 the reference's bounds assume."""
+    for case in range(3):
+        rng = np.random.default_rng(9100 + case)
+        cam = np.array([float(rng.uniform(400, 650)), float(rng.uniform(400, 650)), 0.0 if case == 2 else float(rng.uniform(200, 440)),
+                        float(rng.uniform(150, 330)), 2.5, 2.5], np.float32)
+        poses = np.stack([synth.look_at(tuple(rng.uniform(0.5, 2.5, 3)), tuple(rng.uniform(0.2, 2.8, 3))) @
+                          synth.perturbation(int(rng.integers(1 << 30)), 15.0, 0.0) for _ in range(2)])
+        depth = synth.to_numpy_u16(synth.render_depth(poses, cam=tuple(float(c) for c in cam[:4]))).copy()
+        depth[rng.random(depth.shape) < 0.05] = 0
+        salt = rng.random(depth.shape) < 0.002
+        depth[salt] = rng.integers(1, 12000, int(salt.sum()), dtype=np.uint16)
+        res, length = 8, 3.0
+        k, j, i = np.meshgrid(np.arange(res + 1), np.arange(res + 1), np.arange(res + 1), indexing="ij")
+        base = np.stack([i.ravel(), j.ravel(), k.ravel()], 1) * (length / res)
+        grid = (base + rng.normal(0, 0.01 * (1 + 2 * case), base.shape)).astype(np.float32)
+        cube = synth.basepose()
+        seg = np.stack([cube @ np.linalg.inv(poses[0]) @ P for P in poses])
+        madj = np.stack([np.linalg.inv(poses[f]) @ poses[0] @ np.linalg.inv(seg[0]) for f in range(2)])
+        v, ora = HcVolume(hc, cam), OracleVolume(640, 480, cam)
+        for f in range(2):
+            mine = v.reproject(depth[f], grid, res, length, seg[f], madj[f])
+            want = ora.Reproject(depth[f], grid, res, np.float32(length), seg[f], madj[f])
+            assert np.array_equal(mine, np.asarray(want).reshape(-1)), "case %d frame %d: %d pixels differ" % (
+                case, f, int((mine != np.asarray(want).reshape(-1)).sum()))
+            assert (mine != 0).sum() > 1000
