@@ -154,6 +154,78 @@ int hc_read_unit(void* h, int key, float* sdf, float* w) {
   return 0;
 }
 
+// Stress of the "inside" verdict of patch_may_update on its own: random cameras (focal lengths 20..2000 px, any principal
+// point, images 32..1280 x 32..960), random poses up to 90 m from the origin, patches placed so that they straddle image
+// borders and the camera plane as often as they sit inside.  Whenever the verdict says "inside", all 256 voxels of the patch
+// are re-tested with the full voxel_project.  Returns the number of violations; *n_inside = verdicts that said "inside".
+long hc_inside_stress(unsigned long long seed, long n, long* n_inside) {
+  unsigned long long st = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  auto rnd = [&]() {                                          // xorshift64*, uniform in [0, 1)
+    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+    return (double)((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+  };
+  long viol = 0, ins = 0;
+  for (long it = 0; it < n; it++) {
+    const int cols = 32 + (int)(rnd() * 1249), rows = 32 + (int)(rnd() * 929);
+    Camera cam;
+    cam.fx = (float)(20.0 * pow(100.0, rnd()));
+    cam.fy = (float)(20.0 * pow(100.0, rnd()));
+    cam.cx = (float)(rnd() < 0.1 ? 0.0 : rnd() * cols);
+    cam.cy = (float)(rnd() * rows);
+    cam.icp_trunc = 2.5f; cam.integration_trunc = 2.5f;
+    // random rotation from a unit quaternion, camera centre within a cube of half-width R
+    double q[4], nq = 0;
+    for (double& c : q) { c = rnd() * 2 - 1; nq += c * c; }
+    nq = sqrt(nq) + 1e-300;
+    for (double& c : q) c /= nq;
+    const double Rm[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
+                          2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
+                          2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
+    const double Rw = rnd() < 0.5 ? 3.0 : (rnd() < 0.5 ? 30.0 : 90.0);
+    const double t[3] = {(rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw};
+    FrameXform f;
+    for (int r = 0; r < 3; r++) {                             // inverse pose: [R^T | -R^T t]
+      for (int c = 0; c < 3; c++) f.mi[r * 4 + c] = (float)Rm[c * 3 + r];
+      f.mi[r * 4 + 3] = (float)(-(Rm[0 * 3 + r] * t[0] + Rm[1 * 3 + r] * t[1] + Rm[2 * 3 + r] * t[2]));
+    }
+    f.tx = (float)t[0]; f.ty = (float)t[1]; f.tz = (float)t[2]; f.pad = 0.f;
+    // a world point seen at pixel (pu, pv) -- anywhere from well outside to well inside the image -- at depth D
+    const double pu = (rnd() * 1.6 - 0.3) * cols, pv = (rnd() * 1.6 - 0.3) * rows, D = 0.01 * pow(3000.0, rnd());
+    const double pc[3] = {(pu - cam.cx) / cam.fx * D, (pv - cam.cy) / cam.fy * D, D};
+    double pw[3];
+    for (int r = 0; r < 3; r++) pw[r] = Rm[r * 3] * pc[0] + Rm[r * 3 + 1] * pc[1] + Rm[r * 3 + 2] * pc[2] + t[r];
+    int vi[3];
+    bool ok = true;
+    for (int r = 0; r < 3; r++) {
+      vi[r] = (int)floor(pw[r] / kUnitLength) + 256 * 64;     // voxel index in [0, 512 * 64)
+      ok = ok && vi[r] >= 0 && vi[r] < 512 * 64;
+    }
+    if (!ok) continue;
+    const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
+    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~3;
+    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
+    std::vector<float> tile_max((size_t)tiles_x * tiles_y, 1.0e4f);   // "depth everywhere": the culling half never fires
+    bool inside = false;
+    const float g0 = grid_coord(i, xs);
+    if (!patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs), f, cam, cols, rows,
+                          tile_max.data(), tiles_x, tiles_y, &inside) || !inside)
+      continue;
+    ins++;
+    for (int j = j0; j < j0 + 4; j++)
+      for (int k = 0; k < 64; k++) {
+        const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
+        unsigned ref_pixel = 0;
+        const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
+        const unsigned pixel = voxel_project_inside(g0, g1, g2, f, cam, cols, rows);
+        if (!voxel_project(g0, g1, g2, f, cam, cols, rows, ref_pixel) || ref_pixel != pixel || !(t2 >= 0x1p-30f && t2 <= 0x1p30f) ||
+            pixel >= (unsigned)(cols * rows))
+          viol++;
+      }
+  }
+  if (n_inside) *n_inside = ins;
+  return viol;
+}
+
 // band_quotient_core against the IEEE division it replaces on the device, for every float whose magnitude bits lie in
 // [lo, hi], both signs, compared as float64 bit patterns.  Returns the number of mismatches, the first one in *first.
 long hc_band_quotient_check(unsigned lo, unsigned hi, unsigned* first) {
