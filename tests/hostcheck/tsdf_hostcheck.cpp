@@ -226,6 +226,88 @@ long hc_inside_stress(unsigned long long seed, long n, long* n_inside) {
   return viol;
 }
 
+// Stress of the culling verdict (patch_may_update == false must mean that NO voxel of the patch can be updated): random
+// cameras / poses / patches as above over random scaled-depth images (piecewise-constant tiles with noise, holes and values
+// placed right around the patch's own distance, so that "behind the surface by more than the truncation" is decided both ways).
+// Returns the number of voxels a dropped (patch, frame) pair would have updated; *n_dead = verdicts that dropped the pair.
+long hc_cull_stress(unsigned long long seed, long n, long* n_dead) {
+  unsigned long long st = seed * 0xD1B54A32D192ED03ull + 0x7654321ull;
+  auto rnd = [&]() {
+    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+    return (double)((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+  };
+  long wrong = 0, dead = 0;
+  std::vector<float> img, tile_max;
+  for (long it = 0; it < n; it++) {
+    const int cols = 32 + (int)(rnd() * 289), rows = 32 + (int)(rnd() * 209);
+    Camera cam;
+    cam.fx = (float)(20.0 * pow(30.0, rnd()));
+    cam.fy = (float)(20.0 * pow(30.0, rnd()));
+    cam.cx = (float)(rnd() * cols);
+    cam.cy = (float)(rnd() * rows);
+    cam.icp_trunc = 2.5f; cam.integration_trunc = 2.5f;
+    double q[4], nq = 0;
+    for (double& c : q) { c = rnd() * 2 - 1; nq += c * c; }
+    nq = sqrt(nq) + 1e-300;
+    for (double& c : q) c /= nq;
+    const double Rm[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
+                          2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
+                          2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
+    const double Rw = rnd() < 0.7 ? 3.0 : 40.0;
+    const double t[3] = {(rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw};
+    FrameXform f;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) f.mi[r * 4 + c] = (float)Rm[c * 3 + r];
+      f.mi[r * 4 + 3] = (float)(-(Rm[0 * 3 + r] * t[0] + Rm[1 * 3 + r] * t[1] + Rm[2 * 3 + r] * t[2]));
+    }
+    f.tx = (float)t[0]; f.ty = (float)t[1]; f.tz = (float)t[2]; f.pad = 0.f;
+    const double pu = (rnd() * 1.6 - 0.3) * cols, pv = (rnd() * 1.6 - 0.3) * rows;
+    const double D = (rnd() < 0.15 ? -1.0 : 1.0) * 0.02 * pow(150.0, rnd());     // some patches behind the camera
+    const double pc[3] = {(pu - cam.cx) / cam.fx * D, (pv - cam.cy) / cam.fy * D, D};
+    double pw[3];
+    for (int r = 0; r < 3; r++) pw[r] = Rm[r * 3] * pc[0] + Rm[r * 3 + 1] * pc[1] + Rm[r * 3 + 2] * pc[2] + t[r];
+    int vi[3];
+    bool ok = true;
+    for (int r = 0; r < 3; r++) {
+      vi[r] = (int)floor(pw[r] / kUnitLength) + 256 * 64;
+      ok = ok && vi[r] >= 0 && vi[r] < 512 * 64;
+    }
+    if (!ok) continue;
+    // scaled depth image: tiles around the patch's distance from the camera (+- a few truncation widths), noise, holes
+    const double dist = sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
+    img.assign((size_t)cols * rows, 0.f);
+    tile_max.assign((size_t)tiles_x * tiles_y, 0.f);
+    std::vector<float> tile_depth((size_t)tiles_x * tiles_y);
+    for (float& d : tile_depth) d = rnd() < 0.2 ? 0.f : (float)(dist + (rnd() * 2 - 1) * 0.2 * (rnd() < 0.5 ? 1.0 : 5.0));
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        float d = tile_depth[(size_t)(y / 32) * tiles_x + x / 32];
+        if (d > 0.f) d += (float)((rnd() * 2 - 1) * 0.01);
+        if (rnd() < 0.02) d = 0.f;
+        if (d < 0.f) d = 0.f;
+        img[(size_t)y * cols + x] = d;
+        float& m = tile_max[(size_t)(y / 32) * tiles_x + x / 32];
+        m = std::max(m, d);
+      }
+    const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
+    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~3;
+    const float g0 = grid_coord(i, xs);
+    bool inside = false;
+    if (patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs), f, cam, cols, rows,
+                         tile_max.data(), tiles_x, tiles_y, &inside))
+      continue;
+    dead++;
+    for (int j = j0; j < j0 + 4; j++)
+      for (int k = 0; k < 64; k++) {
+        float S = 0.25f, W = 3.0f;
+        if (voxel_update(S, W, g0, grid_coord(j, ys), grid_coord(k, zs), f, cam, cols, rows, img.data())) wrong++;
+      }
+  }
+  if (n_dead) *n_dead = dead;
+  return wrong;
+}
+
 // band_quotient_core against the IEEE division it replaces on the device, for every float whose magnitude bits lie in
 // [lo, hi], both signs, compared as float64 bit patterns.  Returns the number of mismatches, the first one in *first.
 long hc_band_quotient_check(unsigned lo, unsigned hi, unsigned* first) {

@@ -259,3 +259,22 @@ def test_inside_verdict_stress(hc):
         res = list(ex.map(run, range(1, 9)))
     assert sum(v for v, _ in res) == 0, res
     assert sum(n for _, n in res) > 20000, res                # the verdict does fire: the test is not vacuous
+
+
+def test_culling_verdict_stress(hc):
+    """patch_may_update == false on 80 000 random (camera, pose, patch, depth image) samples built so that every one of its four
+    reasons decides both ways (behind the camera, outside the image, no usable depth under the patch, behind the surface by more
+    than the truncation): a dropped (patch, frame) pair must not contain a single voxel that voxel_update would change."""
+    from concurrent.futures import ThreadPoolExecutor
+    hc.hc_cull_stress.restype = C.c_long
+    hc.hc_cull_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
+
+    def run(seed):
+        n_dead = C.c_long(0)
+        return hc.hc_cull_stress(seed, 10000, C.byref(n_dead)), n_dead.value
+
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(run, range(1, 9)))
+    assert sum(w for w, _ in res) == 0, res
+    dead = sum(n for _, n in res)
+    assert 8000 < dead < 72000, res                          # it decides both ways
