@@ -376,6 +376,13 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
       //  "inside" slack budgets 16u where 3.3u + 4u are needed; not measured yet with the pre-pass chain as the critical one)
       const float rt2 = __builtin_amdgcn_rcpf(t2);
       const float u = (t0 * c.fx) * rt2 + c.cx, v = (t1 * c.fy) * rt2 + c.cy;
+#elif defined(ER_FAST_CULL_HOSTSIM)
+      // tests only (tests/test_hostcheck.py): the same expression with a reciprocal that is off by ER_FAST_CULL_HOSTSIM ulps,
+      // the accuracy v_rcp_f32 guarantees, so that the verdicts can be stressed on the CPU before the variant is enabled
+      float rt2 = 1.0f / t2;
+      for (int s_ = 0; s_ < (ER_FAST_CULL_HOSTSIM < 0 ? -(ER_FAST_CULL_HOSTSIM) : (ER_FAST_CULL_HOSTSIM)); s_++)
+        rt2 = nextafterf(rt2, ER_FAST_CULL_HOSTSIM < 0 ? -3.0e38f : 3.0e38f);
+      const float u = (t0 * c.fx) * rt2 + c.cx, v = (t1 * c.fy) * rt2 + c.cy;
 #else
       const float u = t0 * c.fx / t2 + c.cx, v = t1 * c.fy / t2 + c.cy;
 #endif

@@ -278,3 +278,20 @@ def test_culling_verdict_stress(hc):
     assert sum(w for w, _ in res) == 0, res
     dead = sum(n for _, n in res)
     assert 8000 < dead < 72000, res                          # it decides both ways
+
+
+@pytest.mark.parametrize("ulps", [1, -1, 2, -2])
+def test_verdicts_survive_a_hardware_reciprocal(ulps, tmp_path):
+    """-DER_FAST_CULL (off by default; +1.5 % measured) evaluates the corner projections of patch_may_update with v_rcp_f32
+    instead of an IEEE division.  Before it is enabled: the same header compiled for the host with a reciprocal that is off by
+    1 or 2 ulps in either direction, under both verdict stress tests."""
+    src = os.path.join(HERE, "hostcheck", "tsdf_hostcheck.cpp")
+    out = str(tmp_path / "libhc_sim.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-DER_FAST_CULL_HOSTSIM=(%d)" % ulps, src, "-o", out], check=True)
+    L = C.CDLL(out)
+    for fn in (L.hc_inside_stress, L.hc_cull_stress):
+        fn.restype = C.c_long
+        fn.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
+    n_in, n_dead = C.c_long(0), C.c_long(0)
+    assert L.hc_inside_stress(11, 100000, C.byref(n_in)) == 0 and n_in.value > 5000
+    assert L.hc_cull_stress(12, 15000, C.byref(n_dead)) == 0 and n_dead.value > 2000
