@@ -71,6 +71,19 @@ def test_host_programs_and_every_constructor_refuse_to_run_without_a_gpu(tmp_pat
             and not os.path.exists(os.path.join(d, "pose.log"))
 
 
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/er_hip.h compiles as strict C99 and a C program linked against liber_hip.so runs: the boundary is a C ABI,
+    not a C++ or Python one (examples/abi_probe.c)."""
+    import subprocess
+    lib_dir = os.path.join(ROOT, "elasticreconstruction_amd")
+    exe = str(tmp_path / "abi_probe")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "abi_probe.c"), "-L", lib_dir, "-ler_hip", "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi " in r.stdout and ("no HIP device" in r.stdout or "empty volume: 0 units" in r.stdout), r.stdout
+
+
 def test_product_never_imports_oracle():
     """The product path must not reference oracle/ (only tests/, smoke() and bench.py's cpu_baseline may)."""
     pkg = os.path.join(ROOT, "elasticreconstruction_amd")
