@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("ER_HIP_LIB") or os.path.join(_HERE, "liber_hip.so")
 SYMBOLS = [
     "er_last_error", "er_device_count", "er_abi_version", "er_host_alloc", "er_host_free",
     "er_tsdf_create", "er_tsdf_destroy", "er_tsdf_set_stream", "er_tsdf_synchronize",
+    "er_tsdf_wait_event", "er_tsdf_reset", "er_tsdf_status", "er_tsdf_set_unit_shard", "er_unit_owner",
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
     "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
     "er_tsdf_extract_world", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
@@ -70,6 +71,11 @@ def lib():
     L.er_tsdf_destroy.argtypes = [vp]
     L.er_tsdf_set_stream.argtypes = [vp, vp]
     L.er_tsdf_synchronize.argtypes = [vp]
+    L.er_tsdf_wait_event.argtypes = [vp, vp]
+    L.er_tsdf_reset.argtypes = [vp]
+    L.er_tsdf_status.argtypes = [vp, ip, C.POINTER(C.c_long)]
+    L.er_tsdf_set_unit_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.er_unit_owner.argtypes = [C.c_int, C.c_int]
     L.er_tsdf_scale_depth.argtypes = [vp, vp, vp]
     L.er_tsdf_reproject.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp, vp]
     L.er_tsdf_integrate.argtypes = [vp, vp, vp]

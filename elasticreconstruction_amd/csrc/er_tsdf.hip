@@ -179,10 +179,16 @@ constexpr int kTileKeys = 96;
 
 // Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
 // returned 0) allocates the pool slot on first ever touch and appends the unit to the batch list.
+//
+// Unit-shard mode (the bit-exact multi-GPU alternative): with shard.y > 1 GPUs every GPU runs the pre-pass of
+// ALL frames but only owns -- allocates, integrates, reports -- the units with unit_owner(key) == shard.x.  Units are
+// disjoint (TSDFVolume.cpp:45-63) and each one still sees every frame in order, so the union over the GPUs equals the
+// single-GPU volume bit for bit; no collective touches the volume.
 __device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __restrict__ ht_slot,
                            unsigned long long* __restrict__ ht_mask, int cap_mask, int hash_shift,
                            int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ nbatch,
-                           int* __restrict__ counters) {
+                           int* __restrict__ counters, int2 shard) {
+  if (shard.y > 1 && unit_owner(key, shard.y) != shard.x) return;
   const int e = ht_find_or_insert(ht_key, cap_mask, hash_shift, key);
   if (e < 0) {
     atomicOr(&counters[C_TABLE_FULL], 1);
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max) {
+    int* __restrict__ counters, float* __restrict__ tile_max, int2 shard) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
   __shared__ float s_wmax[kPrepThreads / 64];
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       if (slot < kTileKeys) {
         s_keys[slot] = key;
       } else {                                                          // list full (pathological tile): go direct
-        touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters);
+        touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters, shard);
       }
     }
   }
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     const int k = s_keys[threadIdx.x];
     bool dup = false;
     for (int j = 0; j < (int)threadIdx.x; j++) dup = dup || (s_keys[j] == k);
-    if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters);
+    if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters, shard);
   }
 }
 
@@ -577,7 +583,10 @@ struct er_tsdf_s {
   er::CameraInv cami{};
   hipStream_t own_stream = nullptr, stream = nullptr;   // `stream` carries k_plan/k_integrate/k_reset and every other call
   hipStream_t aux_stream = nullptr;                       // pre-pass of the NEXT batch (reproject, prepare) runs here, overlapped
+  hipStream_t copy_stream = nullptr;                      // host depth -> depth_stage[parity], overlapped with both of the above
+  hipEvent_t copy_done[2] = {nullptr, nullptr};
   int n_cu = 256;
+  int shard_rank = 0, shard_world = 1;                    // unit-shard mode (er_tsdf_set_unit_shard)
   // device memory
   float2* pool = nullptr;
   int *ht_key = nullptr, *ht_slot = nullptr, *unit_key = nullptr, *counters = nullptr;
@@ -594,7 +603,7 @@ struct er_tsdf_s {
   void* pinned[2] = {nullptr, nullptr};                   // host staging of the per-batch constants
   int ht_cap = 0, ht_shift = 0;
   float *lambda = nullptr, *ctr = nullptr;
-  uint16_t* depth_stage = nullptr;
+  uint16_t* depth_stage[2] = {nullptr, nullptr};   // host frames of the batch in flight, by pipeline parity
   uint32_t *zbuf = nullptr, *lastzero = nullptr;
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr, *plan_entry = nullptr;
@@ -685,6 +694,7 @@ struct Staging {
 };
 
 int sync_all(er_tsdf_t h) {
+  ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
   ER_HIP_TRY(hipStreamSynchronize(h->aux_stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
@@ -759,7 +769,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch[p], nbatch, h->counters,
-                     h->tile_max[p]);
+                     h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
@@ -842,7 +852,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
     }                                                                                                \
   } while (0)
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      aux_create(&h->aux_stream) != hipSuccess) {
+      aux_create(&h->aux_stream) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
     return er::fail("er_tsdf_create: hipStreamCreate failed");
   }
@@ -850,6 +860,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   for (int q = 0; q < 2; q++) {
     if (hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->int_done[q], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->copy_done[q], hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&h->pinned[q], sizeof(Staging), hipHostMallocDefault) != hipSuccess) {
       er_tsdf_destroy(h);
       return er::fail("er_tsdf_create: event / pinned staging allocation failed");
@@ -865,7 +876,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   for (int q = 0; q < 2; q++) ER_ALLOC(h->batch[q], (size_t)cap * sizeof(int));
   ER_ALLOC(h->lambda, px * sizeof(float));
   for (int q = 0; q < 2; q++) ER_ALLOC(h->scaled[q], B * px * sizeof(float));
-  ER_ALLOC(h->depth_stage, B * px * sizeof(uint16_t));
+  for (int q = 0; q < 2; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
   ER_ALLOC(h->zbuf, B * px * sizeof(uint32_t));
   ER_ALLOC(h->lastzero, B * px * sizeof(uint32_t));
   for (int q = 0; q < 2; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
@@ -911,15 +922,20 @@ int er_tsdf_destroy(er_tsdf_t h) {
   }
   if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask[0], h->ht_mask[1], h->unit_key, h->counters, h->stats, h->batch[0],
-                  h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage, h->zbuf, h->lastzero, h->dstage[0],
+                  h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage[0], h->depth_stage[1], h->zbuf, h->lastzero, h->dstage[0],
                   h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch,
                   h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1]};
   for (int q = 0; q < 2; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
     if (h->int_done[q]) (void)hipEventDestroy(h->int_done[q]);
+    if (h->copy_done[q]) (void)hipEventDestroy(h->copy_done[q]);
     if (h->pinned[q]) (void)hipHostFree(h->pinned[q]);
   }
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (h->copy_stream) {
+    (void)hipStreamSynchronize(h->copy_stream);
+    (void)hipStreamDestroy(h->copy_stream);
+  }
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -946,8 +962,8 @@ int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_h
   ER_HIP_TRY(hipSetDevice(h->device));
   if (sync_all(h)) return 1;
   const size_t px = (size_t)h->pixels;
-  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_scale_depth, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->depth_stage,
+  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[0], depth_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_scale_depth, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->depth_stage[0],
                      h->lambda, h->scaled[0], h->pixels, h->cam.integration_trunc);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipMemcpyAsync(scaled_host, h->scaled[0], px * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -978,7 +994,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   if (sync_all(h)) return 1;                         // single-frame hook: runs alone on the main stream
   if (upload_ctr(h, ctr_host, (size_t)verts * 3, h->stream)) return 1;
   const int gi = 0;
-  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[0], depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
   double seg16[16] = {0};
   memcpy(seg16, seg, 12 * sizeof(double));
   er::cube_coord_deltas(seg16, h->cam, h->cols, h->rows, seg16 + 12);
@@ -987,14 +1003,14 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   ER_HIP_TRY(hipMemcpyAsync(h->grid_index, &gi, sizeof(int), hipMemcpyHostToDevice, h->stream));
   const float grid_ul = length / (float)resolution;
   const long total = (long)px;
-  const ReprojArgs RA{h->depth_stage, 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
+  const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
                       verts * 3, h->zbuf, h->lastzero, h->counters};
   hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, 1), dim3(kBlock), 0, h->stream, RA);
   hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, h->stream, RA);
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
-                     h->depth_stage, total);
+                     h->depth_stage[0], total);
   ER_HIP_TRY(hipGetLastError());
-  ER_HIP_TRY(hipMemcpyAsync(depth_inout_host, h->depth_stage, px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(depth_inout_host, h->depth_stage[0], px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1011,15 +1027,26 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
     if (upload_ctr(h, warp->ctr, verts * 3 * (size_t)warp->num_grids, h->aux_stream)) return 1;
   }
   const size_t px = (size_t)h->pixels;
-  for (int start = 0; start < n; start += ER_MAX_BATCH) {
-    const int nb = std::min(ER_MAX_BATCH, n - start);
+  // n frames are fused in ceil(n / ER_MAX_BATCH) launches of (nearly) EQUAL size: 150 frames run as 3 x 50, not 64 + 64 + 22
+  // (a voxel is loaded once per launch, so the short tail launch would pay the full volume traffic for a third of the frames)
+  const int launches = (n + ER_MAX_BATCH - 1) / ER_MAX_BATCH;
+  const int per = launches > 0 ? (n + launches - 1) / launches : 0;
+  for (int start = 0; start < n; start += per) {
+    const int nb = std::min(per, n - start);
     const uint16_t* ddev;
     if (depth_on_device) {
       ddev = depth + (size_t)start * px;
     } else {
-      ER_HIP_TRY(hipMemcpyAsync(h->depth_stage, depth + (size_t)start * px, (size_t)nb * px * sizeof(uint16_t),
-                                hipMemcpyHostToDevice, h->aux_stream));     // consumed by the pre-pass on the same stream
-      ddev = h->depth_stage;
+      // Host frames travel on their own stream into the staging buffer of this batch's parity: the copy of batch n+1 overlaps
+      // the pre-pass of batch n (aux stream) and the voxel pass of batch n-1 (main stream) when the caller's memory is
+      // page-locked (er_host_alloc); pageable memory makes hipMemcpyAsync block the host, which is still correct.
+      const int p = h->parity;
+      ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->pre_done[p], 0));       // the pre-pass that last read depth_stage[p] (batch n-2)
+      ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[p], depth + (size_t)start * px, (size_t)nb * px * sizeof(uint16_t),
+                                hipMemcpyHostToDevice, h->copy_stream));
+      ER_HIP_TRY(hipEventRecord(h->copy_done[p], h->copy_stream));
+      ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->copy_done[p], 0));
+      ddev = h->depth_stage[p];
     }
     if (run_batch(h, nb, ddev, T + (size_t)start * 16, warp, start)) return 1;
   }
@@ -1028,6 +1055,57 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
 
 int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16]) {
   return er_tsdf_integrate_frames(h, 1, depth_host, 0, T, nullptr);
+}
+
+int er_tsdf_wait_event(er_tsdf_t h, void* hip_event) {
+  if (!h || !hip_event) return er::fail("er_tsdf_wait_event: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream, (hipEvent_t)hip_event, 0));
+  ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, (hipEvent_t)hip_event, 0));
+  return 0;
+}
+
+int er_tsdf_reset(er_tsdf_t h) {
+  if (!h) return er::fail("er_tsdf_reset: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (sync_all(h)) return 1;
+  int n = 0;
+  ER_HIP_TRY(hipMemcpy(&n, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  n = std::min(std::max(n, 0), h->max_units);
+  hipStream_t s = h->stream;
+  if (n > 0) ER_HIP_TRY(hipMemsetAsync(h->pool, 0, (size_t)n * er::kUnitVox * sizeof(float2), s));   // only the units ever handed out
+  ER_HIP_TRY(hipMemsetAsync(h->ht_key, 0xFF, (size_t)h->ht_cap * sizeof(int), s));
+  ER_HIP_TRY(hipMemsetAsync(h->ht_slot, 0xFF, (size_t)h->ht_cap * sizeof(int), s));
+  for (int q = 0; q < 2; q++) ER_HIP_TRY(hipMemsetAsync(h->ht_mask[q], 0, (size_t)h->ht_cap * sizeof(unsigned long long), s));
+  ER_HIP_TRY(hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s));
+  ER_HIP_TRY(hipStreamSynchronize(s));
+  h->used[0] = h->used[1] = false;
+  h->parity = 0;
+  return 0;
+}
+
+int er_tsdf_set_unit_shard(er_tsdf_t h, int rank, int world) {
+  if (!h) return er::fail("er_tsdf_set_unit_shard: NULL handle");
+  if (world < 1 || rank < 0 || rank >= world) return er::fail("er_tsdf_set_unit_shard: rank %d not in [0,%d)", rank, world);
+  ER_HIP_TRY(hipSetDevice(h->device));
+  int n = 0;
+  ER_HIP_TRY(hipMemcpy(&n, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  if (n != 0) return er::fail("er_tsdf_set_unit_shard: the volume already holds %d units (set the shard before the first frame)", n);
+  h->shard_rank = rank;
+  h->shard_world = world;
+  return 0;
+}
+
+int er_unit_owner(int key, int world) { return er::unit_owner(key, world); }
+
+int er_tsdf_status(er_tsdf_t h, int* flags, long* out_of_range_pixels) {
+  if (!h) return er::fail("er_tsdf_status: NULL handle");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  int c[C_COUNT];
+  ER_HIP_TRY(hipMemcpy(c, h->counters, sizeof c, hipMemcpyDeviceToHost));   // a poll: does not wait for the handle's (non-blocking) streams
+  if (flags) *flags = (c[C_POOL_OVERFLOW] ? ER_STATUS_POOL_EXHAUSTED : 0) | (c[C_TABLE_FULL] ? ER_STATUS_TABLE_FULL : 0);
+  if (out_of_range_pixels) *out_of_range_pixels = c[C_OUT_OF_RANGE];
+  return 0;
 }
 
 int er_tsdf_unit_count(er_tsdf_t h, int* count) {

@@ -130,6 +130,13 @@ ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const CameraInv& 
   return touch_key_exact(u, v, d, c, T);
 }
 
+// Owner of a volume unit when the volume is sharded BY UNIT over `world` GPUs (bit-exact alternative):
+// diagonal stripes of the unit lattice, so the ~30-60 units a frustum touches spread evenly over the GPUs.
+ER_HD int unit_owner(int key, int world) {
+  const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+  return (xi + yi + zi) % world;
+}
+
 // I2F, TSDFVolume.h:66-68: float( (i - 256) * 64 * unit_length_ )
 ER_HD float unit_shift(int idx) { return (float)((double)((idx - 256) * 64) * kUnitLength); }
 

@@ -256,8 +256,10 @@ class COptApp {                                     // OptApp.h:39-124
     std::vector<int> fi, fj, counts;
     std::vector<std::vector<int>> rows;
     for (const auto& t : reg_traj_) {
-      if (t.id1 < 0 || t.id2 < 0 || blacklist_.count(t.id1) || blacklist_.count(t.id2) || t.id1 >= (int)absolute2relative_map_.size() ||
-          t.id2 >= (int)absolute2relative_map_.size())
+      // OptApp.cpp:104: the ids are compared with num_ AFTER InitMap reduced it to the non-blacklisted count (so with a
+      // blacklist the highest absolute ids are dropped too) -- mirrored, the output files must equal the reference program's
+      if (t.id1 < 0 || t.id2 < 0 || blacklist_.count(t.id1) || blacklist_.count(t.id2) || t.id1 >= num_ || t.id2 >= num_ ||
+          t.id1 >= (int)absolute2relative_map_.size() || t.id2 >= (int)absolute2relative_map_.size())
         continue;
       if (t.frame != -1 && t.frame >= blacklist_pair_num_) {
         char fn[1024];
@@ -548,18 +550,19 @@ class COptApp {                                     // OptApp.h:39-124
                       "(use --slac or --rigid, or fewer fragments)\n", M, dense_limit_);
       return false;
     }
-    Vec lat, ctr, ictr;
+    Vec lat, ctr, ictr, oldctr;
     canonical_lattice(lat);
     for (int i = 0; i < num_; i++) pose_[(size_t)i] = ipose_[(size_t)i];
     expand(lat, ctr);                                 // InitCtr, :709-721
     if (init_ctr_file_.length() > 1) LoadInitCtr(ctr, 0, (size_t)num_ * nv_);
     ictr = ctr;
+    oldctr = ctr;                                     // :143
     for (int itr = 0; itr < max_iteration_; itr++) {
       for (int l = 0; l < num_; l++)
         if (er_fopt_update_normals(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       // thisAA = baseAA + data blocks: scattered into a dense matrix and factored in HBM (dense Cholesky, rocSOLVER)
       if (er_fopt_factor_nonrigid(fo_, weight_)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
-      if (sample_num_ > 0) SaveCtr(ctr, "itr" + std::to_string(itr) + ".ctr");              // :213-218
+      if (sample_num_ > 0) SaveCtr(oldctr, "itr" + std::to_string(itr) + ".ctr");           // :213-218 (oldctr: the lattice before the last inner solve)
       for (int m = 0; m < max_inner_iteration_; m++) {
         Vec Ab((size_t)M, 0.0);
         for (int l = 0; l < num_; l++) {
@@ -584,6 +587,7 @@ class COptApp {                                     // OptApp.h:39-124
         }
         double sc = 0;
         for (long q = 0; q < M; q++) sc += (ctr[(size_t)q] - Ab[(size_t)q]) * (ctr[(size_t)q] - Ab[(size_t)q]);
+        oldctr = ctr;                                 // :261
         ctr = Ab;
         printf("Iteration #%d:%d (%d:%d) : score is %.4f\n", itr + 1, m + 1, max_iteration_, max_inner_iteration_, std::sqrt(sc));
         if (sample_num_ > 0) SaveCtr(ctr, "itr" + std::to_string(itr) + "_inner" + std::to_string(m) + "_out.ctr");   // :267-272

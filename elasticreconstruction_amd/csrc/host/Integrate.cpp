@@ -177,6 +177,22 @@ struct App {
     }
     frames_integrated_ += n;
     q_depth_.clear(); q_T_.clear(); q_seg_.clear(); q_madj_.clear(); q_gi_.clear();
+    return CheckStatus(false);
+  }
+
+  // The reference grows data_ on demand; here the unit pool is fixed (--max_units).  Poll the device's sticky flags after
+  // every batch so that an exhausted pool stops the run at once instead of surfacing in SaveWorld after the whole sequence.
+  bool CheckStatus(bool final_report) {
+    int flags = 0;
+    long oor = 0;
+    if (er_tsdf_status(volume_, &flags, &oor) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return false; }
+    if (flags & ER_STATUS_POOL_EXHAUSTED) {
+      fprintf(stderr, "Integrate: the volume needs more than --max_units %d units (2 MiB each); re-run with a larger --max_units\n", max_units_);
+      return false;
+    }
+    if (flags & ER_STATUS_TABLE_FULL) { fprintf(stderr, "Integrate: unit hash table full (raise --max_units)\n"); return false; }
+    if (final_report && oor > 0)
+      fprintf(stderr, "Integrate: warning: %ld depth pixels fell outside the 512^3-unit index range (beyond +-96 m) and were skipped\n", oor);
     return true;
   }
 
@@ -195,6 +211,10 @@ struct App {
     const double* T = traj_[frame_id_ - 1].T;
     if (ctr_num_ > 0) {                                                // Reproject, :228-243
       if (frame_id_ > ctr_interval_ * ctr_num_) { exit_ = true; return true; }
+      if (seg_traj_.empty() || frame_id_ - 1 >= (int)seg_traj_.size()) {  // the reference indexes seg_traj_ unchecked (:243,:251)
+        fprintf(stderr, "Integrate: --seg_traj has %d entries, frame %d needs entry %d\n", (int)seg_traj_.size(), frame_id_, frame_id_ - 1);
+        return false;
+      }
       const int chunk = (frame_id_ - 1) / ctr_interval_;
       double Tinv[16], S0inv[16], tmp[16], madj[16];
       if (!er::mat4_inverse(T, Tinv) || !er::mat4_inverse(seg_traj_[0].T, S0inv)) { fprintf(stderr, "Integrate: singular pose\n"); return false; }
@@ -283,6 +303,7 @@ int main(int argc, char* argv[]) {
       if (!app.Execute(frame)) { rc = 1; break; }
     }
     if (rc == 0 && !app.Flush()) rc = 1;
+    if (rc == 0 && (er_tsdf_synchronize(app.volume_) != 0 || !app.CheckStatus(true))) rc = 1;
     if (rc == 0 && !app.SaveWorld()) rc = 1;
     std::cout << "Total " << app.frame_id_ << " frames processed." << std::endl;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -198,6 +198,15 @@ inline bool load_pcd_fields(const std::string& path, const std::vector<std::stri
   }
   if (!have_points) npts = width * height;
   if (mode.empty() || fields.empty()) return false;
+  // untrusted header: sizes / counts must be positive and small, and the point count must fit the file (every format
+  // spends at least one byte per point and field), so no product below can overflow or trigger a huge allocation
+  size_t rec_check = 0;
+  for (const PcdField& fd : fields) {
+    if (fd.size <= 0 || fd.size > 8 || fd.count <= 0 || fd.count > 65536) return false;
+    rec_check += (size_t)fd.size * (size_t)fd.count;
+  }
+  if (rec_check == 0 || rec_check > (1u << 24)) return false;
+  if (npts > raw.size() * (mode == "binary_compressed" ? 256u : 1u)) return false;      // LZF expands by < 256x
   const float nanv = std::nanf("");
   cols.assign(want.size(), std::vector<float>(npts, nanv));
   std::vector<int> target(fields.size(), -1);
@@ -365,8 +374,11 @@ inline bool load_png16(const std::string& path, int& w, int& h, std::vector<uint
     if (pos + 12 + len > raw.size()) return false;
     const uint8_t* d = &raw[pos + 8];
     if (type == "IHDR") {
-      w = (int)be32(pos + 8);
-      h = (int)be32(pos + 12);
+      if (len != 13) return false;                                      // untrusted input: a short IHDR would be read past its end
+      const uint32_t uw = be32(pos + 8), uh = be32(pos + 12);
+      if (uw == 0 || uh == 0 || uw > 16384u || uh > 16384u) return false;   // bound the allocation below (depth sensors: <= 4k x 4k)
+      w = (int)uw;
+      h = (int)uh;
       depth = d[8]; ctype = d[9]; interlace = d[12];
     } else if (type == "IDAT") {
       idat.insert(idat.end(), d, d + len);
@@ -375,7 +387,8 @@ inline bool load_png16(const std::string& path, int& w, int& h, std::vector<uint
     }
     pos += 12 + len;
   }
-  if (w <= 0 || h <= 0 || ctype != 0 || interlace != 0 || (depth != 16 && depth != 8)) return false;
+  // 8-bit files are refused: the caller treats the values as 16-bit millimetres (an 8-bit image is not a depth map)
+  if (w <= 0 || h <= 0 || ctype != 0 || interlace != 0 || depth != 16) return false;
   const size_t bpp = depth / 8, stride = (size_t)w * bpp;
   std::vector<uint8_t> img((stride + 1) * (size_t)h);
   uLongf out_len = (uLongf)img.size();

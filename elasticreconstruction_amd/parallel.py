@@ -28,13 +28,16 @@ def pair_shard(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def union_keys(local_keys, dist, device, max_keys=4096):
-    """ONE fixed-size all-gather of the per-rank touched unit keys (padded with -1) -> sorted union (int32 numpy)."""
+def union_keys(local_keys, dist, device):
+    """Union of the per-rank touched unit keys (sorted int32 numpy).  The ranks first AGREE on the padded length
+    (all_reduce(MAX) of the local counts), then exchange the keys in ONE fixed-size all-gather (padded with -1): tensor
+    shapes are identical on every rank whatever each rank touched."""
     import torch
     world = dist.get_world_size()
     keys = np.ascontiguousarray(local_keys, np.int32)
-    while max_keys < keys.size:
-        max_keys *= 2
+    cnt = torch.tensor([keys.size], dtype=torch.int64, device=device)
+    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+    max_keys = max(int(cnt.item()), 1)
     pad = torch.full((max_keys,), -1, dtype=torch.int32)
     if keys.size:
         pad[:keys.size] = torch.from_numpy(keys)
@@ -50,8 +53,9 @@ def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
     volume-unit weights" of BASELINE.json; afterwards `root` holds the complete volume (the other ranks keep
     their partial volumes).  mode "all_reduce": every rank ends with the complete volume (about 1.75x the
     link traffic of the reduce on a ring).  Returns the union size.
-    sync_stream: callable that makes the communication stream wait for the volume's kernels and vice
-    versa (None when everything already runs on one in-order stream)."""
+    sync_stream: callable that orders the communication stream after the volume's kernels and vice versa.  None (default)
+    is SAFE for any stream set-up: the volume's streams are drained after the export and torch's current stream (the one
+    the collective is ordered on) is drained before the import -- two host waits, once per job."""
     import torch
     union = union_keys(vol.unit_keys(), dist, device)
     if union.size == 0:
@@ -60,12 +64,16 @@ def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
     vol.export_weighted(union, buf.data_ptr())
     if sync_stream:
         sync_stream()
+    else:
+        vol.synchronize()                                    # k_export_weighted has written buf
     if mode == "all_reduce":
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # the ONLY data-path collective of the pipeline
     else:
         dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
     if sync_stream:
         sync_stream()
+    elif getattr(device, "type", str(device)) != "cpu" and str(device) != "cpu":
+        torch.cuda.current_stream(device).synchronize()      # the reduce has landed in buf
     if mode == "all_reduce" or dist.get_rank() == root:
         vol.import_weighted(union, buf.data_ptr())
     vol.synchronize()

@@ -179,6 +179,56 @@ def sample_fragment(world_T_frag, n_points, seed, length=3.0, lo=ROOM_LO, hi=ROO
     return q[keep].astype(np.float32), qn[keep].astype(np.float32)
 
 
+def _sample_fragment_torch(world_T_frag, n_points, seed, length, device):
+    """sample_fragment with torch ops (any device): same distribution, its own random stream.  Used where hundreds of
+    thousands of surfels per fragment are needed many times over (bench.py, the configs[2]-size GPU test)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    side = ROOM_HI - ROOM_LO
+    areas = torch.tensor([side * side] * 6 + [4 * math.pi * SPHERE_R ** 2], dtype=torch.float64)
+    edges = (torch.cumsum(areas, 0) / areas.sum()).to(device)
+    r = torch.rand(n_points, generator=g, device=device, dtype=torch.float64)
+    face = torch.bucketize(r, edges[:-1], right=True)                       # 0..5 walls, 6 sphere
+    ab = torch.rand((n_points, 2), generator=g, device=device, dtype=torch.float64) * side + ROOM_LO
+    v = torch.randn((n_points, 3), generator=g, device=device, dtype=torch.float64)
+    v = v / v.norm(dim=1, keepdim=True)
+    ax, sgn = face // 2, face % 2
+    wall = torch.where(sgn == 1, torch.full_like(r, ROOM_HI), torch.full_like(r, ROOM_LO))
+    pts = torch.empty((n_points, 3), device=device, dtype=torch.float64)
+    nrm = torch.zeros((n_points, 3), device=device, dtype=torch.float64)
+    for a in range(3):
+        o = [x for x in range(3) if x != a]
+        m = (ax == a) & (face < 6)
+        pts[:, a] = torch.where(m, wall, pts[:, a])
+        nrm[:, a] = torch.where(m, torch.where(sgn == 1, -torch.ones_like(r), torch.ones_like(r)), nrm[:, a])
+        pts[:, o[0]] = torch.where(m, ab[:, 0], pts[:, o[0]])
+        pts[:, o[1]] = torch.where(m, ab[:, 1], pts[:, o[1]])
+    sp = (face == 6)[:, None]
+    c = torch.tensor(SPHERE_C, device=device, dtype=torch.float64)
+    pts = torch.where(sp, c + SPHERE_R * v, pts)
+    nrm = torch.where(sp, v, nrm)
+    F = torch.as_tensor(np.linalg.inv(world_T_frag), device=device, dtype=torch.float64)
+    q = pts @ F[:3, :3].T + F[:3, 3]
+    qn = nrm @ F[:3, :3].T
+    keep = ((q >= 0.0) & (q <= length)).all(dim=1)
+    return q[keep].to(torch.float32).cpu().numpy(), qn[keep].to(torch.float32).cpu().numpy()
+
+
+def fragment_set(num, target_points=250000, seed=SEED, length=3.0, radius=0.6, device="cpu"):
+    """`num` DISTINCT fragments of target_points surfels each (configs[2] / configs[4] shape): fragment i is what a
+    camera at angle 2 pi i / num on the config-2 circle sees inside its own length^3 cube (frame = camera pose x basepose^-1,
+    the kinfu convention of CorresApp.cpp:45-48).  Neighbouring fragments overlap, opposite ones do not.
+    Returns [(xyz float32 [m,3], normals float32 [m,3], world_T_frag float64 4x4)]."""
+    out = []
+    Binv = np.linalg.inv(basepose(length))
+    cams = circle_trajectory(num, radius=radius)
+    for i in range(num):
+        F = cams[i] @ Binv
+        x, n = _sample_fragment_torch(F, 5 * target_points, seed + 7919 * i + 1, length, device)   # 21-31 % fall inside the cube
+        out.append((x[:target_points], n[:target_points], F))                   # (samples are i.i.d.: a prefix is a sample)
+    return out
+
+
 def perturbation(seed, max_rot_deg=2.0, max_trans=0.02):
     """Small seeded rigid perturbation (4x4 float64)."""
     rng = np.random.RandomState(seed)

@@ -62,6 +62,24 @@ class TSDFVolume:
     def synchronize(self):
         _ffi.check(self._lib.er_tsdf_synchronize(self._h), "er_tsdf_synchronize")
 
+    def wait_event(self, hip_event_ptr):
+        """The next IntegrateFrames call's pre-pass waits for this hipEvent_t (device depth produced asynchronously)."""
+        _ffi.check(self._lib.er_tsdf_wait_event(self._h, C.c_void_p(hip_event_ptr)), "er_tsdf_wait_event")
+
+    def reset(self):
+        """data_.clear(): an empty volume in the same buffers."""
+        _ffi.check(self._lib.er_tsdf_reset(self._h), "er_tsdf_reset")
+
+    def set_unit_shard(self, rank, world):
+        """Unit-shard mode (bit-exact): this volume only owns the units with er_unit_owner(key, world) == rank."""
+        _ffi.check(self._lib.er_tsdf_set_unit_shard(self._h, int(rank), int(world)), "er_tsdf_set_unit_shard")
+
+    def status(self):
+        """(flags, out_of_range_pixels): sticky overflow flags (ER_STATUS_*) and the pixels skipped beyond +-96 m; a poll."""
+        f, n = C.c_int(0), C.c_long(0)
+        _ffi.check(self._lib.er_tsdf_status(self._h, C.byref(f), C.byref(n)), "er_tsdf_status")
+        return f.value, n.value
+
     # -- numeric core ---------------------------------------------------------------------------
     def ScaleDepth(self, depth):
         """TSDFVolume::ScaleDepth (TSDFVolume.cpp:19-36)."""

@@ -93,6 +93,21 @@ int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16
 int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int depth_on_device, const double* T,
                              const er_warp* warp);
 
+/* Device depth produced asynchronously: the NEXT er_tsdf_integrate_frames call's pre-pass (and host-frame copies) wait for
+ * this hipEvent_t (recorded by the caller after the producer of the depth buffer) instead of requiring a synchronised stream. */
+int er_tsdf_wait_event(er_tsdf_t h, void* hip_event);
+
+/* Empties the volume (data_.clear()): every unit is released and zero-filled, the hash map is emptied, flags are cleared.
+ * Buffers, streams and the unit-shard setting are kept. */
+int er_tsdf_reset(er_tsdf_t h);
+
+/* Sticky error flags + the number of depth pixels skipped because their unit index left [0,512) (> +-96 m, where the
+ * reference's hash_key would alias another unit).  A POLL: it does not wait for queued batches, so a program can call it
+ * after every er_tsdf_integrate_frames and fail fast instead of learning about an exhausted pool in SaveWorld. */
+#define ER_STATUS_POOL_EXHAUSTED 1
+#define ER_STATUS_TABLE_FULL 2
+int er_tsdf_status(er_tsdf_t h, int* flags, long* out_of_range_pixels);
+
 /* data_ map access (TSDFVolume.h:27) as used by SaveWorld. */
 int er_tsdf_unit_count(er_tsdf_t h, int* count);
 int er_tsdf_unit_keys(er_tsdf_t h, int* keys_host);                  /* ascending hash_key order */
@@ -111,6 +126,13 @@ int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* cou
  * after an external all-reduce(sum) read them back as weight = W, sdf = SW / W. */
 int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
 int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
+
+/* Multi-GPU, the bit-exact alternative: shard the volume BY UNIT.  Every GPU is fed ALL frames and runs
+ * their pre-pass, but only allocates / integrates / reports the units with er_unit_owner(key, world) == rank.  Units are disjoint
+ * (TSDFVolume.cpp:45-63) and each still sees every frame in order, so the union of the GPUs' volumes equals the single-GPU
+ * volume bit for bit and no collective touches the volume.  Must be set before the first frame. */
+int er_tsdf_set_unit_shard(er_tsdf_t h, int rank, int world);
+int er_unit_owner(int key, int world);          /* (xi + yi + zi) mod world: diagonal stripes of the unit lattice */
 
 /* Kernel timing (HIP events on the handle's stream around every IntegrateVolumeUnit launch). */
 int er_tsdf_set_profiling(er_tsdf_t h, int enable);

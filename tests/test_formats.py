@@ -135,7 +135,7 @@ def test_python_compressed_pcd_writer_against_the_programs_reader(tmp_path):
 
 
 def test_host_program_depth_png_reader_and_writer(tmp_path):
-    """load_png16 / save_png16 of csrc/host/er_formats.h (Integrate --depth_list) against Pillow: 16-bit and 8-bit grayscale,
+    """load_png16 / save_png16 of csrc/host/er_formats.h (Integrate --depth_list) against Pillow: 16-bit grayscale (8-bit is refused),
     every PNG filter type (smooth ramps make the encoder pick Sub / Up / Average / Paeth), odd sizes; interlaced and colour
     files are refused."""
     import os
@@ -166,8 +166,20 @@ def test_host_program_depth_png_reader_and_writer(tmp_path):
     g8 = rng.randint(0, 256, (20, 31)).astype(np.uint8)
     Image.fromarray(g8).save(p8)
     raw = str(tmp_path / "px8.bin")
-    subprocess.run([exe, "png", p8, raw], check=True, capture_output=True)
-    assert np.array_equal(np.fromfile(raw, np.uint16).reshape(g8.shape), g8.astype(np.uint16))
+    # 8-bit grayscale is not a millimetre depth map: refused (the caller would read the values as 16-bit millimetres)
+    assert subprocess.run([exe, "png", p8, raw], capture_output=True).returncode != 0
+    # crafted headers: a short IHDR chunk, and dimensions that would ask for a gigantic allocation
+    import struct
+    import zlib
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    sig = bytes([0x89]) + b"PNG" + bytes([0x0D, 0x0A, 0x1A, 0x0A])
+    for name, ihdr in (("short", struct.pack(">II", 4, 4)), ("huge", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 16, 0, 0, 0, 0))):
+        bad = str(tmp_path / (name + ".png"))
+        with open(bad, "wb") as f:
+            f.write(sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\0" * 16)) + chunk(b"IEND", b""))
+        assert subprocess.run([exe, "png", bad, raw], capture_output=True).returncode != 0, name
     rgb = str(tmp_path / "rgb.png")
     Image.fromarray(rng.randint(0, 256, (8, 8, 3)).astype(np.uint8)).save(rgb)
     assert subprocess.run([exe, "png", rgb, raw], capture_output=True).returncode != 0

@@ -222,3 +222,41 @@ def test_ransac_fitness_batch_matches_oracle(gpu):
     assert cnt.shape[0] == 32800 and np.array_equal(cnt[:4], cnt[-4:]) and np.array_equal(cnt.reshape(-1, 4), np.tile(cnt[:4], (8200, 1)))
     with pytest.raises(Exception):
         ransac_fitness_batch(src, tgt, hyps, 0.08)               # radius beyond the target's grid cell
+
+
+def test_config2_size_50_pairs_over_25_distinct_fragments(gpu):
+    """BASELINE.json configs[2] at full size: 50 pairs over 25 DISTINCT fragments of 250 k points each, through the reference's
+    two loops (Registration: pre-check + ICP; FindCorrespondence + information matrix) as bench.py runs them (the *_batch
+    entry points), every pair checked against the CPU oracle: inlier counts, iteration counts, convergence flags and
+    correspondence index lists EXACT, transforms within 1e-5 per float32 entry, information matrices within 1e-9 relative."""
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch, icp_align_batch
+    n_frag, n_pairs = 25, 50
+    frs = synth.fragment_set(n_frag, 250000, device="cuda:0")
+    assert all(len(x) == 250000 for x, _, _ in frs)
+    gc = [Cloud(x, n, 0.03) for x, n, _ in frs]
+    oc = [IcpOracle(x, n, 0.03) for x, n, _ in frs]
+    pairs = []
+    for k in range(n_pairs):
+        a = k % n_frag
+        b = (a + 1 + (k // n_frag) % 3) % n_frag
+        pairs.append((a, b, np.linalg.inv(frs[a][2]) @ frs[b][2] @ synth.perturbation(700 + k, 2.0, 0.02)))
+    assert len({q for a, b, _ in pairs for q in (a, b)}) == n_frag
+    srcs, tgts = [gc[b] for _, b, _ in pairs], [gc[a] for a, _, _ in pairs]
+    cnts = count_inliers_batch(srcs, tgts, [T for _, _, T in pairs], 0.03)
+    fins, iters, conv, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for _, _, T in pairs], 0.03, 20, 1e-6, 0)
+    lists, infos = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in fins], 0.015, 0.8660, True)
+    worst_T = 0.0
+    for k, (a, b, T) in enumerate(pairs):
+        assert int(cnts[k]) == oc[b].count_inliers(oc[a], T, 0.03), "pair %d: inlier count" % k
+        To, ito, co, _ = oc[b].align(oc[a], T.astype(np.float32), 0.03, 20, 1e-6, 0)
+        assert (int(iters[k]), bool(conv[k])) == (ito, co), "pair %d: iterations/converged %s vs %s" % (k, (iters[k], conv[k]), (ito, co))
+        worst_T = max(worst_T, float(np.abs(fins[k] - To).max()))
+        assert np.abs(fins[k] - To).max() <= TOL_T, "pair %d: transform differs by %.3g" % (k, np.abs(fins[k] - To).max())
+        po, io = oc[b].find_correspondence(oc[a], fins[k].astype(np.float64), 0.015, 0.8660, want_info=True)
+        assert np.array_equal(lists[k], po), "pair %d: %d vs %d correspondences" % (k, lists[k].shape[0], po.shape[0])
+        assert np.allclose(infos[k], io, rtol=1e-9, atol=1e-6)
+        # the ICP recovered the ground truth from the <= 2 deg / 2 cm perturbation
+        gt = np.linalg.inv(frs[a][2]) @ frs[b][2]
+        assert np.abs(fins[k].astype(np.float64) - gt).max() < 2e-3, "pair %d: ground truth missed" % k
+    assert int(np.sum(iters)) >= n_pairs and min(l.shape[0] for l in lists) > 50000
+    print("configs[2]: 50 pairs, mean %.2f ICP iterations, max |T_gpu - T_oracle| = %.2g" % (float(np.mean(iters)), worst_T))

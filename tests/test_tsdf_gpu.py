@@ -361,3 +361,59 @@ def test_randomised_configurations_bit_exact(gpu):
             ora.Integrate(d, poses[f])
         helpers.assert_volumes_identical(vol, ora, "fuzz case %d (%dx%d)" % (case, cols, rows))
         vol.close()
+
+
+def test_reset_unit_shard_pinned_input_and_status(gpu):
+    """The round-2 additions of the ABI on the golden warp scene:
+       * er_tsdf_reset          -> an emptied volume integrates to the same golden digest again;
+       * er_tsdf_set_unit_shard -> 3 volumes that each own a third of the units (bit-exact alternative):
+                                   disjoint key sets, union == single-GPU key set, every unit bit-identical;
+       * host frames in page-locked memory (own copy stream, double-buffered staging) -> same digest;
+       * er_tsdf_status         -> reports an exhausted unit pool without waiting for a read-back."""
+    sc = helpers.golden_warp()
+    g = helpers.golden()["warp"]
+    depth = synth.to_numpy_u16(sc["depth"])
+    warp = synth.warp_arrays(sc)
+    vol = TSDFVolume(max_units=256)
+    vol.IntegrateFrames(depth, sc["traj"], warp)
+    assert helpers.volume_digest(vol)["sha256"] == g["sha256"]
+    assert vol.status() == (0, 0)
+    vol.reset()
+    assert vol.unit_count() == 0 and vol.sum_weight() == 0.0
+    # second life of the same handle, this time from page-locked host memory, several frames per call
+    arena = _ffi.PinnedArena()
+    arena.reset(depth.nbytes + 8192)
+    pinned = arena.take(depth.shape, np.uint16)
+    pinned[...] = depth
+    vol.IntegrateFrames(pinned, sc["traj"], warp)
+    d = helpers.volume_digest(vol)
+    assert d["keys"] == g["keys"] and d["sha256"] == g["sha256"]
+    # unit shard
+    world = 3
+    shards = [TSDFVolume(max_units=256) for _ in range(world)]
+    seen = {}
+    for r, sv in enumerate(shards):
+        sv.set_unit_shard(r, world)
+        sv.IntegrateFrames(depth, sc["traj"], warp)
+        for k in sv.unit_keys():
+            assert int(k) not in seen and _ffi.lib().er_unit_owner(int(k), world) == r
+            seen[int(k)] = sv
+    assert sorted(seen) == g["keys"]
+    for k, sv in seen.items():
+        s0, w0 = vol.read_unit(k)
+        s1, w1 = sv.read_unit(k)
+        assert np.array_equal(w0, w1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)), "unit %d differs in shard mode" % k
+    with pytest.raises(_ffi.ErError, match="already holds"):
+        shards[0].set_unit_shard(1, 2)
+    for sv in shards:
+        sv.close()
+    vol.close()
+    arena.close()
+    small = TSDFVolume(max_units=4)
+    small.IntegrateFrames(depth[:2], sc["traj"][:2])
+    small.synchronize()
+    flags, _ = small.status()
+    assert flags & 1, "exhausted pool not reported by er_tsdf_status"
+    with pytest.raises(_ffi.ErError, match="pool exhausted"):
+        small.unit_count()
+    small.close()
