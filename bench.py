@@ -24,6 +24,7 @@ the stream it runs on.  cpu_baseline times the REFERENCE's own code (oracle/_ref
 sample of the same frames; when that build is absent it falls back to the oracle port and says so.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -34,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+C_void = ctypes.c_void_p
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 FRAME_BYTES_RAW = 640 * 480 * 2
 CONFIG2_FRAMES = 3000          # BASELINE.json configs[1]
@@ -54,13 +56,15 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
-def cpu_baseline(sc, depth_host, n_sample):
+def cpu_baseline(sc, depth_host, n_sample, files_dir):
     with _StdoutToStderr():
-        return _cpu_baseline(sc, depth_host, n_sample)
+        return _cpu_baseline(sc, depth_host, n_sample, files_dir)
 
 
-def _cpu_baseline(sc, depth_host, n_sample):
-    """Reference CPU path on the host cores of this box, same frames, same files-based setup as Integrate.exe.
+def _cpu_baseline(sc, depth_host, n_sample, files_dir):
+    """Reference CPU path on the host cores of this box, same frames, same files-based setup as Integrate.exe (pose.log,
+    seg.log and g.ctr are written to files_dir; the GPU leg of the parity check reads the SAME files, so both sides see the
+    same text-rounded poses and lattices).
     Returns (json object, {unit key: (sdf_, weight_)} of the volume the timed run left behind) -- the volume is what
     bench.py's parity check compares the GPU volume of the same frames with."""
     import numpy as np
@@ -70,7 +74,8 @@ def _cpu_baseline(sc, depth_host, n_sample):
     num = n_sample // interval
     if pyoracle.have_ref():
         def run_ref(uncapped, keep_volume):
-            with tempfile.TemporaryDirectory() as d:
+            d = files_dir
+            if True:
                 pose = [formats.FramedTransformation(i, i, i + 1, sc["pose"][i]) for i in range(num)]
                 seg = [formats.FramedTransformation(i, i, i + 1, sc["seg"][i]) for i in range(n_sample)]
                 # one extra fragment of entries so that frame n_sample is still integrated (reference off-by-one)
@@ -497,7 +502,18 @@ def main():
         pinned[...] = synth.to_numpy_u16(depth)
         timed_pass(pinned)
         ts = [timed_pass(pinned)[0] for _ in range(3)]
+        # the PCIe ceiling of this box for the same bytes: one plain H2D copy of the whole pinned block
+        tmp = torch.empty((n_frames, px), dtype=torch.int16, device=dev)
+        tc = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _ffi.lib().er_host_copy_h2d(C_void(tmp.data_ptr()), C_void(pinned.ctypes.data), pinned.nbytes)
+            tc.append(time.perf_counter() - t0)
+        del tmp
         streamed = {"value": n_frames / float(np.median(ts)), "unit": "frames/s", "passes": 3,
+                    "h2d_copy_only": {"frames_per_s": n_frames / float(np.median(tc)), "GB_per_s": pinned.nbytes / float(np.median(tc)) / 1e9,
+                                      "what": "hipMemcpy of the same page-locked frames with no kernel running: this box's PCIe ceiling"},
                     "what": "same K steps, depth frames handed over as page-locked HOST memory (er_host_alloc): H2D copies on their "
                             "own stream overlap the pre-pass and the voxel pass; PCIe Gen5 x16 caps this near 100 k frames/s "
                             "(614 400 B per frame); never the headline value"}
@@ -594,13 +610,29 @@ def main():
         if world == 1 and args.cpu_sample > 0 and warp_on:
             ns = min(n_frames, max(I, (args.cpu_sample // I) * I))
             host = synth.to_numpy_u16(depth[:ns])
-            out["cpu_baseline"], ref_units = cpu_baseline(sc, host, ns)
-            # the same ns frames once more on the GPU, compared unit by unit with the volume the CPU run left behind
-            vol.reset()
-            for lo in range(0, ns, I):
-                vol.IntegrateFrames(None, sc["traj"][lo:lo + I], warp_slice(lo, lo + I), device_ptr=depth.data_ptr() + lo * px * 2)
-            vol.synchronize()
-            out["parity_checked"] = parity_check(vol, ref_units, ns, out["cpu_baseline"]["kind"])
+            with tempfile.TemporaryDirectory() as fdir:
+                out["cpu_baseline"], ref_units = cpu_baseline(sc, host, ns, fdir)
+                # the same ns frames once more on the GPU -- through the host mirror of CIntegrateApp reading the SAME pose.log /
+                # seg.log / g.ctr the reference just read -- compared unit by unit with the volume the CPU run left behind
+                from elasticreconstruction_amd.tsdf import IntegrateApp
+                app = IntegrateApp(max_units=max_units, device=local)
+                if out["cpu_baseline"]["kind"] == "reference":
+                    app.pose_filename_, app.seg_filename_, app.ctr_filename_ = (os.path.join(fdir, n) for n in ("pose.log", "seg.log", "g.ctr"))
+                    app.ctr_num_, app.ctr_resolution_, app.ctr_length_, app.ctr_interval_ = ns // I, sc["resolution"], sc["length"], I
+                    app.Init()
+                    for f in range(ns):
+                        app.Execute(f + 1, host[f])
+                    app.Finish(save=False)
+                    pvol = app.volume_
+                else:                                        # oracle port: it was fed the in-memory matrices
+                    vol.reset()
+                    for lo in range(0, ns, I):
+                        vol.IntegrateFrames(None, sc["traj"][lo:lo + I], warp_slice(lo, lo + I), device_ptr=depth.data_ptr() + lo * px * 2)
+                    vol.synchronize()
+                    pvol = vol
+                out["parity_checked"] = parity_check(pvol, ref_units, ns, out["cpu_baseline"]["kind"])
+                if pvol is not vol:
+                    pvol.close()
         if icp is not None:
             out["icp"] = icp
             if world == 1:

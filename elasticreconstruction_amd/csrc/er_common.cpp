@@ -41,6 +41,11 @@ void* er_host_alloc(size_t bytes) {
   return p;
 }
 
+int er_host_copy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
+  ER_HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+
 int er_host_free(void* p) {
   if (p) ER_HIP_TRY(hipHostFree(p));
   return 0;

@@ -101,18 +101,9 @@ struct ReprojArgs {
   int* counters;
 };
 
-// One source pixel (u, v) of frame f: warp, then scatter (replay = 0) or re-scatter under the replay rule (replay = 1).
-__device__ __forceinline__ void reproject_scatter_px(const ReprojArgs& A, int f, int u, int v, int replay) {
-  const int pixels = A.cols * A.rows;
-  const int p = v * A.cols + u;
-  const uint16_t d = A.depth[(size_t)f * pixels + p];
-  if (d == 0) return;                                                   // UVD2XYZ false
-  int cell;
-  uint16_t dd;
-  if (!reproject_px(u, v, d, A.cam, A.cami, A.cols, A.rows, A.seg12 + f * 16, A.madj12 + f * 12,
-                    A.ctr + (size_t)A.grid_index[f] * A.floats_per_grid, A.res, A.grid_ul, cell, dd))
-    return;
-  const size_t o = (size_t)f * pixels + cell;
+// The write half of one source pixel p of frame f that landed on `cell` with depth dd (IntegrateApp.cpp:260-263).
+__device__ __forceinline__ void scatter_px(const ReprojArgs& A, int f, int p, int cell, uint16_t dd, int replay) {
+  const size_t o = (size_t)f * ((size_t)A.cols * A.rows) + cell;
   if (!replay) {
     if (dd != 0) {
       atomicMin(&A.zbuf[o], (uint32_t)dd);
@@ -126,6 +117,21 @@ __device__ __forceinline__ void reproject_scatter_px(const ReprojArgs& A, int f,
   }
 }
 
+// One source pixel (u, v) of frame f through the EXACT chain: warp, then scatter (replay = 0) or re-scatter under the
+// replay rule (replay = 1).
+__device__ __forceinline__ void reproject_scatter_px(const ReprojArgs& A, int f, int u, int v, int replay) {
+  const int pixels = A.cols * A.rows;
+  const int p = v * A.cols + u;
+  const uint16_t d = A.depth[(size_t)f * pixels + p];
+  if (d == 0) return;                                                   // UVD2XYZ false
+  int cell;
+  uint16_t dd;
+  if (!reproject_px(u, v, d, A.cam, A.cami, A.cols, A.rows, A.seg12 + f * 16, A.madj12 + f * 12,
+                    A.ctr + (size_t)A.grid_index[f] * A.floats_per_grid, A.res, A.grid_ul, cell, dd))
+    return;
+  scatter_px(A, f, p, cell, dd, replay);
+}
+
 __global__ void k_reproject_scatter(ReprojArgs A) {
   // 64 x 4 pixel tiles per 256-thread workgroup, frame = blockIdx.z: no integer divisions for the indices.
   const int f = blockIdx.z;
@@ -133,6 +139,70 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (u >= A.cols || v >= A.rows) return;
   reproject_scatter_px(A, f, u, v, 0);
+}
+
+// Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1").  A workgroup owns a 64 x 16 pixel tile of one frame, each
+// thread 4 pixels of one column.  The frame's control lattice is staged in LDS as one 16-byte vertex each (all pixels of a
+// tile fall into one or two lattice cells, so the 8 vertex reads per pixel are LDS broadcasts instead of 24 global gathers).
+//   tier 1  every pixel: float64 lattice coordinates (no guard needed: they only feed the estimate), float32 trilinear sum,
+//           float32 projection, and the per-pixel proof that the three roundings and every range test of the reference are
+//           decided by the estimate -> scatter (or drop) at once;
+//   tier 2  the few per cent it cannot decide are appended to an LDS list and then run through the exact chain
+//           (reproject_scatter_px) by the first threads of the workgroup: ~50 of 1024 pixels -> one wave instead of sixteen.
+// Results are the reference's for every pixel either way (tests: hostcheck replay on the CPU, golden digests and fuzz on the GPU).
+constexpr int kRtW = 64, kRtH = 16;
+
+__global__ __launch_bounds__(kBlock) void k_reproject_tiered(ReprojArgs A, const ReprojFast* __restrict__ fast, const Vert4* __restrict__ ctr4) {
+  extern __shared__ Vert4 s_ctr[];
+  __shared__ unsigned short s_unsure[kRtW * kRtH];
+  __shared__ int s_n;
+  const int f = blockIdx.z, tid = threadIdx.x;
+  const int n1 = A.res + 1, verts = n1 * n1 * n1;
+  const Vert4* __restrict__ g4 = ctr4 + (size_t)A.grid_index[f] * verts;
+  for (int i = tid; i < verts; i += kBlock) s_ctr[i] = g4[i];
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const ReprojFast& F = fast[f];                                        // wave-uniform: scalar loads
+  const int lx = tid & 63, ly0 = (tid >> 6) * 4;
+  const int u = blockIdx.x * kRtW + lx, v0 = blockIdx.y * kRtH + ly0;
+  const int pixels = A.cols * A.rows;
+  const uint16_t* __restrict__ src = A.depth + (size_t)f * pixels;
+  uint16_t d[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {                                         // clamped address + select: no branches around the loads
+    const uint16_t t = src[min(v0 + j, A.rows - 1) * A.cols + min(u, A.cols - 1)];
+    d[j] = (u < A.cols && v0 + j < A.rows) ? t : (uint16_t)0;
+  }
+  const double up = (double)((float)u - A.cam.cx);                      // UVD2XYZ: int - float in float32, then promoted
+  const double gu[3] = {fma(F.ga[0], up, F.gc[0]), fma(F.ga[1], up, F.gc[1]), fma(F.ga[2], up, F.gc[2])};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (d[j] == 0) continue;                                            // UVD2XYZ false
+    const int v = v0 + j;
+    const double vp = (double)((float)v - A.cam.cy);
+    const double g[3] = {fma(F.gb[0], vp, gu[0]), fma(F.gb[1], vp, gu[1]), fma(F.gb[2], vp, gu[2])};
+    int cell;
+    uint16_t dd;
+    const int cls = reproject_fast(d[j], g, F, A.cam, s_ctr, n1, A.cols, cell, dd);
+    if (cls == kReprojAccept) {
+      scatter_px(A, f, v * A.cols + u, cell, dd, 0);
+    } else if (cls == kReprojUnsure) {
+      s_unsure[atomicAdd(&s_n, 1)] = (unsigned short)((ly0 + j) * kRtW + lx);
+    }
+  }
+  __syncthreads();
+  const int n = s_n;
+  for (int i = tid; i < n; i += kBlock) {
+    const int q = s_unsure[i];
+    reproject_scatter_px(A, f, blockIdx.x * kRtW + (q & 63), blockIdx.y * kRtH + (q >> 6), 0);
+  }
+}
+
+// float[3] vertices -> one 16-byte Vert4 each (tier 1's LDS / 16-byte-load layout).
+__global__ void k_expand_ctr(const float* __restrict__ ctr, Vert4* __restrict__ out, long n) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  out[t] = Vert4{ctr[3 * t], ctr[3 * t + 1], ctr[3 * t + 2], 0.0f};
 }
 
 // The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch that
@@ -603,6 +673,8 @@ struct er_tsdf_s {
   void* pinned[2] = {nullptr, nullptr};                   // host staging of the per-batch constants
   int ht_cap = 0, ht_shift = 0;
   float *lambda = nullptr, *ctr = nullptr;
+  er::Vert4* ctr4 = nullptr;                                // the same lattices, one 16-byte vertex each (tier 1 of Reproject)
+  std::vector<double> grid_cmax, grid_dmax;                 // per lattice: max |component|, max lattice-edge component (host)
   uint16_t* depth_stage[2] = {nullptr, nullptr};   // host frames of the batch in flight, by pipeline parity
   uint32_t *zbuf = nullptr, *lastzero = nullptr;
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
@@ -615,6 +687,8 @@ struct er_tsdf_s {
   double ms_total = 0.0;
   long launches = 0, frames_done = 0;
 };
+
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X);
 
 namespace {
 
@@ -687,6 +761,7 @@ int sorted_units(er_tsdf_t h, std::vector<int>& keys, std::vector<int>& slots) {
 // Host staging layout of one batch's constants inside the pinned buffer of its parity.
 struct Staging {
   er::FrameXform fx[ER_MAX_BATCH];
+  er::ReprojFast fast[ER_MAX_BATCH];
   double t12[ER_MAX_BATCH * 12];
   double seg[ER_MAX_BATCH * 16];
   double madj[ER_MAX_BATCH * 12];
@@ -750,6 +825,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
       const int g = warp->grid_index[frame0 + f];
       if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
       st->gi[f] = g;
+      er::reproj_fast_setup(&st->seg[f * 16], &st->madj[f * 12], h->cam, h->cols, h->rows, warp->resolution,
+                            warp->length / (float)warp->resolution, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g], st->fast[f]);
     }
   }
   // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
@@ -760,9 +837,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
                         verts * 3, h->zbuf, h->lastzero, h->counters};
-    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
-    hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, X, RA);
-    ER_HIP_TRY(hipGetLastError());
+    if (launch_reproject(h, RA, n, reinterpret_cast<const er::ReprojFast*>(dst + offsetof(Staging, fast)), X)) return 1;
     zsrc = h->zbuf;
   }
 
@@ -923,7 +998,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask[0], h->ht_mask[1], h->unit_key, h->counters, h->stats, h->batch[0],
                   h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage[0], h->depth_stage[1], h->zbuf, h->lastzero, h->dstage[0],
-                  h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->key_scratch, h->slot_scratch,
+                  h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->ctr4, h->key_scratch, h->slot_scratch,
                   h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1]};
   for (int q = 0; q < 2; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
@@ -971,16 +1046,45 @@ int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_h
   return 0;
 }
 
-static int upload_ctr(er_tsdf_t h, const float* ctr, size_t floats, hipStream_t stream) {
+// num_grids lattices of (res+1)^3 x 3 floats -> device (float[3] for the exact chain, Vert4 for tier 1) + their host-side bounds.
+static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hipStream_t stream) {
+  const size_t verts = (size_t)(res + 1) * (res + 1) * (res + 1);
+  const size_t floats = verts * 3 * (size_t)num_grids;
   if (floats > h->ctr_cap) {
     if (sync_all(h)) return 1;                       // nobody may still be reading the old grids
     if (h->ctr) (void)hipFree(h->ctr);
+    if (h->ctr4) (void)hipFree(h->ctr4);
     h->ctr = nullptr;
+    h->ctr4 = nullptr;
     h->ctr_cap = 0;
     ER_HIP_TRY(hipMalloc((void**)&h->ctr, floats * sizeof(float)));
+    ER_HIP_TRY(hipMalloc((void**)&h->ctr4, (floats / 3) * sizeof(er::Vert4)));
     h->ctr_cap = floats;
   }
+  h->grid_cmax.resize((size_t)num_grids);
+  h->grid_dmax.resize((size_t)num_grids);
+  for (int g = 0; g < num_grids; g++) er::lattice_bounds(ctr + (size_t)g * verts * 3, res, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g]);
   ER_HIP_TRY(hipMemcpyAsync(h->ctr, ctr, floats * sizeof(float), hipMemcpyHostToDevice, stream));
+  const long nv = (long)(floats / 3);
+  hipLaunchKernelGGL(k_expand_ctr, dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, h->ctr, h->ctr4, nv);
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Reproject of n frames into zbuf (tiered when the lattice fits LDS, else the all-exact kernel) + the replay launch.
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X) {
+  const size_t lds = (size_t)(RA.res + 1) * (RA.res + 1) * (RA.res + 1) * sizeof(er::Vert4);
+#ifndef ER_REPROJECT_EXACT_ONLY
+  if (lds <= 48 * 1024 && dev_fast) {
+    hipLaunchKernelGGL(k_reproject_tiered, dim3((h->cols + kRtW - 1) / kRtW, (h->rows + kRtH - 1) / kRtH, n), dim3(kBlock), lds, X, RA, dev_fast,
+                       h->ctr4);
+  } else
+#endif
+  {
+    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
+  }
+  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, X, RA);
+  ER_HIP_TRY(hipGetLastError());
   return 0;
 }
 
@@ -992,7 +1096,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const size_t px = (size_t)h->pixels;
   const int verts = (resolution + 1) * (resolution + 1) * (resolution + 1);
   if (sync_all(h)) return 1;                         // single-frame hook: runs alone on the main stream
-  if (upload_ctr(h, ctr_host, (size_t)verts * 3, h->stream)) return 1;
+  if (upload_ctr(h, ctr_host, resolution, 1, h->stream)) return 1;
   const int gi = 0;
   ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[0], depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
   double seg16[16] = {0};
@@ -1005,8 +1109,13 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const long total = (long)px;
   const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
                       verts * 3, h->zbuf, h->lastzero, h->counters};
-  hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, 1), dim3(kBlock), 0, h->stream, RA);
-  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, h->stream, RA);
+  {
+    Staging* st = static_cast<Staging*>(h->pinned[0]);                    // idle: sync_all above
+    er::reproj_fast_setup(seg16, madj, h->cam, h->cols, h->rows, resolution, grid_ul, h->grid_cmax[0], h->grid_dmax[0], st->fast[0]);
+    er::ReprojFast* dev_fast = reinterpret_cast<er::ReprojFast*>(static_cast<char*>(h->dstage[0]) + offsetof(Staging, fast));
+    ER_HIP_TRY(hipMemcpyAsync(dev_fast, &st->fast[0], sizeof(er::ReprojFast), hipMemcpyHostToDevice, h->stream));
+    if (launch_reproject(h, RA, 1, dev_fast, h->stream)) return 1;
+  }
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
                      h->depth_stage[0], total);
   ER_HIP_TRY(hipGetLastError());
@@ -1023,8 +1132,7 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
   if (warp) {
     if (!warp->ctr || !warp->grid_index || !warp->seg || !warp->madj || warp->num_grids <= 0 || warp->resolution <= 0)
       return er::fail("er_tsdf_integrate_frames: incomplete er_warp");
-    const size_t verts = (size_t)(warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
-    if (upload_ctr(h, warp->ctr, verts * 3 * (size_t)warp->num_grids, h->aux_stream)) return 1;
+    if (upload_ctr(h, warp->ctr, warp->resolution, warp->num_grids, h->aux_stream)) return 1;
   }
   const size_t px = (size_t)h->pixels;
   // n frames are fused in ceil(n / ER_MAX_BATCH) launches of (nearly) EQUAL size: 150 frames run as 3 x 50, not 64 + 64 + 22

@@ -11,6 +11,8 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
+#include <cmath>
 
 #if defined(__HIPCC__)
 #define ER_HD __host__ __device__ __forceinline__
@@ -378,14 +380,16 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
       const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
       const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
       const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
-#if defined(__HIP_DEVICE_COMPILE__) && defined(ER_FAST_CULL)
-      // (experiment, off by default: the 1-ulp hardware reciprocal is enough for tests whose margins are 1.5 px and whose
-      //  "inside" slack budgets 16u where 3.3u + 4u are needed; not measured yet with the pre-pass chain as the critical one)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_CULL_IEEE_DIV)
+      // The corner projections feed conservative tests only (margins of 1.5 px; the "inside" slack budgets 16u where 3.3u + 4u
+      // are needed), so the 1-ulp hardware reciprocal replaces the two IEEE divisions: 8 fewer division sequences per
+      // (patch, frame).  Validated: the whole -m gpu parity suite is bit-exact with it (profiles/r02a_ab_fast_cull.txt),
+      // and tests/test_hostcheck.py stresses both verdicts on the CPU with a reciprocal that is off by +-1 and +-2 ulps.
       const float rt2 = __builtin_amdgcn_rcpf(t2);
       const float u = (t0 * c.fx) * rt2 + c.cx, v = (t1 * c.fy) * rt2 + c.cy;
 #elif defined(ER_FAST_CULL_HOSTSIM)
       // tests only (tests/test_hostcheck.py): the same expression with a reciprocal that is off by ER_FAST_CULL_HOSTSIM ulps,
-      // the accuracy v_rcp_f32 guarantees, so that the verdicts can be stressed on the CPU before the variant is enabled
+      // the accuracy v_rcp_f32 guarantees, so that the verdicts can be stressed on the CPU
       float rt2 = 1.0f / t2;
       for (int s_ = 0; s_ < (ER_FAST_CULL_HOSTSIM < 0 ? -(ER_FAST_CULL_HOSTSIM) : (ER_FAST_CULL_HOSTSIM)); s_++)
         rt2 = nextafterf(rt2, ER_FAST_CULL_HOSTSIM < 0 ? -3.0e38f : 3.0e38f);
@@ -499,7 +503,8 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
 // madj: rows 0..2 (12 doubles).  ctr: one grid, (res+1)^3 * 3 floats.
 // On success returns true and the target cell (row-major pixel index) plus the 16-bit depth dd.
 ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, int rows, const double* seg,
-                        const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd) {
+                        const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd,
+                        double* e_out = nullptr) {
   float pt[3];
   cube_coords(u, v, d, c, ci, seg, pt);
   // ControlGrid::GetCoordinate, ControlGrid.h:44-81 (float32)
@@ -541,6 +546,7 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   // image size; for images smaller than that its write at vv * cols_ + uu would run past the buffer
   // (undefined behaviour), so the bounds are min(640, cols) x min(480, rows) here -- identical for the
   // 640 x 480 streams the reference supports, and for larger images the 640 x 480 clip is preserved.
+  if (e_out) { e_out[0] = e0; e_out[1] = e1; e_out[2] = e2; }              // (tests: the reference's float64 values)
   if (!(e2 > 0.0)) return false;
   const double re = fast_rcp64(e2);
   double uu = round_pixel(e0, (double)c.fx, e2, re, (double)c.cx, ci.pp_small);
@@ -554,6 +560,186 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   dd = (uint16_t)((uint32_t)(int)dz & 0xFFFFu);
   cell = (int)vv * cols + (int)uu;
   return true;
+}
+
+// ---- Reproject, tier 1: a float32 ESTIMATE of the warp with a rigorous error bound --------------------------------------
+// Only three integers of Reproject are observable per source pixel: the target pixel (uu, vv) = two roundings, and the
+// millimetre depth dd = one rounding (IntegrateApp.cpp:256-263).  reproject_px above evaluates the reference's whole chain
+// exactly (~235 VALU instructions per 64 pixels, most of them float64).  The tier below estimates the same three values with
+// ~100 cheaper instructions and PROVES, per pixel, whether the estimate is far enough from every decision boundary (lattice
+// range test, z > 0, the three roundings, the image-range test) for the integers to be the reference's; pixels it cannot
+// decide (a few per cent) are handed to reproject_px.  Nothing here has to reproduce an intermediate value of the reference.
+//
+// Notation: u32 = 2^-24; a = pt / unit_length_ (lattice coordinates, ControlGrid.h:44-48); for the lattice of a fragment
+// Cmax = max |vertex component|, Dmax = max component of the difference of two lattice-adjacent vertices.
+// (A) lattice coordinates.  Reference: q = seg * UVD2XYZ in float64 (error < 1e-12 relative to the magnitudes involved),
+//     pt = fl32(q), a_ref = fl32(pt / ul): |a_ref - q/ul| <= 2 u32 |a| (1 + u32).  Here: a~ = d (ga u' + gb v' + gc) + gs in
+//     float64 with host-folded coefficients (error < 1e-9 lattice units, enforced by the host: `ok`).  For |a| <= res + 2:
+//         |a~ - a_ref| <= eps_a = 2.001 u32 (res + 2) + 2e-9.
+//     a~ in [eps_a, res - eps_a] on every axis  =>  the reference accepts the point; a~ < -eps_a or > res + eps_a on some axis
+//     =>  it rejects it; otherwise undecided.
+// (B) trilinear position.  The interpolant is continuous across cells and, inside a cell, d pos / d a_k is a convex
+//     combination of four lattice edges, so moving the evaluation point by delta costs <= sum_k |delta_k| Dmax per component
+//     even when floor() lands in the neighbouring cell.  The reference's own float32 evaluation (weights with relative error
+//     <= 5.001 u32 each: three factors, two products; then 8 products, 7 sums; ControlGrid.h:69-87) deviates from the exact interpolant by <= 13.01 u32 Cmax, and
+//     so does the fused evaluation here (r~ rounded to float32: part of delta).  Hence per component
+//         |pos~ - pos_ref| <= eps_pos = 3 (eps_a + u32) Dmax + 27 u32 Cmax.
+// (C) e = madj * (pos, 1): float64 in the reference (exact to 1e-15), three float32 fmas here with float32 coefficients
+//     (rows 0 / 1 pre-scaled by fx / fy):  |e~_r - s_r e_r| <= s_r eps_e,  eps_e = L1 eps_pos + 4.01 u32 (L1 Cmax' + |m_r|)
+//     with L1 = max_r sum_c |M_rc| and Cmax' = Cmax + eps_pos.
+// (D) projection.  With P = fx e0 / e2 (= u - cx):  e~0 / e~2 - P = (delta0 - P delta2) / e~2; the hardware reciprocal adds
+//     <= 2.5 u32 |P|, the final fma u32 |u|, adding 0.5 another u32 |u|.  The tier only DECIDES pixels whose estimate lies
+//     inside the image (|P| <= pmax), with e~2 >= e2_min = 64 eps_e (so 1 / e2 is within 1.6 % of 1 / e~2):
+//         |u~ - u_ref| <= t1 / e~2 + t2,   t1 = 1.04 (f eps_e + (pmax + 2) eps_e),  t2 = 5 u32 (pmax + |c| + 2)
+//     (f = max(fx, fy), c = cx or cy).  Depth: |1000 e~2 - 1000 e2| <= 1000 eps_e (1.02) + 2 u32 (1000 e~2).
+// A rounding floor(x + 0.5) is decided when the fractional part of x~ + 0.5 keeps more than the tolerance away from 0 and 1;
+// then the integer tests against the image bounds are exact as well.  Every constant is rounded UP on the host
+// (reproj_fast_setup); tests/hostcheck replays the tier on the CPU against reproject_px for every pixel of the golden and
+// fuzzed scenes and records the worst observed error as a fraction of its tolerance.
+struct alignas(16) Vert4 { float x, y, z, w; };     // one lattice vertex padded to 16 bytes (one ds_read_b128 / 16-byte load)
+
+struct ReprojFast {
+  double ga[3], gb[3], gc[3], gs[3];   // a_k = d * (ga_k u' + gb_k v' + gc_k) + gs_k, d = raw depth in millimetres
+  float m[12];                         // madj rows 0, 1 scaled by fx, fy; row 2 plain
+  float eps_a, res_hi;                 // lattice range guard: accept inside [eps_a, res_hi], reject outside [-eps_a, res + eps_a]
+  float res_rej;
+  float t1, t2;                        // pixel tolerance = t1 * rcp(e2) + t2
+  float td1;                           // depth tolerance (mm) = td1 + 2 u32 * (1000 e2)
+  float e2_min;
+  float ulim, vlim;                    // min(640, cols), min(480, rows) (reproject_px)
+  int ok;                              // 0: tier disabled for this frame (every pixel goes to the exact path)
+  int pad;
+};
+
+enum { kReprojReject = 0, kReprojAccept = 1, kReprojUnsure = 2 };
+
+// Host side: Cmax / Dmax of one lattice ((res+1)^3 vertices of 3 floats, vertex i + j n1 + k n1^2).  Non-finite -> inf.
+inline void lattice_bounds(const float* ctr, int res, double& cmax, double& dmax) {
+  const int n1 = res + 1, n2 = n1 * n1;
+  cmax = dmax = 0.0;
+  for (int k = 0; k < n1; k++)
+    for (int j = 0; j < n1; j++)
+      for (int i = 0; i < n1; i++) {
+        const int v = i + j * n1 + k * n2;
+        for (int a = 0; a < 3; a++) {
+          const double x = (double)ctr[3 * v + a];
+          if (!std::isfinite(x)) { cmax = dmax = HUGE_VAL; return; }
+          cmax = fmax(cmax, fabs(x));
+          if (i + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + 1) + a] - x));
+          if (j + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + n1) + a] - x));
+          if (k + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + n2) + a] - x));
+        }
+      }
+}
+
+// Host side: constants of one frame.  seg / madj: rows 0..2 of the float64 matrices; cmax / dmax: the lattice bounds above.
+inline void reproj_fast_setup(const double* seg, const double* madj, const Camera& c, int cols, int rows, int res, float grid_ul,
+                              double cmax, double dmax, ReprojFast& F) {
+  memset(&F, 0, sizeof F);
+  const double u32 = 1.0 / 16777216.0;
+  const double ul = (double)grid_ul, fx = (double)c.fx, fy = (double)c.fy;
+  const double umax = fmax(fabs(0.0 - (double)c.cx), fabs((double)(cols - 1) - (double)c.cx)) + 1.0;
+  const double vmax = fmax(fabs(0.0 - (double)c.cy), fabs((double)(rows - 1) - (double)c.cy)) + 1.0;
+  double worst_mag = 0.0;
+  for (int k = 0; k < 3; k++) {
+    F.ga[k] = seg[4 * k] / (fx * ul * 1000.0);
+    F.gb[k] = seg[4 * k + 1] / (fy * ul * 1000.0);
+    F.gc[k] = seg[4 * k + 2] / (ul * 1000.0);
+    F.gs[k] = seg[4 * k + 3] / ul;
+    worst_mag = fmax(worst_mag, 65535.0 * (fabs(F.ga[k]) * umax + fabs(F.gb[k]) * vmax + fabs(F.gc[k])) + fabs(F.gs[k]));
+  }
+  const double eps_a = 2.001 * u32 * (double)(res + 2) + 2e-9;
+  const double eps_pos = 3.0 * (eps_a + u32) * dmax + 27.0 * u32 * cmax + 1e-30;
+  double l1 = 0.0, mabs = 0.0;
+  for (int r = 0; r < 3; r++) {
+    l1 = fmax(l1, fabs(madj[4 * r]) + fabs(madj[4 * r + 1]) + fabs(madj[4 * r + 2]));
+    mabs = fmax(mabs, fabs(madj[4 * r + 3]));
+  }
+  const double eps_e = l1 * eps_pos + 4.01 * u32 * (l1 * (cmax + eps_pos) + mabs);
+  const double ulim = cols < 640 ? (double)cols : 640.0, vlim = rows < 480 ? (double)rows : 480.0;
+  const double pmax = fmax(fmax(fabs((double)c.cx), fabs(ulim - (double)c.cx)), fmax(fabs((double)c.cy), fabs(vlim - (double)c.cy))) + 1.0;
+  const double f = fmax(fabs(fx), fabs(fy)), cc = fmax(fabs((double)c.cx), fabs((double)c.cy));
+  const double t1 = 1.04 * (f * eps_e + (pmax + 2.0) * eps_e), t2 = 5.0 * u32 * (pmax + cc + 2.0);
+  const double up = 1.0 + 1e-6;                                    // float conversion rounds to nearest: push every bound up
+  for (int q = 0; q < 4; q++) {
+    F.m[q] = (float)(madj[q] * fx);
+    F.m[4 + q] = (float)(madj[4 + q] * fy);
+    F.m[8 + q] = (float)madj[8 + q];
+  }
+  F.eps_a = (float)(eps_a * up);
+  F.res_hi = (float)(((double)res - eps_a) / up);
+  F.res_rej = (float)(((double)res + eps_a) * up);
+  F.t1 = (float)(t1 * up);
+  F.t2 = (float)(t2 * up);
+  F.td1 = (float)((1000.0 * eps_e * 1.02 + 1e-9) * up);
+  F.e2_min = (float)(64.0 * eps_e * up);
+  F.ulim = (float)ulim;
+  F.vlim = (float)vlim;
+  // The analysis needs finite, sane magnitudes: float64 evaluation error of a~ below 1e-9 lattice units (20 roundings of
+  // magnitude worst_mag), coefficients that fit float32 comfortably, a lattice spacing in range, a tolerance that can ever pass.
+  const bool sane = std::isfinite(worst_mag) && worst_mag * 20.0 * 1.2e-16 < 1e-9 && std::isfinite(cmax) && std::isfinite(dmax) &&
+                    cmax < 1e6 && std::isfinite(eps_e) && std::isfinite(t1) && std::isfinite(pmax) && pmax < 1e6 && f < 1e6 &&
+                    ul > 1e-6 && ul < 1e6 && res >= 1 && res < 4096 && t2 < 0.25 && mabs < 1e6;
+  F.ok = sane ? 1 : 0;
+}
+
+// Second half of tier 1 (split out so that the cull-stress tests can drive it with a perturbed reciprocal).
+ER_HD int reproject_fast_finish(float e0, float e1, float e2, float rc, const ReprojFast& F, float cxf, float cyf, int cols,
+                                int& cell, uint16_t& dd, float* dbg = nullptr) {
+  const float xu = fmaf(e0, rc, cxf) + 0.5f, xv = fmaf(e1, rc, cyf) + 0.5f;
+  const float xd = fmaf(e2, 1000.0f, 0.5f);
+  const float fu = floorf(xu), fv = floorf(xv), fd = floorf(xd);
+  const float tol = fmaf(F.t1, rc, F.t2), told = fmaf(xd, 0x1p-23f, F.td1);
+  if (dbg) { dbg[0] = xu; dbg[1] = xv; dbg[2] = xd; dbg[3] = tol; dbg[4] = told; }   // (tests: estimates and their tolerances)
+  // decided <=> the fractional part keeps the tolerance away from both ends:  | frac - 0.5 | < 0.5 - tol
+  const bool su = fabsf((xu - fu) - 0.5f) < 0.5f - tol, sv = fabsf((xv - fv) - 0.5f) < 0.5f - tol, sd = fabsf((xd - fd) - 0.5f) < 0.5f - told;
+  const bool sure = su & sv & sd & (fd < 65535.0f);
+  // estimates outside the image by more than a pixel are not priced by t1 / t2 (|P| <= pmax was assumed): undecided
+  const bool near_img = (fu >= -1.0f) & (fu <= F.ulim) & (fv >= -1.0f) & (fv <= F.vlim);
+  if (!(sure & near_img)) return kReprojUnsure;                         // (NaN anywhere lands here too)
+  if (!((fu >= 0.0f) & (fu < F.ulim) & (fv >= 0.0f) & (fv < F.vlim))) return kReprojReject;   // XYZ2UVD's range test, exact on the integers
+  dd = (uint16_t)(int)fd;
+  cell = (int)fv * cols + (int)fu;
+  return kReprojAccept;
+}
+
+// Tier 1 for one source pixel.  g[3] = ga u' + gb v' + gc of this pixel (float64, u' = (double)((float)u - cx) as in
+// UVD2XYZ); ctr4 = the frame's lattice, one Vert4 per vertex (LDS on the device); n1 = res + 1.
+// Returns kReprojAccept with the target cell and depth, kReprojReject, or kReprojUnsure (NaNs fail every compare: unsure).
+ER_HD int reproject_fast(uint16_t d, const double g[3], const ReprojFast& F, const Camera& c, const Vert4* __restrict__ ctr4, int n1,
+                         int cols, int& cell, uint16_t& dd, float* dbg = nullptr) {
+  if (!F.ok) return kReprojUnsure;
+  const double dz = (double)d;
+  const double a0 = fma(dz, g[0], F.gs[0]), a1 = fma(dz, g[1], F.gs[1]), a2 = fma(dz, g[2], F.gs[2]);
+  const double amin = fmin(fmin(a0, a1), a2), amax = fmax(fmax(a0, a1), a2);
+  if (!((amin >= (double)F.eps_a) & (amax <= (double)F.res_hi)))
+    return ((amin < -(double)F.eps_a) | (amax > (double)F.res_rej)) ? kReprojReject : kReprojUnsure;   // GetCoordinate false / undecided
+  const double f0 = floor(a0), f1 = floor(a1), f2 = floor(a2);
+  const float r0 = (float)(a0 - f0), r1 = (float)(a1 - f1), r2 = (float)(a2 - f2);
+  const int n2 = n1 * n1;
+  const Vert4* __restrict__ cb = ctr4 + ((int)f0 + ((int)f1 + (int)f2 * n1) * n1);
+  const float w0 = 1.0f - r0, w1 = 1.0f - r1, w2 = 1.0f - r2;
+  const float w01 = w0 * w1, w0r = w0 * r1, rw1 = r0 * w1, r01 = r0 * r1;
+  const Vert4 c0 = cb[0], c1 = cb[n2], c2 = cb[n1], c3 = cb[n1 + n2], c4 = cb[1], c5 = cb[1 + n2], c6 = cb[1 + n1], c7 = cb[1 + n1 + n2];
+  const float v0 = w01 * w2, v1 = w01 * r2, v2 = w0r * w2, v3 = w0r * r2, v4 = rw1 * w2, v5 = rw1 * r2, v6 = r01 * w2, v7 = r01 * r2;
+  float px = v0 * c0.x, py = v0 * c0.y, pz = v0 * c0.z;
+  px = fmaf(v1, c1.x, px); py = fmaf(v1, c1.y, py); pz = fmaf(v1, c1.z, pz);
+  px = fmaf(v2, c2.x, px); py = fmaf(v2, c2.y, py); pz = fmaf(v2, c2.z, pz);
+  px = fmaf(v3, c3.x, px); py = fmaf(v3, c3.y, py); pz = fmaf(v3, c3.z, pz);
+  px = fmaf(v4, c4.x, px); py = fmaf(v4, c4.y, py); pz = fmaf(v4, c4.z, pz);
+  px = fmaf(v5, c5.x, px); py = fmaf(v5, c5.y, py); pz = fmaf(v5, c5.z, pz);
+  px = fmaf(v6, c6.x, px); py = fmaf(v6, c6.y, py); pz = fmaf(v6, c6.z, pz);
+  px = fmaf(v7, c7.x, px); py = fmaf(v7, c7.y, py); pz = fmaf(v7, c7.z, pz);
+  const float e0 = fmaf(F.m[0], px, fmaf(F.m[1], py, fmaf(F.m[2], pz, F.m[3])));
+  const float e1 = fmaf(F.m[4], px, fmaf(F.m[5], py, fmaf(F.m[6], pz, F.m[7])));
+  const float e2 = fmaf(F.m[8], px, fmaf(F.m[9], py, fmaf(F.m[10], pz, F.m[11])));
+  if (!(e2 >= F.e2_min)) return (e2 < -F.e2_min) ? kReprojReject : kReprojUnsure;     // z <= 0: XYZ2UVD false / undecided
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float rc = __builtin_amdgcn_rcpf(e2);                          // <= 1 ulp
+#else
+  const float rc = 1.0f / e2;
+#endif
+  return reproject_fast_finish(e0, e1, e2, rc, F, c.cx, c.cy, cols, cell, dd, dbg);
 }
 
 }  // namespace er

@@ -214,17 +214,29 @@ def _sample_fragment_torch(world_T_frag, n_points, seed, length, device):
     return q[keep].to(torch.float32).cpu().numpy(), qn[keep].to(torch.float32).cpu().numpy()
 
 
-def fragment_set(num, target_points=250000, seed=SEED, length=3.0, radius=0.6, device="cpu"):
-    """`num` DISTINCT fragments of target_points surfels each (configs[2] / configs[4] shape): fragment i is what a
-    camera at angle 2 pi i / num on the config-2 circle sees inside its own length^3 cube (frame = camera pose x basepose^-1,
-    the kinfu convention of CorresApp.cpp:45-48).  Neighbouring fragments overlap, opposite ones do not.
+def fragment_set(num, target_points=250000, seed=SEED, length=3.0, radius=0.0, device="cpu"):
+    """`num` DISTINCT fragments of target_points surfels each (configs[2] / configs[4] shape), independently sampled.
+    radius == 0 (default): fragment i's length^3 cube is centred on the room centre and turned by 2 pi i / num about the
+    vertical axis, so every fragment holds floor, ceiling, the sphere and a differently clipped part of all four walls: any
+    two fragments overlap and every pair constrains all six degrees of freedom.  (Fragments that see nothing but one wall
+    plus floor and ceiling slide along the wall under point-to-plane ICP -- the reference's just as well -- and a parity
+    test on such a pair compares two arbitrary answers.)
+    radius > 0: fragment i is what a level camera at that distance from the centre, looking outward at angle 2 pi i / num,
+    sees inside its own cube (frame = camera pose x basepose^-1, the kinfu convention of CorresApp.cpp:45-48): neighbours
+    overlap, opposite fragments do not (the all-pairs scene of configs[4] with its pre-check rejects).
     Returns [(xyz float32 [m,3], normals float32 [m,3], world_T_frag float64 4x4)]."""
     out = []
     Binv = np.linalg.inv(basepose(length))
-    cams = circle_trajectory(num, radius=radius)
     for i in range(num):
-        F = cams[i] @ Binv
-        x, n = _sample_fragment_torch(F, 5 * target_points, seed + 7919 * i + 1, length, device)   # 21-31 % fall inside the cube
+        th = 2.0 * math.pi * i / num
+        d = np.array([math.cos(th), 0.0, math.sin(th)])
+        if radius > 0:
+            F = look_at(np.array([1.5, 1.5, 1.5]) + radius * d, d) @ Binv
+        else:
+            C = np.eye(4)
+            C[:3, 3] = -length / 2.0
+            F = look_at(np.array([1.5, 1.5, 1.5]), d) @ C
+        x, n = _sample_fragment_torch(F, (5 if radius > 0 else 2) * target_points, seed + 7919 * i + 1, length, device)
         out.append((x[:target_points], n[:target_points], F))                   # (samples are i.i.d.: a prefix is a sample)
     return out
 

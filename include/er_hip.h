@@ -43,6 +43,7 @@ int er_abi_version(void);
  * that come from er_host_alloc are written by asynchronous device-to-host copies without a staging pass. */
 void* er_host_alloc(size_t bytes);               /* NULL on failure (see er_last_error) */
 int er_host_free(void* p);
+int er_host_copy_h2d(void* dev_dst, const void* host_src, size_t bytes);   /* blocking host -> device copy (current device) */
 
 /* ------------------------------------------------------------ path A: TSDF ---- */
 typedef struct er_tsdf_s* er_tsdf_t;
