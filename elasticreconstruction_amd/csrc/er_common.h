@@ -25,3 +25,10 @@ int fail(const char* fmt, ...);
   } while (0)
 
 }  // namespace er
+
+// internal accessors of a TSDF handle for the other translation units of the library (not part of the C ABI)
+struct er_tsdf_s;
+namespace er {
+hipStream_t tsdf_stream(er_tsdf_s* h);
+int tsdf_device(er_tsdf_s* h);
+}  // namespace er

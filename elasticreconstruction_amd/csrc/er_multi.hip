@@ -1,0 +1,233 @@
+// er_multi.hip -- the multi-GPU side of liber_hip.so: the ONE collective of the pipeline, issued from the
+// library itself so that the C++ drop-in programs (and any other host) need neither torch nor MPI.
+//
+//   frames (path A, as BASELINE.json prescribes): contiguous frame blocks per GPU into private volumes, then
+//       er_tsdf_allreduce = [agree on the key count: all-reduce(MAX) of one int] -> [all-gather of the touched unit keys,
+//       padded to that count] -> union -> ONE ncclReduce / ncclAllReduce (sum, float) over the [key][sdf*weight | weight]
+//       planes of the union -> import (weight = W, sdf = SW / W).  The running mean with unit weights is a sum
+//       (TSDFVolume.cpp:93-94: sdf' = (sdf w + tsdf) / (w + 1), w' = w + 1), so this equals the sequential result up to the
+//       float32 rounding order: weights exact, sdf within 1e-5.
+//   units  (the bit-exact alternative): er_tsdf_set_unit_shard in er_tsdf.hip -- no collective at all.
+//   pairs  (path B): independent, no collective (BuildCorrespondence --gpus).
+//
+// RCCL (= NCCL's API on ROCm; xGMI between the GPUs of a node) is loaded on first use with dlopen, by soname: a process that
+// already carries an RCCL (PyTorch bundles one) keeps that single instance; the C++ programs pick up /opt/rocm/lib/librccl.so.1.
+// One communicator per GPU: er_comm_create (one process per GPU; the 128-byte id travels out of band -- a file, a socket,
+// torch.distributed) or er_comm_create_local (one process driving several GPUs from one host thread each).
+#include "er_common.h"
+
+#include "../../include/er_hip.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: every function is reached through dlsym
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclReduce) Reduce = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+
+Rccl* rccl() {
+  static Rccl R;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char* n : names) {
+      R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (R.lib) break;
+    }
+    if (!R.lib) return;
+#define ER_SYM(field, name) R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.lib, name))
+    ER_SYM(GetUniqueId, "ncclGetUniqueId");
+    ER_SYM(CommInitRank, "ncclCommInitRank");
+    ER_SYM(CommInitAll, "ncclCommInitAll");
+    ER_SYM(CommDestroy, "ncclCommDestroy");
+    ER_SYM(AllReduce, "ncclAllReduce");
+    ER_SYM(Reduce, "ncclReduce");
+    ER_SYM(AllGather, "ncclAllGather");
+    ER_SYM(GetErrorString, "ncclGetErrorString");
+#undef ER_SYM
+    R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllReduce && R.Reduce && R.AllGather && R.GetErrorString;
+  });
+  return R.ok ? &R : nullptr;
+}
+
+#define ER_NCCL_TRY(R, expr)                                                                        \
+  do {                                                                                              \
+    ncclResult_t er_r_ = (expr);                                                                    \
+    if (er_r_ != ncclSuccess)                                                                       \
+      return ::er::fail("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, (R)->GetErrorString(er_r_)); \
+  } while (0)
+
+}  // namespace
+
+struct er_comm_s {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  float* buf = nullptr;        // [union][2][64^3] planes (grow-only)
+  size_t buf_units = 0;
+  int* ikeys = nullptr;        // device scratch: [1 + max_keys * (world + 1)] ints (grow-only)
+  size_t ikeys_cap = 0;
+};
+
+static_assert(ER_COMM_ID_BYTES == sizeof(ncclUniqueId), "ER_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+
+extern "C" {
+
+int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]) {
+  if (!id) return er::fail("er_comm_unique_id: NULL argument");
+  Rccl* R = rccl();
+  if (!R) return er::fail("er_comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  ncclUniqueId u;
+  ER_NCCL_TRY(R, R->GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return 0;
+}
+
+int er_comm_create(const unsigned char id[ER_COMM_ID_BYTES], int rank, int world, int device, er_comm_t* out) {
+  if (!id || !out) return er::fail("er_comm_create: NULL argument");
+  *out = nullptr;
+  if (world < 1 || rank < 0 || rank >= world) return er::fail("er_comm_create: rank %d not in [0,%d)", rank, world);
+  Rccl* R = rccl();
+  if (!R) return er::fail("er_comm_create: librccl.so.1 could not be loaded");
+  ER_HIP_TRY(hipSetDevice(device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  er_comm_t c = new er_comm_s();
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  ncclResult_t r = R->CommInitRank(&c->comm, world, u, rank);
+  if (r != ncclSuccess) {
+    delete c;
+    return er::fail("er_comm_create: ncclCommInitRank failed: %s", R->GetErrorString(r));
+  }
+  *out = c;
+  return 0;
+}
+
+int er_comm_create_local(int n, const int* devices, er_comm_t* out) {
+  if (n < 1 || !devices || !out) return er::fail("er_comm_create_local: bad arguments");
+  for (int i = 0; i < n; i++) out[i] = nullptr;
+  Rccl* R = rccl();
+  if (!R) return er::fail("er_comm_create_local: librccl.so.1 could not be loaded");
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  ER_NCCL_TRY(R, R->CommInitAll(comms.data(), n, devices));
+  for (int i = 0; i < n; i++) {
+    er_comm_t c = new er_comm_s();
+    c->comm = comms[(size_t)i];
+    c->rank = i;
+    c->world = n;
+    c->device = devices[i];
+    out[i] = c;
+  }
+  return 0;
+}
+
+int er_comm_destroy(er_comm_t c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->buf) (void)hipFree(c->buf);
+  if (c->ikeys) (void)hipFree(c->ikeys);
+  Rccl* R = rccl();
+  if (R && c->comm) (void)R->CommDestroy(c->comm);
+  delete c;
+  return 0;
+}
+
+int er_comm_rank(er_comm_t c) { return c ? c->rank : -1; }
+int er_comm_world(er_comm_t c) { return c ? c->world : -1; }
+
+// The frame-split merge (see the file header).  Every rank of the communicator calls it once, each from its own host
+// thread / process; root < 0 leaves the merged volume on every rank, otherwise only on `root`.
+int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
+  if (!h || !c) return er::fail("er_tsdf_allreduce: NULL argument");
+  if (root >= c->world) return er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
+  if (er::tsdf_device(h) != c->device) return er::fail("er_tsdf_allreduce: the volume lives on device %d, the communicator on %d", er::tsdf_device(h), c->device);
+  Rccl* R = rccl();
+  if (!R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded");
+  ER_HIP_TRY(hipSetDevice(c->device));
+  if (er_tsdf_synchronize(h)) return 1;                         // the volume's own two streams are drained once per job
+  hipStream_t S = er::tsdf_stream(h);
+  // ---- 1. agree on the padded key count, exchange the keys -------------------------------------
+  int n_local = 0;
+  if (er_tsdf_unit_count(h, &n_local)) return 1;
+  std::vector<int> keys((size_t)std::max(n_local, 1), -1);
+  if (n_local > 0 && er_tsdf_unit_keys(h, keys.data())) return 1;
+  if (c->ikeys_cap < 2) {
+    if (c->ikeys) (void)hipFree(c->ikeys);
+    c->ikeys = nullptr;
+    ER_HIP_TRY(hipMalloc((void**)&c->ikeys, 64 * sizeof(int)));
+    c->ikeys_cap = 64;
+  }
+  ER_HIP_TRY(hipMemcpyAsync(c->ikeys, &n_local, sizeof(int), hipMemcpyHostToDevice, S));
+  ER_NCCL_TRY(R, R->AllReduce(c->ikeys, c->ikeys + 1, 1, ncclInt32, ncclMax, c->comm, S));
+  int max_keys = 0;
+  ER_HIP_TRY(hipMemcpyAsync(&max_keys, c->ikeys + 1, sizeof(int), hipMemcpyDeviceToHost, S));
+  ER_HIP_TRY(hipStreamSynchronize(S));
+  if (union_units) *union_units = 0;
+  if (max_keys <= 0) return 0;                                  // nobody touched anything
+  const size_t need = (size_t)max_keys * ((size_t)c->world + 1);
+  if (c->ikeys_cap < need) {
+    (void)hipFree(c->ikeys);
+    c->ikeys = nullptr;
+    c->ikeys_cap = 0;
+    ER_HIP_TRY(hipMalloc((void**)&c->ikeys, need * sizeof(int)));
+    c->ikeys_cap = need;
+  }
+  std::vector<int> padded((size_t)max_keys, -1);
+  std::copy(keys.begin(), keys.begin() + n_local, padded.begin());
+  int* d_mine = c->ikeys;
+  int* d_all = c->ikeys + max_keys;
+  ER_HIP_TRY(hipMemcpyAsync(d_mine, padded.data(), (size_t)max_keys * sizeof(int), hipMemcpyHostToDevice, S));
+  ER_NCCL_TRY(R, R->AllGather(d_mine, d_all, (size_t)max_keys, ncclInt32, c->comm, S));
+  std::vector<int> all((size_t)max_keys * c->world);
+  ER_HIP_TRY(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, S));
+  ER_HIP_TRY(hipStreamSynchronize(S));
+  std::sort(all.begin(), all.end());
+  all.erase(std::unique(all.begin(), all.end()), all.end());
+  all.erase(std::remove_if(all.begin(), all.end(), [](int k) { return k < 0; }), all.end());
+  const int nu = (int)all.size();
+  if (union_units) *union_units = nu;
+  if (nu == 0) return 0;
+  // ---- 2. planes of the union, ONE reduction, import ---------------------------------------------
+  if (c->buf_units < (size_t)nu) {
+    if (c->buf) (void)hipFree(c->buf);
+    c->buf = nullptr;
+    c->buf_units = 0;
+    ER_HIP_TRY(hipMalloc((void**)&c->buf, (size_t)nu * 2 * ER_UNIT_VOX * sizeof(float)));
+    c->buf_units = (size_t)nu;
+  }
+  if (er_tsdf_export_weighted(h, all.data(), nu, c->buf)) return 1;       // on S
+  const size_t count = (size_t)nu * 2 * ER_UNIT_VOX;
+  if (root < 0)
+    ER_NCCL_TRY(R, R->AllReduce(c->buf, c->buf, count, ncclFloat32, ncclSum, c->comm, S));     // the only data-path collective
+  else
+    ER_NCCL_TRY(R, R->Reduce(c->buf, c->buf, count, ncclFloat32, ncclSum, root, c->comm, S));
+  if (root < 0 || root == c->rank)
+    if (er_tsdf_import_weighted(h, all.data(), nu, c->buf)) return 1;     // on S, after the reduction
+  ER_HIP_TRY(hipStreamSynchronize(S));
+  return 0;
+}
+
+void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi) {
+  const int per = world > 0 ? (n_frames + world - 1) / world : n_frames;
+  const int a = std::min(rank * per, n_frames);
+  if (lo) *lo = a;
+  if (hi) *hi = std::min(a + per, n_frames);
+}
+
+}  // extern "C"

@@ -150,7 +150,10 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
 //   tier 2  the few per cent it cannot decide are appended to an LDS list and then run through the exact chain
 //           (reproject_scatter_px) by the first threads of the workgroup: ~50 of 1024 pixels -> one wave instead of sixteen.
 // Results are the reference's for every pixel either way (tests: hostcheck replay on the CPU, golden digests and fuzz on the GPU).
-constexpr int kRtW = 64, kRtH = 16;
+#ifndef ER_RT_PIX
+#define ER_RT_PIX 4                      // pixels per thread (one column of the tile)
+#endif
+constexpr int kRtW = 64, kRtPix = ER_RT_PIX, kRtH = 4 * kRtPix;
 
 __global__ __launch_bounds__(kBlock) void k_reproject_tiered(ReprojArgs A, const ReprojFast* __restrict__ fast, const Vert4* __restrict__ ctr4) {
   extern __shared__ Vert4 s_ctr[];
@@ -161,33 +164,43 @@ __global__ __launch_bounds__(kBlock) void k_reproject_tiered(ReprojArgs A, const
   const Vert4* __restrict__ g4 = ctr4 + (size_t)A.grid_index[f] * verts;
   for (int i = tid; i < verts; i += kBlock) s_ctr[i] = g4[i];
   if (tid == 0) s_n = 0;
-  __syncthreads();
   const ReprojFast& F = fast[f];                                        // wave-uniform: scalar loads
-  const int lx = tid & 63, ly0 = (tid >> 6) * 4;
+  const int lx = tid & 63, ly0 = (tid >> 6) * kRtPix;
   const int u = blockIdx.x * kRtW + lx, v0 = blockIdx.y * kRtH + ly0;
   const int pixels = A.cols * A.rows;
   const uint16_t* __restrict__ src = A.depth + (size_t)f * pixels;
-  uint16_t d[4];
+  int d[kRtPix];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {                                         // clamped address + select: no branches around the loads
-    const uint16_t t = src[min(v0 + j, A.rows - 1) * A.cols + min(u, A.cols - 1)];
-    d[j] = (u < A.cols && v0 + j < A.rows) ? t : (uint16_t)0;
+  for (int j = 0; j < kRtPix; j++) {                                    // clamped address + select: no branches around the loads
+    const int t = src[min(v0 + j, A.rows - 1) * A.cols + min(u, A.cols - 1)];
+    d[j] = (u < A.cols && v0 + j < A.rows) ? t : 0;
   }
-  const double up = (double)((float)u - A.cam.cx);                      // UVD2XYZ: int - float in float32, then promoted
-  const double gu[3] = {fma(F.ga[0], up, F.gc[0]), fma(F.ga[1], up, F.gc[1]), fma(F.ga[2], up, F.gc[2])};
+  // stage A for every pixel of the thread
+  RtPix P[kRtPix];
+  {
+    const double up = (double)((float)u - A.cam.cx);                    // UVD2XYZ: int - float in float32, then promoted
+    const double gu[3] = {fma(F.ga[0], up, F.gc[0]), fma(F.ga[1], up, F.gc[1]), fma(F.ga[2], up, F.gc[2])};
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (d[j] == 0) continue;                                            // UVD2XYZ false
-    const int v = v0 + j;
-    const double vp = (double)((float)v - A.cam.cy);
-    const double g[3] = {fma(F.gb[0], vp, gu[0]), fma(F.gb[1], vp, gu[1]), fma(F.gb[2], vp, gu[2])};
-    int cell;
-    uint16_t dd;
-    const int cls = reproject_fast(d[j], g, F, A.cam, s_ctr, n1, A.cols, cell, dd);
+    for (int j = 0; j < kRtPix; j++) {
+      const double vp = (double)((float)(v0 + j) - A.cam.cy);
+      const double g[3] = {fma(F.gb[0], vp, gu[0]), fma(F.gb[1], vp, gu[1]), fma(F.gb[2], vp, gu[2])};
+      rt_stage_a(d[j], g, F, n1, P[j]);
+    }
+  }
+  __syncthreads();                                                      // the lattice is in LDS
+  // stages C and E two pixels at a time: 16 LDS vertex reads in flight, registers for two pixels' vertices only
+#pragma unroll
+  for (int j = 0; j < kRtPix; j++) {
+    float pos[3];
+    rt_stage_c(P[j], s_ctr, n1, pos);
+    int cell, dd;
+    const int cls = rt_stage_e(d[j] != 0, P[j], pos, F, A.cam.cx, A.cam.cy, A.cols, cell, dd);
     if (cls == kReprojAccept) {
-      scatter_px(A, f, v * A.cols + u, cell, dd, 0);
+      scatter_px(A, f, (v0 + j) * A.cols + u, cell, (uint16_t)dd, 0);
     } else if (cls == kReprojUnsure) {
+#ifndef ER_RT_NO_TIER2
       s_unsure[atomicAdd(&s_n, 1)] = (unsigned short)((ly0 + j) * kRtW + lx);
+#endif
     }
   }
   __syncthreads();
@@ -687,6 +700,9 @@ struct er_tsdf_s {
   double ms_total = 0.0;
   long launches = 0, frames_done = 0;
 };
+
+hipStream_t er::tsdf_stream(er_tsdf_s* h) { return h->stream; }
+int er::tsdf_device(er_tsdf_s* h) { return h->device; }
 
 static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X);
 

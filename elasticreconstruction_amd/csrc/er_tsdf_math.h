@@ -683,44 +683,53 @@ inline void reproj_fast_setup(const double* seg, const double* madj, const Camer
   F.ok = sane ? 1 : 0;
 }
 
-// Second half of tier 1 (split out so that the cull-stress tests can drive it with a perturbed reciprocal).
-ER_HD int reproject_fast_finish(float e0, float e1, float e2, float rc, const ReprojFast& F, float cxf, float cyf, int cols,
-                                int& cell, uint16_t& dd, float* dbg = nullptr) {
-  const float xu = fmaf(e0, rc, cxf) + 0.5f, xv = fmaf(e1, rc, cyf) + 0.5f;
-  const float xd = fmaf(e2, 1000.0f, 0.5f);
-  const float fu = floorf(xu), fv = floorf(xv), fd = floorf(xd);
-  const float tol = fmaf(F.t1, rc, F.t2), told = fmaf(xd, 0x1p-23f, F.td1);
-  if (dbg) { dbg[0] = xu; dbg[1] = xv; dbg[2] = xd; dbg[3] = tol; dbg[4] = told; }   // (tests: estimates and their tolerances)
-  // decided <=> the fractional part keeps the tolerance away from both ends:  | frac - 0.5 | < 0.5 - tol
-  const bool su = fabsf((xu - fu) - 0.5f) < 0.5f - tol, sv = fabsf((xv - fv) - 0.5f) < 0.5f - tol, sd = fabsf((xd - fd) - 0.5f) < 0.5f - told;
-  const bool sure = su & sv & sd & (fd < 65535.0f);
-  // estimates outside the image by more than a pixel are not priced by t1 / t2 (|P| <= pmax was assumed): undecided
-  const bool near_img = (fu >= -1.0f) & (fu <= F.ulim) & (fv >= -1.0f) & (fv <= F.vlim);
-  if (!(sure & near_img)) return kReprojUnsure;                         // (NaN anywhere lands here too)
-  if (!((fu >= 0.0f) & (fu < F.ulim) & (fv >= 0.0f) & (fv < F.vlim))) return kReprojReject;   // XYZ2UVD's range test, exact on the integers
-  dd = (uint16_t)(int)fd;
-  cell = (int)fv * cols + (int)fu;
-  return kReprojAccept;
+// Tier 1 in three branch-free stages, so that a thread can run each stage for ALL its pixels before the next one (the frame
+// constants of a stage are then fetched once per thread, and the LDS reads of several pixels are in flight together):
+//   rt_stage_a   lattice coordinates -> cell + residuals + range verdict                       (float64, (A) above)
+//   rt_stage_c   trilinear sum over the 8 vertices of the (clamped) cell                        (float32, (B))
+//   rt_stage_e   e = madj * pos, projection, the three roundings with their tolerances          (float32, (C), (D))
+// Nothing branches on data: undecidable or irrelevant pixels run the same arithmetic on clamped indices and are sorted out
+// by the flags at the end.  NaNs fail every compare and end up "unsure".
+struct RtPix {
+  float r0, r1, r2;      // residuals inside the cell
+  int base;              // index of the cell's corner vertex (clamped into the lattice)
+  bool in, out;          // inside the lattice for sure / outside for sure
+};
+
+// clamp(x, lo, hi) in ONE instruction on the device (v_med3_f32; a NaN comes out as lo or hi, never as NaN)
+ER_HD float rt_med3(float x, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(x, lo, hi);
+#else
+  return x != x ? lo : fminf(fmaxf(x, lo), hi);
+#endif
 }
 
-// Tier 1 for one source pixel.  g[3] = ga u' + gb v' + gc of this pixel (float64, u' = (double)((float)u - cx) as in
-// UVD2XYZ); ctr4 = the frame's lattice, one Vert4 per vertex (LDS on the device); n1 = res + 1.
-// Returns kReprojAccept with the target cell and depth, kReprojReject, or kReprojUnsure (NaNs fail every compare: unsure).
-ER_HD int reproject_fast(uint16_t d, const double g[3], const ReprojFast& F, const Camera& c, const Vert4* __restrict__ ctr4, int n1,
-                         int cols, int& cell, uint16_t& dd, float* dbg = nullptr) {
-  if (!F.ok) return kReprojUnsure;
+// g[3] = ga u' + gb v' + gc of this pixel (float64, u' = (double)((float)u - cx) as in UVD2XYZ); n1 = res + 1.
+ER_HD void rt_stage_a(int d, const double g[3], const ReprojFast& F, int n1, RtPix& P) {
   const double dz = (double)d;
   const double a0 = fma(dz, g[0], F.gs[0]), a1 = fma(dz, g[1], F.gs[1]), a2 = fma(dz, g[2], F.gs[2]);
   const double amin = fmin(fmin(a0, a1), a2), amax = fmax(fmax(a0, a1), a2);
-  if (!((amin >= (double)F.eps_a) & (amax <= (double)F.res_hi)))
-    return ((amin < -(double)F.eps_a) | (amax > (double)F.res_rej)) ? kReprojReject : kReprojUnsure;   // GetCoordinate false / undecided
+  const bool in = (amin >= (double)F.eps_a) & (amax <= (double)F.res_hi);
+  const bool out = (amin < -(double)F.eps_a) | (amax > (double)F.res_rej);
   const double f0 = floor(a0), f1 = floor(a1), f2 = floor(a2);
-  const float r0 = (float)(a0 - f0), r1 = (float)(a1 - f1), r2 = (float)(a2 - f2);
+  P.r0 = (float)(a0 - f0);
+  P.r1 = (float)(a1 - f1);
+  P.r2 = (float)(a2 - f2);
+  const float res1 = (float)(n1 - 2);                                    // res - 1: the cell index is clamped into the lattice
+  const int c0 = (int)rt_med3((float)f0, 0.0f, res1), c1 = (int)rt_med3((float)f1, 0.0f, res1), c2 = (int)rt_med3((float)f2, 0.0f, res1);
+  P.base = c0 + (c1 + c2 * n1) * n1;
+  P.in = in;
+  P.out = out;
+}
+
+ER_HD void rt_stage_c(const RtPix& P, const Vert4* __restrict__ ctr4, int n1, float pos[3]) {
   const int n2 = n1 * n1;
-  const Vert4* __restrict__ cb = ctr4 + ((int)f0 + ((int)f1 + (int)f2 * n1) * n1);
+  const Vert4* __restrict__ cb = ctr4 + P.base;
+  const Vert4 c0 = cb[0], c1 = cb[n2], c2 = cb[n1], c3 = cb[n1 + n2], c4 = cb[1], c5 = cb[1 + n2], c6 = cb[1 + n1], c7 = cb[1 + n1 + n2];
+  const float r0 = P.r0, r1 = P.r1, r2 = P.r2;
   const float w0 = 1.0f - r0, w1 = 1.0f - r1, w2 = 1.0f - r2;
   const float w01 = w0 * w1, w0r = w0 * r1, rw1 = r0 * w1, r01 = r0 * r1;
-  const Vert4 c0 = cb[0], c1 = cb[n2], c2 = cb[n1], c3 = cb[n1 + n2], c4 = cb[1], c5 = cb[1 + n2], c6 = cb[1 + n1], c7 = cb[1 + n1 + n2];
   const float v0 = w01 * w2, v1 = w01 * r2, v2 = w0r * w2, v3 = w0r * r2, v4 = rw1 * w2, v5 = rw1 * r2, v6 = r01 * w2, v7 = r01 * r2;
   float px = v0 * c0.x, py = v0 * c0.y, pz = v0 * c0.z;
   px = fmaf(v1, c1.x, px); py = fmaf(v1, c1.y, py); pz = fmaf(v1, c1.z, pz);
@@ -730,16 +739,52 @@ ER_HD int reproject_fast(uint16_t d, const double g[3], const ReprojFast& F, con
   px = fmaf(v5, c5.x, px); py = fmaf(v5, c5.y, py); pz = fmaf(v5, c5.z, pz);
   px = fmaf(v6, c6.x, px); py = fmaf(v6, c6.y, py); pz = fmaf(v6, c6.z, pz);
   px = fmaf(v7, c7.x, px); py = fmaf(v7, c7.y, py); pz = fmaf(v7, c7.z, pz);
-  const float e0 = fmaf(F.m[0], px, fmaf(F.m[1], py, fmaf(F.m[2], pz, F.m[3])));
-  const float e1 = fmaf(F.m[4], px, fmaf(F.m[5], py, fmaf(F.m[6], pz, F.m[7])));
-  const float e2 = fmaf(F.m[8], px, fmaf(F.m[9], py, fmaf(F.m[10], pz, F.m[11])));
-  if (!(e2 >= F.e2_min)) return (e2 < -F.e2_min) ? kReprojReject : kReprojUnsure;     // z <= 0: XYZ2UVD false / undecided
+  pos[0] = px; pos[1] = py; pos[2] = pz;
+}
+
+// valid = the source pixel carries a depth (UVD2XYZ true).  Returns the class; cell / dd are meaningful for kReprojAccept.
+ER_HD int rt_stage_e(bool valid, const RtPix& P, const float pos[3], const ReprojFast& F, float cxf, float cyf, int cols, int& cell, int& dd,
+                     float* dbg = nullptr) {
+  const float e0 = fmaf(F.m[0], pos[0], fmaf(F.m[1], pos[1], fmaf(F.m[2], pos[2], F.m[3])));
+  const float e1 = fmaf(F.m[4], pos[0], fmaf(F.m[5], pos[1], fmaf(F.m[6], pos[2], F.m[7])));
+  const float e2 = fmaf(F.m[8], pos[0], fmaf(F.m[9], pos[1], fmaf(F.m[10], pos[2], F.m[11])));
 #if defined(__HIP_DEVICE_COMPILE__)
-  const float rc = __builtin_amdgcn_rcpf(e2);                          // <= 1 ulp
+  const float rc = __builtin_amdgcn_rcpf(e2);                            // <= 1 ulp
 #else
   const float rc = 1.0f / e2;
 #endif
-  return reproject_fast_finish(e0, e1, e2, rc, F, c.cx, c.cy, cols, cell, dd, dbg);
+  const float xu = fmaf(e0, rc, cxf) + 0.5f, xv = fmaf(e1, rc, cyf) + 0.5f;
+  const float xd = fmaf(e2, 1000.0f, 0.5f);
+  const float fu = floorf(xu), fv = floorf(xv), fd = floorf(xd);
+  const float tol = fmaf(F.t1, rc, F.t2), told = fmaf(xd, 0x1p-23f, F.td1);
+  if (dbg) { dbg[0] = xu; dbg[1] = xv; dbg[2] = xd; dbg[3] = tol; dbg[4] = told; }   // (tests: estimates and their tolerances)
+  // a rounding is decided <=> the fractional part keeps the tolerance away from both ends:  | frac - 0.5 | < 0.5 - tol
+  const bool su = fabsf((xu - fu) - 0.5f) < 0.5f - tol, sv = fabsf((xv - fv) - 0.5f) < 0.5f - tol, sd = fabsf((xd - fd) - 0.5f) < 0.5f - told;
+  // estimates outside the image by more than a pixel are not priced by t1 / t2 (|P| <= pmax was assumed): undecided
+  const bool near_img = (fu >= -1.0f) & (fu <= F.ulim) & (fv >= -1.0f) & (fv <= F.vlim);
+  const bool in_img = (fu >= 0.0f) & (fu < F.ulim) & (fv >= 0.0f) & (fv < F.vlim);    // XYZ2UVD's range test, exact on decided integers
+  const bool zpos = e2 >= F.e2_min, zneg = e2 < -F.e2_min;                            // z > 0 / z <= 0 for sure (XYZ2UVD)
+  const bool lat_in = P.in, lat_out = P.out;
+  const bool decided_px = zpos & su & sv & sd & (fd < 65535.0f) & near_img;
+  const bool accept = valid & (F.ok != 0) & lat_in & decided_px & in_img;
+  const bool reject = !valid | ((F.ok != 0) & (lat_out | (lat_in & (zneg | (decided_px & !in_img)))));
+  // only read when the pixel is accepted (then fd is in [0, 65535) and fu, fv are inside the image)
+  dd = accept ? (int)fd : 0;
+  cell = accept ? (int)fv * cols + (int)fu : 0;
+  return accept ? kReprojAccept : (reject ? kReprojReject : kReprojUnsure);
+}
+
+// The three stages for one pixel (tests/hostcheck; the kernel interleaves the stages of its pixels instead).
+ER_HD int reproject_fast(uint16_t d, const double g[3], const ReprojFast& F, const Camera& c, const Vert4* __restrict__ ctr4, int n1,
+                         int cols, int& cell, uint16_t& dd, float* dbg = nullptr) {
+  RtPix P;
+  float pos[3];
+  rt_stage_a((int)d, g, F, n1, P);
+  rt_stage_c(P, ctr4, n1, pos);
+  int ddi = 0;
+  const int cls = rt_stage_e(d != 0, P, pos, F, c.cx, c.cy, cols, cell, ddi, dbg);
+  dd = (uint16_t)ddi;
+  return cls;
 }
 
 }  // namespace er

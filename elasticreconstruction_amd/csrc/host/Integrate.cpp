@@ -10,7 +10,15 @@
 //   -oni <file> | --depth_raw <file>   raw stream of 640x480 little-endian uint16 frames, FrameID = 1,2,...
 //                                      (-oni with a real OpenNI recording is rejected with a clear message)
 //   --depth_list <txt>                 one 16-bit grayscale PNG path per line, line i = frame i
-// New, additive: --device <gpu> (0), --max_units <n> (2048), --batch <frames fused per launch> (64).
+// New, additive: --device <gpu> (0), --max_units <n> (2048), --batch <frames fused per launch> (64),
+//   --gpus <N>            N GPUs (devices --device ... --device + N - 1), one host thread per GPU
+//   --shard frame|unit    frame (default, what BASELINE.json names): the active frame range is cut into N contiguous blocks,
+//                         every GPU integrates its block into a private volume, then ONE RCCL reduce(sum) of the
+//                         [sdf*weight | weight] planes of the key union to the first GPU (er_tsdf_allreduce; weights exact,
+//                         sdf within 1e-5 of the single-GPU run: float32 summation order);
+//                         unit: every GPU is fed all frames and owns the units with er_unit_owner(key, N) == its rank
+//                         (er_tsdf_set_unit_shard): no collective, world.pcd BIT-identical to the single-GPU run
+//   --force_merge         with --gpus 1: run the frame-split merge anyway (exercises the RCCL path on a 1-GPU box)
 //
 // Control flow = CIntegrateApp::StartMainLoop/Execute: 1-based frame ids, frame_ == -1 skips a frame,
 // start_from/end_at window, the end-of-trajectory off-by-one (frame N of an N-entry trajectory is never
@@ -21,7 +29,9 @@
 #include <cstdio>
 #include <iostream>
 #include <memory>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../er_mat4.h"
@@ -51,6 +61,7 @@ int print_help() {
   std::cout << "    -oni <raw_file> | --depth_raw <raw_file> : 640x480 uint16 frames; --depth_list <txt> : 16-bit PNG per line" << std::endl;
   std::cout << "MI355X options:" << std::endl;
   std::cout << "    --device <gpu> (0)  --max_units <n> (2048)  --batch <frames> (64)" << std::endl;
+  std::cout << "    --gpus <N> (1)  --shard frame|unit (frame: frame blocks + one RCCL reduce; unit: bit-exact, no collective)  --force_merge" << std::endl;
   return 0;
 }
 
@@ -63,7 +74,18 @@ struct RawStream : DepthSource {
   FILE* f = nullptr;
   int id = 0;
   size_t px;
-  RawStream(const std::string& p, size_t pixels) : px(pixels) { f = fopen(p.c_str(), "rb"); }
+  RawStream(const std::string& p, size_t pixels, long first_id = 1) : px(pixels) {
+    f = fopen(p.c_str(), "rb");
+    if (f && first_id > 1) { fseek(f, (long)((first_id - 1) * (long)(px * sizeof(uint16_t))), SEEK_SET); id = (int)first_id - 1; }
+  }
+  static long count(const std::string& p, size_t pixels) {
+    FILE* g = fopen(p.c_str(), "rb");
+    if (!g) return 0;
+    fseek(g, 0, SEEK_END);
+    const long n = ftell(g) / (long)(pixels * sizeof(uint16_t));
+    fclose(g);
+    return n;
+  }
   ~RawStream() { if (f) fclose(f); }
   bool next(std::vector<uint16_t>& frame, int& frame_id) override {
     frame.resize(px);
@@ -77,7 +99,8 @@ struct PngList : DepthSource {
   std::vector<std::string> files;
   size_t at = 0;
   int cols, rows;
-  PngList(const std::string& list, int c, int r) : cols(c), rows(r) {
+  PngList(const std::string& list, int c, int r, long first_id = 1) : cols(c), rows(r) {
+    at = first_id > 1 ? (size_t)(first_id - 1) : 0;
     FILE* f = fopen(list.c_str(), "r");
     if (!f) return;
     std::string dir;
@@ -118,6 +141,8 @@ struct App {
   // device side
   er_tsdf_t volume_ = nullptr;
   int device_ = 0, max_units_ = 2048, batch_ = ER_MAX_BATCH;
+  int rank_ = 0, gpus_ = 1;                                            // this worker / number of workers (--gpus)
+  bool unit_shard_ = false;                                            // --shard unit
   std::vector<uint16_t> q_depth_;
   std::vector<double> q_T_, q_seg_, q_madj_;
   std::vector<int> q_gi_;
@@ -127,6 +152,10 @@ struct App {
     float cam[6];
     erfmt::load_camera(erfmt::file_exists(camera_filename_) ? camera_filename_ : std::string(), cam);
     if (er_tsdf_create(cols_, rows_, cam, max_units_, device_, &volume_) != 0) {
+      fprintf(stderr, "Integrate: %s\n", er_last_error());
+      return false;
+    }
+    if (unit_shard_ && gpus_ > 1 && er_tsdf_set_unit_shard(volume_, rank_, gpus_) != 0) {
       fprintf(stderr, "Integrate: %s\n", er_last_error());
       return false;
     }
@@ -150,7 +179,7 @@ struct App {
             er::mat4_mul(pose_traj_[i].T, seg_traj_[idx].T, t.T);     // :71
             traj_.push_back(t);
           }
-        printf("Trajectory created from pose and segment trajectories.\n");
+        if (rank_ == 0) printf("Trajectory created from pose and segment trajectories.\n");
       }
     }
     return true;
@@ -203,7 +232,7 @@ struct App {
     }
     if (traj_[frame_id_ - 1].frame == -1) return true;
     if (frame_id_ >= (int)traj_.size()) { exit_ = true; return true; }
-    if (frame_id_ % 100 == 0) printf("Frames processed : %d / %d\n", frame_id_, (int)traj_.size());
+    if (frame_id_ % 100 == 0 && (rank_ == 0 || !unit_shard_)) printf("Frames processed : %d / %d\n", frame_id_, (int)traj_.size());
     if (frame_id_ < start_from_ || frame_id_ > end_at_) {
       if (frame_id_ > end_at_) { printf("Reaching the specified end point.\n"); exit_ = true; }
       return true;
@@ -232,16 +261,54 @@ struct App {
     return true;
   }
 
-  bool SaveWorld() {                                                   // TSDFVolume::SaveWorld, TSDFVolume.cpp:104-132
+  bool ExtractWorld(std::vector<float>& pts) {                         // TSDFVolume::SaveWorld's voxel filter, TSDFVolume.cpp:104-132
     long n = 0;
     if (er_tsdf_extract_world(volume_, nullptr, 0, &n) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return false; }
-    std::vector<float> pts((size_t)n * 4);
+    pts.assign((size_t)n * 4, 0.f);
     if (n > 0 && er_tsdf_extract_world(volume_, pts.data(), n, &n) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return false; }
-    if (!erfmt::save_pcd_xyzi(pcd_filename_, pts.data(), (size_t)n)) { fprintf(stderr, "Integrate: cannot write %s\n", pcd_filename_.c_str()); return false; }
-    printf("%ld voxel points have been written.\n", n);
+    return true;
+  }
+
+  bool SaveWorld() {
+    std::vector<float> pts;
+    if (!ExtractWorld(pts)) return false;
+    if (!erfmt::save_pcd_xyzi(pcd_filename_, pts.data(), pts.size() / 4)) { fprintf(stderr, "Integrate: cannot write %s\n", pcd_filename_.c_str()); return false; }
+    printf("%ld voxel points have been written.\n", (long)(pts.size() / 4));
     return true;
   }
 };
+
+// hash_key of the unit a SaveWorld point (voxel index coordinates, TSDFVolume.cpp:119-121) belongs to.
+int unit_key_of_point(const float* p) {
+  const int xi = ((int)p[0] + 256 * 64) / 64, yi = ((int)p[1] + 256 * 64) / 64, zi = ((int)p[2] + 256 * 64) / 64;
+  return xi * 512 * 512 + yi * 512 + zi;
+}
+
+// --shard unit: every worker holds a disjoint set of units; world.pcd lists the units in ascending key order exactly like
+// the single-GPU program, so the per-worker lists (each already ascending) are merged unit by unit.
+bool SaveWorldSharded(std::vector<App>& apps, const std::string& filename) {
+  struct Seg { int key, worker; size_t begin, end; };
+  std::vector<std::vector<float>> pts(apps.size());
+  std::vector<Seg> segs;
+  for (size_t w = 0; w < apps.size(); w++) {
+    if (!apps[w].ExtractWorld(pts[w])) return false;
+    const size_t n = pts[w].size() / 4;
+    size_t b = 0;
+    while (b < n) {
+      const int key = unit_key_of_point(&pts[w][b * 4]);
+      size_t e = b + 1;
+      while (e < n && unit_key_of_point(&pts[w][e * 4]) == key) e++;
+      segs.push_back(Seg{key, (int)w, b, e});
+      b = e;
+    }
+  }
+  std::sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.key < b.key; });
+  std::vector<float> all;
+  for (const Seg& sg : segs) all.insert(all.end(), pts[(size_t)sg.worker].begin() + (long)(sg.begin * 4), pts[(size_t)sg.worker].begin() + (long)(sg.end * 4));
+  if (!erfmt::save_pcd_xyzi(filename, all.data(), all.size() / 4)) { fprintf(stderr, "Integrate: cannot write %s\n", filename.c_str()); return false; }
+  printf("%ld voxel points have been written.\n", (long)(all.size() / 4));
+  return true;
+}
 
 }  // namespace
 
@@ -250,7 +317,7 @@ int main(int argc, char* argv[]) {
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
 
   App app;
-  std::string raw_file, list_file, dev_name;
+  std::string raw_file, list_file, dev_name, shard = "frame";
   if (parse_argument(argc, argv, "-dev", dev_name) > 0) {
     std::cout << "Can't open depth source" << std::endl;               // no OpenNI device on this platform
     return -1;
@@ -263,16 +330,22 @@ int main(int argc, char* argv[]) {
                  "raw uint16 frames (--depth_raw) or 16-bit PNGs (--depth_list))" << std::endl;
     return -1;
   }
-  std::unique_ptr<DepthSource> source;
+  const size_t px = (size_t)app.cols_ * app.rows_;
+  long source_frames = 0;
   if (!list_file.empty()) {
-    source.reset(new PngList(list_file, app.cols_, app.rows_));
+    source_frames = (long)PngList(list_file, app.cols_, app.rows_).files.size();
   } else if (!raw_file.empty() && file_exists(raw_file)) {
-    source.reset(new RawStream(raw_file, (size_t)app.cols_ * app.rows_));
+    source_frames = RawStream::count(raw_file, px);
   } else {
     std::cout << "Can't open depth source" << std::endl;
     return -1;
   }
+  auto open_source = [&](long first_id) -> std::unique_ptr<DepthSource> {
+    if (!list_file.empty()) return std::unique_ptr<DepthSource>(new PngList(list_file, app.cols_, app.rows_, first_id));
+    return std::unique_ptr<DepthSource>(new RawStream(raw_file, px, first_id));
+  };
 
+  int gpus = 1;
   parse_argument(argc, argv, "--ref_traj", app.traj_filename_);
   parse_argument(argc, argv, "--pose_traj", app.pose_filename_);
   parse_argument(argc, argv, "--seg_traj", app.seg_filename_);
@@ -288,29 +361,102 @@ int main(int argc, char* argv[]) {
   parse_argument(argc, argv, "--device", app.device_);
   parse_argument(argc, argv, "--max_units", app.max_units_);
   parse_argument(argc, argv, "--batch", app.batch_);
+  parse_argument(argc, argv, "--gpus", gpus);
+  parse_argument(argc, argv, "--shard", shard);
+  const bool force_merge = find_switch(argc, argv, "--force_merge");
+  // test hook: all workers share ONE device (lets a 1-GPU box run the N-worker unit-shard logic; RCCL refuses two ranks on
+  // one device, so it is only accepted with --shard unit)
+  const bool same_device = find_switch(argc, argv, "--same_device");
   if (app.batch_ < 1) app.batch_ = 1;
   if (app.batch_ > ER_MAX_BATCH) app.batch_ = ER_MAX_BATCH;
+  if (gpus < 1) gpus = 1;
+  if (shard != "frame" && shard != "unit") { fprintf(stderr, "Integrate: --shard must be frame or unit\n"); return 1; }
+  const bool unit_shard = shard == "unit";
+  if (same_device && !unit_shard && gpus > 1) { fprintf(stderr, "Integrate: --same_device needs --shard unit\n"); return 1; }
+  if (!same_device && gpus > 1 && er_device_count() > 0 && app.device_ + gpus > er_device_count()) {
+    fprintf(stderr, "Integrate: --gpus %d from --device %d, but %d HIP devices are visible\n", gpus, app.device_, er_device_count());
+    return 1;
+  }
 
-  if (!app.Init()) return 1;
+  // one worker (= one copy of the application state, one volume, one host thread) per GPU
+  std::vector<App> apps((size_t)gpus, app);
+  for (int g = 0; g < gpus; g++) {
+    apps[(size_t)g].device_ = app.device_ + (same_device ? 0 : g);
+    apps[(size_t)g].rank_ = g;
+    apps[(size_t)g].gpus_ = gpus;
+    apps[(size_t)g].unit_shard_ = unit_shard;
+    if (!apps[(size_t)g].Init()) return 1;
+  }
+  const bool merge = !unit_shard && (gpus > 1 || force_merge);
+  std::vector<er_comm_t> comms((size_t)gpus, nullptr);
+  if (merge) {
+    std::vector<int> devs((size_t)gpus);
+    for (int g = 0; g < gpus; g++) devs[(size_t)g] = app.device_ + g;
+    if (er_comm_create_local(gpus, devs.data(), comms.data()) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return 1; }
+  }
+
+  // The frame ids Execute can let through (IntegrateApp.cpp:200-216,230-233): [first, last].  --shard frame cuts this range
+  // into contiguous blocks; --shard unit hands all of it to every worker.
+  const App& a0 = apps[0];
+  long first = std::max(1L, (long)a0.start_from_), last = std::min(source_frames, (long)a0.traj_.size() - 1);
+  last = std::min(last, (long)a0.end_at_);
+  if (a0.ctr_num_ > 0) last = std::min(last, (long)a0.ctr_interval_ * a0.ctr_num_);
+  const long active = std::max(0L, last - first + 1);
+
   int rc = 0;
-  {
-    const auto t0 = std::chrono::steady_clock::now();
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<int> wrc((size_t)gpus, 0);
+  auto worker = [&](int g) {
+    App& w = apps[(size_t)g];
+    long lo_id = 1, hi_id = source_frames;                             // single GPU / unit shard: the whole stream, like the reference
+    if (gpus > 1 && !unit_shard) {
+      int lo = 0, hi = 0;
+      er_frame_block((int)active, g, gpus, &lo, &hi);
+      lo_id = first + lo;
+      hi_id = first + hi - 1;
+    }
+    std::unique_ptr<DepthSource> source = open_source(lo_id);
     std::vector<uint16_t> frame;
-    while (!app.exit_) {
+    while (!w.exit_) {
       int id = 0;
       if (!source->next(frame, id)) break;                             // end of stream (reference: ten timeouts, :125)
-      app.frame_id_ = id;
-      if (!app.Execute(frame)) { rc = 1; break; }
+      if (id > hi_id) break;
+      w.frame_id_ = id;
+      if (!w.Execute(frame)) { wrc[(size_t)g] = 1; break; }
     }
-    if (rc == 0 && !app.Flush()) rc = 1;
-    if (rc == 0 && (er_tsdf_synchronize(app.volume_) != 0 || !app.CheckStatus(true))) rc = 1;
-    if (rc == 0 && !app.SaveWorld()) rc = 1;
-    std::cout << "Total " << app.frame_id_ << " frames processed." << std::endl;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::cerr << "Integrate All took " << ms << "ms." << std::endl;
-    if (ms > 0 && app.frames_integrated_ > 0)
-      std::cerr << app.frames_integrated_ << " frames integrated, " << 1000.0 * app.frames_integrated_ / ms << " frames/s end to end (incl. file I/O)" << std::endl;
+    if (wrc[(size_t)g] == 0 && !w.Flush()) wrc[(size_t)g] = 1;
+    if (wrc[(size_t)g] == 0 && (er_tsdf_synchronize(w.volume_) != 0 || !w.CheckStatus(true))) wrc[(size_t)g] = 1;
+    // every rank of the communicator must take part in the collective, failed or not (a rank that failed contributes what it has)
+    if (merge) {
+      int nu = 0;
+      if (er_tsdf_allreduce(w.volume_, comms[(size_t)g], 0, &nu) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); wrc[(size_t)g] = 1; }
+      else if (g == 0) fprintf(stderr, "Integrate: merged %d GPU volumes over RCCL, %d units in the union\n", gpus, nu);
+    }
+  };
+  if (gpus == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int g = 0; g < gpus; g++) th.emplace_back(worker, g);
+    for (auto& t : th) t.join();
   }
-  er_tsdf_destroy(app.volume_);
+  long frames_integrated = 0;
+  int last_id = 0;
+  for (int g = 0; g < gpus; g++) {
+    rc |= wrc[(size_t)g];
+    frames_integrated += unit_shard && g > 0 ? 0 : apps[(size_t)g].frames_integrated_;
+    last_id = std::max(last_id, apps[(size_t)g].frame_id_);
+  }
+  if (rc == 0) {
+    if (unit_shard && gpus > 1) { if (!SaveWorldSharded(apps, app.pcd_filename_)) rc = 1; }
+    else if (!apps[0].SaveWorld()) rc = 1;
+  }
+  std::cout << "Total " << last_id << " frames processed." << std::endl;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  std::cerr << "Integrate All took " << ms << "ms." << std::endl;
+  if (ms > 0 && frames_integrated > 0)
+    std::cerr << frames_integrated << " frames integrated, " << 1000.0 * frames_integrated / ms << " frames/s end to end (incl. file I/O)" << std::endl;
+  for (er_comm_t c : comms) er_comm_destroy(c);
+  for (App& w : apps) er_tsdf_destroy(w.volume_);
   return rc;
 }

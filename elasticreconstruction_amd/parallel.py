@@ -90,3 +90,37 @@ def gather_pair_results(local_results, n_pairs, dist):
         for k, v in part.items():
             out[k] = v
     return out
+
+
+class AbiComm:
+    """The frame-split merge through liber_hip.so's OWN RCCL calls (er_comm_* / er_tsdf_allreduce, what bin/Integrate --gpus
+    uses) for a one-process-per-GPU job: rank 0 draws the 128-byte communicator id, torch.distributed only carries it to the
+    other ranks (out of band), every rank then creates its communicator and the collectives are issued from the library."""
+
+    def __init__(self, dist, device_index):
+        import ctypes as C
+        from . import _ffi
+        self._lib = _ffi.lib()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            _ffi.check(self._lib.er_comm_unique_id(ident), "er_comm_unique_id")
+        box = [bytes(ident)]
+        dist.broadcast_object_list(box, src=0)
+        ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        _ffi.check(self._lib.er_comm_create(ident, rank, world, int(device_index), C.byref(h)), "er_comm_create")
+        self._h = h
+
+    def allreduce(self, vol, root=0):
+        """root < 0: merged volume on every rank; else only on `root`.  Returns the size of the key union."""
+        import ctypes as C
+        from . import _ffi
+        n = C.c_int(0)
+        _ffi.check(self._lib.er_tsdf_allreduce(vol._h, self._h, int(root), C.byref(n)), "er_tsdf_allreduce")
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.er_comm_destroy(self._h)
+            self._h = None

@@ -135,6 +135,30 @@ int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const
 int er_tsdf_set_unit_shard(er_tsdf_t h, int rank, int world);
 int er_unit_owner(int key, int world);          /* (xi + yi + zi) mod world: diagonal stripes of the unit lattice */
 
+/* Multi-GPU frame split behind the C ABI (the Python path over torch.distributed is parallel.py).  One
+ * communicator per GPU over RCCL (xGMI inside a node; librccl is loaded on first use):
+ *   er_comm_unique_id + er_comm_create   one PROCESS per GPU: rank 0 draws the 128-byte id and hands it to the other ranks
+ *                                        out of band (a file, a socket, torch.distributed), then every rank creates its
+ *                                        communicator (ncclCommInitRank; collective: all ranks must call it);
+ *   er_comm_create_local                 ONE process, n GPUs, one host thread per GPU afterwards (ncclCommInitAll).
+ * er_tsdf_allreduce merges the private volumes of the ranks after each integrated its own contiguous frame block
+ * (er_frame_block): agree on the key count, all-gather the touched unit keys, ONE reduction (sum) of the
+ * [key][sdf*weight | weight] planes of the union, import with sdf = SW / W -- algebraically the sequential running mean of
+ * TSDFVolume.cpp:93-94 (weights exact, sdf within 1e-5: the float32 summation order differs).  Every rank calls it once;
+ * root < 0 leaves the merged volume on every rank (ncclAllReduce), otherwise only on `root` (ncclReduce).
+ * union_units (nullable) receives the size of the key union. */
+typedef struct er_comm_s* er_comm_t;
+#define ER_COMM_ID_BYTES 128
+int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]);
+int er_comm_create(const unsigned char id[ER_COMM_ID_BYTES], int rank, int world, int device, er_comm_t* out);
+int er_comm_create_local(int n, const int* devices, er_comm_t* out /* n handles */);
+int er_comm_destroy(er_comm_t c);
+int er_comm_rank(er_comm_t c);
+int er_comm_world(er_comm_t c);
+int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units);
+/* Contiguous frame block [lo, hi) of `rank` (IntegrateApp.cpp:190-226 is the loop being split). */
+void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi);
+
 /* Kernel timing (HIP events on the handle's stream around every IntegrateVolumeUnit launch). */
 int er_tsdf_set_profiling(er_tsdf_t h, int enable);
 int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate_launches, long* frames,

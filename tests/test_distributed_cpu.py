@@ -122,3 +122,27 @@ def test_frame_block_partition():
         blocks = [parallel.frame_block(n, r, w) for r in range(w)]
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+
+
+def test_c_abi_shard_helpers_match_the_python_protocol():
+    """The pieces of the multi-GPU host protocol that live behind the C ABI and need no GPU: er_frame_block (the contiguous
+    frame blocks bin/Integrate --gpus cuts) equals parallel.frame_block, and er_unit_owner (--shard unit) assigns every unit
+    of a 512^3-unit lattice to exactly one of `world` ranks, evenly along every lattice line."""
+    import ctypes as C
+    from elasticreconstruction_amd import _ffi, parallel
+    L = _ffi.lib()
+    lo, hi = C.c_int(), C.c_int()
+    for n, w in ((10000, 8), (3000, 4), (3000, 7), (7, 3), (2, 4), (0, 2), (5, 1)):
+        for r in range(w):
+            L.er_frame_block(n, r, w, C.byref(lo), C.byref(hi))
+            assert (lo.value, hi.value) == parallel.frame_block(n, r, w)
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 3, 8):
+        xyz = rng.integers(200, 312, (2000, 3))
+        keys = xyz[:, 0] * 512 * 512 + xyz[:, 1] * 512 + xyz[:, 2]
+        owners = np.array([L.er_unit_owner(int(k), world) for k in keys])
+        assert ((owners >= 0) & (owners < world)).all() and np.array_equal(owners, xyz.sum(1) % world)
+        # the 8x8x8 units of the 512^3 region: every rank gets its share (+-1 lattice plane)
+        region = np.array([[x, y, z] for x in range(252, 260) for y in range(252, 260) for z in range(252, 260)])
+        cnt = np.bincount(region.sum(1) % world, minlength=world)
+        assert cnt.max() - cnt.min() <= 64
