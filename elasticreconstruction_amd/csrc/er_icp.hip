@@ -26,6 +26,8 @@
 
 #include "../../include/er_hip.h"
 
+#include <hipcub/hipcub.hpp>   // device radix sort / prefix sum of the grid build (library primitives; everything else is hand-written)
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -332,6 +334,128 @@ __global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restric
   }
 }
 
+// ---- the ICP loop's state lives on the device ------------------------------------------------------------------------
+// pcl::IterativeClosestPoint::align's loop variables (final_transformation_, the last increment, the previous MSE, the
+// iteration counter and the convergence flags).  k_icp_final updates them from the iteration's sums -- 6x6 solve, increment,
+// PCL's stop rule -- and k_icp_iter reads the increment (and the `done` flag) from here, so a whole chunk of iterations is
+// enqueued without a host round trip; launches that find `done` set return at once.
+struct IcpDev {
+  float fin[16];           // final_transformation_
+  float delta[16];         // last increment (identity before the first solve)
+  float prev_delta[16];
+  double prev_mse;
+  int iter, done, conv, apply;   // apply: the next k_icp_iter multiplies X by delta first
+};
+
+struct IcpParams {
+  double eps;
+  int max_iter, stop_rule;
+};
+
+// Dense 6x6 solve by Gaussian elimination with partial pivoting (PCL: ATA.inverse() * ATb).
+__device__ bool dev_solve6x6(double A[6][6], double b[6], double x[6]) {
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    for (int r = c + 1; r < 6; r++)
+      if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+    if (A[p][c] == 0.0 || !isfinite(A[p][c])) return false;
+    if (p != c) {
+      for (int k = 0; k < 6; k++) { const double t = A[p][k]; A[p][k] = A[c][k]; A[c][k] = t; }
+      const double t = b[p]; b[p] = b[c]; b[c] = t;
+    }
+    for (int r = c + 1; r < 6; r++) {
+      const double f = A[r][c] / A[c][c];
+      for (int k = c; k < 6; k++) A[r][k] -= f * A[c][k];
+      b[r] -= f * b[c];
+    }
+  }
+  for (int r = 5; r >= 0; r--) {
+    double s = b[r];
+    for (int k = r + 1; k < 6; k++) s -= A[r][k] * x[k];
+    x[r] = s / A[r][r];
+  }
+  return true;
+}
+
+// TransformationEstimationPointToPlaneLLS::constructTransformationMatrix: Rz(gamma) Ry(beta) Rx(alpha), float storage.
+__device__ void dev_construct_increment(const double x[6], float M[16]) {
+  const double al = x[0], be = x[1], ga = x[2];
+  for (int i = 0; i < 16; i++) M[i] = 0.f;
+  M[0] = (float)(cos(ga) * cos(be));
+  M[1] = (float)(-sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al));
+  M[2] = (float)(sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al));
+  M[4] = (float)(sin(ga) * cos(be));
+  M[5] = (float)(cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al));
+  M[6] = (float)(-cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al));
+  M[8] = (float)(-sin(be));
+  M[9] = (float)(cos(be) * sin(al));
+  M[10] = (float)(cos(be) * cos(al));
+  M[3] = (float)x[3];
+  M[7] = (float)x[4];
+  M[11] = (float)x[5];
+  M[15] = 1.f;
+}
+
+// One step of IterativeClosestPoint's loop after the correspondences of the iteration have been summed (acc[0..28]):
+// min_number_correspondences_, estimateRigidTransformation, final = increment * final, ++iterations, the stop rule.
+__device__ void dev_icp_decide(const double* acc, IcpDev* st, IcpParams P) {
+  const double cnt = acc[28];
+  double A[6][6], b[6], x[6];
+  bool stop = false;
+  st->apply = 0;
+  if (cnt < 3.0) {                                           // min_number_correspondences_
+    st->conv = 0;
+    stop = true;
+  } else {
+    int t = 0;
+    for (int r = 0; r < 6; r++)
+      for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
+    for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
+    if (!dev_solve6x6(A, b, x)) {
+      st->conv = 0;
+      stop = true;
+    }
+  }
+  if (!stop) {
+    float D[16], F[16];
+    for (int i = 0; i < 16; i++) st->prev_delta[i] = st->delta[i];
+    dev_construct_increment(x, D);
+    for (int r = 0; r < 4; r++)                              // final = increment * final
+      for (int c = 0; c < 4; c++)
+        F[r * 4 + c] = ((D[r * 4] * st->fin[c] + D[r * 4 + 1] * st->fin[4 + c]) + D[r * 4 + 2] * st->fin[8 + c]) + D[r * 4 + 3] * st->fin[12 + c];
+    for (int i = 0; i < 16; i++) {
+      st->fin[i] = F[i];
+      st->delta[i] = D[i];
+    }
+    st->iter += 1;
+    st->apply = 1;
+    if (st->iter >= P.max_iter) {
+      st->conv = 1;
+      stop = true;
+    } else if (P.stop_rule == 0) {                           // PCL 1.7 DefaultConvergenceCriteria
+      const double cos_angle = 0.5 * (double)(D[0] + D[5] + D[10] - 1.f);
+      const double tr2 = (double)(D[3] * D[3] + D[7] * D[7] + D[11] * D[11]);
+      const double cur = acc[27] / cnt;
+      if (cos_angle >= 1.0 - P.eps && tr2 <= P.eps) {
+        st->conv = 1;
+        stop = true;
+      } else if (fabs(cur - st->prev_mse) < 1e-12) {
+        st->conv = 1;
+        stop = true;
+      }
+      st->prev_mse = cur;
+    } else {                                                 // PCL <= 1.6
+      float sum = 0.f;
+      for (int i = 0; i < 16; i++) sum += D[i] - st->prev_delta[i];
+      if (fabs((double)sum) < P.eps) {
+        st->conv = 1;
+        stop = true;
+      }
+    }
+  }
+  if (stop) st->done = 1;
+}
+
 // One ICP iteration in one launch:
 //   X <- delta * X (the previous iteration's increment, float32); correspondence estimation (exact NN, kept if
 //   d^2 <= max_dist^2); the sums of TransformationEstimationPointToPlaneLLS over the kept correspondences:
@@ -339,19 +463,22 @@ __global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restric
 // Reduction: thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in `partial`; k_icp_final adds
 // the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from run to run (they
 // still differ from a sequential CPU sum in the last bits).
-__global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int n, Mat12f delta, int apply, Grid g, float radius,
+__global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int n, const IcpDev* __restrict__ st, Grid g, float radius,
                                                      double maxd2, const float* __restrict__ tgt_xyz, const float* __restrict__ tgt_nrm,
                                                      double* __restrict__ partial) {
   __shared__ NnShared sh;
+  if (st->done) return;                                      // the loop has ended: this launch of the chunk is a no-op
+  const int apply = st->apply;                               // wave-uniform (scalar loads)
+  const float* __restrict__ dm = st->delta;
   const int k = blockIdx.x * kBlock + threadIdx.x;
   float sx = 0.f, sy = 0.f, sz = 0.f;
   if (k < n) {
     sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
     if (apply) {
       const float x = sx, y = sy, z = sz;
-      sx = ((delta.m[0] * x + delta.m[1] * y) + delta.m[2] * z) + delta.m[3];
-      sy = ((delta.m[4] * x + delta.m[5] * y) + delta.m[6] * z) + delta.m[7];
-      sz = ((delta.m[8] * x + delta.m[9] * y) + delta.m[10] * z) + delta.m[11];
+      sx = ((dm[0] * x + dm[1] * y) + dm[2] * z) + dm[3];
+      sy = ((dm[4] * x + dm[5] * y) + dm[6] * z) + dm[7];
+      sz = ((dm[8] * x + dm[9] * y) + dm[10] * z) + dm[11];
       X[3 * k] = sx;
       X[3 * k + 1] = sy;
       X[3 * k + 2] = sz;
@@ -404,7 +531,9 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int 
 // slices per value, then the slices in order) -> acc[0..28].  A separate launch on purpose: finishing inside
 // k_icp_iter ("last workgroup done" ticket + __threadfence) costs an L2 write-back per workgroup on this
 // multi-XCD part (measured: 100-600 us per launch instead of ~25).
-__global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__ partial, int nparts, double* __restrict__ acc) {
+__global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__ partial, int nparts, double* __restrict__ acc,
+                                                      IcpDev* __restrict__ st, IcpParams P) {
+  if (st->done) return;
   const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;   // 32 x 8
   double q = 0.0;
   if (val < 29) {
@@ -414,12 +543,16 @@ __global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__
   __shared__ double fin[8][32];
   fin[slice][val] = q;
   __syncthreads();
+  __shared__ double tot[32];
   if (threadIdx.x < 29) {
     double r = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 8; sl++) r += fin[sl][threadIdx.x];
     acc[threadIdx.x] = r;
+    tot[threadIdx.x] = r;
   }
+  __syncthreads();
+  if (threadIdx.x == 0) dev_icp_decide(tot, st, P);          // solve, increment, stop rule: the loop never leaves the device
 }
 
 // getFitnessScore-style diagnostic: squared NN distance of final * source inside the search radius (-1 = none).
@@ -563,57 +696,99 @@ __global__ __launch_bounds__(kBlock) void k_compact(const int* __restrict__ matc
   }
 }
 
-// ---- host-side small algebra -------------------------------------------------------------------
-// Dense 6x6 solve by Gaussian elimination with partial pivoting (PCL: ATA.inverse() * ATb).
-bool solve6x6(double A[6][6], double b[6], double x[6]) {
-  for (int c = 0; c < 6; c++) {
-    int p = c;
-    for (int r = c + 1; r < 6; r++)
-      if (std::fabs(A[r][c]) > std::fabs(A[p][c])) p = r;
-    if (A[p][c] == 0.0 || !std::isfinite(A[p][c])) return false;
-    if (p != c) {
-      for (int k = 0; k < 6; k++) std::swap(A[p][k], A[c][k]);
-      std::swap(b[p], b[c]);
-    }
-    for (int r = c + 1; r < 6; r++) {
-      const double f = A[r][c] / A[c][c];
-      for (int k = c; k < 6; k++) A[r][k] -= f * A[c][k];
-      b[r] -= f * b[c];
-    }
-  }
-  for (int r = 5; r >= 0; r--) {
-    double s = b[r];
-    for (int k = r + 1; k < 6; k++) s -= A[r][k] * x[k];
-    x[r] = s / A[r][r];
-  }
-  return true;
+// ---- uniform grid of a cloud, built on the device ---------------------------------------------------------------------
+// (the reference builds a kd-tree per pair and per function, CorresApp.cpp:129,238; here once per fragment)
+//   k_grid_bounds   min / max of the coordinates (float bits mapped to ordered ints, block reduce, 6 atomics per block) + a
+//                   non-finite flag;
+//   k_grid_cells    cell id of every point (the same float32 expression nn_block evaluates for a query) + histogram;
+//   hipcub          stable radix sort of (cell id, original index) and the prefix sum of the histogram -> cell_start;
+//   k_grid_gather   sorted[s] = {x, y, z, original index}.
+// A stable sort keeps the points of a cell in file order, like a counting sort on the host would: the layout -- and with it the
+// order of every float64 reduction that walks the cloud -- is reproducible from run to run.
+__device__ __forceinline__ int ordered_int(float f) {
+  const int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__host__ __device__ __forceinline__ float ordered_float(int i) {
+  const int b = i >= 0 ? i : i ^ 0x7fffffff;
+  float f;
+  memcpy(&f, &b, sizeof f);
+  return f;
 }
 
-// TransformationEstimationPointToPlaneLLS::constructTransformationMatrix: Rz(gamma) Ry(beta) Rx(alpha), float storage.
-void construct_increment(const double x[6], float M[16]) {
-  const double al = x[0], be = x[1], ga = x[2];
-  for (int i = 0; i < 16; i++) M[i] = 0.f;
-  M[0] = (float)(cos(ga) * cos(be));
-  M[1] = (float)(-sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al));
-  M[2] = (float)(sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al));
-  M[4] = (float)(sin(ga) * cos(be));
-  M[5] = (float)(cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al));
-  M[6] = (float)(-cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al));
-  M[8] = (float)(-sin(be));
-  M[9] = (float)(cos(be) * sin(al));
-  M[10] = (float)(cos(be) * cos(al));
-  M[3] = (float)x[3];
-  M[7] = (float)x[4];
-  M[11] = (float)x[5];
-  M[15] = 1.f;
+__global__ __launch_bounds__(kBlock) void k_grid_bounds(const float* __restrict__ xyz, int n, int* __restrict__ out7) {
+  int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
+  int bad = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const float v = xyz[3 * (size_t)i + a];
+      bad |= !isfinite(v);
+      const int o = ordered_int(v);
+      lo[a] = min(lo[a], o);
+      hi[a] = max(hi[a], o);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = min(lo[a], __shfl_down(lo[a], off));
+      hi[a] = max(hi[a], __shfl_down(hi[a], off));
+    }
+  bad = __any(bad) ? 1 : 0;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      atomicMin(&out7[a], lo[a]);
+      atomicMax(&out7[3 + a], hi[a]);
+    }
+    if (bad) atomicOr(&out7[6], 1);
+  }
 }
 
-void mul4f(const float* A, const float* B, float* C) {
-  float t[16];
-  for (int r = 0; r < 4; r++)
-    for (int c = 0; c < 4; c++)
-      t[r * 4 + c] = ((A[r * 4] * B[c] + A[r * 4 + 1] * B[4 + c]) + A[r * 4 + 2] * B[8 + c]) + A[r * 4 + 3] * B[12 + c];
-  memcpy(C, t, sizeof t);
+struct GridDims {
+  float org[3];
+  float cell;
+  int dim[3];
+};
+
+__global__ __launch_bounds__(kBlock) void k_grid_cells(const float* __restrict__ xyz, int n, GridDims G, unsigned* __restrict__ key,
+                                                       unsigned* __restrict__ idx, int* __restrict__ count) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  int q[3];
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    q[a] = (int)floorf((xyz[3 * (size_t)i + a] - G.org[a]) / G.cell);
+    q[a] = min(max(q[a], 0), G.dim[a] - 1);
+  }
+  const int c = (q[2] * G.dim[1] + q[1]) * G.dim[0] + q[0];
+  key[i] = (unsigned)c;
+  idx[i] = (unsigned)i;
+  atomicAdd(&count[c + 1], 1);                               // integer histogram: the result does not depend on the order
+}
+
+__global__ __launch_bounds__(kBlock) void k_grid_gather(const float* __restrict__ xyz, const unsigned* __restrict__ idx, int n,
+                                                        float4* __restrict__ sorted) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= n) return;
+  const unsigned i = idx[s];
+  sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float((int)i));
+}
+
+// Grow-only scratch of the grid build, one per device, handed out under a mutex (er_cloud_create may be called from
+// several host threads; builds on one device then take turns).
+struct GridScratch {
+  std::mutex mu;
+  int device = -1;
+  unsigned *key[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
+  void* cub = nullptr;
+  int* bounds = nullptr;
+  size_t n_cap = 0, cub_cap = 0;
+};
+GridScratch& grid_scratch(int device) {
+  static GridScratch* tab = new GridScratch[64];             // intentionally leaked (see WsPool)
+  return tab[device & 63];
 }
 
 }  // namespace
@@ -639,6 +814,7 @@ Grid grid_of(const er_cloud_s* c) { return c->grid; }
 struct HostBlock {
   double acc[kAcc];
   int count[4];
+  IcpDev state;                 // the ICP loop's state: uploaded at the start of a job, read back after every chunk of iterations
 };
 
 struct IcpWs {
@@ -649,6 +825,7 @@ struct IcpWs {
   float *X = nullptr, *nd = nullptr;
   int *match = nullptr, *block_count = nullptr, *block_offset = nullptr, *pairs = nullptr, *icount = nullptr;
   double* acc = nullptr;
+  IcpDev* dstate = nullptr;     // the ICP loop's state on the device
   double* partial = nullptr;    // one 32-double vector per workgroup of k_icp_iter
   HostBlock* host = nullptr;    // pinned
   int* stage = nullptr;         // pinned, cap * 2 ints: pair lists on their way to pageable caller memory (lazy)
@@ -672,6 +849,7 @@ void ws_destroy(IcpWs* w) {
   ws_free_buffers(w);
   if (w->icount) (void)hipFree(w->icount);
   if (w->acc) (void)hipFree(w->acc);
+  if (w->dstate) (void)hipFree(w->dstate);
   if (w->host) (void)hipHostFree(w->host);
   if (w->stage) (void)hipHostFree(w->stage);
   if (w->ev) (void)hipEventDestroy(w->ev);
@@ -728,6 +906,7 @@ IcpWs* ws_acquire(int device, size_t n) {
     if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void**)&w->icount, 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&w->acc, kAcc * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&w->dstate, sizeof(IcpDev)) != hipSuccess ||
         hipHostMalloc((void**)&w->host, sizeof(HostBlock), hipHostMallocDefault) != hipSuccess) {
       er::fail("ICP workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
       ws_destroy(w);
@@ -797,10 +976,10 @@ int count_enqueue(IcpWs* w, er_cloud_t src, er_cloud_t tgt, const double* T, dou
 // ---- ICP as a resumable job ---------------------------------------------------------------------
 struct AlignJob {
   er_cloud_t src = nullptr, tgt = nullptr;
-  float fin[16], delta[16], prev_delta[16];
+  float fin[16];
   int iter = 0;
   bool conv = false;
-  double prev_mse = DBL_MAX, fitness = DBL_MAX;
+  double fitness = DBL_MAX;
   enum { ITERATING, FITNESS, DONE } state = ITERATING;
 };
 
@@ -810,20 +989,22 @@ struct AlignParams {
   bool want_fitness;
 };
 
-int align_enqueue_iteration(IcpWs* w, AlignJob& j, const AlignParams& P) {
+// Iterations enqueued per host visit.  PCL's loop runs 3-4 iterations on the fragment pairs of the pipeline: one chunk
+// usually ends the job, the launches of a chunk that come after the stop decision return at once (~3 us each).
+constexpr int kIcpChunk = 4;
+
+// A chunk of ICP iterations with NO host round trip in between: k_icp_iter (apply the last increment, exact NN, point-to-plane
+// sums) + k_icp_final (fixed-order total, 6x6 solve, increment, stop rule -- on the device), then the state comes back once.
+int align_enqueue_chunk(IcpWs* w, AlignJob& j, const AlignParams& P) {
   const int n = j.src->n;
-  memcpy(j.prev_delta, j.delta, sizeof j.delta);
-  Mat12f D;
-  for (int q = 0; q < 12; q++) D.m[q] = j.delta[q];
-  if (n > 0 && j.tgt->n > 0) {
-    hipLaunchKernelGGL(k_icp_iter, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->X, n, D, j.iter > 0 ? 1 : 0, grid_of(j.tgt),
-                       (float)P.max_dist, P.max_dist * P.max_dist, j.tgt->xyz, j.tgt->nrm, w->partial);
-    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(kBlock), 0, w->stream, w->partial, nblocks_of(n), w->acc);
-    ER_HIP_TRY(hipGetLastError());
-  } else {
-    ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
+  const IcpParams IP{P.eps, P.max_iter, P.stop_rule};
+  for (int c = 0; c < kIcpChunk; c++) {
+    hipLaunchKernelGGL(k_icp_iter, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->X, n, w->dstate, grid_of(j.tgt), (float)P.max_dist,
+                       P.max_dist * P.max_dist, j.tgt->xyz, j.tgt->nrm, w->partial);
+    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(kBlock), 0, w->stream, w->partial, nblocks_of(n), w->acc, w->dstate, IP);
   }
-  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(&w->host->state, w->dstate, sizeof(IcpDev), hipMemcpyDeviceToHost, w->stream));
   ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
   return 0;
 }
@@ -849,72 +1030,45 @@ int align_start(IcpWs* w, AlignJob& j, er_cloud_t src, er_cloud_t tgt, const flo
   j.src = src;
   j.tgt = tgt;
   memcpy(j.fin, guess, sizeof j.fin);                        // final_transformation_ = guess
+  if (src->n == 0 || tgt->n == 0 || P.max_iter <= 0) {       // fewer than 3 correspondences by construction: nothing to enqueue
+    j.iter = 0;
+    j.conv = false;
+    if (P.want_fitness) return align_enqueue_fitness(w, j, P);
+    j.state = AlignJob::DONE;
+    ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+    return 0;
+  }
   bool ident = true;
   for (int i = 0; i < 16; i++) ident = ident && guess[i] == ((i % 5 == 0) ? 1.f : 0.f);
-  for (int i = 0; i < 16; i++) j.delta[i] = j.prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
+  // The previous job's state read-back has been consumed (the lane's event was waited for), so the pinned block is free.
+  IcpDev& st = w->host->state;
+  memset(&st, 0, sizeof st);
+  memcpy(st.fin, guess, sizeof st.fin);
+  for (int i = 0; i < 16; i++) st.delta[i] = st.prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
+  st.prev_mse = DBL_MAX;
+  ER_HIP_TRY(hipMemcpyAsync(w->dstate, &st, sizeof st, hipMemcpyHostToDevice, w->stream));
   Mat12f G;
   for (int q = 0; q < 12; q++) G.m[q] = guess[q];
-  if (src->n > 0) {
-    hipLaunchKernelGGL(k_init_x, dim3(nblocks_of(src->n)), dim3(kBlock), 0, w->stream, src->sorted, w->X, src->n, G, ident ? 0 : 1);
-    ER_HIP_TRY(hipGetLastError());
-  }
-  return align_enqueue_iteration(w, j, P);
+  hipLaunchKernelGGL(k_init_x, dim3(nblocks_of(src->n)), dim3(kBlock), 0, w->stream, src->sorted, w->X, src->n, G, ident ? 0 : 1);
+  ER_HIP_TRY(hipGetLastError());
+  return align_enqueue_chunk(w, j, P);
 }
 
-// The host half of a step: wait for the lane's event, decide, enqueue what follows.
+// The host half of a job: wait for the lane's event; either the loop has ended on the device (collect) or another chunk goes out.
 int align_advance(IcpWs* w, AlignJob& j, const AlignParams& P) {
   ER_HIP_TRY(hipEventSynchronize(w->ev));
-  const double* acc = w->host->acc;
+  if (j.state == AlignJob::DONE) return 0;
   if (j.state == AlignJob::FITNESS) {
+    const double* acc = w->host->acc;
     j.fitness = acc[1] > 0 ? acc[0] / acc[1] : DBL_MAX;
     j.state = AlignJob::DONE;
     return 0;
   }
-  bool stop = false;
-  const double cnt = acc[28];
-  double A[6][6], b[6], x[6];
-  if (cnt < 3.0) {                                           // min_number_correspondences_
-    j.conv = false;
-    stop = true;
-  } else {
-    int t = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
-    for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
-    if (!solve6x6(A, b, x)) {
-      j.conv = false;
-      stop = true;
-    }
-  }
-  if (!stop) {
-    construct_increment(x, j.delta);
-    mul4f(j.delta, j.fin, j.fin);                            // final = increment * final
-    ++j.iter;
-    if (j.iter >= P.max_iter) {
-      j.conv = true;
-      stop = true;
-    } else if (P.stop_rule == 0) {                           // PCL 1.7 DefaultConvergenceCriteria
-      const double cos_angle = 0.5 * (double)(j.delta[0] + j.delta[5] + j.delta[10] - 1.f);
-      const double tr2 = (double)(j.delta[3] * j.delta[3] + j.delta[7] * j.delta[7] + j.delta[11] * j.delta[11]);
-      const double cur = acc[27] / cnt;
-      if (cos_angle >= 1.0 - P.eps && tr2 <= P.eps) {
-        j.conv = true;
-        stop = true;
-      } else if (std::fabs(cur - j.prev_mse) < 1e-12) {
-        j.conv = true;
-        stop = true;
-      }
-      j.prev_mse = cur;
-    } else {                                                 // PCL <= 1.6
-      float s = 0.f;
-      for (int i = 0; i < 16; i++) s += j.delta[i] - j.prev_delta[i];
-      if (std::fabs((double)s) < P.eps) {
-        j.conv = true;
-        stop = true;
-      }
-    }
-  }
-  if (!stop) return align_enqueue_iteration(w, j, P);
+  const IcpDev& st = w->host->state;
+  if (!st.done) return align_enqueue_chunk(w, j, P);         // (h2d of the state is NOT repeated: it lives on the device)
+  memcpy(j.fin, st.fin, sizeof j.fin);
+  j.iter = st.iter;
+  j.conv = st.conv != 0;
   if (P.want_fitness) return align_enqueue_fitness(w, j, P);
   j.state = AlignJob::DONE;
   return 0;
@@ -1039,55 +1193,6 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
   c->device = device;
   c->n = n;
   c->radius_cap = grid_cell;
-  // ---- uniform grid on the host (once per fragment; every pair that uses it as target reuses it) ----
-  float cell = grid_cell * 1.001f;               // strictly larger than any admissible radius
-  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  if (n > 0) {
-    for (int a = 0; a < 3; a++) lo[a] = FLT_MAX, hi[a] = -FLT_MAX;
-    for (int i = 0; i < n; i++)
-      for (int a = 0; a < 3; a++) {
-        const float v = xyz_host[3 * (size_t)i + a];
-        if (v < lo[a]) lo[a] = v;
-        if (v > hi[a]) hi[a] = v;
-      }
-    for (int a = 0; a < 3; a++)
-      if (!std::isfinite(lo[a]) || !std::isfinite(hi[a])) {
-        delete c;
-        return er::fail("er_cloud_create: non-finite coordinates");
-      }
-  }
-  int dim[3];
-  for (;;) {
-    long total = 1;
-    for (int a = 0; a < 3; a++) {
-      dim[a] = (int)std::floor((hi[a] - lo[a]) / cell) + 1;
-      total *= dim[a];
-    }
-    if (total <= (1L << 25)) break;
-    cell *= 2.f;
-  }
-  const int ncell = dim[0] * dim[1] * dim[2];
-  std::vector<int> cs((size_t)ncell + 1, 0), id((size_t)n);
-  for (int i = 0; i < n; i++) {
-    int q[3];
-    for (int a = 0; a < 3; a++) {
-      q[a] = (int)std::floor((xyz_host[3 * (size_t)i + a] - lo[a]) / cell);
-      q[a] = std::min(std::max(q[a], 0), dim[a] - 1);
-    }
-    id[(size_t)i] = (q[2] * dim[1] + q[1]) * dim[0] + q[0];
-    cs[(size_t)id[(size_t)i] + 1]++;
-  }
-  for (int k = 0; k < ncell; k++) cs[(size_t)k + 1] += cs[(size_t)k];
-  std::vector<float4> sorted((size_t)n);
-  {
-    std::vector<int> fill(cs.begin(), cs.end() - 1);
-    for (int i = 0; i < n; i++) {
-      const int s = fill[(size_t)id[(size_t)i]]++;
-      float w;
-      memcpy(&w, &i, sizeof w);
-      sorted[(size_t)s] = make_float4(xyz_host[3 * (size_t)i], xyz_host[3 * (size_t)i + 1], xyz_host[3 * (size_t)i + 2], w);
-    }
-  }
   const size_t nn = (size_t)std::max(n, 1);
 #define ER_CALLOC(ptr, bytes)                                                                 \
   do {                                                                                        \
@@ -1098,22 +1203,104 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
       return 1;                                                                               \
     }                                                                                         \
   } while (0)
-  ER_CALLOC(c->xyz, nn * 3 * sizeof(float));
-  ER_CALLOC(c->nrm, nn * 3 * sizeof(float));
-  ER_CALLOC(c->sorted, nn * sizeof(float4));
-  ER_CALLOC(c->cell_start, ((size_t)ncell + 1) * sizeof(int));
-#undef ER_CALLOC
-  bool ok = true;
+#define ER_CTRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      er::fail("er_cloud_create: %s failed: %s", #expr, hipGetErrorString(e_));               \
+      er_cloud_destroy(c);                                                                    \
+      return 1;                                                                               \
+    }                                                                                         \
+  } while (0)
+  // one allocation for the three per-point arrays: [xyz 3n | normals 3n | sorted n float4]
+  const size_t off_sorted = (nn * 6 + 3) / 4 * 4;                 // float4 needs 16-byte alignment
+  ER_CALLOC(c->xyz, (off_sorted + nn * 4) * sizeof(float));
+  c->nrm = c->xyz + nn * 3;
+  c->sorted = reinterpret_cast<float4*>(c->xyz + off_sorted);
   if (n > 0) {
-    ok = ok && hipMemcpy(c->xyz, xyz_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(c->nrm, normal_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemcpy(c->sorted, sorted.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess;
+    ER_CTRY(hipMemcpyAsync(c->xyz, xyz_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    ER_CTRY(hipMemcpyAsync(c->nrm, normal_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
   }
-  ok = ok && hipMemcpy(c->cell_start, cs.data(), cs.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
-  if (!ok) {
-    er_cloud_destroy(c);
-    return er::fail("er_cloud_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  // ---- uniform grid on the DEVICE (once per fragment; every pair that uses it as target reuses it) ----
+  float cell = grid_cell * 1.001f;               // strictly larger than any admissible radius
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  int dim[3] = {1, 1, 1};
+  GridScratch& gs = grid_scratch(device);
+  std::lock_guard<std::mutex> lock(gs.mu);
+  if (!gs.bounds) ER_CTRY(hipMalloc((void**)&gs.bounds, 8 * sizeof(int)));
+  if (n > 0) {
+    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    int got[8];
+    ER_CTRY(hipMemcpyAsync(gs.bounds, init, sizeof init, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 1024)), dim3(kBlock), 0, nullptr, c->xyz, n, gs.bounds);
+    ER_CTRY(hipMemcpyAsync(got, gs.bounds, sizeof got, hipMemcpyDeviceToHost, nullptr));
+    ER_CTRY(hipStreamSynchronize(nullptr));
+    if (got[6]) {
+      er_cloud_destroy(c);
+      return er::fail("er_cloud_create: non-finite coordinates");
+    }
+    for (int a = 0; a < 3; a++) {
+      lo[a] = ordered_float(got[a]);
+      hi[a] = ordered_float(got[3 + a]);
+    }
   }
+  for (;;) {
+    long total = 1;
+    for (int a = 0; a < 3; a++) {
+      dim[a] = (int)std::floor((hi[a] - lo[a]) / cell) + 1;
+      total *= dim[a];
+    }
+    if (total <= (1L << 25)) break;
+    cell *= 2.f;
+  }
+  const int ncell = dim[0] * dim[1] * dim[2];
+  ER_CALLOC(c->cell_start, ((size_t)ncell + 1) * sizeof(int));
+  ER_CTRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), nullptr));
+  if (n > 0) {
+    if (gs.n_cap < (size_t)n) {
+      for (int q = 0; q < 2; q++) {
+        if (gs.key[q]) (void)hipFree(gs.key[q]);
+        if (gs.idx[q]) (void)hipFree(gs.idx[q]);
+        gs.key[q] = gs.idx[q] = nullptr;
+      }
+      gs.n_cap = 0;
+      const size_t cap = (size_t)n + (size_t)n / 8;
+      for (int q = 0; q < 2; q++) {
+        ER_CTRY(hipMalloc((void**)&gs.key[q], cap * sizeof(unsigned)));
+        ER_CTRY(hipMalloc((void**)&gs.idx[q], cap * sizeof(unsigned)));
+      }
+      gs.n_cap = cap;
+    }
+    GridDims G;
+    for (int a = 0; a < 3; a++) {
+      G.org[a] = lo[a];
+      G.dim[a] = dim[a];
+    }
+    G.cell = cell;
+    hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, n, G, gs.key[0], gs.idx[0], c->cell_start);
+    int bits = 1;
+    while ((1L << bits) < (long)ncell) bits++;
+    size_t need_sort = 0, need_scan = 0;
+    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, (hipStream_t) nullptr));
+    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, c->cell_start, c->cell_start, ncell + 1, (hipStream_t) nullptr));
+    const size_t need = std::max(need_sort, need_scan);
+    if (gs.cub_cap < need) {
+      if (gs.cub) (void)hipFree(gs.cub);
+      gs.cub = nullptr;
+      gs.cub_cap = 0;
+      ER_CTRY(hipMalloc(&gs.cub, need + need / 4));
+      gs.cub_cap = need + need / 4;
+    }
+    size_t tmp = gs.cub_cap;
+    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(gs.cub, tmp, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, (hipStream_t) nullptr));
+    tmp = gs.cub_cap;
+    ER_CTRY(hipcub::DeviceScan::InclusiveSum(gs.cub, tmp, c->cell_start, c->cell_start, ncell + 1, (hipStream_t) nullptr));
+    hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, gs.idx[1], n, c->sorted);
+    ER_CTRY(hipGetLastError());
+  }
+  ER_CTRY(hipStreamSynchronize(nullptr));          // the caller's host arrays and the shared scratch are free again
+#undef ER_CALLOC
+#undef ER_CTRY
   c->grid.pts = c->sorted;
   c->grid.cell_start = c->cell_start;
   c->grid.cell = cell;
@@ -1128,7 +1315,7 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
 int er_cloud_destroy(er_cloud_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  void* ptrs[] = {c->xyz, c->nrm, c->sorted, c->cell_start};
+  void* ptrs[] = {c->xyz, c->cell_start};          // xyz heads the one allocation that also holds nrm and sorted
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete c;

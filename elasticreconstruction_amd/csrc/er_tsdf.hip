@@ -141,6 +141,38 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   reproject_scatter_px(A, f, u, v, 0);
 }
 
+// The same, with the frame's control lattice staged in LDS (one 16-byte vertex each): the pixels of a 64 x 8 tile fall into
+// one or two lattice cells, so the 8 vertex reads per pixel become LDS broadcasts instead of 24 global gathers with their
+// 64-bit address arithmetic.  Used when the lattice fits (res <= 13 at 48 KB); identical arithmetic, identical results.
+#ifndef ER_RS_ROWS
+#define ER_RS_ROWS 2
+#endif
+constexpr int kRsRows = ER_RS_ROWS;                         // pixels per thread (consecutive rows of one column)
+__global__ __launch_bounds__(kBlock) void k_reproject_scatter_lds(ReprojArgs A, const Vert4* __restrict__ ctr4) {
+  extern __shared__ Vert4 s_lat[];
+  const int f = blockIdx.z, tid = threadIdx.x;
+  const int n1 = A.res + 1, verts = n1 * n1 * n1;
+  const Vert4* __restrict__ g4 = ctr4 + (size_t)A.grid_index[f] * verts;
+  for (int i = tid; i < verts; i += kBlock) s_lat[i] = g4[i];
+  __syncthreads();
+  const int u = blockIdx.x * 64 + (tid & 63);
+  const int v0 = blockIdx.y * (4 * kRsRows) + (tid >> 6) * kRsRows;
+  if (u >= A.cols) return;
+  const int pixels = A.cols * A.rows;
+#pragma unroll
+  for (int j = 0; j < kRsRows; j++) {
+    const int v = v0 + j;
+    if (v >= A.rows) break;
+    const int p = v * A.cols + u;
+    const uint16_t d = A.depth[(size_t)f * pixels + p];
+    if (d == 0) continue;                                               // UVD2XYZ false
+    int cell;
+    uint16_t dd;
+    if (reproject_px(u, v, d, A.cam, A.cami, A.cols, A.rows, A.seg12 + f * 16, A.madj12 + f * 12, s_lat, A.res, A.grid_ul, cell, dd))
+      scatter_px(A, f, p, cell, dd, 0);
+  }
+}
+
 // Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1").  A workgroup owns a 64 x 16 pixel tile of one frame, each
 // thread 4 pixels of one column.  The frame's control lattice is staged in LDS as one 16-byte vertex each (all pixels of a
 // tile fall into one or two lattice cells, so the 8 vertex reads per pixel are LDS broadcasts instead of 24 global gathers).
@@ -1090,9 +1122,15 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
 // Reproject of n frames into zbuf (tiered when the lattice fits LDS, else the all-exact kernel) + the replay launch.
 static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X) {
   const size_t lds = (size_t)(RA.res + 1) * (RA.res + 1) * (RA.res + 1) * sizeof(er::Vert4);
-#ifndef ER_REPROJECT_EXACT_ONLY
+#ifdef ER_REPROJECT_TIERED             // measured slower than the all-exact kernel (profiles/r02c_ab_tiered_reproject_v2.txt): off by default
   if (lds <= 48 * 1024 && dev_fast) {
     hipLaunchKernelGGL(k_reproject_tiered, dim3((h->cols + kRtW - 1) / kRtW, (h->rows + kRtH - 1) / kRtH, n), dim3(kBlock), lds, X, RA, dev_fast,
+                       h->ctr4);
+  } else
+#endif
+#ifndef ER_REPROJECT_NO_LDS
+  if (lds <= 48 * 1024) {
+    hipLaunchKernelGGL(k_reproject_scatter_lds, dim3((h->cols + 63) / 64, (h->rows + 4 * kRsRows - 1) / (4 * kRsRows), n), dim3(kBlock), lds, X, RA,
                        h->ctr4);
   } else
 #endif

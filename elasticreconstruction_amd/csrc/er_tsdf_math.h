@@ -499,11 +499,18 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
   return floor((e * f / e2 + cc) + 0.5);
 }
 
+struct alignas(16) Vert4 { float x, y, z, w; };     // one lattice vertex padded to 16 bytes (one LDS / 16-byte read per vertex)
+
+// The lattice as ControlGrid keeps it (3 floats per vertex) or as Vert4 (the LDS copy k_reproject_scatter stages per workgroup).
+ER_HD void lattice_vertex(const float* __restrict__ ctr, int idx, float v[3]) { v[0] = ctr[idx * 3]; v[1] = ctr[idx * 3 + 1]; v[2] = ctr[idx * 3 + 2]; }
+ER_HD void lattice_vertex(const Vert4* __restrict__ ctr, int idx, float v[3]) { const Vert4 t = ctr[idx]; v[0] = t.x; v[1] = t.y; v[2] = t.z; }
+
 // seg: rows 0..2 of the float64 4x4 followed by the three rounding bounds of cube_coords (15 doubles used, stride 16);
 // madj: rows 0..2 (12 doubles).  ctr: one grid, (res+1)^3 * 3 floats.
 // On success returns true and the target cell (row-major pixel index) plus the 16-bit depth dd.
+template <typename Lattice>
 ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, int cols, int rows, const double* seg,
-                        const double* madj, const float* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd,
+                        const double* madj, const Lattice* __restrict__ ctr, int res, float grid_ul, int& cell, uint16_t& dd,
                         double* e_out = nullptr) {
   float pt[3];
   cube_coords(u, v, d, c, ci, seg, pt);
@@ -532,11 +539,16 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   int idx[8] = {base,     base + n2,     base + n1,     base + n1 + n2,
                 base + 1, base + 1 + n2, base + 1 + n1, base + 1 + n1 + n2};
   // ControlGrid::GetPosition, ControlGrid.h:82-87: left-to-right float32 sum
-  float pos[3];
-  for (int a = 0; a < 3; a++) {
-    float s = val[0] * ctr[idx[0] * 3 + a];
-    for (int t = 1; t < 8; t++) s = s + val[t] * ctr[idx[t] * 3 + a];
-    pos[a] = s;
+  float pos[3], vt[3];
+  lattice_vertex(ctr, idx[0], vt);
+  pos[0] = val[0] * vt[0];
+  pos[1] = val[0] * vt[1];
+  pos[2] = val[0] * vt[2];
+  for (int t = 1; t < 8; t++) {
+    lattice_vertex(ctr, idx[t], vt);
+    pos[0] = pos[0] + val[t] * vt[0];
+    pos[1] = pos[1] + val[t] * vt[1];
+    pos[2] = pos[2] + val[t] * vt[2];
   }
   double pa = (double)pos[0], pb = (double)pos[1], pc = (double)pos[2];
   double e0 = ((madj[0] * pa + madj[1] * pb) + madj[2] * pc) + madj[3];
@@ -596,8 +608,6 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
 // then the integer tests against the image bounds are exact as well.  Every constant is rounded UP on the host
 // (reproj_fast_setup); tests/hostcheck replays the tier on the CPU against reproject_px for every pixel of the golden and
 // fuzzed scenes and records the worst observed error as a fraction of its tolerance.
-struct alignas(16) Vert4 { float x, y, z, w; };     // one lattice vertex padded to 16 bytes (one ds_read_b128 / 16-byte load)
-
 struct ReprojFast {
   double ga[3], gb[3], gc[3], gs[3];   // a_k = d * (ga_k u' + gb_k v' + gc_k) + gs_k, d = raw depth in millimetres
   float m[12];                         // madj rows 0, 1 scaled by fx, fy; row 2 plain
