@@ -270,6 +270,73 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     return res
 
 
+def allpairs_section(n_frag, device, rank=0, world=1, with_cpu=True):
+    """configs[4] shape, first half: ALL pairs of an n_frag-fragment scene (n_frag (n_frag - 1) / 2 = 4950 for 100) through the
+    reference's BuildCorrespondence flow -- Registration pre-check on every pair (CorresApp.cpp:257-281: accepted iff the
+    inlier count reaches reg_num_ = 40000 or both ratios exceed 0.25), ICP + FindCorrespondence on the accepted ones --
+    with the pairs dealt to the ranks by parallel.pair_shard and no collective.  Fragments: outward-looking views from a
+    circle (neighbours overlap, distant ones do not, so the pre-check really rejects most pairs)."""
+    import numpy as np
+    from elasticreconstruction_amd import parallel, synth
+    from elasticreconstruction_amd.icp import Cloud, count_inliers_batch, find_correspondence_batch, icp_align_batch
+    frs = synth.fragment_set(n_frag, 250000, radius=0.6, device="cuda:%d" % device)
+    clouds = [Cloud(x, n, 0.03, device) for x, n, _ in frs]
+    allp = [(i, j) for i in range(n_frag) for j in range(i + 1, n_frag)]
+    mine = [allp[p] for p in parallel.pair_shard(len(allp), rank, world)]
+    Ts = [np.linalg.inv(frs[i][2]) @ frs[j][2] @ synth.perturbation(9000 + i * n_frag + j, 1.0, 0.01) for i, j in mine]
+
+    def run():
+        t0 = time.perf_counter()
+        cnts = count_inliers_batch([clouds[j] for _, j in mine], [clouds[i] for i, _ in mine], Ts, 0.03)
+        npts = np.array([[len(clouds[i]), len(clouds[j])] for i, j in mine], np.float64)
+        acc = (cnts >= 40000) | ((cnts / npts[:, 0] > 0.25) & (cnts / npts[:, 1] > 0.25))
+        ai = np.nonzero(acc)[0]
+        t1 = time.perf_counter()
+        fins, iters, _, _ = icp_align_batch([clouds[mine[k][1]] for k in ai], [clouds[mine[k][0]] for k in ai],
+                                            [Ts[k].astype(np.float32) for k in ai], 0.03, 20, 1e-6, 0)
+        t2 = time.perf_counter()
+        lists, _ = find_correspondence_batch([clouds[mine[k][1]] for k in ai], [clouds[mine[k][0]] for k in ai],
+                                             [F.astype(np.float64) for F in fins], 0.015, 0.8660, True, copy=False)
+        t3 = time.perf_counter()
+        return cnts, acc, iters, [l.shape[0] for l in lists], (t1 - t0, t2 - t1, t3 - t2)
+    run()
+    cnts, acc, iters, ncs, ph = run()
+    dt = sum(ph)
+    res = {"fragments": n_frag, "pairs_total": len(allp), "pairs_this_rank": len(mine), "accepted_this_rank": int(acc.sum()),
+           "rejected_by_pre_check": int((~acc).sum()), "pairs_per_s": len(mine) / dt, "accepted_pairs_per_s": int(acc.sum()) / dt,
+           "mean_icp_iterations": float(np.mean(iters)) if len(iters) else 0.0, "mean_correspondences": float(np.mean(ncs)) if ncs else 0.0,
+           "phase_ms": {"pre_check_all_pairs": 1e3 * ph[0], "icp_accepted": 1e3 * ph[1], "find_correspondence_accepted": 1e3 * ph[2]},
+           "sharding": "pair p -> rank p mod %d, fragments replicated, no collective" % world, "_pass_s": dt}
+    if with_cpu:
+        try:
+            from oracle.pyoracle import IcpOracle
+            rng = np.random.default_rng(5)
+            pick = sorted(set(int(k) for k in rng.choice(len(mine), 24, replace=False)) | set(int(k) for k in np.nonzero(acc)[0][:4]))
+            oc = {}
+            ok = True
+            for k in pick:
+                i, j = mine[k]
+                for q in (i, j):
+                    if q not in oc:
+                        oc[q] = IcpOracle(frs[q][0], frs[q][1], 0.03)
+                ok = ok and int(oc[j].count_inliers(oc[i], Ts[k], 0.03)) == int(cnts[k])
+            # correspondence lists of three accepted pairs at the ground-truth transform (integers: exact)
+            from elasticreconstruction_amd.icp import find_correspondence
+            for k in [int(q) for q in np.nonzero(acc)[0][:3]]:
+                i, j = mine[k]
+                gt = np.linalg.inv(frs[i][2]) @ frs[j][2]
+                lg, _ = find_correspondence(clouds[j], clouds[i], gt, 0.015, 0.8660)
+                lo, _ = oc[j].find_correspondence(oc[i], gt, 0.015, 0.8660)
+                ok = ok and np.array_equal(lg, np.asarray(lo))
+            res["parity_checked"] = {"pre_check_counts_exact_on_pairs": len(pick), "correspondence_lists_exact_on_pairs": 3,
+                                     "against": "oracle/icp_oracle.cpp (parity unpinned: PCL absent)", "ok": bool(ok)}
+        except Exception as ex:
+            res["parity_checked"] = {"ok": None, "note": "oracle not available: %s" % ex}
+    for c in clouds:
+        c.close()
+    return res
+
+
 def fopt_section(device):
     """SURVEY.md 8f-2 figure: Hessian assembly of the reference's FragmentOptimizer (SLAC and rigid modes) for 4 fragments
     of ~250 k points / 6 pairs with exact correspondence lists, GPU (er_fopt_assemble_*) vs the sequential oracle."""
@@ -347,6 +414,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5],
+                    help="BASELINE.json config (1-based): 2 = the headline (3000 frames, 512^3, warp; the default and what the driver "
+                         "runs); 4 = 10 000 frames on a drifting path through a 6 m room into the hashed unit grid (> 512 units), frame "
+                         "blocks per rank + the RCCL merge (run on one GPU it exercises the same code at G = 1); 5 = the 100-fragment "
+                         "scene: all 4950 pairs through BuildCorrespondence's flow, then 5000 frames integrated")
     ap.add_argument("--interval", type=int, default=50, help="frames per fragment / control grid (--interval of Integrate)")
     ap.add_argument("--frames-per-step", type=int, default=0,
                     help="frames handed to the hot path per step (one er_tsdf_integrate_frames call); 0 = as many whole fragments "
@@ -383,7 +455,7 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or args.force_merge
+    use_dist = world > 1 or args.force_merge or args.config == 4
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -392,6 +464,10 @@ def main():
 
     K, W, I = args.steps, args.warmup, args.interval
     S = args.frames_per_step
+    job_frames = {2: None, 4: 10000, 5: 5000}[args.config]          # configs 4 / 5 fix the JOB's frame count (strong scaling)
+    if job_frames:
+        S = S if S > 0 else 4 * I
+        K = max(1, job_frames // (world * S))
     if S <= 0:
         S = max(I, (CONFIG2_FRAMES // max(K, 1)) // I * I)     # whole fragments per step; K steps cover configs[1] when K divides 60
     if S % I:
@@ -399,8 +475,10 @@ def main():
     n_frames = K * S
     warp_on = not args.no_warp
     # one long trajectory split into contiguous per-rank blocks (config 4's frame-batch shard)
+    big_room = args.config == 4
     sc = synth.make_scenario(n_frames, interval=I, warp=warp_on, frame_offset=rank * n_frames,
                              total_frames=world * n_frames, revolutions=max(1.0, world * n_frames / float(CONFIG2_FRAMES)),
+                             radius_drift=1.5 if big_room else 0.0, room=(-1.5, 4.5) if big_room else (synth.ROOM_LO, synth.ROOM_HI),
                              device=dev)
     depth = sc["depth"]                                    # uint16 [n_frames, 307200] in HBM
     warp_all = synth.warp_arrays(sc) if warp_on else None
@@ -442,7 +520,7 @@ def main():
             return comm.allreduce(vol, root=0)
         return parallel.merge_volumes(vol, dist, dev)
 
-    max_units = 640 if world == 1 else 1024
+    max_units = 4096 if big_room else (640 if world == 1 else 1024)
     vol = TSDFVolume(max_units=max_units, device=local)
     vol.set_stream(stream.cuda_stream)
     # ---- warm-up (the volume is emptied afterwards) --------------------------------------------
@@ -520,7 +598,15 @@ def main():
         arena.close()
 
     icp = None
-    if args.icp_pairs > 0:
+    if args.config == 5:
+        icp = allpairs_section(100, local, rank, world, with_cpu=(rank == 0))
+        ap_s = icp.pop("_pass_s")
+        if use_dist:
+            t = torch.tensor([ap_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ap_s = float(t.item())
+        icp["pairs_per_s"] = icp["pairs_total"] / ap_s           # whole job: every rank's share done when the slowest is
+    elif args.icp_pairs > 0 and args.config == 2:
         # secondary metric on every rank (pairs shard with no collective: each GPU runs the same pair list, weak scaling)
         icp = icp_section(args.icp_pairs, local, with_cpu=(rank == 0 and world == 1))
         icp_pass_s = icp.pop("_pass_s")
@@ -544,15 +630,18 @@ def main():
             "warmup": W,
             "ms_per_step": 1000.0 * dt / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if job_frames else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %d synthetic 640x480 frames per GPU (box room + sphere, circular trajectory), "
-                                   "512^3 TSDF = 8x8x8 units of 64^3 at 3/512 m, %s, %d frames per step"
+            "config": {"workload": {2: "configs[1]", 4: "configs[3] (10 000 frames, 6 m room, drifting path, hashed unit grid)",
+                                    5: "configs[4] (100-fragment scene: all-pairs ICP, then 5000 frames)"}[args.config] +
+                                   ": %d synthetic 640x480 frames per GPU (box room + sphere, circular trajectory), "
+                                   "TSDF units of 64^3 at 3/512 m, %s, %d frames per step"
                                    % (n_frames, "ControlGrid warp res 8 / %d grids" % (n_frames // I) if warp_on else "rigid", S),
+                       "baseline_config": args.config,
                        "frames_per_step": S, "frames_per_gpu": n_frames, "volume_units_touched": n_units,
-                       "covers_all_of_configs1": bool(n_frames == CONFIG2_FRAMES),
+                       "covers_all_of_configs1": bool(args.config == 2 and n_frames == CONFIG2_FRAMES),
                        "parallelism": "frame-block shard x%d + one final reduce to rank 0" % world if world > 1 else "single GPU",
                        "inputs": "HOST memory, copied over PCIe inside the timed region (not the headline configuration)"
                        if args.host_input else "resident in HBM before the timed region"},
@@ -635,7 +724,7 @@ def main():
                     pvol.close()
         if icp is not None:
             out["icp"] = icp
-            if world == 1:
+            if world == 1 and args.config == 2:
                 out["fragment_optimizer"] = fopt_section(local)
         print(json.dumps(out), flush=True)
     vol.close()

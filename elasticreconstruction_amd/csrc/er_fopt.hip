@@ -284,6 +284,50 @@ __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const C
 // Row-major UPPER triangle throughout (= column-major lower triangle for rocSOLVER).
 // AddHessian2( {v, w}, {1, -1} ) for every (vertex, neighbour) ordered pair of the lattice (OptApp.cpp:765-800, 811-836):
 // +scale on both diagonals, -scale on the coupling, per xyz component.
+// The non-rigid system either as ONE dense matrix (base, ld) or as the block-sparse lower triangle of fragment blocks
+// (bs x bs blocks of one fragment's lattice each; blk_off[bq * nb + br] = offset of block (bq, br), bq >= br, column-major
+// inside the block -- which is the same "row r, column q, r <= q -> base[r * ld + q]" addressing as the dense row-major
+// upper triangle, applied inside the block).
+struct MatView {
+  double* base;
+  long ld;
+  const long* blk_off;        // nullptr: dense
+  int nb;
+  long bs;
+};
+__device__ __forceinline__ double* mat_at(const MatView& V, long r, long q) {      // r <= q
+  if (!V.blk_off) return V.base + r * V.ld + q;
+  const long br = r / V.bs, bq = q / V.bs;
+  return V.base + V.blk_off[bq * V.nb + br] + (r - br * V.bs) * V.bs + (q - bq * V.bs);
+}
+
+__global__ void k_fopt_add_laplacian_v(MatView V, long off, int res, double scale) {
+  const int n1 = res + 1, nv = n1 * n1 * n1;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nv * 6) return;
+  const int v = t / 6, dir = t % 6;
+  const int i = v % n1, j = (v / n1) % n1, k = v / (n1 * n1);
+  int w = -1;
+  if (dir == 0 && i > 0) w = v - 1;
+  if (dir == 1 && i < res) w = v + 1;
+  if (dir == 2 && j > 0) w = v - n1;
+  if (dir == 3 && j < res) w = v + n1;
+  if (dir == 4 && k > 0) w = v - n1 * n1;
+  if (dir == 5 && k < res) w = v + n1 * n1;
+  if (w < 0) return;
+  for (int c = 0; c < 3; c++) {
+    const long a = off + (long)v * 3 + c, b = off + (long)w * 3 + c;
+    atomicAdd(mat_at(V, a, a), scale);
+    atomicAdd(mat_at(V, b, b), scale);
+    atomicAdd(mat_at(V, a < b ? a : b, a < b ? b : a), -scale);
+  }
+}
+
+__global__ void k_fopt_add_diag_v(MatView V, long first, int count, double value) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < count) atomicAdd(mat_at(V, first + t, first + t), value);
+}
+
 __global__ void k_fopt_add_laplacian(double* __restrict__ A, long ld, long off, int res, double scale) {
   const int n1 = res + 1, nv = n1 * n1 * n1;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,7 +357,7 @@ __global__ void k_fopt_add_diag(double* __restrict__ A, long ld, long first, int
 
 // non-rigid: the 24x24 blocks of er_fopt_assemble_nonrigid scattered into the dense upper triangle
 __global__ void k_fopt_scatter_blocks(const double* __restrict__ blocks, long n_blocks, const int* __restrict__ info, int diag_mode, int nv,
-                                      int res, long nper, double* __restrict__ A, long ld) {
+                                      int res, long nper, MatView V) {
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_blocks * 576) return;
   const double v = blocks[t];
@@ -330,9 +374,9 @@ __global__ void k_fopt_scatter_blocks(const double* __restrict__ blocks, long n_
   }
   const long r = bi + vertex_offset(a & 7, res) + (a >> 3), q = bj + vertex_offset(c & 7, res) + (c >> 3);
   if (diag_mode) {
-    if (r <= q) atomicAdd(&A[r * ld + q], v);                 // both triangles are present in the block: keep the upper one
+    if (r <= q) atomicAdd(mat_at(V, r, q), v);                // both triangles are present in the block: keep the upper one
   } else {
-    atomicAdd(&A[(r < q ? r : q) * ld + (r < q ? q : r)], v);
+    atomicAdd(mat_at(V, r < q ? r : q, r < q ? q : r), v);
   }
 }
 
@@ -352,8 +396,15 @@ struct RocSolver {
   int (*set_stream)(void*, hipStream_t) = nullptr;
   int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
   int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
+  // block-sparse factorisation of the non-rigid system: level-3 BLAS on fragment blocks
+  int (*dtrsm)(void*, int, int, int, int, int, int, const double*, const double*, int, double*, int) = nullptr;
+  int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
+  int (*dsyrk)(void*, int, int, int, int, const double*, const double*, int, const double*, double*, int) = nullptr;
+  int (*dgemv)(void*, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
+  int (*dtrsv)(void*, int, int, int, int, const double*, int, double*, int) = nullptr;
 };
 constexpr int kFillLower = 122;                                 // rocblas_fill_lower
+constexpr int kOpN = 111, kOpT = 112, kDiagNonUnit = 131, kSideRight = 142;   // rocblas_operation / diagonal / side
 
 int rocsolver_load(RocSolver& R, hipStream_t stream) {
   if (R.handle) return 0;
@@ -367,7 +418,13 @@ int rocsolver_load(RocSolver& R, hipStream_t stream) {
   R.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(R.blas, "rocblas_set_stream"));
   R.dpotrf = reinterpret_cast<int (*)(void*, int, int, double*, int, int*)>(dlsym(R.solver, "rocsolver_dpotrf"));
   R.dpotrs = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, int)>(dlsym(R.solver, "rocsolver_dpotrs"));
-  if (!R.create_handle || !R.destroy_handle || !R.set_stream || !R.dpotrf || !R.dpotrs) return er::fail("rocSOLVER symbols not found");
+  R.dtrsm = reinterpret_cast<decltype(R.dtrsm)>(dlsym(R.blas, "rocblas_dtrsm"));
+  R.dgemm = reinterpret_cast<decltype(R.dgemm)>(dlsym(R.blas, "rocblas_dgemm"));
+  R.dsyrk = reinterpret_cast<decltype(R.dsyrk)>(dlsym(R.blas, "rocblas_dsyrk"));
+  R.dgemv = reinterpret_cast<decltype(R.dgemv)>(dlsym(R.blas, "rocblas_dgemv"));
+  R.dtrsv = reinterpret_cast<decltype(R.dtrsv)>(dlsym(R.blas, "rocblas_dtrsv"));
+  if (!R.create_handle || !R.destroy_handle || !R.set_stream || !R.dpotrf || !R.dpotrs || !R.dtrsm || !R.dgemm || !R.dsyrk || !R.dgemv || !R.dtrsv)
+    return er::fail("rocSOLVER / rocBLAS symbols not found");
   if (R.create_handle(&R.handle) != 0 || R.set_stream(R.handle, stream) != 0) {
     R.handle = nullptr;
     return er::fail("rocblas_create_handle failed");
@@ -398,6 +455,11 @@ struct er_fopt_s {
   double *d_sys = nullptr, *d_rhs = nullptr;       // d_sys aliases d_JJ in the SLAC mode, own allocation in the non-rigid mode
   double* d_big = nullptr;
   size_t big_cap = 0;
+  // block-sparse lower triangle of the non-rigid system (fragment blocks; er_fopt_factor_nonrigid when the dense matrix is too big)
+  bool blocked = false;
+  std::vector<long> blk_off;                       // [nb * nb]: offset (doubles) of block (row, col), row >= col, or -1
+  std::vector<std::vector<int>> blk_rows;          // per block column: rows > column with a structurally non-zero block (ascending)
+  long* d_blk_off = nullptr;
   long sys_n = 0;
   int* d_info = nullptr;
   int* d_ginfo = nullptr;
@@ -541,7 +603,7 @@ int er_fopt_destroy(er_fopt_t h) {
   for (auto& f : h->frag) free_frag(f);
   if (h->roc.handle && h->roc.destroy_handle) (void)h->roc.destroy_handle(h->roc.handle);
   void* ptrs[] = {h->d_frags, h->d_first, h->d_second, h->d_chunks, h->d_JJ, h->d_Jb, h->d_rot, h->d_ctr, h->d_M, h->d_diag, h->d_off,
-                  h->d_big, h->d_rhs, h->d_info, h->d_ginfo};
+                  h->d_big, h->d_rhs, h->d_info, h->d_ginfo, h->d_blk_off};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -772,6 +834,7 @@ static int factor_common(er_fopt_t h, double* A, long n) {
   if (info != 0) return er::fail("the assembled system is not positive definite (rocsolver_dpotrf info = %d)", info);
   h->d_sys = A;
   h->sys_n = n;
+  h->blocked = false;
   h->factored = true;
   return 0;
 }
@@ -802,10 +865,137 @@ int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_we
   return factor_common(h, h->d_JJ, (long)N);
 }
 
+// ---- block-sparse Cholesky of the non-rigid system --------------------------------------------------------------------
+// The reference factors thisAA with CHOLMOD's supernodal sparse Cholesky on the host (OptApp.cpp:155-211).  Here the
+// matrix is kept as the lower triangle of FRAGMENT blocks (nper x nper = 2187 x 2187 at resolution 8, column-major): block
+// (i, j) exists iff fragments i and j share a correspondence list or it fills in during the elimination (symbolic pass on
+// the host over the fragment graph, natural order); the numeric factorisation is right-looking over those dense blocks --
+// rocSOLVER potrf on the diagonal block, rocBLAS trsm down the column, syrk / gemm into the trailing blocks -- and a solve is
+// a block forward / backward substitution (trsv + gemv).  A 100-fragment scene whose pairs link neighbours needs a few
+// hundred 38 MB blocks; even the complete graph of 100 fragments (5050 blocks, 193 GB) fits the 288 GB of one MI355X, where
+// the dense square of the same system (383 GB) does not.
+static int block_symbolic(er_fopt_t h) {
+  const int nb = h->num;
+  std::vector<std::vector<char>> nz((size_t)nb, std::vector<char>((size_t)nb, 0));
+  for (int i = 0; i < nb; i++) nz[(size_t)i][(size_t)i] = 1;
+  for (int g = 0; g < h->n_groups; g++) {
+    const int a = h->group_info[(size_t)g * 4], b = h->group_info[(size_t)g * 4 + 1];
+    if (a < 0 || b < 0 || a >= nb || b >= nb) continue;
+    nz[(size_t)std::max(a, b)][(size_t)std::min(a, b)] = 1;
+  }
+  for (int k = 0; k < nb; k++)                                   // fill-in: rows i > j > k of column k couple (i, j)
+    for (int i = k + 1; i < nb; i++)
+      if (nz[(size_t)i][(size_t)k])
+        for (int j = k + 1; j < i; j++)
+          if (nz[(size_t)j][(size_t)k]) nz[(size_t)i][(size_t)j] = 1;
+  h->blk_off.assign((size_t)nb * nb, -1);
+  h->blk_rows.assign((size_t)nb, std::vector<int>());
+  long off = 0;
+  const long bsz = (long)h->nper * h->nper;
+  for (int j = 0; j < nb; j++)
+    for (int i = j; i < nb; i++)
+      if (nz[(size_t)i][(size_t)j]) {
+        h->blk_off[(size_t)i * nb + j] = off;
+        off += bsz;
+        if (i > j) h->blk_rows[(size_t)j].push_back(i);
+      }
+  return (int)(off / bsz);
+}
+
+static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
+  if (rocsolver_load(h->roc, h->stream)) return 1;
+  const int nb = h->num;
+  const int B = h->nper;
+  const long bsz = (long)B * B;
+  const int n_blocks = block_symbolic(h);
+  const size_t need = (size_t)n_blocks * (size_t)bsz;
+  if (need > h->big_cap) {
+    if (h->d_big) (void)hipFree(h->d_big);
+    h->d_big = nullptr;
+    h->big_cap = 0;
+    hipError_t e = hipMalloc((void**)&h->d_big, need * sizeof(double));
+    if (e != hipSuccess)
+      return er::fail("er_fopt_factor_nonrigid: %d fragment blocks of %d x %d float64 (%.1f GB) do not fit: %s", n_blocks, B, B, (double)need * 8 / 1e9,
+                      hipGetErrorString(e));
+    h->big_cap = need;
+  }
+  if (h->d_blk_off) (void)hipFree(h->d_blk_off);
+  h->d_blk_off = nullptr;
+  ER_HIP_TRY(hipMalloc((void**)&h->d_blk_off, (size_t)nb * nb * sizeof(long)));
+  ER_HIP_TRY(hipMemcpyAsync(h->d_blk_off, h->blk_off.data(), (size_t)nb * nb * sizeof(long), hipMemcpyHostToDevice, h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_big, 0, need * sizeof(double), h->stream));
+  const MatView V{h->d_big, 0, h->d_blk_off, nb, (long)B};
+  hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)((nd + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_diag, (long)(nd / 576),
+                     (const int*)nullptr, 1, (int)nv, h->res, (long)h->nper, V);
+  if (h->n_groups > 0)
+    hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)(((size_t)h->n_groups * 576 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_off,
+                       (long)h->n_groups, h->d_ginfo, 0, (int)nv, h->res, (long)h->nper, V);
+  for (int l = 0; l < h->num; l++)                                            // baseAA, OptApp.cpp:765-810
+    hipLaunchKernelGGL(k_fopt_add_laplacian_v, dim3((unsigned)((nv * 6 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, V, (long)l * h->nper, h->res, 1.0);
+  hipLaunchKernelGGL(k_fopt_add_diag_v, dim3(1), dim3(64), 0, h->stream, V, 0L, 3, 1.0);
+  ER_HIP_TRY(hipGetLastError());
+  // ---- numeric factorisation, right-looking over the blocks ----
+  if (!h->d_info) ER_HIP_TRY(hipMalloc((void**)&h->d_info, sizeof(int)));
+  if (h->d_rhs) {
+    (void)hipFree(h->d_rhs);
+    h->d_rhs = nullptr;
+  }
+  ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)nb * B * sizeof(double)));
+  const double one = 1.0, minus = -1.0;
+  auto blk = [&](int i, int j) { return h->d_big + h->blk_off[(size_t)i * nb + j]; };
+  for (int k = 0; k < nb; k++) {
+    if (h->roc.dpotrf(h->roc.handle, kFillLower, B, blk(k, k), B, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed (block %d)", k);
+    int info = 0;
+    ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    ER_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (info != 0) return er::fail("the assembled system is not positive definite (fragment block %d, rocsolver_dpotrf info = %d)", k, info);
+    const std::vector<int>& rows = h->blk_rows[(size_t)k];
+    for (int i : rows)                                            // L_ik = A_ik L_kk^-T
+      if (h->roc.dtrsm(h->roc.handle, kSideRight, kFillLower, kOpT, kDiagNonUnit, B, B, &one, blk(k, k), B, blk(i, k), B) != 0)
+        return er::fail("rocblas_dtrsm failed (block %d,%d)", i, k);
+    for (size_t a = 0; a < rows.size(); a++)                      // trailing update: A_ij -= L_ik L_jk^T
+      for (size_t b = 0; b <= a; b++) {
+        const int i = rows[a], j = rows[b];
+        int rc;
+        if (i == j)
+          rc = h->roc.dsyrk(h->roc.handle, kFillLower, kOpN, B, B, &minus, blk(i, k), B, &one, blk(i, i), B);
+        else
+          rc = h->roc.dgemm(h->roc.handle, kOpN, kOpT, B, B, B, &minus, blk(i, k), B, blk(j, k), B, &one, blk(i, j), B);
+        if (rc != 0) return er::fail("rocblas trailing update failed (block %d,%d)", i, j);
+      }
+  }
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->d_sys = h->d_big;
+  h->sys_n = (long)nb * B;
+  h->blocked = true;
+  h->factored = true;
+  return 0;
+}
+
+static int solve_blocked(er_fopt_t h) {                              // d_rhs <- (L L^T)^-1 d_rhs
+  const int nb = h->num, B = h->nper;
+  const double one = 1.0, minus = -1.0;
+  auto blk = [&](int i, int j) { return h->d_big + h->blk_off[(size_t)i * nb + j]; };
+  for (int k = 0; k < nb; k++) {                                     // forward: L y = b
+    if (h->roc.dtrsv(h->roc.handle, kFillLower, kOpN, kDiagNonUnit, B, blk(k, k), B, h->d_rhs + (size_t)k * B, 1) != 0) return er::fail("rocblas_dtrsv failed");
+    for (int i : h->blk_rows[(size_t)k])
+      if (h->roc.dgemv(h->roc.handle, kOpN, B, B, &minus, blk(i, k), B, h->d_rhs + (size_t)k * B, 1, &one, h->d_rhs + (size_t)i * B, 1) != 0)
+        return er::fail("rocblas_dgemv failed");
+  }
+  for (int k = nb - 1; k >= 0; k--) {                                // backward: L^T x = y
+    for (int i : h->blk_rows[(size_t)k])
+      if (h->roc.dgemv(h->roc.handle, kOpT, B, B, &minus, blk(i, k), B, h->d_rhs + (size_t)i * B, 1, &one, h->d_rhs + (size_t)k * B, 1) != 0)
+        return er::fail("rocblas_dgemv failed");
+    if (h->roc.dtrsv(h->roc.handle, kFillLower, kOpT, kDiagNonUnit, B, blk(k, k), B, h->d_rhs + (size_t)k * B, 1) != 0) return er::fail("rocblas_dtrsv failed");
+  }
+  return 0;
+}
+
 int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
   if (!h) return er::fail("er_fopt_factor_nonrigid: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
   h->factored = false;
+  h->blocked = false;
   const size_t nv = (size_t)h->nper / 3, M = (size_t)h->num * h->nper;
   const size_t nd = (size_t)h->num * nv * 576, no = (size_t)std::max(h->n_groups, 1) * 576;
   if (nd > h->diag_cap) {
@@ -822,6 +1012,22 @@ int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
     ER_HIP_TRY(hipMalloc((void**)&h->d_off, no * sizeof(double)));
     h->off_cap = no;
   }
+  if (!h->d_ginfo && h->n_groups > 0) {
+    ER_HIP_TRY(hipMalloc((void**)&h->d_ginfo, (size_t)h->n_groups * 4 * sizeof(int)));
+    ER_HIP_TRY(hipMemcpyAsync(h->d_ginfo, h->group_info.data(), (size_t)h->n_groups * 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  ER_HIP_TRY(hipMemsetAsync(h->d_diag, 0, nd * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemsetAsync(h->d_off, 0, no * sizeof(double), h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(h->d_rot, &weight, sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if (h->n_chunks > 0)
+    hipLaunchKernelGGL(k_fopt_gram<2>, dim3((h->n_chunks * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks,
+                       h->d_frags, h->d_first, h->d_second, h->d_rot, h->num, h->res, 0, h->d_diag, h->d_off, (double*)nullptr);
+  ER_HIP_TRY(hipGetLastError());
+  // Dense while the square matrix is small (one potrf); block-sparse over fragments beyond ER_FOPT_DENSE_MAX unknowns
+  // (default 30 000 = 7.2 GB dense; ER_FOPT_DENSE_MAX=0 forces the block path, used by the tests to compare the two).
+  const char* env = getenv("ER_FOPT_DENSE_MAX");
+  const size_t dense_max = env ? (size_t)atol(env) : 30000;
+  if (M > dense_max) return factor_nonrigid_blocked(h, nv, nd);
   if (M * M > h->big_cap) {
     if (h->d_big) (void)hipFree(h->d_big);
     h->d_big = nullptr;
@@ -830,22 +1036,13 @@ int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
     if (e != hipSuccess) return er::fail("er_fopt_factor_nonrigid: %zu x %zu float64 system (%.1f GB) does not fit: %s", M, M, (double)(M * M * 8) / 1e9, hipGetErrorString(e));
     h->big_cap = M * M;
   }
-  if (!h->d_ginfo && h->n_groups > 0) {
-    ER_HIP_TRY(hipMalloc((void**)&h->d_ginfo, (size_t)h->n_groups * 4 * sizeof(int)));
-    ER_HIP_TRY(hipMemcpyAsync(h->d_ginfo, h->group_info.data(), (size_t)h->n_groups * 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  }
-  ER_HIP_TRY(hipMemsetAsync(h->d_diag, 0, nd * sizeof(double), h->stream));
-  ER_HIP_TRY(hipMemsetAsync(h->d_off, 0, no * sizeof(double), h->stream));
   ER_HIP_TRY(hipMemsetAsync(h->d_big, 0, M * M * sizeof(double), h->stream));
-  ER_HIP_TRY(hipMemcpyAsync(h->d_rot, &weight, sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if (h->n_chunks > 0)
-    hipLaunchKernelGGL(k_fopt_gram<2>, dim3((h->n_chunks * 64 + kBlock - 1) / kBlock), dim3(kBlock), 0, h->stream, h->d_chunks, h->n_chunks,
-                       h->d_frags, h->d_first, h->d_second, h->d_rot, h->num, h->res, 0, h->d_diag, h->d_off, (double*)nullptr);
+  const MatView V{h->d_big, (long)M, nullptr, 0, 0};
   hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)((nd + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_diag, (long)(nd / 576),
-                     (const int*)nullptr, 1, (int)nv, h->res, (long)h->nper, h->d_big, (long)M);
+                     (const int*)nullptr, 1, (int)nv, h->res, (long)h->nper, V);
   if (h->n_groups > 0)
     hipLaunchKernelGGL(k_fopt_scatter_blocks, dim3((unsigned)(((size_t)h->n_groups * 576 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_off,
-                       (long)h->n_groups, h->d_ginfo, 0, (int)nv, h->res, (long)h->nper, h->d_big, (long)M);
+                       (long)h->n_groups, h->d_ginfo, 0, (int)nv, h->res, (long)h->nper, V);
   for (int l = 0; l < h->num; l++)                                            // baseAA, OptApp.cpp:765-810
     hipLaunchKernelGGL(k_fopt_add_laplacian, dim3((unsigned)((nv * 6 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_big, (long)M,
                        (long)l * h->nper, h->res, 1.0);
@@ -865,7 +1062,11 @@ int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* 
     hipLaunchKernelGGL(k_fopt_axpy, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->d_rhs, h->d_Jb, n);
     ER_HIP_TRY(hipGetLastError());
   }
-  if (h->roc.dpotrs(h->roc.handle, kFillLower, (int)n, 1, h->d_sys, (int)n, h->d_rhs, (int)n) != 0) return er::fail("rocsolver_dpotrs failed");
+  if (h->blocked) {
+    if (solve_blocked(h)) return 1;
+  } else if (h->roc.dpotrs(h->roc.handle, kFillLower, (int)n, 1, h->d_sys, (int)n, h->d_rhs, (int)n) != 0) {
+    return er::fail("rocsolver_dpotrs failed");
+  }
   ER_HIP_TRY(hipMemcpyAsync(x_host, h->d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;

@@ -377,19 +377,72 @@ __device__ bool dev_solve6x6(double A[6][6], double b[6], double x[6]) {
   return true;
 }
 
+// The same system by an LDL^T factorisation with compile-time indices (everything stays in registers; the pivoting
+// elimination above indexes its rows dynamically, which puts the matrix into scratch memory: ~10 us for one thread).  A^T A is
+// symmetric positive definite whenever the correspondences constrain all six degrees of freedom; returns false (caller
+// falls back to the pivoting elimination) as soon as a pivot is not safely positive.
+__device__ bool dev_solve6x6_spd(const double* acc, double x[6]) {
+  double a[6][6];
+  {
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+      for (int c = r; c < 6; c++) a[r][c] = a[c][r] = acc[t++];
+  }
+  double d[6], y[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {                               // a[i][j] (i > j) becomes L_ij, d[j] the pivot
+    double dj = a[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) dj -= a[j][k] * a[j][k] * d[k];
+    if (!(dj > 1e-300) || !isfinite(dj)) return false;
+    d[j] = dj;
+    const double inv = 1.0 / dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      double s = a[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= a[i][k] * a[j][k] * d[k];
+      a[i][j] = s * inv;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) {                               // L y = b
+    double s = acc[21 + i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= a[i][k] * y[k];
+    y[i] = s;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {                              // L^T x = D^-1 y
+    double s = y[i] / d[i];
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) s -= a[k][i] * x[k];
+    x[i] = s;
+  }
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 6; i++) ok = ok && isfinite(x[i]);
+  return ok;
+}
+
 // TransformationEstimationPointToPlaneLLS::constructTransformationMatrix: Rz(gamma) Ry(beta) Rx(alpha), float storage.
 __device__ void dev_construct_increment(const double x[6], float M[16]) {
-  const double al = x[0], be = x[1], ga = x[2];
+  double sa, ca, sb, cb, sg, cg;
+  sincos(x[0], &sa, &ca);
+  sincos(x[1], &sb, &cb);
+  sincos(x[2], &sg, &cg);
   for (int i = 0; i < 16; i++) M[i] = 0.f;
-  M[0] = (float)(cos(ga) * cos(be));
-  M[1] = (float)(-sin(ga) * cos(al) + cos(ga) * sin(be) * sin(al));
-  M[2] = (float)(sin(ga) * sin(al) + cos(ga) * sin(be) * cos(al));
-  M[4] = (float)(sin(ga) * cos(be));
-  M[5] = (float)(cos(ga) * cos(al) + sin(ga) * sin(be) * sin(al));
-  M[6] = (float)(-cos(ga) * sin(al) + sin(ga) * sin(be) * cos(al));
-  M[8] = (float)(-sin(be));
-  M[9] = (float)(cos(be) * sin(al));
-  M[10] = (float)(cos(be) * cos(al));
+  M[0] = (float)(cg * cb);
+  M[1] = (float)(-sg * ca + cg * sb * sa);
+  M[2] = (float)(sg * sa + cg * sb * ca);
+  M[4] = (float)(sg * cb);
+  M[5] = (float)(cg * ca + sg * sb * sa);
+  M[6] = (float)(-cg * sa + sg * sb * ca);
+  M[8] = (float)(-sb);
+  M[9] = (float)(cb * sa);
+  M[10] = (float)(cb * ca);
   M[3] = (float)x[3];
   M[7] = (float)x[4];
   M[11] = (float)x[5];
@@ -407,13 +460,15 @@ __device__ void dev_icp_decide(const double* acc, IcpDev* st, IcpParams P) {
     st->conv = 0;
     stop = true;
   } else {
-    int t = 0;
-    for (int r = 0; r < 6; r++)
-      for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
-    for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
-    if (!dev_solve6x6(A, b, x)) {
-      st->conv = 0;
-      stop = true;
+    if (!dev_solve6x6_spd(acc, x)) {                         // (not positive definite: the general elimination decides)
+      int t = 0;
+      for (int r = 0; r < 6; r++)
+        for (int c2 = r; c2 < 6; c2++) A[r][c2] = A[c2][r] = acc[t++];
+      for (int r = 0; r < 6; r++) b[r] = acc[21 + r];
+      if (!dev_solve6x6(A, b, x)) {
+        st->conv = 0;
+        stop = true;
+      }
     }
   }
   if (!stop) {
@@ -736,13 +791,24 @@ __global__ __launch_bounds__(kBlock) void k_grid_bounds(const float* __restrict_
       hi[a] = max(hi[a], __shfl_down(hi[a], off));
     }
   bad = __any(bad) ? 1 : 0;
+  __shared__ int part[kBlock / 64][7];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      atomicMin(&out7[a], lo[a]);
-      atomicMax(&out7[3 + a], hi[a]);
+      part[wave][a] = lo[a];
+      part[wave][3 + a] = hi[a];
     }
-    if (bad) atomicOr(&out7[6], 1);
+    part[wave][6] = bad;
+  }
+  __syncthreads();
+  if (threadIdx.x < 7) {                                      // 7 atomics per workgroup (one per wave serialised on 6 words: 245 us)
+    int v = part[0][threadIdx.x];
+    for (int w = 1; w < kBlock / 64; w++)
+      v = threadIdx.x < 3 ? min(v, part[w][threadIdx.x]) : (threadIdx.x < 6 ? max(v, part[w][threadIdx.x]) : (v | part[w][threadIdx.x]));
+    if (threadIdx.x < 3) atomicMin(&out7[threadIdx.x], v);
+    else if (threadIdx.x < 6) atomicMax(&out7[threadIdx.x], v);
+    else if (v) atomicOr(&out7[6], 1);
   }
 }
 
@@ -989,9 +1055,9 @@ struct AlignParams {
   bool want_fitness;
 };
 
-// Iterations enqueued per host visit.  PCL's loop runs 3-4 iterations on the fragment pairs of the pipeline: one chunk
-// usually ends the job, the launches of a chunk that come after the stop decision return at once (~3 us each).
-constexpr int kIcpChunk = 4;
+// Iterations enqueued per host visit.  PCL's loop runs 3 iterations on most fragment pairs of the pipeline (the third one
+// meets the stop rule): one chunk usually ends the job; launches of a chunk that come after the stop decision return at once.
+constexpr int kIcpChunk = 3;
 
 // A chunk of ICP iterations with NO host round trip in between: k_icp_iter (apply the last increment, exact NN, point-to-plane
 // sums) + k_icp_final (fixed-order total, 6x6 solve, increment, stop rule -- on the device), then the state comes back once.
@@ -1232,7 +1298,7 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
     int got[8];
     ER_CTRY(hipMemcpyAsync(gs.bounds, init, sizeof init, hipMemcpyHostToDevice, nullptr));
-    hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 1024)), dim3(kBlock), 0, nullptr, c->xyz, n, gs.bounds);
+    hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, nullptr, c->xyz, n, gs.bounds);
     ER_CTRY(hipMemcpyAsync(got, gs.bounds, sizeof got, hipMemcpyDeviceToHost, nullptr));
     ER_CTRY(hipStreamSynchronize(nullptr));
     if (got[6]) {

@@ -141,38 +141,6 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   reproject_scatter_px(A, f, u, v, 0);
 }
 
-// The same, with the frame's control lattice staged in LDS (one 16-byte vertex each): the pixels of a 64 x 8 tile fall into
-// one or two lattice cells, so the 8 vertex reads per pixel become LDS broadcasts instead of 24 global gathers with their
-// 64-bit address arithmetic.  Used when the lattice fits (res <= 13 at 48 KB); identical arithmetic, identical results.
-#ifndef ER_RS_ROWS
-#define ER_RS_ROWS 2
-#endif
-constexpr int kRsRows = ER_RS_ROWS;                         // pixels per thread (consecutive rows of one column)
-__global__ __launch_bounds__(kBlock) void k_reproject_scatter_lds(ReprojArgs A, const Vert4* __restrict__ ctr4) {
-  extern __shared__ Vert4 s_lat[];
-  const int f = blockIdx.z, tid = threadIdx.x;
-  const int n1 = A.res + 1, verts = n1 * n1 * n1;
-  const Vert4* __restrict__ g4 = ctr4 + (size_t)A.grid_index[f] * verts;
-  for (int i = tid; i < verts; i += kBlock) s_lat[i] = g4[i];
-  __syncthreads();
-  const int u = blockIdx.x * 64 + (tid & 63);
-  const int v0 = blockIdx.y * (4 * kRsRows) + (tid >> 6) * kRsRows;
-  if (u >= A.cols) return;
-  const int pixels = A.cols * A.rows;
-#pragma unroll
-  for (int j = 0; j < kRsRows; j++) {
-    const int v = v0 + j;
-    if (v >= A.rows) break;
-    const int p = v * A.cols + u;
-    const uint16_t d = A.depth[(size_t)f * pixels + p];
-    if (d == 0) continue;                                               // UVD2XYZ false
-    int cell;
-    uint16_t dd;
-    if (reproject_px(u, v, d, A.cam, A.cami, A.cols, A.rows, A.seg12 + f * 16, A.madj12 + f * 12, s_lat, A.res, A.grid_ul, cell, dd))
-      scatter_px(A, f, p, cell, dd, 0);
-  }
-}
-
 // Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1").  A workgroup owns a 64 x 16 pixel tile of one frame, each
 // thread 4 pixels of one column.  The frame's control lattice is staged in LDS as one 16-byte vertex each (all pixels of a
 // tile fall into one or two lattice cells, so the 8 vertex reads per pixel are LDS broadcasts instead of 24 global gathers).
@@ -627,6 +595,76 @@ __global__ __launch_bounds__(64) void k_world(const float2* __restrict__ pool, c
   if (!pass && lane == 0) slab_count[blockIdx.x] = total;
 }
 
+// Zero-crossing extraction on the resident volume (what the out-of-repo kinfu "mesh_output" step does with
+// world.pcd, done where the volume lives).  For every observed voxel (weight != 0) and each of its +x, +y, +z neighbours --
+// inside the unit or in the adjacent unit, found through the hash map -- that is observed too: if the two sdf values have
+// strictly opposite signs, the surface crosses that lattice edge at t = F / (F - Fn) and the point
+//     p = voxel position + t * voxel size along the axis            (float32; position = (float)(global index * 3/512))
+// is emitted (kinfu's extractCloud rule).  Order: units by ascending key, voxels in i,j,k order, axes x,y,z -- a stable
+// ballot-prefix compaction in two passes like k_world, so the list is reproducible and a CPU restatement can match it
+// element for element (tests/test_tsdf_gpu.py).
+__device__ __forceinline__ int ht_lookup_slot(const int* __restrict__ ht_key, const int* __restrict__ ht_slot, int cap_mask, int shift, int key) {
+  unsigned h = hash_unit_key(key, shift);
+  for (int probe = 0; probe <= cap_mask; ++probe) {
+    const int e = (int)((h + (unsigned)probe) & (unsigned)cap_mask);
+    const int k = ht_key[e];
+    if (k == key) return ht_slot[e];
+    if (k == kEmptyKey) return -1;
+  }
+  return -1;
+}
+
+__device__ __forceinline__ bool crosses(float2 a, float2 b) {
+  return a.y != 0.0f && b.y != 0.0f && ((a.x > 0.0f && b.x < 0.0f) || (a.x < 0.0f && b.x > 0.0f));
+}
+
+__global__ __launch_bounds__(64) void k_surface(const float2* __restrict__ pool, const int* __restrict__ slots, const int* __restrict__ keys,
+                                                const int* __restrict__ ht_key, const int* __restrict__ ht_slot, int cap_mask, int shift,
+                                                long* __restrict__ slab_count, const long* __restrict__ slab_offset,
+                                                float4* __restrict__ out, int pass) {
+  const int rank = blockIdx.x >> 6;          // unit in ascending key order
+  const int i = blockIdx.x & 63;
+  const int lane = threadIdx.x;              // = k
+  const int key = keys[rank];
+  const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+  const float2* unit = pool + (size_t)slots[rank] * kUnitVox;
+  const float2* slab = unit + (size_t)i * 4096;
+  // neighbours that live in adjacent units (wave-uniform lookups; -1 = that unit does not exist)
+  const int sx = (i == 63 && xi < 511) ? ht_lookup_slot(ht_key, ht_slot, cap_mask, shift, key + 512 * 512) : -1;
+  const int sy = yi < 511 ? ht_lookup_slot(ht_key, ht_slot, cap_mask, shift, key + 512) : -1;
+  const int sz = zi < 511 ? ht_lookup_slot(ht_key, ht_slot, cap_mask, shift, key + 1) : -1;
+  const float2 none = make_float2(0.0f, 0.0f);
+  const float2* slab_x = i < 63 ? slab + 4096 : (sx >= 0 ? pool + (size_t)sx * kUnitVox : nullptr);              // i + 1 (slab 0 of the next unit)
+  const float2* unit_y = sy >= 0 ? pool + (size_t)sy * kUnitVox + (size_t)i * 4096 : nullptr;                      // j + 1 == 64: row 0 there
+  const float2* unit_z = sz >= 0 ? pool + (size_t)sz * kUnitVox + (size_t)i * 4096 : nullptr;                      // k + 1 == 64: voxel 0 there
+  const float ulf = (float)kUnitLength;
+  const float gx = (float)((double)(i + (xi - 256) * 64) * kUnitLength);
+  const float gz = (float)((double)(lane + (zi - 256) * 64) * kUnitLength);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  long base = pass ? slab_offset[blockIdx.x] : 0;
+  long total = 0;
+  for (int j = 0; j < 64; j++) {
+    const float2 v = slab[j * 64 + lane];
+    const float2 nx = slab_x ? slab_x[j * 64 + lane] : none;
+    const float2 ny = j < 63 ? slab[(j + 1) * 64 + lane] : (unit_y ? unit_y[lane] : none);
+    float2 nz;
+    nz.x = __shfl_down(v.x, 1);
+    nz.y = __shfl_down(v.y, 1);
+    if (lane == 63) nz = unit_z ? unit_z[j * 64] : none;
+    const bool cx = crosses(v, nx), cy = crosses(v, ny), cz = crosses(v, nz);
+    const unsigned long long bx = __ballot(cx), by = __ballot(cy), bz = __ballot(cz);
+    if (pass) {
+      long o = base + total + __popcll(bx & lt) + __popcll(by & lt) + __popcll(bz & lt);
+      const float gy = (float)((double)(j + (yi - 256) * 64) * kUnitLength);
+      if (cx) out[o++] = make_float4(gx + (v.x / (v.x - nx.x)) * ulf, gy, gz, 0.0f);
+      if (cy) out[o++] = make_float4(gx, gy + (v.x / (v.x - ny.x)) * ulf, gz, 1.0f);
+      if (cz) out[o++] = make_float4(gx, gy, gz + (v.x / (v.x - nz.x)) * ulf, 2.0f);
+    }
+    total += __popcll(bx) + __popcll(by) + __popcll(bz);
+  }
+  if (!pass && lane == 0) slab_count[blockIdx.x] = total;
+}
+
 // Multi-GPU frame split: planes [key][0] = sdf*weight, [key][1] = weight.
 __global__ void k_export_weighted(const float2* __restrict__ pool, const int* __restrict__ slots, float* __restrict__ buf) {
   const int q = blockIdx.y;
@@ -700,6 +738,7 @@ struct er_tsdf_s {
   hipStream_t aux_stream = nullptr;                       // pre-pass of the NEXT batch (reproject, prepare) runs here, overlapped
   hipStream_t copy_stream = nullptr;                      // host depth -> depth_stage[parity], overlapped with both of the above
   hipEvent_t copy_done[2] = {nullptr, nullptr};
+  hipEvent_t consts_done[2] = {nullptr, nullptr};         // the per-batch constants of parity p have left the pinned block
   int n_cu = 256;
   int shard_rank = 0, shard_world = 1;                    // unit-shard mode (er_tsdf_set_unit_shard)
   // device memory
@@ -719,6 +758,10 @@ struct er_tsdf_s {
   int ht_cap = 0, ht_shift = 0;
   float *lambda = nullptr, *ctr = nullptr;
   er::Vert4* ctr4 = nullptr;                                // the same lattices, one 16-byte vertex each (tier 1 of Reproject)
+  float* ctr_pinned[2] = {nullptr, nullptr};                // page-locked staging of the caller's lattices, by call parity
+  size_t ctr_pinned_cap[2] = {0, 0};
+  hipEvent_t ctr_ev[2] = {nullptr, nullptr};
+  int ctr_parity = 0;
   std::vector<double> grid_cmax, grid_dmax;                 // per lattice: max |component|, max lattice-edge component (host)
   uint16_t* depth_stage[2] = {nullptr, nullptr};   // host frames of the batch in flight, by pipeline parity
   uint32_t *zbuf = nullptr, *lastzero = nullptr;
@@ -833,8 +876,11 @@ int sync_all(er_tsdf_t h) {
 int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, const er_warp* warp, int frame0) {
   const int p = h->parity;
   h->parity ^= 1;
-  // parity p was last used by batch n-2: its k_integrate must be done before its buffers are refilled
-  if (h->used[p]) ER_HIP_TRY(hipEventSynchronize(h->int_done[p]));
+  // Parity p was last used by batch n-2.  The HOST only needs its pinned constants block back (the H2D copy of batch n-2, an
+  // early event); the DEVICE buffers of the parity (scaled depth, masks, frame constants) are protected on the device: the
+  // pre-pass stream waits for k_integrate of batch n-2 before it touches them.  The host therefore never blocks on a voxel
+  // pass and runs up to two batches ahead (host-frame copies and pre-passes queue up behind the events).
+  if (h->used[p]) ER_HIP_TRY(hipEventSynchronize(h->consts_done[p]));
   Staging* st = static_cast<Staging*>(h->pinned[p]);
   for (int f = 0; f < n; f++) {
     const double* Tf = T + (size_t)f * 16;
@@ -873,12 +919,16 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
       const int g = warp->grid_index[frame0 + f];
       if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
       st->gi[f] = g;
+#ifdef ER_REPROJECT_TIERED
       er::reproj_fast_setup(&st->seg[f * 16], &st->madj[f * 12], h->cam, h->cols, h->rows, warp->resolution,
                             warp->length / (float)warp->resolution, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g], st->fast[f]);
+#endif
     }
   }
   // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
+  if (h->used[p]) ER_HIP_TRY(hipStreamWaitEvent(X, h->int_done[p], 0));     // k_integrate of batch n-2 still reads dstage[p] / scaled[p] / masks[p]
   ER_HIP_TRY(hipMemcpyAsync(h->dstage[p], st, sizeof(Staging), hipMemcpyHostToDevice, X));
+  ER_HIP_TRY(hipEventRecord(h->consts_done[p], X));
   if (warp) {
     // zbuf is all-empty here: filled at create, re-armed by its consumer (k_prepare / k_zbuf_to_depth)
     const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
@@ -984,6 +1034,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
     if (hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->int_done[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->copy_done[q], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->consts_done[q], hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(&h->pinned[q], sizeof(Staging), hipHostMallocDefault) != hipSuccess) {
       er_tsdf_destroy(h);
       return er::fail("er_tsdf_create: event / pinned staging allocation failed");
@@ -1052,12 +1103,17 @@ int er_tsdf_destroy(er_tsdf_t h) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
     if (h->int_done[q]) (void)hipEventDestroy(h->int_done[q]);
     if (h->copy_done[q]) (void)hipEventDestroy(h->copy_done[q]);
+    if (h->consts_done[q]) (void)hipEventDestroy(h->consts_done[q]);
     if (h->pinned[q]) (void)hipHostFree(h->pinned[q]);
   }
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   if (h->copy_stream) {
     (void)hipStreamSynchronize(h->copy_stream);
     (void)hipStreamDestroy(h->copy_stream);
+  }
+  for (int q = 0; q < 2; q++) {
+    if (h->ctr_ev[q]) (void)hipEventDestroy(h->ctr_ev[q]);
+    if (h->ctr_pinned[q]) (void)hipHostFree(h->ctr_pinned[q]);
   }
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1109,32 +1165,45 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
     ER_HIP_TRY(hipMalloc((void**)&h->ctr4, (floats / 3) * sizeof(er::Vert4)));
     h->ctr_cap = floats;
   }
-  h->grid_cmax.resize((size_t)num_grids);
-  h->grid_dmax.resize((size_t)num_grids);
+  h->grid_cmax.assign((size_t)num_grids, 0.0);
+  h->grid_dmax.assign((size_t)num_grids, 0.0);
+  // The lattices travel through a page-locked block of the handle: the copy is then truly asynchronous (a copy from the
+  // caller's pageable memory would make the host wait for everything queued on this stream at every call) and the caller's
+  // memory is free again when the call returns.
+  const int q = h->ctr_parity;
+  h->ctr_parity ^= 1;
+  if (!h->ctr_ev[q]) ER_HIP_TRY(hipEventCreateWithFlags(&h->ctr_ev[q], hipEventDisableTiming));
+  else ER_HIP_TRY(hipEventSynchronize(h->ctr_ev[q]));        // the upload of two calls ago
+  if (floats > h->ctr_pinned_cap[q]) {
+    if (h->ctr_pinned[q]) (void)hipHostFree(h->ctr_pinned[q]);
+    h->ctr_pinned[q] = nullptr;
+    h->ctr_pinned_cap[q] = 0;
+    ER_HIP_TRY(hipHostMalloc((void**)&h->ctr_pinned[q], floats * sizeof(float), hipHostMallocDefault));
+    h->ctr_pinned_cap[q] = floats;
+  }
+  memcpy(h->ctr_pinned[q], ctr, floats * sizeof(float));
+  ER_HIP_TRY(hipMemcpyAsync(h->ctr, h->ctr_pinned[q], floats * sizeof(float), hipMemcpyHostToDevice, stream));
+  ER_HIP_TRY(hipEventRecord(h->ctr_ev[q], stream));
+#ifdef ER_REPROJECT_TIERED               // the float32 tier's inputs: lattice bounds (host) and the 16-byte vertex copy (device)
   for (int g = 0; g < num_grids; g++) er::lattice_bounds(ctr + (size_t)g * verts * 3, res, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g]);
-  ER_HIP_TRY(hipMemcpyAsync(h->ctr, ctr, floats * sizeof(float), hipMemcpyHostToDevice, stream));
   const long nv = (long)(floats / 3);
   hipLaunchKernelGGL(k_expand_ctr, dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, h->ctr, h->ctr4, nv);
   ER_HIP_TRY(hipGetLastError());
+#endif
   return 0;
 }
 
 // Reproject of n frames into zbuf (tiered when the lattice fits LDS, else the all-exact kernel) + the replay launch.
 static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X) {
-  const size_t lds = (size_t)(RA.res + 1) * (RA.res + 1) * (RA.res + 1) * sizeof(er::Vert4);
-#ifdef ER_REPROJECT_TIERED             // measured slower than the all-exact kernel (profiles/r02c_ab_tiered_reproject_v2.txt): off by default
+#ifdef ER_REPROJECT_TIERED
+  const size_t lds = (size_t)(RA.res + 1) * (RA.res + 1) * (RA.res + 1) * sizeof(er::Vert4);             // measured slower than the all-exact kernel (profiles/r02c_ab_tiered_reproject_v2.txt): off by default
   if (lds <= 48 * 1024 && dev_fast) {
     hipLaunchKernelGGL(k_reproject_tiered, dim3((h->cols + kRtW - 1) / kRtW, (h->rows + kRtH - 1) / kRtH, n), dim3(kBlock), lds, X, RA, dev_fast,
                        h->ctr4);
   } else
 #endif
-#ifndef ER_REPROJECT_NO_LDS
-  if (lds <= 48 * 1024) {
-    hipLaunchKernelGGL(k_reproject_scatter_lds, dim3((h->cols + 63) / 64, (h->rows + 4 * kRsRows - 1) / (4 * kRsRows), n), dim3(kBlock), lds, X, RA,
-                       h->ctr4);
-  } else
-#endif
   {
+    // (staging the lattice in LDS for this kernel was measured as well: slower, profiles/r02d_ab_lds_lattice.txt)
     hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
   }
   hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, X, RA);
@@ -1164,10 +1233,12 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
                       verts * 3, h->zbuf, h->lastzero, h->counters};
   {
+    er::ReprojFast* dev_fast = reinterpret_cast<er::ReprojFast*>(static_cast<char*>(h->dstage[0]) + offsetof(Staging, fast));
+#ifdef ER_REPROJECT_TIERED
     Staging* st = static_cast<Staging*>(h->pinned[0]);                    // idle: sync_all above
     er::reproj_fast_setup(seg16, madj, h->cam, h->cols, h->rows, resolution, grid_ul, h->grid_cmax[0], h->grid_dmax[0], st->fast[0]);
-    er::ReprojFast* dev_fast = reinterpret_cast<er::ReprojFast*>(static_cast<char*>(h->dstage[0]) + offsetof(Staging, fast));
     ER_HIP_TRY(hipMemcpyAsync(dev_fast, &st->fast[0], sizeof(er::ReprojFast), hipMemcpyHostToDevice, h->stream));
+#endif
     if (launch_reproject(h, RA, 1, dev_fast, h->stream)) return 1;
   }
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
@@ -1212,6 +1283,8 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
     }
     if (run_batch(h, nb, ddev, T + (size_t)start * 16, warp, start)) return 1;
   }
+  // The caller may reuse or free its HOST frames as soon as the call returns: wait for the copies (not for the kernels).
+  if (!depth_on_device && n > 0) ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
   return 0;
 }
 
@@ -1323,7 +1396,12 @@ int er_tsdf_sum_weight(er_tsdf_t h, double* sum) {
   return 0;
 }
 
-int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* count) {
+static int extract_points(er_tsdf_t h, float* out_host, long capacity, long* count, int surface);
+
+int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* count) { return extract_points(h, out_host, capacity, count, 0); }
+int er_tsdf_extract_surface(er_tsdf_t h, float* out_host, long capacity, long* count) { return extract_points(h, out_host, capacity, count, 1); }
+
+static int extract_points(er_tsdf_t h, float* out_host, long capacity, long* count, int surface) {
   if (!h || !count) return er::fail("er_tsdf_extract_world: NULL argument");
   ER_HIP_TRY(hipSetDevice(h->device));
   std::vector<int> keys, slots;
@@ -1352,7 +1430,11 @@ int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* cou
   ER_W(hipMalloc((void**)&d_off, (size_t)nslab * sizeof(long)));
   ER_W(hipMemcpyAsync(d_keys, keys.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
   ER_W(hipMemcpyAsync(d_slots, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, (float4*)nullptr, 0);
+  if (surface)
+    hipLaunchKernelGGL(k_surface, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, h->ht_key, h->ht_slot, h->ht_cap - 1, h->ht_shift,
+                       d_cnt, d_off, (float4*)nullptr, 0);
+  else
+    hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, (float4*)nullptr, 0);
   ER_W(hipGetLastError());
   ER_W(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nslab * sizeof(long), hipMemcpyDeviceToHost, h->stream));
   ER_W(hipStreamSynchronize(h->stream));
@@ -1368,7 +1450,11 @@ int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* cou
     }
     ER_W(hipMalloc((void**)&d_out, (size_t)total * sizeof(float4)));
     ER_W(hipMemcpyAsync(d_off, off.data(), (size_t)nslab * sizeof(long), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, d_out, 1);
+    if (surface)
+      hipLaunchKernelGGL(k_surface, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, h->ht_key, h->ht_slot, h->ht_cap - 1,
+                         h->ht_shift, d_cnt, d_off, d_out, 1);
+    else
+      hipLaunchKernelGGL(k_world, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, d_cnt, d_off, d_out, 1);
     ER_W(hipGetLastError());
     ER_W(hipMemcpyAsync(out_host, d_out, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, h->stream));
     ER_W(hipStreamSynchronize(h->stream));

@@ -5,9 +5,11 @@
 // three modes -- runs in liber_hip.so (er_fopt_*, csrc/er_fopt.hip).  The host keeps what the reference keeps on the host:
 // the lattice regularizer, gauge terms, the pose / lattice updates and the linear solve.  The reference solves with CHOLMOD
 // (sparse supernodal LL^T); here the SLAC and non-rigid systems are assembled, factored and solved in HBM by a dense Cholesky
-// (er_fopt_factor_* / er_fopt_solve, rocSOLVER), the small rigid system (6 num unknowns) by a dense Cholesky on the host.  The non-rigid mode's system has num * 2187 unknowns: it is
-// assembled as a dense matrix in HBM (288 GB hold ~180 k unknowns = 82 fragments) and refused beyond --dense_limit unknowns
-// (default 200000) or when the allocation fails, with a clear message.
+// (er_fopt_factor_* / er_fopt_solve, rocSOLVER), the small rigid system (6 num unknowns) by a dense Cholesky on the host.  The non-rigid mode's system has num * 2187 unknowns: up to
+// --dense_limit unknowns (default 30000) it is one dense matrix in HBM, beyond that the library keeps and factors it as the
+// block-sparse lower triangle of fragment blocks (rocSOLVER potrf / rocBLAS trsm, syrk, gemm per 2187 x 2187 block; fill-in
+// from a symbolic pass over the fragment graph) -- a 100-fragment scene needs a few hundred 38 MB blocks when its pairs link
+// neighbours, 193 GB for the complete graph, both inside one MI355X.  A failed allocation is reported with a clear message.
 #include <omp.h>
 
 #include <algorithm>
@@ -146,7 +148,7 @@ class COptApp {                                     // OptApp.h:39-124
   int max_iteration_ = 5, max_inner_iteration_ = 10;
   std::string dir_prefix_, ctr_filename_ = "output.ctr", pose_filename_ = "pose.log", init_ctr_file_, sample_filename_ = "sample.pcd";
   int sample_num_ = -1, blacklist_pair_num_ = 10000, device_ = 0;
-  long dense_limit_ = 200000;
+  long dense_limit_ = 30000;
   std::set<int> blacklist_;
   std::vector<int> absolute2relative_map_, relative2absolute_map_;
   std::vector<std::vector<double>> ipose_, pose_;    // 16 doubles each, row-major
@@ -545,10 +547,11 @@ class COptApp {                                     // OptApp.h:39-124
     printf("Nonrigid optimization.\nParameters: weight %.5f, resolution %d, piece number %d, max iteration %d\n", weight_, resolution_, num_, max_iteration_);
     if (!Prepare()) return false;
     const long M = (long)num_ * nper_;
-    if (M > dense_limit_) {
-      fprintf(stderr, "FragmentOptimizer: the non-rigid system has %ld unknowns; this build solves it densely up to --dense_limit %ld "
-                      "(use --slac or --rigid, or fewer fragments)\n", M, dense_limit_);
-      return false;
+    {
+      char lim[32];
+      snprintf(lim, sizeof lim, "%ld", dense_limit_);
+      setenv("ER_FOPT_DENSE_MAX", lim, 1);                   // the library's switch between the dense and the block-sparse factorisation
+      if (M > dense_limit_) printf("Non-rigid system of %ld unknowns: block-sparse Cholesky over %d fragment blocks.\n", M, num_);
     }
     Vec lat, ctr, ictr, oldctr;
     canonical_lattice(lat);
@@ -617,7 +620,7 @@ int print_help() {
          "    --blacklistpair <threshold>     : threshold of accepting pairwise registration, default - 10000\n"
          "    --ipose <log_file>              : get ipose from log file\n"
          "    --write_xyzn_sample <sample_num>: per <sample_num> write a point into sample.pcd\n"
-         "    --device <id>, --dense_limit <n>: (new) HIP device; largest system solved densely in the non-rigid mode\n"
+         "    --device <id>, --dense_limit <n>: (new) HIP device; largest non-rigid system factored as ONE dense matrix (beyond: block-sparse)\n"
          "Optimization options:\n"
          "    --nonrigid                      : default, nonrigid alignment published in ICCV 2013\n"
          "    --rigid                         : dense rigid optimization\n"

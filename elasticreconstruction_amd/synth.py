@@ -258,13 +258,15 @@ def perturbation(seed, max_rot_deg=2.0, max_trans=0.02):
 
 # ----------------------------------------------------------------------------------------------
 def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, amplitude=0.005, revolutions=None,
-                  frame_offset=0, total_frames=None, radius_drift=0.0, device="cpu", seed=SEED):
+                  frame_offset=0, total_frames=None, radius_drift=0.0, device="cpu", seed=SEED, room=(ROOM_LO, ROOM_HI)):
     """Everything one Integrate run needs (BASELINE.json configs 1/2/4), all in memory:
       depth  uint16 [n, 480*640] torch tensor on `device`
       traj   float64 [n,4,4]  world_T_camera as the reference composes it: pose[i] * seg[i*interval+j]
       pose   float64 [n/interval,4,4], seg float64 [n,4,4]
       grids  float32 [n/interval, (res+1)^3, 3] (None when warp is False)
-    frame_offset/total_frames select a window of a longer trajectory (multi-GPU frame split)."""
+    frame_offset/total_frames select a window of a longer trajectory (multi-GPU frame split).
+    room = (lo, hi) of the box room; the default keeps every surface inside 8x8x8 volume units ("512^3"), a larger room
+    (config 4) makes the hashed unit grid grow past 512 units."""
     from .tsdf import mat4_mul
     total = total_frames if total_frames is not None else n_frames
     revs = revolutions if revolutions is not None else max(1.0, total / 3000.0)
@@ -278,7 +280,7 @@ def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, am
         for j in range(interval):
             traj[i * interval + j] = mat4_mul(pose[i], seg[i * interval + j])
     grids = control_grids(pose, resolution, length, amplitude, seed) if warp else None
-    depth = render_depth(w, device=device)
+    depth = render_depth(w, lo=room[0], hi=room[1], device=device)
     return dict(depth=depth, traj=traj, pose=pose, seg=seg, grids=grids, interval=interval, resolution=resolution,
                 length=length, n=n_frames)
 

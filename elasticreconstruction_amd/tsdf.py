@@ -169,6 +169,15 @@ class TSDFVolume:
             _ffi.check(self._lib.er_tsdf_extract_world(self._h, _ffi.ptr(out), n.value, C.byref(n)), "er_tsdf_extract_world")
         return out
 
+    def extract_surface(self):
+        """Zero-crossing points of the volume (er_tsdf_extract_surface) as float32[n, 4] = x y z axis, metres."""
+        n = C.c_long(0)
+        _ffi.check(self._lib.er_tsdf_extract_surface(self._h, None, 0, C.byref(n)), "er_tsdf_extract_surface")
+        out = np.empty((n.value, 4), dtype=np.float32)
+        if n.value:
+            _ffi.check(self._lib.er_tsdf_extract_surface(self._h, _ffi.ptr(out), n.value, C.byref(n)), "er_tsdf_extract_surface")
+        return out
+
     def SaveWorld(self, filename):
         pts = self.extract_world()
         formats.save_pcd_xyzi(filename, pts)

@@ -122,6 +122,14 @@ int er_tsdf_sum_weight(er_tsdf_t h, double* sum);
  * the count; capacity is in points. */
 int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* count);
 
+/* Zero-crossing points of the resident volume (the consumer of world.pcd, kinfu's mesh/point output, does this
+ * on the host after reading the file back): for every observed voxel and its +x / +y / +z neighbour (also across unit
+ * borders), both with weight != 0 and sdf of strictly opposite sign, the point where the surface crosses the lattice edge,
+ * p = voxel position + F / (F - Fn) * voxel size along that axis (metres, float32; position = (float)(global index * 3/512)).
+ * float4 per point = x y z axis(0,1,2); units in ascending key order, voxels in i,j,k order, axes x,y,z.
+ * out_host may be NULL to query the count; capacity is in points. */
+int er_tsdf_extract_surface(er_tsdf_t h, float* out_host, long capacity, long* count);
+
 /* Multi-GPU frame split: for the given key list write sum-ready planes into dev_buf
  * (n_keys * 2 * 64^3 floats: [key][0] = sdf*weight, [key][1] = weight; zeros for keys absent here), and
  * after an external all-reduce(sum) read them back as weight = W, sdf = SW / W. */

@@ -201,3 +201,35 @@ def test_optimisation_loops_match_the_reference_program(gpu, tmp_path):
         g = fresh(sc4)
         ctr, _ = g.OptimizeNonrigid(poses4, weight=1.7, max_iteration=1, max_inner_iteration=2, solver=solver)
         assert np.abs(ctr - ref_ctr).max() < 1e-6, solver
+
+
+def test_block_sparse_cholesky_equals_dense(gpu, monkeypatch):
+    """The non-rigid system factored as the block-sparse lower triangle of fragment blocks (ER_FOPT_DENSE_MAX=0) against the
+    dense factorisation of the same system: 5 fragments whose pair graph is a ring with one chord -- (0,1) (1,2) (2,3) (3,4)
+    (0,4) (1,3) -- so the symbolic pass has to create fill-in blocks ((4,1), (4,2), (4,3) ...) that no correspondence
+    list touches.  The solutions of three right-hand sides must agree to 1e-9 relative."""
+    sc = make_scene(num=5, n=12000)
+    keep = {(0, 1), (1, 2), (2, 3), (3, 4), (0, 4), (1, 3)}
+    pairs = [(i, j, pr[:3000]) for i, j, pr in sc["pairs"] if (i, j) in keep]
+    assert len(pairs) == len(keep) and all(len(pr) > 500 for _, _, pr in pairs)
+    rng = np.random.default_rng(4)
+    ctr = lattice_ctr(sc["num"], sc["res"], sc["length"], [np.eye(4)] * sc["num"], 0.003, rng)
+    M = 2187 * sc["num"]
+    rhs = [rng.normal(size=M) for _ in range(3)]
+    sols = {}
+    for mode, dense_max in (("dense", "1000000"), ("blocked", "0")):
+        monkeypatch.setenv("ER_FOPT_DENSE_MAX", dense_max)
+        g = FragmentOptimizer(sc["num"], sc["res"], sc["length"])
+        for f, (x, n) in enumerate(sc["frags"]):
+            assert g.SetCloud(f, x, n) == -1
+        g.UpdateAllNormal(ctr)
+        g.SetCorrespondences(pairs)
+        g.FactorNonrigid(1.0)
+        sols[mode] = [g.Solve(b) for b in rhs]
+        g.FactorNonrigid(2.5)                                   # a second factorisation in the same handle (buffers reused)
+        sols[mode].append(g.Solve(rhs[0]))
+        g.close()
+    for a, b in zip(sols["dense"], sols["blocked"]):
+        assert np.isfinite(b).all()
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), "block-sparse and dense solutions differ by %.3g (scale %.3g)" % (np.abs(a - b).max(), np.abs(a).max())
+    assert np.abs(sols["dense"][0] - sols["dense"][3]).max() > 1e-6 * np.abs(sols["dense"][0]).max()      # the weight does matter

@@ -417,3 +417,65 @@ def test_reset_unit_shard_pinned_input_and_status(gpu):
     with pytest.raises(_ffi.ErError, match="pool exhausted"):
         small.unit_count()
     small.close()
+
+
+def _surface_oracle(units):
+    """CPU restatement of er_tsdf_extract_surface over {key: (sdf, weight)} (numpy float32, same operation order): for every
+    observed voxel and its +x/+y/+z neighbour (also across unit borders) with strictly opposite sdf signs, the crossing point
+    p = position + F / (F - Fn) * voxel size; units ascending, voxels i,j,k, axes x,y,z."""
+    ul = 3.0 / 512.0
+    ulf = np.float32(ul)
+    out = []
+    for key in sorted(units):
+        xi, yi, zi = key >> 18, (key >> 9) & 511, key & 511
+        F = units[key][0].reshape(64, 64, 64)
+        W = units[key][1].reshape(64, 64, 64)
+
+        def nb(dk, axis):
+            Fn, Wn = np.zeros_like(F), np.zeros_like(W)
+            sl_to = [slice(None)] * 3
+            sl_from = [slice(None)] * 3
+            sl_to[axis], sl_from[axis] = slice(0, 63), slice(1, 64)
+            Fn[tuple(sl_to)], Wn[tuple(sl_to)] = F[tuple(sl_from)], W[tuple(sl_from)]
+            if dk in units:
+                F2, W2 = units[dk][0].reshape(64, 64, 64), units[dk][1].reshape(64, 64, 64)
+                sl_to[axis], sl_from[axis] = 63, 0
+                Fn[tuple(sl_to)], Wn[tuple(sl_to)] = F2[tuple(sl_from)], W2[tuple(sl_from)]
+            return Fn, Wn
+        nbs = [nb(key + 512 * 512 if xi < 511 else -1, 0), nb(key + 512 if yi < 511 else -1, 1), nb(key + 1 if zi < 511 else -1, 2)]
+        cross = np.stack([(W != 0) & (Wn != 0) & (((F > 0) & (Fn < 0)) | ((F < 0) & (Fn > 0))) for Fn, Wn in nbs], axis=3)
+        ii, jj, kk, aa = np.nonzero(cross)
+        if ii.size == 0:
+            continue
+        g = np.stack([(ii + (xi - 256) * 64), (jj + (yi - 256) * 64), (kk + (zi - 256) * 64)], 1)
+        p = (g.astype(np.float64) * ul).astype(np.float32)
+        Fv = F[ii, jj, kk]
+        Fnv = np.choose(aa, [nbs[0][0][ii, jj, kk], nbs[1][0][ii, jj, kk], nbs[2][0][ii, jj, kk]])
+        t = (Fv / (Fv - Fnv)).astype(np.float32) * ulf
+        p[np.arange(ii.size), aa] = p[np.arange(ii.size), aa] + t
+        out.append(np.concatenate([p, aa[:, None].astype(np.float32)], 1))
+    return np.concatenate(out) if out else np.zeros((0, 4), np.float32)
+
+
+def test_zero_crossing_extraction_matches_cpu_restatement(gpu):
+    """er_tsdf_extract_surface on the golden rigid scene: the point list equals a numpy restatement element
+    for element (same float32 operations, same order, neighbours across unit borders included), and the points lie on the
+    scene's surfaces (the walls of the synthetic room at 0.01 / 2.99 m, or the sphere) within a voxel."""
+    poses, depth = helpers.golden_rigid()
+    vol = TSDFVolume(max_units=256)
+    vol.IntegrateFrames(depth, poses)
+    got = vol.extract_surface()
+    units = {int(k): vol.read_unit(k) for k in vol.unit_keys()}
+    want = _surface_oracle(units)
+    assert got.shape == want.shape and got.shape[0] > 20000, (got.shape, want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d rows differ" % int((got != want).any(1).sum())
+    # some crossings must come from unit borders (i/j/k == 63 against the neighbouring unit)
+    ul = 3.0 / 512.0
+    idx = np.floor(got[:, :3] / ul + 1e-3).astype(np.int64) % 64
+    assert ((idx == 63) & (got[:, 3:4] == np.arange(3)[None, :])).any()
+    # geometry: distance to the nearest wall or to the sphere below one voxel diagonal for the bulk of the points
+    dw = np.minimum(np.abs(got[:, :3] - synth.ROOM_LO), np.abs(got[:, :3] - synth.ROOM_HI)).min(1)
+    ds = np.abs(np.linalg.norm(got[:, :3] - np.asarray(synth.SPHERE_C, np.float32), axis=1) - synth.SPHERE_R)
+    near = np.minimum(dw, ds) < 2.0 * ul
+    assert near.mean() > 0.9, "only %.1f %% of the zero crossings lie on a surface" % (100 * near.mean())
+    vol.close()
