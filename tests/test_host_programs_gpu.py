@@ -228,11 +228,14 @@ def test_fragment_optimizer_program_equals_reference_program(gpu, tmp_path):
     assert s.shape == ref_s.shape and np.abs(s - ref_s).max() < 5e-6
     for f, r in zip(dumps, ref_d):
         assert np.abs(np.loadtxt(os.path.join(d4, f)) - r).max() < 1e-6, f
-    # the dense limit of the non-rigid mode is enforced with a message, not a crash
-    r = subprocess.run([os.path.join(BIN, "FragmentOptimizer"), "--num", "3", "--resolution", "4", "--dense_limit", "100", "--registration",
-                        os.path.join(d4, "reg_output.log"), "--dir", d4 + "/", "--rgbdslam", os.path.join(d4, "rgbd.log"), "--interval", "1",
-                        "--blacklistpair", "0"], cwd=d4, capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "dense_limit" in r.stderr
+    # beyond --dense_limit unknowns the program keeps and factors the system as the block-sparse lower triangle of fragment
+    # blocks (the reference: CHOLMOD's sparse Cholesky, OptApp.cpp:155-211): same files as the dense run and as the reference
+    out = run_ours(d4, "nonrigid", ["--dense_limit", "100"] + args4, "ours_blocked.ctr")
+    assert "block-sparse Cholesky over 3 fragment blocks" in out
+    blocked = np.loadtxt(os.path.join(d4, "ours_blocked.ctr"))
+    assert np.abs(blocked - np.loadtxt(os.path.join(d4, "ours.ctr"))).max() < 1e-9
+    _run_ref(d4, "nonrigid", "reg_output.log", args4)
+    assert np.abs(blocked - np.loadtxt(os.path.join(d4, "out_nonrigid.ctr"))).max() < 1e-6
 
 
 def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
