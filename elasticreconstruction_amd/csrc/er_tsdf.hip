@@ -458,15 +458,13 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     float S[kRows], W[kRows], W0[kRows], g1[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; r++) g1[r] = grid_coord(j0 + r, ys);
-#ifndef ER_CULL_FIRST
 #pragma unroll
     for (int r = 0; r < kRows; r++) {                                   // loads in flight while the culling preamble computes
-      const float2 v = slab[(j0 + r) * kUnitRes];
-      S[r] = v.x;
-      W[r] = v.y;
+      const float2 v = slab[(j0 + r) * kUnitRes];                       // (loading only the surviving patches, after the culling,
+      S[r] = v.x;                                                       //  was measured: no change, the kernel is VALU-bound --
+      W[r] = v.y;                                                       //  profiles/r02f_ab_k_integrate_variants.txt)
       W0[r] = v.y;
     }
-#endif
     // Exact culling: lane f tests frame f of the batch against this wave's 4 x 64 voxel patch; frames that
     // provably cannot update any voxel of the patch leave the mask (er_tsdf_math.h: patch_may_update).
     // The same test also tells which of the remaining frames see the WHOLE patch inside the image and clear of the camera
@@ -480,18 +478,6 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
     }
-#ifdef ER_CULL_FIRST
-    // (A/B variant: the voxel rows are only loaded for patches that survive the culling -- 8x fewer row loads than row
-    //  stores were measured -- at the price of an exposed load latency per surviving patch)
-    if (m == 0ull) continue;
-#pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      const float2 v = slab[(j0 + r) * kUnitRes];
-      S[r] = v.x;
-      W[r] = v.y;
-      W0[r] = v.y;
-    }
-#endif
     while (m) {
       const int f = __builtin_ctzll(m);
       m &= m - 1;

@@ -315,26 +315,23 @@ ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float 
   // below 0.03 and is the float nearest to it, so for a float sdf:  sdf >= -0.03 <=> sdf >= -0.03f  and
   // sdf < 0.03 <=> sdf <= 0.03f -- float compares, no conversion on the common path.
   static_assert((double)0.03f < kTsdfTrunc && (double)0.030000003f > kTsdfTrunc, "float neighbours of tsdf_trunc_");
-#if defined(ER_FINISH_BRANCHY)
   if (!((dp > 0.001f) & (sdf >= -0.03f))) return false;
-#endif
-  const bool upd = (dp > 0.001f) & (sdf >= -0.03f);
+  // (A branch-FREE form -- update computed for every lane, committed by two selects -- was measured: k_integrate 0.413 ms
+  //  instead of 0.357 ms per 50-frame launch, profiles/r02f_ab_k_integrate_variants.txt.  The branch stays.)
   // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1
-  // <=> min(1, q) == 1, so the float64 quotient only matters inside the truncation band; the value is identical either way.
-  // Everything below is computed for every lane and COMMITTED by two selects: 96.6 % of the visited rows update at least one
-  // voxel, so a branch around the update saves nothing and costs the compiler's register shuffles around it (six 64-bit moves
-  // per row in the ISA of the branchy form; profiles/r02f_ab_branchfree_finish.txt).  Lanes that do not update may compute on
-  // garbage (NaN, inf): the results are discarded.
-  const float q = (float)band_quotient(sdf);
-  const float tsdf = (sdf <= 0.03f) ? (q < 1.0f ? q : 1.0f) : 1.0f;
+  // <=> min(1, q) == 1, so the (slow) float64 division is only evaluated inside the truncation band;
+  // the value is identical either way.
+  float tsdf = 1.0f;
+  if (sdf <= 0.03f) {
+    const float q = (float)band_quotient(sdf);
+    tsdf = q < 1.0f ? q : 1.0f;
+  }
   // :93  (w == 1.0f, w * tsdf == tsdf).  W + 1 is an integer-valued float in [1, 2^25]; the numerator is 0 or at
   // least ~1e-17 in magnitude (|S| <= 1, |tsdf| is 0 or >= 3e-9 because |sdf| is 0 or >= ulp(0.001)) and at most
   // 2^25: always inside the domain of the core.
-  const float Wn = W + 1.0f;                                             // :94
-  const float Sn = div_inrange(S * W + tsdf, Wn);
-  S = upd ? Sn : S;
-  W = upd ? Wn : W;
-  return upd;
+  S = div_inrange(S * W + tsdf, W + 1.0f);
+  W = W + 1.0f;                                                          // :94
+  return true;
 }
 
 ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
