@@ -334,6 +334,18 @@ ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float 
   return true;
 }
 
+// voxel_finish for a voxel of a patch that patch_may_update has proven "free space" for this frame: sdf >= trunc is known,
+// so tsdf = 1 and only ":82 dp > 0.001" remains to be tested.  (S W + 1) / (W + 1) is EXACTLY 1 when S == 1 (W + 1 is an
+// exact integer-valued float, W < 2^24) or W == 0 (0 * S + 1 = 1, 1 / 1): `trivial` tells the caller whether that holds,
+// and the division is only evaluated otherwise.
+ER_HD bool voxel_free_trivial(float S, float W) { return (S == 1.0f) | (W == 0.0f); }
+ER_HD bool voxel_finish_free(float& S, float& W, float dp) {
+  if (!(dp > 0.001f)) return false;
+  S = voxel_free_trivial(S, W) ? 1.0f : div_inrange(S * W + 1.0f, W + 1.0f);
+  W = W + 1.0f;
+  return true;
+}
+
 ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
                         int cols, int rows, const float* __restrict__ scaled) {
   unsigned pixel;
@@ -371,9 +383,20 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 //     umax <= cols - 1.5 puts it inside [0.25, cols - 1.25].  Same for v.
 // NaNs anywhere make a comparison false and the verdict false.  tests/hostcheck cross-checks every "inside" voxel of the golden
 // and fuzz scenes against voxel_project itself.
+//
+// *free_space (third verdict, optional): true only if every voxel of the patch that this frame can update lies IN FRONT of
+// the surface by more than the truncation distance, so that its update is the constant tsdf = 1 (TSDFVolume.cpp:88:
+// min(1, sdf / trunc) with sdf >= trunc).  With m = the smallest usable scaled depth (> 0.001) over the tiles under the
+// patch's pixel hull (tile_min, written by k_prepare next to tile_max) and D = the distance from the camera centre to the
+// FARTHEST point of the rectangle (a corner), every voxel has  sdf = dp - dist >= m - D;  the verdict demands
+// m - D > trunc + 1e-4 + 1e-6 D (float32 rounding of dp - dist and of D itself stays below 4e-7 D).  k_integrate then skips
+// distance, square root and band quotient for the patch, and -- when every updating voxel of a row holds S == 1 or W == 0,
+// for which (S W + 1) / (W + 1) is exactly 1 -- the division too (voxel_finish_free).
 ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
-                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
+                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
+                            const float* __restrict__ tile_min = nullptr, bool* free_space = nullptr) {
   *inside = false;
+  if (free_space) *free_space = false;
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
   for (int a = 0; a < 2; a++) {
     const float g1 = a ? g1hi : g1lo;
@@ -407,15 +430,20 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
   }
   if (t2max < -1e-3f) return false;                       // whole patch behind the camera
   float dmax_tile = 3.0e38f;                              // upper bound of the scaled depth any voxel can see
+  float dmin_tile = 0.0f;                                 // lower bound of the USABLE scaled depth any voxel can see (0: unknown)
   if (t2min > 0.02f) {                                    // hull argument needs the patch clear of the camera plane
     if (umax < -1.5f || umin > (float)cols + 0.5f || vmax < -1.5f || vmin > (float)rows + 0.5f) return false;
     const int x0 = (int)fmaxf(umin - 1.5f, 0.0f) >> 5, x1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> 5;
     const int y0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> 5, y1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> 5;
     if ((x1 - x0 + 1) * (y1 - y0 + 1) <= 48) {
-      float m = 0.0f;
+      float m = 0.0f, mn = 3.0e38f;
       for (int ty = y0; ty <= y1; ty++)
-        for (int tx = x0; tx <= x1; tx++) m = fmaxf(m, tile_max[ty * tiles_x + tx]);
+        for (int tx = x0; tx <= x1; tx++) {
+          m = fmaxf(m, tile_max[ty * tiles_x + tx]);
+          if (tile_min) mn = fminf(mn, tile_min[ty * tiles_x + tx]);
+        }
       dmax_tile = m;
+      if (tile_min) dmin_tile = mn;
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
@@ -424,6 +452,11 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
   const float dz = f.tz < g2lo ? g2lo - f.tz : (f.tz > g2hi ? f.tz - g2hi : 0.0f);
   const float dmin = sqrtf((dx * dx + dy * dy) + dz * dz);
   if (dmax_tile - dmin < -(float)kTsdfTrunc - 1e-4f) return false;   // every voxel is behind the surface by more than trunc
+  if (free_space && dmin_tile > 0.0f) {
+    const float ey = fmaxf(fabsf(g1lo - f.ty), fabsf(g1hi - f.ty)), ez = fmaxf(fabsf(g2lo - f.tz), fabsf(g2hi - f.tz));
+    const float dfar = sqrtf((dx * dx + ey * ey) + ez * ez);
+    *free_space = dmin_tile - dfar > ((float)kTsdfTrunc + 1e-4f) + 1e-6f * dfar;   // (NaN / inf: false)
+  }
   {
     const float a0 = fabsf(g0), G1 = fmaxf(fabsf(g1lo), fabsf(g1hi)), G2 = fmaxf(fabsf(g2lo), fabsf(g2hi));
     const float e0 = 0x1p-21f * (((fabsf(f.mi[0]) * a0 + fabsf(f.mi[1]) * G1) + fabsf(f.mi[2]) * G2) + fabsf(f.mi[3]));

@@ -45,6 +45,12 @@ def hc():
     L.hc_inside.argtypes = [vp]
     L.hc_inside_violations.restype = C.c_long
     L.hc_inside_violations.argtypes = [vp]
+    L.hc_free.restype = C.c_long
+    L.hc_free.argtypes = [vp]
+    L.hc_free_violations.restype = C.c_long
+    L.hc_free_violations.argtypes = [vp]
+    L.hc_free_stress.restype = C.c_long
+    L.hc_free_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_unit_keys.argtypes = [vp, vp]
     L.hc_read_unit.argtypes = [vp, C.c_int, vp, vp]
     return L
@@ -131,6 +137,10 @@ def test_device_math_warp_matches_golden(hc):
     d = helpers.volume_digest(v)
     assert d["keys"] == g["keys"] and d["sha256"] == g["sha256"]
     assert hc.hc_inside_violations(v.h) == 0 and hc.hc_inside(v.h) > 0
+    # the free-space shortcut of k_integrate (tsdf == 1 proven per patch, S == 1 / fresh voxels need no division): taken for a
+    # large share of the surviving (patch, frame) pairs and bit-identical to the full update wherever it was taken
+    assert hc.hc_free_violations(v.h) == 0 and hc.hc_free(v.h) > 0.2 * hc.hc_kept(v.h), (hc.hc_free(v.h), hc.hc_kept(v.h))
+    print("free-space patch-frames: %d of %d kept (%.1f %%)" % (hc.hc_free(v.h), hc.hc_kept(v.h), 100.0 * hc.hc_free(v.h) / hc.hc_kept(v.h)))
 
 
 def test_device_math_custom_camera_vs_oracle(hc):
@@ -365,6 +375,15 @@ def test_culling_verdict_stress(hc):
     assert sum(w for w, _ in res) == 0, res
     dead = sum(n for _, n in res)
     assert 8000 < dead < 72000, res                          # it decides both ways
+
+
+def test_free_space_verdict_stress(hc):
+    """patch_may_update's third verdict on its own: random cameras, poses, patches and depth images whose surface lies around
+    and behind the patch; wherever it says "free", the shortcut (voxel_finish_free) must reproduce the full update bit for bit
+    from fresh, S == 1 and arbitrary voxel states."""
+    n_free = C.c_long(0)
+    assert hc.hc_free_stress(21, 60000, C.byref(n_free)) == 0
+    assert n_free.value > 3000, n_free.value
 
 
 @pytest.mark.parametrize("ulps", [1, -1, 2, -2])
