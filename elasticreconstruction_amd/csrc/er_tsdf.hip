@@ -302,10 +302,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_min, int2 shard) {
+    int* __restrict__ counters, float* __restrict__ tile_max, int2 shard) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
-  __shared__ float s_wmax[kPrepThreads / 64], s_wmin[kPrepThreads / 64];
+  __shared__ float s_wmax[kPrepThreads / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
   const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;      // ty in [0, 8)
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       lam[q] = lambda[p];
     }
   }
-  float wmax = 0.0f, wmin = 3.0e38f;
+  float wmax = 0.0f;
 #pragma unroll
   for (int q = 0; q < kPrepPix; q++) {
     const int y = blockIdx.y * kTile + ty + q * (kTile / kPrepPix);
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
       scaled[(size_t)f * pixels + y * cols + x] = sc;
       wmax = fmaxf(wmax, sc);
-      wmin = sc > 0.001f ? fminf(wmin, sc) : wmin;                      // usable depths only (TSDFVolume.cpp:82)
       if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
         key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
         if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
@@ -360,25 +359,14 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       }
     }
   }
-  // max of the scaled depth and min of the USABLE scaled depth over the tile (consumed by patch_may_update in k_integrate)
-  for (int off = 32; off > 0; off >>= 1) {
-    wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-    wmin = fminf(wmin, __shfl_xor(wmin, off));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_wmax[threadIdx.x >> 6] = wmax;
-    s_wmin[threadIdx.x >> 6] = wmin;
-  }
+  // max of the scaled depth over the tile (consumed by patch_may_update in k_integrate)
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmax;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float m = 0.0f, mn = 3.0e38f;
-    for (int w = 0; w < kPrepThreads / 64; w++) {
-      m = fmaxf(m, s_wmax[w]);
-      mn = fminf(mn, s_wmin[w]);
-    }
-    const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    tile_max[t] = m;
-    tile_min[t] = mn;
+    float m = 0.0f;
+    for (int w = 0; w < kPrepThreads / 64; w++) m = fmaxf(m, s_wmax[w]);
+    tile_max[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
   }
   const int n = min(s_n, kTileKeys);
   if ((int)threadIdx.x < n) {
@@ -445,11 +433,14 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 #ifndef ER_INT_MINBLOCKS
 #define ER_INT_MINBLOCKS 1
 #endif
+// kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
+// from integration_trunc, which bounds every scaled depth).
+template <bool kSure>
 __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, const Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    const float* __restrict__ tile_min, int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
+    int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
@@ -457,7 +448,18 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int e = plan_entry[item >> 8];
     const int i = (item >> 2) & 63;
+#ifdef ER_ROW_PATCH
+    // (round-1 mapping, kept for A/B: the wave owns 4 whole rows of 64 voxels, lane = k)
     const int j0 = (item & 3) * 16 + wave * kRows;
+    const int jlane = 0, jstep = 1, k0 = 0, klane = lane, jspan = kRows, kspan = kUnitRes;
+#else
+    // The wave owns a COMPACT 16 x 16 (j, k) square of the slab: register row r holds rows j0 + 4 r .. + 3, 16 voxels of k each
+    // (lane = 16 jj + kk), so every access is four fully used 128-byte lines.  A 9.4 cm square instead of a 2.3 x 37.5 cm strip:
+    // a tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and
+    // far fewer patches that cross a surface (the sure path below applies to most visits).
+    const int j0 = (item & 3) * 16;
+    const int jlane = lane >> 4, jstep = 4, k0 = wave * 16, klane = lane & 15, jspan = 16, kspan = 16;
+#endif
     const int slot = __builtin_amdgcn_readfirstlane(ht_slot[e]);
     if (slot < 0) continue;                                             // pool overflow: reported by the host
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
@@ -465,107 +467,80 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     const float g0 = grid_coord(i, xs);
-    const float g2 = grid_coord(lane, zs);
-    float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + lane;
+    const float g2 = grid_coord(k0 + klane, zs);
+    float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + (j0 + jlane) * kUnitRes + k0 + klane;
     float S[kRows], W[kRows], W0[kRows], g1[kRows];
 #pragma unroll
-    for (int r = 0; r < kRows; r++) g1[r] = grid_coord(j0 + r, ys);
+    for (int r = 0; r < kRows; r++) g1[r] = grid_coord(j0 + jlane + r * jstep, ys);
 #pragma unroll
     for (int r = 0; r < kRows; r++) {                                   // loads in flight while the culling preamble computes
-      const float2 v = slab[(j0 + r) * kUnitRes];                       // (loading only the surviving patches, after the culling,
+      const float2 v = slab[r * jstep * kUnitRes];                      // (loading only the surviving patches, after the culling,
       S[r] = v.x;                                                       //  was measured: no change, the kernel is VALU-bound --
       W[r] = v.y;                                                       //  profiles/r02f_ab_k_integrate_variants.txt)
       W0[r] = v.y;
     }
-    // Exact culling: lane f tests frame f of the batch against this wave's 4 x 64 voxel patch; frames that
+    // Exact culling: lane f tests frame f of the batch against this wave's patch of 256 voxels; frames that
     // provably cannot update any voxel of the patch leave the mask (er_tsdf_math.h: patch_may_update).
     // The same test also tells which of the remaining frames see the WHOLE patch inside the image and clear of the camera
     // plane (m_in): for those the per-voxel range tests are proven true and the loop below skips them.
-    // Third verdict (m_free): every voxel the frame can update lies in front of the surface by more than the truncation, so
-    // its update is the constant tsdf = 1 -- no distance, no square root, no band quotient, and no division either while
-    // the voxel already holds S == 1 (or is fresh): most of the frustum is such free space.
-    unsigned long long m_in, m_free;
+    unsigned long long m_in;
     {
-      bool keep = ((m >> lane) & 1ull) != 0ull, inside = false, free_space = false;
+      bool keep = ((m >> lane) & 1ull) != 0ull, inside = false;
       if (keep)
-        keep = patch_may_update(g0, g1[0], g1[kRows - 1], grid_coord(0, zs), grid_coord(kUnitRes - 1, zs), frames[lane], cam, cols,
-                                rows, tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside,
-                                tile_min + (size_t)lane * tiles_x * tiles_y, &free_space);
+        keep = patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs),
+                                frames[lane], cam, cols, rows, tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside);
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
-#ifndef ER_NO_FREE_PATH
-      m_free = __ballot(keep && free_space);
-#else
-      m_free = 0ull;
-#endif
     }
     while (m) {
       const int f = __builtin_ctzll(m);
       m &= m - 1;
       const FrameXform fx = frames[f];
       const float* __restrict__ sc = scaled + (size_t)f * pixels;
+      // phase 1: project every row and issue its depth gather; phase 2: the arithmetic that needs the sample (the gathers'
+      // L2 latency overlaps the other rows' work: k_integrate 0.418 -> 0.390 ms, profiles/r01_ab_variants.txt run 11)
       float dp[kRows];
-      const bool fr = ((m_free >> f) & 1ull) != 0ull;                    // wave-uniform
 #ifndef ER_NO_INSIDE_PATH
       if ((m_in >> f) & 1ull) {                                          // wave-uniform
 #pragma unroll
         for (int r = 0; r < kRows; r++) dp[r] = sc[voxel_project_inside(g0, g1[r], g2, fx, cam, cols, rows)];
-        if (fr) {
-#pragma unroll
-          for (int r = 0; r < kRows; r++) {
-            const bool upd = dp[r] > 0.001f;
-            if (__ballot(upd && !voxel_free_trivial(S[r], W[r])) == 0ull) {      // the whole row: S stays / becomes exactly 1
-              S[r] = upd ? 1.0f : S[r];
-              W[r] = upd ? W[r] + 1.0f : W[r];
-            } else {
-              (void)voxel_finish_free(S[r], W[r], dp[r]);
-            }
-          }
-          continue;
-        }
+      } else
+#endif
+      {
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
-          const bool upd = voxel_finish(S[r], W[r], dp[r], g0, g1[r], g2, fx);
-#ifdef ER_STATS
-          const unsigned long long b = __ballot(upd);
-          if (lane == 0) {
-            atomicAdd(&g_stats[0], 1ull);
-            if (b) atomicAdd(&g_stats[1], 1ull);
-            atomicAdd(&g_stats[2], (unsigned long long)__popcll(b));
-            atomicAdd(&g_stats[3], 1ull);
-          }
-#else
-          (void)upd;
-#endif
+          unsigned pixel;
+          const bool ok = voxel_project(g0, g1[r], g2, fx, cam, cols, rows, pixel);
+          dp[r] = ok ? sc[pixel] : 0.0f;                                 // dp = 0 fails ":82 dp > 0.001" like the reference's early out
+        }
+      }
+      float d2[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0, g1[r], g2, fx);
+      if (kSure) {
+      // Sure path (er_tsdf_math.h: voxel_classify): if every lane of the four rows is provably in free space (tsdf = 1) or
+      // provably behind the surface (no update) and every free lane holds S == 1 or W == 0, the whole update of this frame is
+      // "W += 1, S = 1" on the free lanes -- no square root, no band quotient, no division.  ~60 % of the (patch, frame)
+      // visits of configs[1] (every row that does not cross a surface); one wave-uniform branch per frame.
+      bool fre[kRows], need = false;
+#pragma unroll
+      for (int r = 0; r < kRows; r++) {
+        bool behind;
+        voxel_classify(dp[r], d2[r], fre[r], behind);
+        need = need | !(fre[r] | behind) | (fre[r] & !voxel_free_trivial(S[r], W[r]));
+      }
+      if (__ballot(need) == 0ull) {
+#pragma unroll
+        for (int r = 0; r < kRows; r++) {
+          S[r] = fre[r] ? 1.0f : S[r];
+          W[r] = fre[r] ? W[r] + 1.0f : W[r];
         }
         continue;
       }
-#endif
-      // phase 1: project every row and issue its depth gather; phase 2: the arithmetic that needs the sample (the gathers'
-      // L2 latency overlaps the other rows' work: k_integrate 0.418 -> 0.390 ms, profiles/r01_ab_variants.txt run 11)
-      bool ok[kRows];
-#pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        unsigned pixel;
-        ok[r] = voxel_project(g0, g1[r], g2, fx, cam, cols, rows, pixel);
-        dp[r] = ok[r] ? sc[pixel] : 0.0f;
-      }
-      if (fr) {
-#pragma unroll
-        for (int r = 0; r < kRows; r++) {
-          const bool upd = ok[r] && dp[r] > 0.001f;                      // (dp is 0 where the projection failed)
-          if (__ballot(upd && !voxel_free_trivial(S[r], W[r])) == 0ull) {
-            S[r] = upd ? 1.0f : S[r];
-            W[r] = upd ? W[r] + 1.0f : W[r];
-          } else if (ok[r]) {
-            (void)voxel_finish_free(S[r], W[r], dp[r]);
-          }
-        }
-        continue;
       }
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
-        const bool upd = ok[r] && voxel_finish(S[r], W[r], dp[r], g0, g1[r], g2, fx);
+        const bool upd = voxel_finish_d2(S[r], W[r], dp[r], d2[r]);
 #ifdef ER_STATS
         const unsigned long long b = __ballot(upd);
         if (lane == 0) {
@@ -580,7 +555,7 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     }
 #pragma unroll
     for (int r = 0; r < kRows; r++)
-      if (W[r] != W0[r]) slab[(j0 + r) * kUnitRes] = make_float2(S[r], W[r]);
+      if (W[r] != W0[r]) slab[r * jstep * kUnitRes] = make_float2(S[r], W[r]);
   }
 }
 
@@ -799,7 +774,7 @@ struct er_tsdf_s {
   bool used[2] = {false, false};
   int* batch[2] = {nullptr, nullptr};
   unsigned long long* ht_mask[2] = {nullptr, nullptr};
-  float *scaled[2] = {nullptr, nullptr}, *tile_max[2] = {nullptr, nullptr}, *tile_min[2] = {nullptr, nullptr};
+  float *scaled[2] = {nullptr, nullptr}, *tile_max[2] = {nullptr, nullptr};
   er::FrameXform* frames[2] = {nullptr, nullptr};   // = &dstage[q]->fx
   void* dstage[2] = {nullptr, nullptr};             // device twin of the pinned per-batch constants (struct Staging)
   hipEvent_t pre_done[2] = {nullptr, nullptr}, int_done[2] = {nullptr, nullptr};
@@ -991,7 +966,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch[p], nbatch, h->counters,
-                     h->tile_max[p], h->tile_min[p], make_int2(h->shard_rank, h->shard_world));
+                     h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
@@ -1004,9 +979,14 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipEventCreate(&e1));
     ER_HIP_TRY(hipEventRecord(e0, S));
   }
-  hipLaunchKernelGGL(k_integrate, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot, h->ht_mask[p], h->plan_entry,
-                     h->plan, h->frames[p], h->scaled[p], h->tile_max[p], h->tile_min[p], (h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile,
-                     h->cam, h->cols, h->rows);
+#ifndef ER_NO_SURE_PATH
+  const bool sure = h->cam.integration_trunc < 64.0f;                   // voxel_classify's bound on the scaled depth (false for NaN)
+#else
+  const bool sure = false;
+#endif
+  hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
+                     h->ht_mask[p], h->plan_entry, h->plan, h->frames[p], h->scaled[p], h->tile_max[p], (h->cols + kTile - 1) / kTile,
+                     (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows);
   if (h->profiling) {
     ER_HIP_TRY(hipEventRecord(e1, S));
     h->events.emplace_back(e0, e1);
@@ -1110,7 +1090,6 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
   for (int q = 0; q < 2; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->tile_min[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   ER_ALLOC(h->plan_entry, (size_t)cap * sizeof(int));
   ER_ALLOC(h->plan, sizeof(Plan));
 #undef ER_ALLOC
@@ -1148,7 +1127,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask[0], h->ht_mask[1], h->unit_key, h->counters, h->stats, h->batch[0],
                   h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage[0], h->depth_stage[1], h->zbuf, h->lastzero, h->dstage[0],
                   h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->ctr4, h->key_scratch, h->slot_scratch,
-                  h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1], h->tile_min[0], h->tile_min[1]};
+                  h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1]};
   for (int q = 0; q < 2; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
     if (h->int_done[q]) (void)hipEventDestroy(h->int_done[q]);

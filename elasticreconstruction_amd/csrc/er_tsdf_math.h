@@ -302,9 +302,14 @@ ER_HD unsigned voxel_project_inside(float g0, float g1, float g2, const FrameXfo
   return (unsigned)(py * cols + px);
 }
 
-ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float g2, const FrameXform& f) {
+// Squared camera distance of a voxel, TSDFVolume.cpp:83-85 (the argument of the :85 square root).
+ER_HD float voxel_dist2(float g0, float g1, float g2, const FrameXform& f) {
   const float rx = g0 - f.tx, ry = g1 - f.ty, rz = g2 - f.tz;            // :83-85
-  const float d2 = (rx * rx + ry * ry) + rz * rz;
+  return (rx * rx + ry * ry) + rz * rz;
+}
+
+// voxel_finish with the squared distance d2 = voxel_dist2(..) already evaluated.
+ER_HD bool voxel_finish_d2(float& S, float& W, float dp, float d2) {
   // No range guard: for d2 < 2^-96 (voxel within 4e-15 m of the camera centre; hipcc's sqrtf would rescale)
   // the core still returns a non-negative value below 1e-14, and "dp - dist" with dp > 0.001 (the only case
   // that survives the next test) equals dp for any dist below half an ulp of dp (>= 2.9e-11).  +inf and
@@ -334,17 +339,33 @@ ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float 
   return true;
 }
 
-// voxel_finish for a voxel of a patch that patch_may_update has proven "free space" for this frame: sdf >= trunc is known,
-// so tsdf = 1 and only ":82 dp > 0.001" remains to be tested.  (S W + 1) / (W + 1) is EXACTLY 1 when S == 1 (W + 1 is an
-// exact integer-valued float, W < 2^24) or W == 0 (0 * S + 1 = 1, 1 / 1): `trivial` tells the caller whether that holds,
-// and the division is only evaluated otherwise.
-ER_HD bool voxel_free_trivial(float S, float W) { return (S == 1.0f) | (W == 0.0f); }
-ER_HD bool voxel_finish_free(float& S, float& W, float dp) {
-  if (!(dp > 0.001f)) return false;
-  S = voxel_free_trivial(S, W) ? 1.0f : div_inrange(S * W + 1.0f, W + 1.0f);
-  W = W + 1.0f;
-  return true;
+ER_HD bool voxel_finish(float& S, float& W, float dp, float g0, float g1, float g2, const FrameXform& f) {
+  return voxel_finish_d2(S, W, dp, voxel_dist2(g0, g1, g2, f));
 }
+
+// ---- "sure" classification of one (voxel, frame) WITHOUT the square root --------------------------------------------------
+// Nearly every voxel a frame visits lies far in front of the surface (free space: sdf >= trunc, so tsdf = 1) or far behind
+// it (sdf < -trunc: no update); only the +-5 voxels around the surface need the value of sdf.  With c = 0.0301f (trunc plus
+// 1e-4) and the float values a = fl(dp - c), b = fl(dp + c):
+//   free   :  a > 0  and  d2 < fl(a a)   ==>  dist = RN(sqrt d2) <= (dp - c)(1 + 3 2^-24)  ==>  dp - dist >= c - 1.8e-7 dp
+//             (evaluated as d2 < fl(a |a|): the product carries the sign of a, so a <= 0 fails without a second compare)
+//   behind :            d2 > fl(b b)   ==>  dist >= (dp + c)(1 - 3 2^-24)                ==>  dp - dist <= -c + 1.8e-7 (dp + c)
+// (fl(a a) <= a^2 (1 + 2^-24), sqrt and RN are monotonic, a <= (dp - c)(1 + 2^-24); likewise for b.)  For dp < 64 the
+// slack 1.8e-7 * 64.03 = 1.2e-5 is an eighth of the 1e-4 margin, so RN(dp - dist) >= 0.03008 > 0.03f (free: :82 and :87
+// pass -- dp > c > 0.001 -- and :88 yields exactly 1) or <= -0.03008 < -0.03f (behind: :87 fails).  dp never exceeds
+// integration_trunc (scale_depth_px), so k_integrate enables the shortcut when integration_trunc < 64; a NaN dp or d2 fails
+// every comparison and is "unsure".  A lane whose projection failed carries dp = 0: b b = 9.06e-4, so it is "behind" (no
+// update -- correct) unless it sits within 3 cm of the camera centre, where it is "unsure" and takes the exact path.
+// For a free voxel the update (S W + 1) / (W + 1) is EXACTLY 1 when S == 1 (S W = W and W + 1 are exact for W < 2^24,
+// x / x = 1; for W >= 2^24 numerator and denominator are the same rounded sum) or W == 0 (0 S + 1 = 1, 1 / 1); k_integrate
+// takes the shortcut for a wave only if every lane of its rows is sure and every free lane is trivial in that sense.
+constexpr float kSureBand = 0.0301f;
+ER_HD void voxel_classify(float dp, float d2, bool& free_sure, bool& behind_sure) {
+  const float a = dp - kSureBand, b = dp + kSureBand;
+  free_sure = d2 < a * fabsf(a);
+  behind_sure = d2 > b * b;
+}
+ER_HD bool voxel_free_trivial(float S, float W) { return (S == 1.0f) | (W == 0.0f); }
 
 ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const FrameXform& f, const Camera& c,
                         int cols, int rows, const float* __restrict__ scaled) {
@@ -384,19 +405,9 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 // NaNs anywhere make a comparison false and the verdict false.  tests/hostcheck cross-checks every "inside" voxel of the golden
 // and fuzz scenes against voxel_project itself.
 //
-// *free_space (third verdict, optional): true only if every voxel of the patch that this frame can update lies IN FRONT of
-// the surface by more than the truncation distance, so that its update is the constant tsdf = 1 (TSDFVolume.cpp:88:
-// min(1, sdf / trunc) with sdf >= trunc).  With m = the smallest usable scaled depth (> 0.001) over the tiles under the
-// patch's pixel hull (tile_min, written by k_prepare next to tile_max) and D = the distance from the camera centre to the
-// FARTHEST point of the rectangle (a corner), every voxel has  sdf = dp - dist >= m - D;  the verdict demands
-// m - D > trunc + 1e-4 + 1e-6 D (float32 rounding of dp - dist and of D itself stays below 4e-7 D).  k_integrate then skips
-// distance, square root and band quotient for the patch, and -- when every updating voxel of a row holds S == 1 or W == 0,
-// for which (S W + 1) / (W + 1) is exactly 1 -- the division too (voxel_finish_free).
 ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
-                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
-                            const float* __restrict__ tile_min = nullptr, bool* free_space = nullptr) {
+                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
   *inside = false;
-  if (free_space) *free_space = false;
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
   for (int a = 0; a < 2; a++) {
     const float g1 = a ? g1hi : g1lo;
@@ -430,20 +441,15 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
   }
   if (t2max < -1e-3f) return false;                       // whole patch behind the camera
   float dmax_tile = 3.0e38f;                              // upper bound of the scaled depth any voxel can see
-  float dmin_tile = 0.0f;                                 // lower bound of the USABLE scaled depth any voxel can see (0: unknown)
   if (t2min > 0.02f) {                                    // hull argument needs the patch clear of the camera plane
     if (umax < -1.5f || umin > (float)cols + 0.5f || vmax < -1.5f || vmin > (float)rows + 0.5f) return false;
     const int x0 = (int)fmaxf(umin - 1.5f, 0.0f) >> 5, x1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> 5;
     const int y0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> 5, y1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> 5;
     if ((x1 - x0 + 1) * (y1 - y0 + 1) <= 48) {
-      float m = 0.0f, mn = 3.0e38f;
+      float m = 0.0f;
       for (int ty = y0; ty <= y1; ty++)
-        for (int tx = x0; tx <= x1; tx++) {
-          m = fmaxf(m, tile_max[ty * tiles_x + tx]);
-          if (tile_min) mn = fminf(mn, tile_min[ty * tiles_x + tx]);
-        }
+        for (int tx = x0; tx <= x1; tx++) m = fmaxf(m, tile_max[ty * tiles_x + tx]);
       dmax_tile = m;
-      if (tile_min) dmin_tile = mn;
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
@@ -452,11 +458,6 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
   const float dz = f.tz < g2lo ? g2lo - f.tz : (f.tz > g2hi ? f.tz - g2hi : 0.0f);
   const float dmin = sqrtf((dx * dx + dy * dy) + dz * dz);
   if (dmax_tile - dmin < -(float)kTsdfTrunc - 1e-4f) return false;   // every voxel is behind the surface by more than trunc
-  if (free_space && dmin_tile > 0.0f) {
-    const float ey = fmaxf(fabsf(g1lo - f.ty), fabsf(g1hi - f.ty)), ez = fmaxf(fabsf(g2lo - f.tz), fabsf(g2hi - f.tz));
-    const float dfar = sqrtf((dx * dx + ey * ey) + ez * ez);
-    *free_space = dmin_tile - dfar > ((float)kTsdfTrunc + 1e-4f) + 1e-6f * dfar;   // (NaN / inf: false)
-  }
   {
     const float a0 = fabsf(g0), G1 = fmaxf(fabsf(g1lo), fabsf(g1hi)), G2 = fmaxf(fabsf(g2lo), fabsf(g2hi));
     const float e0 = 0x1p-21f * (((fabsf(f.mi[0]) * a0 + fabsf(f.mi[1]) * G1) + fabsf(f.mi[2]) * G2) + fabsf(f.mi[3]));

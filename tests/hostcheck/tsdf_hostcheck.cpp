@@ -14,7 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
-struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, free_pf = 0, free_violations = 0; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -138,12 +138,10 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
   // tile maxima of the scaled depth, as k_prepare writes them (32 x 32 pixel tiles)
   const int tiles_x = (v->cols + 31) / 32, tiles_y = (v->rows + 31) / 32;
   std::vector<std::vector<float>> tile_max(n, std::vector<float>((size_t)tiles_x * tiles_y, 0.f));
-  std::vector<std::vector<float>> tile_min(n, std::vector<float>((size_t)tiles_x * tiles_y, 3.0e38f));
   for (int f = 0; f < n; f++)
     for (int p = 0; p < px; p++) {
       const size_t t = (size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32;
       tile_max[f][t] = std::max(tile_max[f][t], scaled[f][p]);
-      if (scaled[f][p] > 0.001f) tile_min[f][t] = std::min(tile_min[f][t], scaled[f][p]);
     }
   long culled = 0, kept = 0;
   for (auto& kv : v->units) {
@@ -153,58 +151,76 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     for (int i = 0; i < 64; i++)
-      for (int j0 = 0; j0 < 64; j0 += 4) {
-        // the same (4 rows x 64 voxels, frame) culling k_integrate applies before its frame loop
+      for (int jk = 0; jk < 16; jk++) {
+        const int j0 = (jk >> 2) * 16, k0 = (jk & 3) * 16;
+        // the same (16 x 16 voxel square of slab i, frame) culling k_integrate applies before its frame loop
         std::vector<int> frames;
-        std::vector<char> in, fre;
+        std::vector<char> in;
         for (int f : u.frames) {
-          bool inside = false, free_space = false;
-          if (patch_may_update(grid_coord(i, xs), grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs),
-                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside, tile_min[f].data(), &free_space)) {
+          bool inside = false;
+          if (patch_may_update(grid_coord(i, xs), grid_coord(j0, ys), grid_coord(j0 + 15, ys), grid_coord(k0, zs), grid_coord(k0 + 15, zs),
+                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside)) {
             frames.push_back(f);
             in.push_back(inside);
-            fre.push_back(free_space);
             kept++;
             v->inside += inside;
-            v->free_pf += free_space;
           } else {
             culled++;
           }
         }
-        for (int j = j0; j < j0 + 4; j++)
-          for (int k = 0; k < 64; k++) {
-            const int l = (i * 64 + j) * 64 + k;
-            float S = u.sdf[l], W = u.w[l];
-            const float g0 = grid_coord(i, xs), g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
-            for (size_t q = 0; q < frames.size(); q++) {
-              const int f = frames[q];
-              if (in[q]) {                                  // k_integrate's shortcut, cross-checked against the full test
-                const unsigned pixel = voxel_project_inside(g0, g1, g2, fx[f], v->cam, v->cols, v->rows);
-                unsigned ref_pixel = 0;
-                const float t2 = ((fx[f].mi[8] * g0 + fx[f].mi[9] * g1) + fx[f].mi[10] * g2) + fx[f].mi[11];
-                if (!voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, ref_pixel) || ref_pixel != pixel ||
-                    !(t2 >= 0x1p-30f && t2 <= 0x1p30f) || pixel >= (unsigned)px) {
-                  v->inside_violations++;
-                } else if (fre[q]) {                        // k_integrate's free-space path, cross-checked against the full update
-                  float S2 = S, W2 = W;
-                  voxel_finish(S2, W2, scaled[f][pixel], g0, g1, g2, fx[f]);
-                  voxel_finish_free(S, W, scaled[f][pixel]);
-                  if (memcmp(&S, &S2, 4) != 0 || memcmp(&W, &W2, 4) != 0) v->free_violations++;
-                } else {
-                  voxel_finish(S, W, scaled[f][pixel], g0, g1, g2, fx[f]);
-                }
-              } else if (fre[q]) {
-                float S2 = S, W2 = W;
-                voxel_update(S2, W2, g0, g1, g2, fx[f], v->cam, v->cols, v->rows, scaled[f].data());
-                unsigned pixel = 0;
-                if (voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, pixel)) voxel_finish_free(S, W, scaled[f][pixel]);
-                if (memcmp(&S, &S2, 4) != 0 || memcmp(&W, &W2, 4) != 0) v->free_violations++;
+        // frame-major over the patch, like the wave of k_integrate: all 256 lanes against frame q, then the next frame
+        const float g0 = grid_coord(i, xs);
+        float dpv[256], d2v[256];
+        bool frev[256], behv[256];
+        for (size_t q = 0; q < frames.size(); q++) {
+          const int f = frames[q];
+          bool need = false, unsure_any = false;
+          for (int t = 0; t < 256; t++) {
+            const int j = j0 + (t >> 4), k = k0 + (t & 15), l = (i * 64 + j) * 64 + k;
+            const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
+            float dp = 0.0f;                                // k_integrate: dp = 0 where the projection fails
+            if (in[q]) {                                    // k_integrate's shortcut, cross-checked against the full test
+              const unsigned pixel = voxel_project_inside(g0, g1, g2, fx[f], v->cam, v->cols, v->rows);
+              unsigned ref_pixel = 0;
+              const float t2 = ((fx[f].mi[8] * g0 + fx[f].mi[9] * g1) + fx[f].mi[10] * g2) + fx[f].mi[11];
+              if (!voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, ref_pixel) || ref_pixel != pixel ||
+                  !(t2 >= 0x1p-30f && t2 <= 0x1p30f) || pixel >= (unsigned)px) {
+                v->inside_violations++;
+                if (voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, ref_pixel)) dp = scaled[f][ref_pixel];
               } else {
-                voxel_update(S, W, g0, g1, g2, fx[f], v->cam, v->cols, v->rows, scaled[f].data());
+                dp = scaled[f][pixel];
               }
+            } else {
+              unsigned pixel = 0;
+              if (voxel_project(g0, g1, g2, fx[f], v->cam, v->cols, v->rows, pixel)) dp = scaled[f][pixel];
             }
-            u.sdf[l] = S; u.w[l] = W;
+            dpv[t] = dp;
+            d2v[t] = voxel_dist2(g0, g1, g2, fx[f]);
+            frev[t] = behv[t] = false;
+            if (v->cam.integration_trunc < 64.0f) voxel_classify(dp, d2v[t], frev[t], behv[t]);
+            const bool unsure = !(frev[t] | behv[t]);
+            unsure_any |= unsure;
+            need |= unsure | (frev[t] & !voxel_free_trivial(u.sdf[l], u.w[l]));
           }
+          // k_integrate's "sure" path: taken for the wave when no lane needs the exact update; cross-checked lane by lane
+          // against the full update (a provably-behind lane must not change, a provably-free trivial lane becomes (1, W + 1)).
+          // Lanes that classify as sure in a wave that takes the exact path are checked too: the per-lane claim must hold.
+          v->visited++;
+          v->sure += !need;
+          v->unsure_pf += unsure_any;
+          for (int t = 0; t < 256; t++) {
+            const int j = j0 + (t >> 4), k = k0 + (t & 15), l = (i * 64 + j) * 64 + k;
+            float S2 = u.sdf[l], W2 = u.w[l];
+            voxel_finish_d2(S2, W2, dpv[t], d2v[t]);
+            if (behv[t] || (frev[t] && voxel_free_trivial(u.sdf[l], u.w[l]))) {
+              const float S3 = frev[t] ? 1.0f : u.sdf[l], W3 = frev[t] ? u.w[l] + 1.0f : u.w[l];
+              if (memcmp(&S3, &S2, 4) != 0 || memcmp(&W3, &W2, 4) != 0 || (frev[t] && behv[t])) v->sure_violations++;
+            } else if (!need) {
+              v->sure_violations++;                         // (cannot happen: need covers every such lane)
+            }
+            u.sdf[l] = S2; u.w[l] = W2;
+          }
+        }
       }
   }
   v->culled += culled;
@@ -212,8 +228,10 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
   return 0;
 }
 
-long hc_free(void* h) { return static_cast<HcVolume*>(h)->free_pf; }
-long hc_free_violations(void* h) { return static_cast<HcVolume*>(h)->free_violations; }
+long hc_sure(void* h) { return static_cast<HcVolume*>(h)->sure; }
+long hc_visited(void* h) { return static_cast<HcVolume*>(h)->visited; }
+long hc_unsure_pf(void* h) { return static_cast<HcVolume*>(h)->unsure_pf; }
+long hc_sure_violations(void* h) { return static_cast<HcVolume*>(h)->sure_violations; }
 long hc_culled(void* h) { return static_cast<HcVolume*>(h)->culled; }
 long hc_inside(void* h) { return static_cast<HcVolume*>(h)->inside; }
 long hc_inside_violations(void* h) { return static_cast<HcVolume*>(h)->inside_violations; }
@@ -383,94 +401,49 @@ long hc_cull_stress(unsigned long long seed, long n, long* n_dead) {
   return wrong;
 }
 
-// Stress of the FREE-SPACE verdict: same random cameras / poses / patches / depth images (tiles placed around the patch's own
-// distance, so that "in front of the surface by more than the truncation" is decided both ways).  Whenever the verdict says
-// "free", every voxel of the patch is updated twice from several (S, W) states -- fresh, S == 1, and arbitrary -- by the full
-// voxel_update and by the shortcut (voxel_project + voxel_finish_free): the float bits must agree.  Returns the number of
-// disagreements; *n_free = verdicts that said "free".
-long hc_free_stress(unsigned long long seed, long n, long* n_free) {
+// Stress of voxel_classify (the square-root-free "sure" path of k_integrate) on its own: scaled depths dp from 1 mm up to the
+// 64 m the shortcut is enabled for (and the special values 0, 0.001f and its neighbours, c and its neighbours), squared
+// distances d2 placed ON and within a few ulps of the two decision thresholds fl(a|a|) and fl(b b), at dist = dp +- trunc
+// exactly, and anywhere; voxel states fresh, S == 1, arbitrary.  Whenever a lane classifies as sure (behind, or free and
+// trivial) the shortcut result must equal voxel_finish_d2's bit for bit.  Returns the violations; *n_sure = sure cases.
+long hc_sure_stress(unsigned long long seed, long n, long* n_sure) {
   unsigned long long st = seed * 0xD1B54A32D192ED03ull + 0x7654321ull;
   auto rnd = [&]() {
     st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
     return (double)((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
   };
-  long wrong = 0, nfree = 0;
-  std::vector<float> img, tile_max;
+  auto bump = [](float x, int ulps) {
+    for (int q = 0; q < (ulps < 0 ? -ulps : ulps); q++) x = nextafterf(x, ulps < 0 ? -3.0e38f : 3.0e38f);
+    return x;
+  };
+  const float special[] = {0.0f, 0.001f, bump(0.001f, 1), bump(0.001f, -1), kSureBand, bump(kSureBand, 1), bump(kSureBand, -1),
+                           0.03f, 0.0602f, 63.999996f, 1e-30f};
+  const float states[5][2] = {{0.f, 0.f}, {1.f, 7.f}, {1.f, 16777216.f}, {0.25f, 3.f}, {-0.6f, 1000.f}};
+  long wrong = 0, sure = 0;
   for (long it = 0; it < n; it++) {
-    const int cols = 32 + (int)(rnd() * 289), rows = 32 + (int)(rnd() * 209);
-    Camera cam;
-    cam.fx = (float)(20.0 * pow(30.0, rnd()));
-    cam.fy = (float)(20.0 * pow(30.0, rnd()));
-    cam.cx = (float)(rnd() * cols);
-    cam.cy = (float)(rnd() * rows);
-    cam.icp_trunc = 2.5f; cam.integration_trunc = 2.5f;
-    double q[4], nq = 0;
-    for (double& c : q) { c = rnd() * 2 - 1; nq += c * c; }
-    nq = sqrt(nq) + 1e-300;
-    for (double& c : q) c /= nq;
-    const double Rm[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
-                          2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
-                          2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
-    const double Rw = rnd() < 0.7 ? 3.0 : 40.0;
-    const double t[3] = {(rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw};
-    FrameXform f;
-    for (int r = 0; r < 3; r++) {
-      for (int c = 0; c < 3; c++) f.mi[r * 4 + c] = (float)Rm[c * 3 + r];
-      f.mi[r * 4 + 3] = (float)(-(Rm[0 * 3 + r] * t[0] + Rm[1 * 3 + r] * t[1] + Rm[2 * 3 + r] * t[2]));
+    float dp = rnd() < 0.1 ? special[(int)(rnd() * 11) % 11] : (float)(0.001 * pow(64000.0, rnd()));
+    if (!(dp < 64.0f)) dp = 63.999996f;
+    const float a = dp - kSureBand, b = dp + kSureBand;
+    float d2;
+    const double pick = rnd();
+    if (pick < 0.3) d2 = bump(a * fabsf(a), (int)(rnd() * 9) - 4);
+    else if (pick < 0.6) d2 = bump(b * b, (int)(rnd() * 9) - 4);
+    else if (pick < 0.7) { const double d = (double)dp - 0.03 + (rnd() * 2 - 1) * 2e-4; d2 = (float)(d * fabs(d)); }
+    else if (pick < 0.8) { const double d = (double)dp + 0.03 + (rnd() * 2 - 1) * 2e-4; d2 = (float)(d * d); }
+    else { const double d = (double)dp * (0.2 + 1.6 * rnd()); d2 = (float)(d * d); }
+    if (d2 < 0.0f) d2 = 0.0f;                                        // voxel_dist2 is a sum of squares
+    bool fre = false, beh = false;
+    voxel_classify(dp, d2, fre, beh);
+    for (int q = 0; q < 5; q++) {
+      float S = states[q][0], W = states[q][1], S2 = S, W2 = W;
+      voxel_finish_d2(S2, W2, dp, d2);
+      if (!(beh || (fre && voxel_free_trivial(S, W)))) continue;
+      sure++;
+      const float S3 = fre ? 1.0f : S, W3 = fre ? W + 1.0f : W;
+      if (memcmp(&S3, &S2, 4) != 0 || memcmp(&W3, &W2, 4) != 0 || (fre && beh)) wrong++;
     }
-    f.tx = (float)t[0]; f.ty = (float)t[1]; f.tz = (float)t[2]; f.pad = 0.f;
-    const double pu = (rnd() * 1.6 - 0.3) * cols, pv = (rnd() * 1.6 - 0.3) * rows;
-    const double D = (rnd() < 0.15 ? -1.0 : 1.0) * 0.02 * pow(150.0, rnd());     // some patches behind the camera
-    const double pc[3] = {(pu - cam.cx) / cam.fx * D, (pv - cam.cy) / cam.fy * D, D};
-    double pw[3];
-    for (int r = 0; r < 3; r++) pw[r] = Rm[r * 3] * pc[0] + Rm[r * 3 + 1] * pc[1] + Rm[r * 3 + 2] * pc[2] + t[r];
-    int vi[3];
-    bool ok = true;
-    for (int r = 0; r < 3; r++) {
-      vi[r] = (int)floor(pw[r] / kUnitLength) + 256 * 64;
-      ok = ok && vi[r] >= 0 && vi[r] < 512 * 64;
-    }
-    if (!ok) continue;
-    // scaled depth image: tiles around the patch's distance from the camera (+- a few truncation widths), noise, holes
-    const double dist = sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
-    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
-    img.assign((size_t)cols * rows, 0.f);
-    tile_max.assign((size_t)tiles_x * tiles_y, 0.f);
-    std::vector<float> tile_depth((size_t)tiles_x * tiles_y), tile_min((size_t)tiles_x * tiles_y, 3.0e38f);
-    const double behind = rnd() * 1.5;                             // the surface lies mostly BEHIND the patch here
-    for (float& d : tile_depth) d = rnd() < 0.1 ? 0.f : (float)(dist + behind + (rnd() * 2 - 1) * 0.2 * (rnd() < 0.5 ? 1.0 : 5.0));
-    for (int y = 0; y < rows; y++)
-      for (int x = 0; x < cols; x++) {
-        float d = tile_depth[(size_t)(y / 32) * tiles_x + x / 32];
-        if (d > 0.f) d += (float)((rnd() * 2 - 1) * 0.01);
-        if (rnd() < 0.02) d = 0.f;
-        if (d < 0.f) d = 0.f;
-        img[(size_t)y * cols + x] = d;
-        float& m = tile_max[(size_t)(y / 32) * tiles_x + x / 32];
-        m = std::max(m, d);
-        if (d > 0.001f) tile_min[(size_t)(y / 32) * tiles_x + x / 32] = std::min(tile_min[(size_t)(y / 32) * tiles_x + x / 32], d);
-      }
-    const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
-    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~3;
-    const float g0 = grid_coord(i, xs);
-    bool inside = false, free_space = false;
-    if (!patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs), f, cam, cols, rows,
-                          tile_max.data(), tiles_x, tiles_y, &inside, tile_min.data(), &free_space) || !free_space)
-      continue;
-    nfree++;
-    const float states[4][2] = {{0.f, 0.f}, {1.f, 7.f}, {0.25f, 3.f}, {-0.6f, 1000.f}};
-    for (int j = j0; j < j0 + 4; j++)
-      for (int k = 0; k < 64; k++)
-        for (int q = 0; q < 4; q++) {
-          float S = states[q][0], W = states[q][1], S2 = S, W2 = W;
-          const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
-          voxel_update(S2, W2, g0, g1, g2, f, cam, cols, rows, img.data());
-          unsigned pixel = 0;
-          if (voxel_project(g0, g1, g2, f, cam, cols, rows, pixel)) voxel_finish_free(S, W, img[pixel]);
-          if (memcmp(&S, &S2, 4) != 0 || memcmp(&W, &W2, 4) != 0) wrong++;
-        }
   }
-  if (n_free) *n_free = nfree;
+  if (n_sure) *n_sure = sure;
   return wrong;
 }
 

@@ -45,12 +45,11 @@ def hc():
     L.hc_inside.argtypes = [vp]
     L.hc_inside_violations.restype = C.c_long
     L.hc_inside_violations.argtypes = [vp]
-    L.hc_free.restype = C.c_long
-    L.hc_free.argtypes = [vp]
-    L.hc_free_violations.restype = C.c_long
-    L.hc_free_violations.argtypes = [vp]
-    L.hc_free_stress.restype = C.c_long
-    L.hc_free_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
+    for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations"):
+        getattr(L, name).restype = C.c_long
+        getattr(L, name).argtypes = [vp]
+    L.hc_sure_stress.restype = C.c_long
+    L.hc_sure_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_unit_keys.argtypes = [vp, vp]
     L.hc_read_unit.argtypes = [vp, C.c_int, vp, vp]
     return L
@@ -137,10 +136,11 @@ def test_device_math_warp_matches_golden(hc):
     d = helpers.volume_digest(v)
     assert d["keys"] == g["keys"] and d["sha256"] == g["sha256"]
     assert hc.hc_inside_violations(v.h) == 0 and hc.hc_inside(v.h) > 0
-    # the free-space shortcut of k_integrate (tsdf == 1 proven per patch, S == 1 / fresh voxels need no division): taken for a
-    # large share of the surviving (patch, frame) pairs and bit-identical to the full update wherever it was taken
-    assert hc.hc_free_violations(v.h) == 0 and hc.hc_free(v.h) > 0.2 * hc.hc_kept(v.h), (hc.hc_free(v.h), hc.hc_kept(v.h))
-    print("free-space patch-frames: %d of %d kept (%.1f %%)" % (hc.hc_free(v.h), hc.hc_kept(v.h), 100.0 * hc.hc_free(v.h) / hc.hc_kept(v.h)))
+    # the square-root-free "sure" path of k_integrate (voxel_classify), replayed wave by wave: a good share of the (patch, frame)
+    # visits take it, and every lane that classifies as sure equals the full update bit for bit
+    assert hc.hc_sure_violations(v.h) == 0 and hc.hc_sure(v.h) > 0.25 * hc.hc_visited(v.h), (hc.hc_sure(v.h), hc.hc_visited(v.h))
+    print("sure (patch, frame) visits: %d of %d (%.1f %%); with an unsure lane: %d" %
+          (hc.hc_sure(v.h), hc.hc_visited(v.h), 100.0 * hc.hc_sure(v.h) / hc.hc_visited(v.h), hc.hc_unsure_pf(v.h)))
 
 
 def test_device_math_custom_camera_vs_oracle(hc):
@@ -377,13 +377,13 @@ def test_culling_verdict_stress(hc):
     assert 8000 < dead < 72000, res                          # it decides both ways
 
 
-def test_free_space_verdict_stress(hc):
-    """patch_may_update's third verdict on its own: random cameras, poses, patches and depth images whose surface lies around
-    and behind the patch; wherever it says "free", the shortcut (voxel_finish_free) must reproduce the full update bit for bit
-    from fresh, S == 1 and arbitrary voxel states."""
-    n_free = C.c_long(0)
-    assert hc.hc_free_stress(21, 60000, C.byref(n_free)) == 0
-    assert n_free.value > 3000, n_free.value
+def test_sure_classification_stress(hc):
+    """voxel_classify on its own: scaled depths up to the 64 m bound, squared distances on and within a few ulps of both decision
+    thresholds and at dist = dp +- trunc; wherever a lane classifies as sure (behind, or free with S == 1 / W == 0) the
+    shortcut must reproduce voxel_finish_d2 bit for bit from fresh, S == 1 (also W = 2^24) and arbitrary voxel states."""
+    n_sure = C.c_long(0)
+    assert hc.hc_sure_stress(21, 4000000, C.byref(n_sure)) == 0
+    assert n_sure.value > 2000000, n_sure.value
 
 
 @pytest.mark.parametrize("ulps", [1, -1, 2, -2])
