@@ -31,6 +31,9 @@ import sys
 import tempfile
 import time
 
+# before the HIP runtime initialises (torch.cuda below): one hardware queue per stream of the TSDF pipeline, see er_common.cpp
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -3,6 +3,16 @@
 
 #include "../../include/er_hip.h"
 
+#include <cstdlib>
+
+// HIP multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
+// run in order.  A TSDF volume drives four streams (voxel pass, two pre-passes, host-frame copies) next to the caller's own,
+// and their overlap is the point (er_tsdf.hip: run_batch).  The variable is read when the HIP runtime initialises, i.e. at the
+// process's first HIP call: setting it here -- never overriding the user's value -- covers every program that has not touched
+// HIP before it loads this library; programs that have (a Python process that used torch.cuda first) set it themselves
+// (bench.py, elasticreconstruction_amd/__init__.py).
+__attribute__((constructor)) static void er_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 namespace er {
 
 char* error_buffer() {

@@ -42,8 +42,19 @@ constexpr int kEmptyKey = -1;
 constexpr uint32_t kZEmpty = 0xFFFFFFFFu;
 
 // counters[] slots
-enum { C_NUNITS = 0, C_NBATCH = 1 /* and 6: one per pipeline parity */, C_POOL_OVERFLOW = 2, C_TABLE_FULL = 3, C_OUT_OF_RANGE = 4,
-       C_ZERO_WRITE = 5, C_NBATCH1 = 6, C_COUNT = 8 };
+enum { C_NUNITS = 0, C_NBATCH = 1 /* and 6, 7: one per pipeline slot */, C_POOL_OVERFLOW = 2, C_TABLE_FULL = 3, C_OUT_OF_RANGE = 4,
+       C_ZERO_WRITE = 5 /* and 8: one per pre-pass stream */, C_NBATCH1 = 6, C_NBATCH2 = 7, C_ZERO_WRITE1 = 8, C_COUNT = 12 };
+#ifndef ER_PIPE_DEPTH
+#define ER_PIPE_DEPTH 3                  // (2 with ER_AUX_STREAMS 1 = the round-1 pipeline, kept for A/B)
+#endif
+#ifndef ER_AUX_STREAMS
+#define ER_AUX_STREAMS 2
+#endif
+constexpr int kDepth = ER_PIPE_DEPTH;    // batches in flight: voxel pass of n, pre-passes of n+1 and n+2
+constexpr int kAux = ER_AUX_STREAMS;     // pre-pass streams (batch b runs on stream b mod kAux)
+static_assert(kDepth >= 2 && kDepth <= 3 && kAux >= 1 && kAux <= 2 && kAux < kDepth, "pipeline shape");
+constexpr int kNbatchSlot[3] = {C_NBATCH, C_NBATCH1, C_NBATCH2};
+constexpr int kZeroFlagSlot[2] = {C_ZERO_WRITE, C_ZERO_WRITE1};
 
 __device__ __forceinline__ unsigned hash_unit_key(int key, int shift) { return ((unsigned)key * 2654435761u) >> shift; }
 
@@ -98,7 +109,7 @@ struct ReprojArgs {
   int floats_per_grid;
   uint32_t* zbuf;
   uint32_t* lastzero;
-  int* counters;
+  int* zero_flag;                        // raised by a write of dd == 0 (one flag per pre-pass stream)
 };
 
 // The write half of one source pixel p of frame f that landed on `cell` with depth dd (IntegrateApp.cpp:260-263).
@@ -109,7 +120,7 @@ __device__ __forceinline__ void scatter_px(const ReprojArgs& A, int f, int p, in
       atomicMin(&A.zbuf[o], (uint32_t)dd);
     } else {
       atomicMax(&A.lastzero[o], (uint32_t)p + 1u);
-      atomicOr(&A.counters[C_ZERO_WRITE], 1);
+      atomicOr(A.zero_flag, 1);
     }
   } else {
     const uint32_t lz = A.lastzero[o];
@@ -224,8 +235,8 @@ __global__ void k_expand_ctr(const float* __restrict__ ctr, Vert4* __restrict__ 
 // every source pixel is scattered again under the replay rule (only writes that come after the cell's last zero
 // write count); lastzero and the flag are re-armed.  Slow (one workgroup) by design: keeping it to one launch saves
 // three idle launches per batch on the pre-pass stream.
-__global__ __launch_bounds__(1024) void k_reproject_fix(ReprojArgs A) {
-  if (A.counters[C_ZERO_WRITE] == 0) return;
+__global__ __launch_bounds__(256) void k_reproject_fix(ReprojArgs A) {
+  if (*A.zero_flag == 0) return;
   const long total = (long)A.n_frames * A.cols * A.rows;
   for (long t = threadIdx.x; t < total; t += blockDim.x)
     if (A.lastzero[t] > 0) A.zbuf[t] = kZEmpty;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(1024) void k_reproject_fix(ReprojArgs A) {
   __syncthreads();
   for (long t = threadIdx.x; t < total; t += blockDim.x) A.lastzero[t] = 0;
   __syncthreads();
-  if (threadIdx.x == 0) A.counters[C_ZERO_WRITE] = 0;
+  if (threadIdx.x == 0) *A.zero_flag = 0;
 }
 
 __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
@@ -261,7 +272,8 @@ constexpr int kTile = 32;
 constexpr int kTileKeys = 96;
 
 // Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
-// returned 0) allocates the pool slot on first ever touch and appends the unit to the batch list.
+// returned 0) appends the unit to the batch list.  The pool slot of a unit that is new to the volume is handed out
+// by k_plan on the main stream (the pre-passes of two batches run concurrently; the main stream is in order).
 //
 // Unit-shard mode (the bit-exact multi-GPU alternative): with shard.y > 1 GPUs every GPU runs the pre-pass of
 // ALL frames but only owns -- allocates, integrates, reports -- the units with unit_owner(key) == shard.x.  Units are
@@ -269,8 +281,7 @@ constexpr int kTileKeys = 96;
 // single-GPU volume bit for bit; no collective touches the volume.
 __device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __restrict__ ht_slot,
                            unsigned long long* __restrict__ ht_mask, int cap_mask, int hash_shift,
-                           int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ nbatch,
-                           int* __restrict__ counters, int2 shard) {
+                           int* __restrict__ batch, int* __restrict__ nbatch, int* __restrict__ counters, int2 shard) {
   if (shard.y > 1 && unit_owner(key, shard.y) != shard.x) return;
   const int e = ht_find_or_insert(ht_key, cap_mask, hash_shift, key);
   if (e < 0) {
@@ -282,15 +293,6 @@ __device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __rest
   if (seen & bit) return;                                               // touched_unit.find, TSDFVolume.cpp:53
   const unsigned long long old = atomicOr(&ht_mask[e], bit);
   if (old != 0ull) return;
-  if (ht_slot[e] < 0) {                                                 // data_.find( key ) == end, TSDFVolume.cpp:55
-    const int s = atomicAdd(&counters[C_NUNITS], 1);
-    if (s < max_units) {
-      ht_slot[e] = s;                                                   // pool memory is zero-filled up front
-      unit_key[s] = key;
-    } else {
-      atomicOr(&counters[C_POOL_OVERFLOW], 1);
-    }
-  }
   batch[atomicAdd(nbatch, 1)] = e;
 }
 
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     const uint16_t* __restrict__ depth, uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
-    int hash_shift, int* __restrict__ unit_key, int max_units, int* __restrict__ batch, int* __restrict__ nbatch,
+    int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
     int* __restrict__ counters, float* __restrict__ tile_max, int2 shard) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       if (slot < kTileKeys) {
         s_keys[slot] = key;
       } else {                                                          // list full (pathological tile): go direct
-        touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters, shard);
+        touch_unit(key, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, batch, nbatch, counters, shard);
       }
     }
   }
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     const int k = s_keys[threadIdx.x];
     bool dup = false;
     for (int j = 0; j < (int)threadIdx.x; j++) dup = dup || (s_keys[j] == k);
-    if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, unit_key, max_units, batch, nbatch, counters, shard);
+    if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, batch, nbatch, counters, shard);
   }
 }
 
@@ -389,13 +391,28 @@ struct Plan {
 
 __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, const int* __restrict__ nbatch,
                                               const unsigned long long* __restrict__ ht_mask, int* __restrict__ plan_entry,
-                                              Plan* __restrict__ plan) {
+                                              Plan* __restrict__ plan, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
+                                              int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
   __shared__ int hist[65];
   __shared__ int start[66];
   const int n = *nbatch;                            // <= hash capacity = size of plan_entry
   for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&hist[__popcll(ht_mask[batch[t]])], 1);
+  for (int t = threadIdx.x; t < n; t += blockDim.x) {
+    const int e = batch[t];
+    atomicAdd(&hist[__popcll(ht_mask[e])], 1);
+    // data_.find( key ) == end, TSDFVolume.cpp:55: a unit that is new to the volume gets its pool slot here -- on the main
+    // stream, one batch after the other, every unit once per batch list (pool memory is zero-filled up front)
+    if (ht_slot[e] < 0) {
+      const int s = atomicAdd(&counters[C_NUNITS], 1);
+      if (s < max_units) {
+        ht_slot[e] = s;
+        unit_key[s] = ht_key[e];
+      } else {
+        atomicOr(&counters[C_POOL_OVERFLOW], 1);
+      }
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     int acc = 0;
@@ -759,40 +776,47 @@ struct er_tsdf_s {
   er::Camera cam{};
   er::CameraInv cami{};
   hipStream_t own_stream = nullptr, stream = nullptr;   // `stream` carries k_plan/k_integrate/k_reset and every other call
-  hipStream_t aux_stream = nullptr;                       // pre-pass of the NEXT batch (reproject, prepare) runs here, overlapped
-  hipStream_t copy_stream = nullptr;                      // host depth -> depth_stage[parity], overlapped with both of the above
-  hipEvent_t copy_done[2] = {nullptr, nullptr};
-  hipEvent_t consts_done[2] = {nullptr, nullptr};         // the per-batch constants of parity p have left the pinned block
+  hipStream_t aux_stream[kAux] = {};                      // pre-passes (reproject, prepare) of the NEXT TWO batches run here, overlapped
+  hipStream_t copy_stream = nullptr;                      // host depth -> depth_stage[slot], overlapped with all of the above; created on
+                                                          // first use (HIP multiplexes streams over 4 hardware queues by default, see er_tsdf_create)
+  hipEvent_t copy_done[kDepth] = {};
+  hipEvent_t consts_done[kDepth] = {};                    // the per-batch constants of slot q have left the pinned block
   int n_cu = 256;
   int shard_rank = 0, shard_world = 1;                    // unit-shard mode (er_tsdf_set_unit_shard)
   // device memory
   float2* pool = nullptr;
   int *ht_key = nullptr, *ht_slot = nullptr, *unit_key = nullptr, *counters = nullptr;
   unsigned long long* stats = nullptr;
-  // double-buffered batch state (two batches in flight: pre-pass of n+1 overlaps k_integrate of n)
-  int parity = 0;
-  bool used[2] = {false, false};
-  int* batch[2] = {nullptr, nullptr};
-  unsigned long long* ht_mask[2] = {nullptr, nullptr};
-  float *scaled[2] = {nullptr, nullptr}, *tile_max[2] = {nullptr, nullptr};
-  er::FrameXform* frames[2] = {nullptr, nullptr};   // = &dstage[q]->fx
-  void* dstage[2] = {nullptr, nullptr};             // device twin of the pinned per-batch constants (struct Staging)
-  hipEvent_t pre_done[2] = {nullptr, nullptr}, int_done[2] = {nullptr, nullptr};
-  void* pinned[2] = {nullptr, nullptr};                   // host staging of the per-batch constants
+  // triple-buffered batch state (three batches in flight: pre-passes of n+1 and n+2 overlap k_integrate of n)
+  long batch_no = 0;                                // batch b uses slot b mod kDepth and pre-pass stream b mod kAux
+  bool used[kDepth] = {};
+  int* batch[kDepth] = {};
+  unsigned long long* ht_mask[kDepth] = {};
+  float *scaled[kDepth] = {}, *tile_max[kDepth] = {};
+  er::FrameXform* frames[kDepth] = {};              // = &dstage[q]->fx
+  void* dstage[kDepth] = {};                        // device twin of the pinned per-batch constants (struct Staging)
+  hipEvent_t pre_done[kDepth] = {}, int_done[kDepth] = {};
+  void* pinned[kDepth] = {};                              // host staging of the per-batch constants
   int ht_cap = 0, ht_shift = 0;
   float *lambda = nullptr, *ctr = nullptr;
   er::Vert4* ctr4 = nullptr;                                // the same lattices, one 16-byte vertex each (tier 1 of Reproject)
-  float* ctr_pinned[2] = {nullptr, nullptr};                // page-locked staging of the caller's lattices, by call parity
-  size_t ctr_pinned_cap[2] = {0, 0};
-  hipEvent_t ctr_ev[2] = {nullptr, nullptr};
-  int ctr_parity = 0;
+  // The caller's lattices, double-buffered by call parity on the host (page-locked staging) AND on the device, so that the
+  // upload of call c (copy stream) never waits for the pre-passes of call c-1 that still read the other buffer.
+  float* ctr_pinned[2] = {nullptr, nullptr};
+  float* ctr_dev[2] = {nullptr, nullptr};
+  er::Vert4* ctr4_dev[2] = {nullptr, nullptr};
+  size_t ctr_pinned_cap[2] = {0, 0}, ctr_dev_cap[2] = {0, 0};
+  hipEvent_t ctr_ev[2] = {nullptr, nullptr};                // upload of the buffer done
+  hipEvent_t ctr_rd[2][kAux] = {};                          // last pre-pass reader of the buffer, per pre-pass stream
+  bool ctr_rd_set[2] = {false, false};
+  int ctr_parity = 0, ctr_cur = 0;
   std::vector<double> grid_cmax, grid_dmax;                 // per lattice: max |component|, max lattice-edge component (host)
-  uint16_t* depth_stage[2] = {nullptr, nullptr};   // host frames of the batch in flight, by pipeline parity
-  uint32_t *zbuf = nullptr, *lastzero = nullptr;
+  uint16_t* depth_stage[kDepth] = {};              // host frames of the batch in flight, by pipeline slot
+  uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr, *plan_entry = nullptr;
   Plan* plan = nullptr;
-  size_t ctr_cap = 0, key_scratch_cap = 0;
+  size_t key_scratch_cap = 0;
   // profiling
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -884,26 +908,28 @@ struct Staging {
 };
 
 int sync_all(er_tsdf_t h) {
-  ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
-  ER_HIP_TRY(hipStreamSynchronize(h->aux_stream));
+  if (h->copy_stream) ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
+  for (int a = 0; a < kAux; a++) ER_HIP_TRY(hipStreamSynchronize(h->aux_stream[a]));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
 
 // One batch (<= ER_MAX_BATCH frames).  depth_dev: n * pixels uint16 on device (must be complete: the
 // pre-pass runs on the handle's auxiliary stream, which does not wait for the caller's stream).
-// Two-stage pipeline over two in-order streams, batch state double-buffered by parity p = batch & 1:
-//   aux stream : [H2D constants] -> k_reproject_* -> k_prepare(p)            -> event pre_done[p]
-//   main stream: wait pre_done[p] -> k_plan -> k_integrate(p) -> k_reset(p)  -> event int_done[p]
-// so the pre-pass of batch n+1 (latency / float64 bound) overlaps k_integrate of batch n (float32 VALU
-// bound); measured +23 % aggregate when two such kernel streams run concurrently on one MI355X.
+// Pipeline over three in-order streams, batch state triple-buffered by slot p = batch mod 3:
+//   aux stream b mod 2: [H2D constants] -> k_reproject_* -> k_prepare(p)        -> event pre_done[p]
+//   main stream       : wait pre_done[p] -> k_plan -> k_integrate(p) -> k_reset(p)  -> event int_done[p]
+// so the pre-passes of batches n+1 and n+2 (latency / float64 bound, each a serial chain of launches) overlap each other and
+// k_integrate of batch n (float32 VALU bound).  Round 1 ran one pre-pass stream (+23 % over no overlap); since the compact
+// patches of round 2 made k_integrate shorter than the pre-pass chain, the second pre-pass stream keeps the chip busy while
+// the voxel pass waits (profiles/r02l_*).  Batches still reach the volume strictly in order (main stream).
 int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, const er_warp* warp, int frame0) {
-  const int p = h->parity;
-  h->parity ^= 1;
-  // Parity p was last used by batch n-2.  The HOST only needs its pinned constants block back (the H2D copy of batch n-2, an
-  // early event); the DEVICE buffers of the parity (scaled depth, masks, frame constants) are protected on the device: the
-  // pre-pass stream waits for k_integrate of batch n-2 before it touches them.  The host therefore never blocks on a voxel
-  // pass and runs up to two batches ahead (host-frame copies and pre-passes queue up behind the events).
+  const int p = (int)(h->batch_no % kDepth), a = (int)(h->batch_no % kAux);
+  h->batch_no++;
+  // Slot p was last used by batch n-3.  The HOST only needs its pinned constants block back (the H2D copy of batch n-3, an
+  // early event); the DEVICE buffers of the slot (scaled depth, masks, frame constants) are protected on the device: the
+  // pre-pass stream waits for k_integrate of batch n-3 before it touches them.  The host therefore never blocks on a voxel
+  // pass and runs up to three batches ahead (host-frame copies and pre-passes queue up behind the events).
   if (h->used[p]) ER_HIP_TRY(hipEventSynchronize(h->consts_done[p]));
   Staging* st = static_cast<Staging*>(h->pinned[p]);
   for (int f = 0; f < n; f++) {
@@ -919,8 +945,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     st->fx[f].tz = (float)Tf[11];
     st->fx[f].pad = 0.f;
   }
-  hipStream_t X = h->aux_stream, S = h->stream;
-  int* nbatch = h->counters + (p ? C_NBATCH1 : C_NBATCH);
+  hipStream_t X = h->aux_stream[a], S = h->stream;
+  int* nbatch = h->counters + kNbatchSlot[p];
 
 #ifndef ER_INT_BLOCKS_PER_CU
 #define ER_INT_BLOCKS_PER_CU 8
@@ -950,7 +976,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     }
   }
   // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
-  if (h->used[p]) ER_HIP_TRY(hipStreamWaitEvent(X, h->int_done[p], 0));     // k_integrate of batch n-2 still reads dstage[p] / scaled[p] / masks[p]
+  if (h->used[p]) ER_HIP_TRY(hipStreamWaitEvent(X, h->int_done[p], 0));     // k_integrate of batch n-3 still reads dstage[p] / scaled[p] / masks[p]
   ER_HIP_TRY(hipMemcpyAsync(h->dstage[p], st, sizeof(Staging), hipMemcpyHostToDevice, X));
   ER_HIP_TRY(hipEventRecord(h->consts_done[p], X));
   if (warp) {
@@ -958,20 +984,21 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
-                        verts * 3, h->zbuf, h->lastzero, h->counters};
+                        verts * 3, h->zbuf[a], h->lastzero[a], h->counters + kZeroFlagSlot[a]};
     if (launch_reproject(h, RA, n, reinterpret_cast<const er::ReprojFast*>(dst + offsetof(Staging, fast)), X)) return 1;
-    zsrc = h->zbuf;
+    zsrc = h->zbuf[a];
   }
 
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
-                     h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->unit_key, h->max_units, h->batch[p], nbatch, h->counters,
+                     h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
                      h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
   ER_HIP_TRY(hipStreamWaitEvent(S, h->pre_done[p], 0));
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, S, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry, h->plan);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, S, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry, h->plan, h->ht_key, h->ht_slot,
+                     h->unit_key, h->max_units, h->counters);
   ER_HIP_TRY(hipGetLastError());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling) {
@@ -1054,12 +1081,13 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
     }                                                                                                \
   } while (0)
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-      aux_create(&h->aux_stream) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+      aux_create(&h->aux_stream[0]) != hipSuccess || (kAux > 1 && aux_create(&h->aux_stream[kAux - 1]) != hipSuccess) ||
+      false) {
     delete h;
     return er::fail("er_tsdf_create: hipStreamCreate failed");
   }
   h->stream = h->own_stream;
-  for (int q = 0; q < 2; q++) {
+  for (int q = 0; q < kDepth; q++) {
     if (hipEventCreateWithFlags(&h->pre_done[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->int_done[q], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->copy_done[q], hipEventDisableTiming) != hipSuccess ||
@@ -1072,24 +1100,24 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->pool, (size_t)max_units * er::kUnitVox * sizeof(float2));
   ER_ALLOC(h->ht_key, (size_t)cap * sizeof(int));
   ER_ALLOC(h->ht_slot, (size_t)cap * sizeof(int));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->ht_mask[q], (size_t)cap * sizeof(unsigned long long));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->ht_mask[q], (size_t)cap * sizeof(unsigned long long));
   ER_ALLOC(h->unit_key, (size_t)max_units * sizeof(int));
   ER_ALLOC(h->counters, C_COUNT * sizeof(int));
   ER_ALLOC(h->stats, 4 * sizeof(unsigned long long));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->batch[q], (size_t)cap * sizeof(int));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->batch[q], (size_t)cap * sizeof(int));
   ER_ALLOC(h->lambda, px * sizeof(float));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->scaled[q], B * px * sizeof(float));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
-  ER_ALLOC(h->zbuf, B * px * sizeof(uint32_t));
-  ER_ALLOC(h->lastzero, B * px * sizeof(uint32_t));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
-  for (int q = 0; q < 2; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->scaled[q], B * px * sizeof(float));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
+  for (int q = 0; q < kAux; q++) ER_ALLOC(h->zbuf[q], B * px * sizeof(uint32_t));
+  for (int q = 0; q < kAux; q++) ER_ALLOC(h->lastzero[q], B * px * sizeof(uint32_t));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
+  for (int q = 0; q < kDepth; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
   ER_ALLOC(h->seg12, B * 16 * sizeof(double));
   ER_ALLOC(h->madj12, B * 12 * sizeof(double));
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
-  for (int q = 0; q < 2; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   ER_ALLOC(h->plan_entry, (size_t)cap * sizeof(int));
   ER_ALLOC(h->plan, sizeof(Plan));
 #undef ER_ALLOC
@@ -1097,12 +1125,12 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   bool ok = hipMemsetAsync(h->pool, 0, (size_t)max_units * er::kUnitVox * sizeof(float2), s) == hipSuccess &&
             hipMemsetAsync(h->ht_key, 0xFF, (size_t)cap * sizeof(int), s) == hipSuccess &&
             hipMemsetAsync(h->ht_slot, 0xFF, (size_t)cap * sizeof(int), s) == hipSuccess &&
-            hipMemsetAsync(h->ht_mask[0], 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess &&
-            hipMemsetAsync(h->ht_mask[1], 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess &&
             hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s) == hipSuccess &&
-            hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), s) == hipSuccess &&
-            hipMemsetAsync(h->lastzero, 0, B * px * sizeof(uint32_t), s) == hipSuccess &&
-            hipMemsetAsync(h->zbuf, 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
+            hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), s) == hipSuccess;
+  for (int q = 0; q < kDepth; q++) ok = ok && hipMemsetAsync(h->ht_mask[q], 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess;
+  for (int q = 0; q < kAux; q++)
+    ok = ok && hipMemsetAsync(h->lastzero[q], 0, B * px * sizeof(uint32_t), s) == hipSuccess &&
+         hipMemsetAsync(h->zbuf[q], 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(k_lambda, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->lambda, cols, rows, h->cam);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
@@ -1123,25 +1151,35 @@ int er_tsdf_destroy(er_tsdf_t h) {
     (void)hipEventDestroy(ev.first);
     (void)hipEventDestroy(ev.second);
   }
-  if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
-  void* ptrs[] = {h->pool, h->ht_key, h->ht_slot, h->ht_mask[0], h->ht_mask[1], h->unit_key, h->counters, h->stats, h->batch[0],
-                  h->batch[1], h->lambda, h->scaled[0], h->scaled[1], h->depth_stage[0], h->depth_stage[1], h->zbuf, h->lastzero, h->dstage[0],
-                  h->dstage[1], h->T12, h->seg12, h->madj12, h->grid_index, h->dsum, h->ctr, h->ctr4, h->key_scratch, h->slot_scratch,
-                  h->plan_entry, h->plan, h->tile_max[0], h->tile_max[1]};
-  for (int q = 0; q < 2; q++) {
+  for (int a = 0; a < kAux; a++)
+    if (h->aux_stream[a]) (void)hipStreamSynchronize(h->aux_stream[a]);
+  std::vector<void*> ptrs = {h->pool, h->ht_key, h->ht_slot, h->unit_key, h->counters, h->stats, h->lambda, h->T12, h->seg12, h->madj12,
+                             h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->ctr4_dev[0], h->ctr4_dev[1], h->key_scratch,
+                             h->slot_scratch, h->plan_entry, h->plan};
+  for (int q = 0; q < kDepth; q++)
+    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q]})
+      ptrs.push_back(x);
+  for (int q = 0; q < kAux; q++) {
+    ptrs.push_back(h->zbuf[q]);
+    ptrs.push_back(h->lastzero[q]);
+  }
+  for (int q = 0; q < kDepth; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
     if (h->int_done[q]) (void)hipEventDestroy(h->int_done[q]);
     if (h->copy_done[q]) (void)hipEventDestroy(h->copy_done[q]);
     if (h->consts_done[q]) (void)hipEventDestroy(h->consts_done[q]);
     if (h->pinned[q]) (void)hipHostFree(h->pinned[q]);
   }
-  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  for (int a = 0; a < kAux; a++)
+    if (h->aux_stream[a]) (void)hipStreamDestroy(h->aux_stream[a]);
   if (h->copy_stream) {
     (void)hipStreamSynchronize(h->copy_stream);
     (void)hipStreamDestroy(h->copy_stream);
   }
   for (int q = 0; q < 2; q++) {
     if (h->ctr_ev[q]) (void)hipEventDestroy(h->ctr_ev[q]);
+    for (int a = 0; a < kAux; a++)
+      if (h->ctr_rd[q][a]) (void)hipEventDestroy(h->ctr_rd[q][a]);
     if (h->ctr_pinned[q]) (void)hipHostFree(h->ctr_pinned[q]);
   }
   for (void* p : ptrs)
@@ -1180,29 +1218,36 @@ int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_h
 }
 
 // num_grids lattices of (res+1)^3 x 3 floats -> device (float[3] for the exact chain, Vert4 for tier 1) + their host-side bounds.
-static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hipStream_t stream) {
+// The copy runs on the pre-pass stream of the call's first batch into the device buffer of this call's parity (so it never
+// waits for the previous call's pre-passes, which read the other buffer); the other pre-pass stream (and `also`, if given)
+// waits for it.  Sets h->ctr / h->ctr4 to the buffer the kernels of this call read.
+static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hipStream_t also) {
   const size_t verts = (size_t)(res + 1) * (res + 1) * (res + 1);
   const size_t floats = verts * 3 * (size_t)num_grids;
-  if (floats > h->ctr_cap) {
-    if (sync_all(h)) return 1;                       // nobody may still be reading the old grids
-    if (h->ctr) (void)hipFree(h->ctr);
-    if (h->ctr4) (void)hipFree(h->ctr4);
-    h->ctr = nullptr;
-    h->ctr4 = nullptr;
-    h->ctr_cap = 0;
-    ER_HIP_TRY(hipMalloc((void**)&h->ctr, floats * sizeof(float)));
-    ER_HIP_TRY(hipMalloc((void**)&h->ctr4, (floats / 3) * sizeof(er::Vert4)));
-    h->ctr_cap = floats;
+  const int q = h->ctr_parity;
+  h->ctr_parity ^= 1;
+  if (floats > h->ctr_dev_cap[q]) {
+    if (sync_all(h)) return 1;                       // nobody may still be reading the old buffer
+    if (h->ctr_dev[q]) (void)hipFree(h->ctr_dev[q]);
+    if (h->ctr4_dev[q]) (void)hipFree(h->ctr4_dev[q]);
+    h->ctr_dev[q] = nullptr;
+    h->ctr4_dev[q] = nullptr;
+    h->ctr_dev_cap[q] = 0;
+    ER_HIP_TRY(hipMalloc((void**)&h->ctr_dev[q], floats * sizeof(float)));
+    ER_HIP_TRY(hipMalloc((void**)&h->ctr4_dev[q], (floats / 3) * sizeof(er::Vert4)));
+    h->ctr_dev_cap[q] = floats;
   }
   h->grid_cmax.assign((size_t)num_grids, 0.0);
   h->grid_dmax.assign((size_t)num_grids, 0.0);
   // The lattices travel through a page-locked block of the handle: the copy is then truly asynchronous (a copy from the
   // caller's pageable memory would make the host wait for everything queued on this stream at every call) and the caller's
   // memory is free again when the call returns.
-  const int q = h->ctr_parity;
-  h->ctr_parity ^= 1;
-  if (!h->ctr_ev[q]) ER_HIP_TRY(hipEventCreateWithFlags(&h->ctr_ev[q], hipEventDisableTiming));
-  else ER_HIP_TRY(hipEventSynchronize(h->ctr_ev[q]));        // the upload of two calls ago
+  if (!h->ctr_ev[q]) {
+    ER_HIP_TRY(hipEventCreateWithFlags(&h->ctr_ev[q], hipEventDisableTiming));
+    for (int a = 0; a < kAux; a++) ER_HIP_TRY(hipEventCreateWithFlags(&h->ctr_rd[q][a], hipEventDisableTiming));
+  } else {
+    ER_HIP_TRY(hipEventSynchronize(h->ctr_ev[q]));          // the upload of two calls ago (pinned block free again)
+  }
   if (floats > h->ctr_pinned_cap[q]) {
     if (h->ctr_pinned[q]) (void)hipHostFree(h->ctr_pinned[q]);
     h->ctr_pinned[q] = nullptr;
@@ -1211,14 +1256,25 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
     h->ctr_pinned_cap[q] = floats;
   }
   memcpy(h->ctr_pinned[q], ctr, floats * sizeof(float));
-  ER_HIP_TRY(hipMemcpyAsync(h->ctr, h->ctr_pinned[q], floats * sizeof(float), hipMemcpyHostToDevice, stream));
-  ER_HIP_TRY(hipEventRecord(h->ctr_ev[q], stream));
+  const int a0 = (int)(h->batch_no % kAux);
+  hipStream_t C = h->aux_stream[a0];
+  if (h->ctr_rd_set[q])                                     // the pre-passes of two calls ago read this device buffer
+    for (int a = 0; a < kAux; a++)
+      if (a != a0) ER_HIP_TRY(hipStreamWaitEvent(C, h->ctr_rd[q][a], 0));
+  ER_HIP_TRY(hipMemcpyAsync(h->ctr_dev[q], h->ctr_pinned[q], floats * sizeof(float), hipMemcpyHostToDevice, C));
 #ifdef ER_REPROJECT_TIERED               // the float32 tier's inputs: lattice bounds (host) and the 16-byte vertex copy (device)
   for (int g = 0; g < num_grids; g++) er::lattice_bounds(ctr + (size_t)g * verts * 3, res, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g]);
   const long nv = (long)(floats / 3);
-  hipLaunchKernelGGL(k_expand_ctr, dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, h->ctr, h->ctr4, nv);
+  hipLaunchKernelGGL(k_expand_ctr, dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, C, h->ctr_dev[q], h->ctr4_dev[q], nv);
   ER_HIP_TRY(hipGetLastError());
 #endif
+  ER_HIP_TRY(hipEventRecord(h->ctr_ev[q], C));
+  for (int a = 0; a < kAux; a++)
+    if (a != a0) ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream[a], h->ctr_ev[q], 0));
+  if (also) ER_HIP_TRY(hipStreamWaitEvent(also, h->ctr_ev[q], 0));
+  h->ctr = h->ctr_dev[q];
+  h->ctr4 = h->ctr4_dev[q];
+  h->ctr_cur = q;
   return 0;
 }
 
@@ -1235,7 +1291,7 @@ static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::
     // (staging the lattice in LDS for this kernel was measured as well: slower, profiles/r02d_ab_lds_lattice.txt)
     hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
   }
-  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(1024), 0, X, RA);
+  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(256), 0, X, RA);      // (one small workgroup: it has to find room next to two busy kernels)
   ER_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1248,7 +1304,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const size_t px = (size_t)h->pixels;
   const int verts = (resolution + 1) * (resolution + 1) * (resolution + 1);
   if (sync_all(h)) return 1;                         // single-frame hook: runs alone on the main stream
-  if (upload_ctr(h, ctr_host, resolution, 1, h->stream)) return 1;
+  if (upload_ctr(h, ctr_host, resolution, 1, h->stream)) return 1;      // (on a pre-pass stream; the main stream waits for it)
   const int gi = 0;
   ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[0], depth_inout_host, px * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
   double seg16[16] = {0};
@@ -1260,7 +1316,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const float grid_ul = length / (float)resolution;
   const long total = (long)px;
   const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
-                      verts * 3, h->zbuf, h->lastzero, h->counters};
+                      verts * 3, h->zbuf[0], h->lastzero[0], h->counters + kZeroFlagSlot[0]};
   {
     er::ReprojFast* dev_fast = reinterpret_cast<er::ReprojFast*>(static_cast<char*>(h->dstage[0]) + offsetof(Staging, fast));
 #ifdef ER_REPROJECT_TIERED
@@ -1270,7 +1326,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
 #endif
     if (launch_reproject(h, RA, 1, dev_fast, h->stream)) return 1;
   }
-  hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf,
+  hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf[0],
                      h->depth_stage[0], total);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipMemcpyAsync(depth_inout_host, h->depth_stage[0], px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
@@ -1286,7 +1342,7 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
   if (warp) {
     if (!warp->ctr || !warp->grid_index || !warp->seg || !warp->madj || warp->num_grids <= 0 || warp->resolution <= 0)
       return er::fail("er_tsdf_integrate_frames: incomplete er_warp");
-    if (upload_ctr(h, warp->ctr, warp->resolution, warp->num_grids, h->aux_stream)) return 1;
+    if (upload_ctr(h, warp->ctr, warp->resolution, warp->num_grids, nullptr)) return 1;
   }
   const size_t px = (size_t)h->pixels;
   // n frames are fused in ceil(n / ER_MAX_BATCH) launches of (nearly) EQUAL size: 150 frames run as 3 x 50, not 64 + 64 + 22
@@ -1299,18 +1355,23 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
     if (depth_on_device) {
       ddev = depth + (size_t)start * px;
     } else {
-      // Host frames travel on their own stream into the staging buffer of this batch's parity: the copy of batch n+1 overlaps
-      // the pre-pass of batch n (aux stream) and the voxel pass of batch n-1 (main stream) when the caller's memory is
+      // Host frames travel on their own stream into the staging buffer of this batch's slot: the copy of batch n+1 overlaps
+      // the pre-passes of the batches before it (aux streams) and the voxel pass (main stream) when the caller's memory is
       // page-locked (er_host_alloc); pageable memory makes hipMemcpyAsync block the host, which is still correct.
-      const int p = h->parity;
-      ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->pre_done[p], 0));       // the pre-pass that last read depth_stage[p] (batch n-2)
+      const int p = (int)(h->batch_no % kDepth);
+      if (!h->copy_stream) ER_HIP_TRY(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+      if (h->used[p]) ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, h->pre_done[p], 0));   // the pre-pass that last read depth_stage[p] (batch n-3)
       ER_HIP_TRY(hipMemcpyAsync(h->depth_stage[p], depth + (size_t)start * px, (size_t)nb * px * sizeof(uint16_t),
                                 hipMemcpyHostToDevice, h->copy_stream));
       ER_HIP_TRY(hipEventRecord(h->copy_done[p], h->copy_stream));
-      ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream, h->copy_done[p], 0));
+      ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream[h->batch_no % kAux], h->copy_done[p], 0));
       ddev = h->depth_stage[p];
     }
     if (run_batch(h, nb, ddev, T + (size_t)start * 16, warp, start)) return 1;
+  }
+  if (warp) {                                               // the last readers of this call's lattice buffer, per pre-pass stream
+    for (int a = 0; a < kAux; a++) ER_HIP_TRY(hipEventRecord(h->ctr_rd[h->ctr_cur][a], h->aux_stream[a]));
+    h->ctr_rd_set[h->ctr_cur] = true;
   }
   // The caller may reuse or free its HOST frames as soon as the call returns: wait for the copies (not for the kernels).
   if (!depth_on_device && n > 0) ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
@@ -1324,8 +1385,8 @@ int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16
 int er_tsdf_wait_event(er_tsdf_t h, void* hip_event) {
   if (!h || !hip_event) return er::fail("er_tsdf_wait_event: NULL argument");
   ER_HIP_TRY(hipSetDevice(h->device));
-  ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream, (hipEvent_t)hip_event, 0));
-  ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, (hipEvent_t)hip_event, 0));
+  for (int a = 0; a < kAux; a++) ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream[a], (hipEvent_t)hip_event, 0));
+  if (h->copy_stream) ER_HIP_TRY(hipStreamWaitEvent(h->copy_stream, (hipEvent_t)hip_event, 0));
   return 0;
 }
 
@@ -1340,11 +1401,11 @@ int er_tsdf_reset(er_tsdf_t h) {
   if (n > 0) ER_HIP_TRY(hipMemsetAsync(h->pool, 0, (size_t)n * er::kUnitVox * sizeof(float2), s));   // only the units ever handed out
   ER_HIP_TRY(hipMemsetAsync(h->ht_key, 0xFF, (size_t)h->ht_cap * sizeof(int), s));
   ER_HIP_TRY(hipMemsetAsync(h->ht_slot, 0xFF, (size_t)h->ht_cap * sizeof(int), s));
-  for (int q = 0; q < 2; q++) ER_HIP_TRY(hipMemsetAsync(h->ht_mask[q], 0, (size_t)h->ht_cap * sizeof(unsigned long long), s));
+  for (int q = 0; q < kDepth; q++) ER_HIP_TRY(hipMemsetAsync(h->ht_mask[q], 0, (size_t)h->ht_cap * sizeof(unsigned long long), s));
   ER_HIP_TRY(hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s));
   ER_HIP_TRY(hipStreamSynchronize(s));
-  h->used[0] = h->used[1] = false;
-  h->parity = 0;
+  for (int q = 0; q < kDepth; q++) h->used[q] = false;
+  h->batch_no = 0;
   return 0;
 }
 

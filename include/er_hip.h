@@ -88,14 +88,15 @@ int er_tsdf_integrate(er_tsdf_t h, const uint16_t* depth_host, const double T[16
  * ER_MAX_BATCH at a time so each voxel is read and written once per batch.
  * depth: n*rows*cols uint16, host memory if depth_on_device == 0 else device memory (left untouched).
  * Device depth must be COMPLETE when the call is made (synchronise the stream that produced it): the
- * per-pixel pre-pass of a batch runs on the handle's auxiliary stream so that it overlaps the voxel pass of
- * the previous batch, and that stream does not wait for the caller's.
+ * per-pixel pre-passes of the next two batches run on the handle's two auxiliary streams so that they overlap each other
+ * and the voxel pass of the previous batch, and those streams do not wait for the caller's (er_tsdf_wait_event).
  * T: n*16 host doubles (traj_[frame_id-1]).  warp may be NULL (rigid, --ref_traj). */
 int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int depth_on_device, const double* T,
                              const er_warp* warp);
 
-/* Device depth produced asynchronously: the NEXT er_tsdf_integrate_frames call's pre-pass (and host-frame copies) wait for
- * this hipEvent_t (recorded by the caller after the producer of the depth buffer) instead of requiring a synchronised stream. */
+/* Device depth produced asynchronously: the pre-passes of the NEXT er_tsdf_integrate_frames calls (both internal pre-pass
+ * streams) wait for this hipEvent_t (recorded by the caller after the producer of the depth buffer) instead of requiring a
+ * synchronised stream.  (Host depth needs no event: it is read by the copy inside the call.) */
 int er_tsdf_wait_event(er_tsdf_t h, void* hip_event);
 
 /* Empties the volume (data_.clear()): every unit is released and zero-filled, the hash map is emptied, flags are cleared.

@@ -2,7 +2,12 @@
 kernel-trace CSV: python scripts/timeline.py <kernel_trace.csv> [first_integrate_index] [count]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), (r["Kernel_Name"].split("(anonymous namespace)::", 1)[1] if r["Kernel_Name"].startswith("(anonymous") else r["Kernel_Name"]).split("(")[0][:22], r.get("Queue_Id", "?")) for r in rows]
+def short(name):
+    # "(anonymous namespace)::k_x(args)" and "void (anonymous namespace)::k_x<true>(args)" -> k_x
+    if name.startswith("(anonymous namespace)::") or name.startswith("void (anonymous namespace)::"):
+        name = name.split("(anonymous namespace)::", 1)[1]
+    return name.split("(")[0].split("<")[0][:22]
+ks = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Queue_Id", "?")) for r in rows]
 ks.sort()
 ints = [i for i, k in enumerate(ks) if k[2].startswith("k_integrate")]
 first = ints[int(sys.argv[2]) if len(sys.argv) > 2 else len(ints) // 2]
