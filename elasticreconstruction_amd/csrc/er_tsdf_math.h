@@ -107,28 +107,32 @@ ER_HD int touch_key_exact(int u, int v, uint16_t d, const Camera& c, const doubl
   return key_from_voxels(floor(p0 / kUnitLength + 0.5), floor(p1 / kUnitLength + 0.5), floor(p2 / kUnitLength + 0.5));
 }
 
-// Division-free evaluation with an exactness guard.  Only floor( p/ul + 0.5 ) of the reference value is
-// observable.  Replacing every division by a multiplication with a rounded reciprocal perturbs p by at most
-// ~1e-14 * (|T0 x| + |T1 y| + |T2 z| + |T3|); for magnitudes below 20000 voxels (117 m, guarded) that is
-// < 1e-9 voxel.  If the approximate w = p'/ul + 0.5 keeps a distance > 1e-6 from the nearest integer, the
-// reference value lies in the same unit interval and has the same floor; otherwise (about 6 pixels per
-// million) the exact expression is evaluated.  Result: identical keys, ~5x fewer float64 instructions.
+// Division-free evaluation with an exactness guard.  Only the UNIT index of the reference's voxel index is observable:
+//   voxel = floor( p/ul + 0.5 ),  unit = (voxel + 256*64) / 64  =  floor( (p/ul + 0.5) / 64 ) + 256
+// (floor( floor(w) / 64 ) = floor( w / 64 )), so one fused multiply-add per axis yields W = (p/ul + 0.5)/64 + 256 and the unit
+// is floor(W).  p itself is evaluated in ray form, z (T0 (u-cx)/fx + T1 (v-cy)/fy + T2) + T3, with rounded reciprocals: it
+// differs from the reference's float64 value by at most ~1e-14 * (|T0 x| + |T1 y| + |T2 z| + |T3|); for magnitudes below 20000
+// voxels (117 m) that is < 1e-9 voxel = 1.6e-11 in W.  If W keeps a distance > 1.5e-8 from the nearest integer the reference
+// value has the same floor; otherwise (a pixel in 10^7) the exact expression is evaluated.  Beyond 20000 voxels the bound is
+// not claimed, but there W lies outside [0, 512) by more than 56 units while the error stays relative (~1e-14): the key is -1
+// either way.  NaN and |W| >= 2^52 fail the guard (the fraction is NaN or 0) and take the exact path.
 ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, const double* T) {
   const double z = (double)d * 0.001;
-  const double x = (double)((float)u - c.cx) * z * ci.inv_fx;
-  const double y = (double)((float)v - c.cy) * z * ci.inv_fy;
-  const double inv_ul = 512.0 / 3.0;
-  // fused: 4 operations per row instead of 8, and closer to the true value than the reference's own rounding sequence
-  // (the innermost product and sum stay separate: both coefficients are scalar registers, one too many for a single fma)
-  const double w0 = fma(fma(T[0], x, fma(T[1], y, T[2] * z + T[3])), inv_ul, 0.5);
-  const double w1 = fma(fma(T[4], x, fma(T[5], y, T[6] * z + T[7])), inv_ul, 0.5);
-  const double w2 = fma(fma(T[8], x, fma(T[9], y, T[10] * z + T[11])), inv_ul, 0.5);
+  const double xr = (double)((float)u - c.cx) * ci.inv_fx;
+  const double yr = (double)((float)v - c.cy) * ci.inv_fy;
+  const double k = (512.0 / 3.0) / 64.0, k0 = 0.5 / 64.0 + 256.0;
+  const double w0 = fma(fma(z, fma(T[0], xr, fma(T[1], yr, T[2])), T[3]), k, k0);
+  const double w1 = fma(fma(z, fma(T[4], xr, fma(T[5], yr, T[6])), T[7]), k, k0);
+  const double w2 = fma(fma(z, fma(T[8], xr, fma(T[9], yr, T[10])), T[11]), k, k0);
   const double f0 = floor(w0), f1 = floor(w1), f2 = floor(w2);
-  const double r0 = w0 - f0, r1 = w1 - f1, r2 = w2 - f2;
-  const double m = 1e-6;
-  const bool safe = fabs(w0) < 20000.0 && fabs(w1) < 20000.0 && fabs(w2) < 20000.0 &&
-                    r0 > m && r0 < 1.0 - m && r1 > m && r1 < 1.0 - m && r2 > m && r2 < 1.0 - m;
-  if (safe) return key_from_voxels(f0, f1, f2);
+  const double m = 0.5 - 1.5e-8;
+  const bool safe = (fabs((w0 - f0) - 0.5) < m) & (fabs((w1 - f1) - 0.5) < m) & (fabs((w2 - f2) - 0.5) < m);
+  if (safe) {
+    // a W that passed the guard is no integer, so floor(W) in [0, 512) <=> 0 < W < 512 <=> |W - 256| < 256 (tested on the float64
+    // value, before any integer conversion: NaN / overflow safe)
+    if (!((fabs(w0 - 256.0) < 256.0) & (fabs(w1 - 256.0) < 256.0) & (fabs(w2 - 256.0) < 256.0))) return -1;
+    return ((int)f0 << 18) | ((int)f1 << 9) | (int)f2;
+  }
   return touch_key_exact(u, v, d, c, T);
 }
 
@@ -494,19 +498,21 @@ ER_HD double fast_rcp64(double x) {
 // q' - delta and q' + delta round to the same float, so does the reference value (rounding is monotonic).
 // Otherwise (a few pixels per million) the exact expression with its three divisions is evaluated.
 ER_HD void cube_coords(int u, int v, uint16_t d, const Camera& c, const CameraInv& ci, const double* seg, float out[3]) {
+  // Ray form: seg (x, y, z) = z (s0 (u - cx)/fx + s1 (v - cy)/fy + s2) + s3 -- 2 + 3 x 3 float64 operations.  Error against
+  // the reference's float64 value, in ulps of the summed magnitudes |s0| |x| + |s1| |y| + |s2| |z| + |s3|: z carries <= 2
+  // (the product with the rounded 0.001), the ray component <= 3.5 (rounded reciprocal focal length, three fused operations),
+  // the last fma 0.5, the reference's own sequence <= 5.5: <= 12 of the 18 the bound delta budgets.
   const double z = (double)d * 0.001;
-  const double x = (double)((float)u - c.cx) * z * ci.inv_fx;
-  const double y = (double)((float)v - c.cy) * z * ci.inv_fy;
+  const double xr = (double)((float)u - c.cx) * ci.inv_fx;
+  const double yr = (double)((float)v - c.cy) * ci.inv_fy;
   bool safe = true;
   for (int r = 0; r < 3; r++) {
-    // fused (4 operations instead of 6): fewer roundings than the reference's sequence, well inside delta (the bound
-    // budgets 18 ulp of the summed magnitudes; x, y, z carry <= 8 and the four operations <= 4 more)
-    // (the innermost product and sum stay separate: two scalar-register coefficients are one too many for a single fma)
-    const double q = fma(seg[4 * r], x, fma(seg[4 * r + 1], y, seg[4 * r + 2] * z + seg[4 * r + 3]));
+    const double q = fma(z, fma(seg[4 * r], xr, fma(seg[4 * r + 1], yr, seg[4 * r + 2])), seg[4 * r + 3]);
     const double delta = seg[12 + r];
-    const float f = (float)q;
-    safe = safe & ((float)(q - delta) == f) & ((float)(q + delta) == f);
-    out[r] = f;
+    // rounding is monotonic: when q - delta and q + delta round to the same float, so do q and the reference value between them
+    const float lo = (float)(q - delta), hi = (float)(q + delta);
+    safe = safe & (lo == hi);
+    out[r] = lo;
   }
   if (safe) return;
   double xe, ye, ze;
@@ -537,9 +543,19 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
 
 struct alignas(16) Vert4 { float x, y, z, w; };     // one lattice vertex padded to 16 bytes (one LDS / 16-byte read per vertex)
 
-// The lattice as ControlGrid keeps it (3 floats per vertex) or as Vert4 (the LDS copy k_reproject_scatter stages per workgroup).
-ER_HD void lattice_vertex(const float* __restrict__ ctr, int idx, float v[3]) { v[0] = ctr[idx * 3]; v[1] = ctr[idx * 3 + 1]; v[2] = ctr[idx * 3 + 2]; }
-ER_HD void lattice_vertex(const Vert4* __restrict__ ctr, int idx, float v[3]) { const Vert4 t = ctr[idx]; v[0] = t.x; v[1] = t.y; v[2] = t.z; }
+// The lattice as ControlGrid keeps it (3 floats per vertex) or as Vert4 (tier 1's 16-byte vertices).  Vertices are addressed by
+// UNSIGNED BYTE offsets from the (wave-uniform) lattice pointer: one 32-bit add per vertex and a scalar-base load, instead of
+// a sign extension, a multiplication by the vertex size and a 64-bit add each.
+ER_HD unsigned lattice_stride(const float*) { return 12u; }
+ER_HD unsigned lattice_stride(const Vert4*) { return 16u; }
+ER_HD void lattice_vertex(const float* __restrict__ ctr, unsigned byte_off, float v[3]) {
+  const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ctr) + byte_off);
+  v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+}
+ER_HD void lattice_vertex(const Vert4* __restrict__ ctr, unsigned byte_off, float v[3]) {
+  const Vert4 t = *reinterpret_cast<const Vert4*>(reinterpret_cast<const char*>(ctr) + byte_off);
+  v[0] = t.x; v[1] = t.y; v[2] = t.z;
+}
 
 // seg: rows 0..2 of the float64 4x4 followed by the three rounding bounds of cube_coords (15 doubles used, stride 16);
 // madj: rows 0..2 (12 doubles).  ctr: one grid, (res+1)^3 * 3 floats.
@@ -568,12 +584,13 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
   float r0 = a0 - f0, r1 = a1 - f1, r2 = a2 - f2;
   int n1 = res + 1, n2 = n1 * n1;
-  int base = c0 + c1 * n1 + c2 * n2;
+  const unsigned vs = lattice_stride(ctr);                                 // bytes per vertex
+  const unsigned base = (unsigned)(c0 + c1 * n1 + c2 * n2) * vs, s1 = (unsigned)n1 * vs, s2 = (unsigned)n2 * vs;
   float w0 = 1.0f - r0, w1 = 1.0f - r1, w2 = 1.0f - r2;
   float val[8] = {(w0 * w1) * w2, (w0 * w1) * r2, (w0 * r1) * w2, (w0 * r1) * r2,
                   (r0 * w1) * w2, (r0 * w1) * r2, (r0 * r1) * w2, (r0 * r1) * r2};
-  int idx[8] = {base,     base + n2,     base + n1,     base + n1 + n2,
-                base + 1, base + 1 + n2, base + 1 + n1, base + 1 + n1 + n2};
+  unsigned idx[8] = {base,      base + s2,      base + s1,      base + s1 + s2,
+                     base + vs, base + vs + s2, base + vs + s1, base + vs + s1 + s2};
   // ControlGrid::GetPosition, ControlGrid.h:82-87: left-to-right float32 sum
   float pos[3], vt[3];
   lattice_vertex(ctr, idx[0], vt);

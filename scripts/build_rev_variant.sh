@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build liber_hip.so of a git revision as an A/B variant:  scripts/build_rev_variant.sh NAME REV [-DFLAG ...]
+set -e
+R="$(cd "$(dirname "$0")/.." && pwd)"; name=$1; rev=$2; shift; shift
+T=$(mktemp -d); git -C "$R" archive "$rev" elasticreconstruction_amd/csrc include | tar -x -C "$T"
+mkdir -p "$R/elasticreconstruction_amd/_ab" "$T/o"
+cd "$T/elasticreconstruction_amd/csrc"
+for f in er_common.cpp er_tsdf.hip er_icp.hip er_fopt.hip er_multi.hip; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -Wno-bitwise-instead-of-logical "$@" -I../../include -x hip -c $f -o "$T/o/$f.o" &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "$T"/o/*.o -o "$R/elasticreconstruction_amd/_ab/liber_hip_$name.so"
+rm -rf "$T"; echo "built _ab/liber_hip_$name.so from $rev"

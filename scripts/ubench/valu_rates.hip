@@ -31,6 +31,21 @@ KERNEL(k_cvt_i32_f32, F32DECL, OP1("v_cvt_i32_f32"))
 KERNEL(k_cmp_f32, F32DECL, CMP("v_cmp_lt_f32"))
 KERNEL(k_divfixup_f32, F32DECL, OP3("v_div_fixup_f32"))
 KERNEL(k_divfmas_f32, F32DECL, OP3("v_div_fmas_f32"))
+KERNEL(k_mul_f32, F32DECL, OP2("v_mul_f32"))
+KERNEL(k_sub_f32, F32DECL, OP2("v_sub_f32"))
+KERNEL(k_max_f32, F32DECL, OP2("v_max_f32"))
+KERNEL(k_fmac_f32, F32DECL, OP2("v_fmac_f32"))
+KERNEL(k_mov_b32, F32DECL, OP1("v_mov_b32"))
+KERNEL(k_cvt_f32_i32, F32DECL, OP1("v_cvt_f32_i32"))
+// (round 2) integer and select instructions of the address / pixel-index arithmetic
+#define I32DECL unsigned a0 = (unsigned)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = a0 * 3 + 1
+KERNEL(k_add_u32, I32DECL, OP2("v_add_u32"))
+KERNEL(k_and_b32, I32DECL, OP2("v_and_b32"))
+KERNEL(k_mul_lo_u32, I32DECL, OP2("v_mul_lo_u32"))
+KERNEL(k_mul_u32_u24, I32DECL, OP2("v_mul_u32_u24"))
+KERNEL(k_mad_u32_u24, I32DECL, OP3("v_mad_u32_u24"))
+KERNEL(k_lshl_add_u32, I32DECL, OP3("v_lshl_add_u32"))
+KERNEL(k_cndmask_b32, I32DECL, asm volatile("v_cndmask_b32 %0, %0, %4, vcc\nv_cndmask_b32 %1, %1, %4, vcc\nv_cndmask_b32 %2, %2, %4, vcc\nv_cndmask_b32 %3, %3, %4, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b) : "vcc");)
 KERNEL(k_add_f64, F64DECL, OP2("v_add_f64"))
 KERNEL(k_fma_f64, F64DECL, OP3("v_fma_f64"))
 KERNEL(k_mul_f64, F64DECL, OP2("v_mul_f64"))
@@ -45,6 +60,28 @@ __global__ void k_cvt_f64_f32(float* out, float seed) {
     REP8(B) REP8(B) REP8(B) REP8(B)
   }
   if (seed == 12345.f) out[threadIdx.x] = (float)(d0 + d1 + d2 + d3);
+}
+#define PKKERNEL(name, ins)                                                                                          \
+  __global__ void name(float* out, float seed) {                                                                     \
+    typedef float f2 __attribute__((ext_vector_type(2)));                                                            \
+    f2 a0 = {seed, seed}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, b = a0 * .5f;                                 \
+    for (int it = 0; it < ITER; ++it) {                                                                               \
+      REP8(asm volatile(ins " %0, %0, %4\n" ins " %1, %1, %4\n" ins " %2, %2, %4\n" ins " %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) \
+      REP8(asm volatile(ins " %0, %0, %4\n" ins " %1, %1, %4\n" ins " %2, %2, %4\n" ins " %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) \
+      REP8(asm volatile(ins " %0, %0, %4\n" ins " %1, %1, %4\n" ins " %2, %2, %4\n" ins " %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) \
+      REP8(asm volatile(ins " %0, %0, %4\n" ins " %1, %1, %4\n" ins " %2, %2, %4\n" ins " %3, %3, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));) \
+    }                                                                                                                 \
+    if (seed == 12345.f) out[threadIdx.x] = a0.x + a1.y + a2.x + a3.y;                                               \
+  }
+PKKERNEL(k_pk_mul_f32, "v_pk_mul_f32")
+PKKERNEL(k_pk_add_f32, "v_pk_add_f32")
+__global__ void k_lshl_add_u64(float* out, float seed) {
+  unsigned long long a0 = (unsigned long long)seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, b = a0 * 3 + 1;
+  for (int it = 0; it < ITER; ++it) {
+#define L64 asm volatile("v_lshl_add_u64 %0, %0, 2, %4\nv_lshl_add_u64 %1, %1, 2, %4\nv_lshl_add_u64 %2, %2, 2, %4\nv_lshl_add_u64 %3, %3, 2, %4" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b));
+    REP8(L64) REP8(L64) REP8(L64) REP8(L64)
+  }
+  if (seed == 12345.f) out[threadIdx.x] = (float)(a0 + a1 + a2 + a3);
 }
 __global__ void k_pk_fma_f32(float* out, float seed) {
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -83,6 +120,12 @@ int main() {
     run("v_add_f64", k_add_f64, out, w); run("v_mul_f64", k_mul_f64, out, w); run("v_fma_f64", k_fma_f64, out, w);
     run("v_floor_f64", k_floor_f64, out, w); run("v_rcp_f64", k_rcp_f64, out, w); run("v_cmp_lt_f64", k_cmp_f64, out, w);
     run("v_cvt_f64_f32", k_cvt_f64_f32, out, w);
+    run("v_mul_f32", k_mul_f32, out, w); run("v_sub_f32", k_sub_f32, out, w); run("v_max_f32", k_max_f32, out, w); run("v_fmac_f32", k_fmac_f32, out, w);
+    run("v_mov_b32", k_mov_b32, out, w); run("v_cvt_f32_i32", k_cvt_f32_i32, out, w);
+    run("v_pk_mul_f32", k_pk_mul_f32, out, w); run("v_pk_add_f32", k_pk_add_f32, out, w);
+    run("v_add_u32", k_add_u32, out, w); run("v_and_b32", k_and_b32, out, w); run("v_mul_lo_u32", k_mul_lo_u32, out, w);
+    run("v_mul_u32_u24", k_mul_u32_u24, out, w); run("v_mad_u32_u24", k_mad_u32_u24, out, w); run("v_lshl_add_u32", k_lshl_add_u32, out, w);
+    run("v_cndmask_b32", k_cndmask_b32, out, w); run("v_lshl_add_u64", k_lshl_add_u64, out, w);
   }
   return 0;
 }

@@ -447,6 +447,53 @@ long hc_sure_stress(unsigned long long seed, long n, long* n_sure) {
   return wrong;
 }
 
+// touch_key (division-free, guarded) against touch_key_exact (the reference's expression): random cameras and poses with the
+// camera up to 150 m from the origin (so that keys outside the 512^3 unit lattice, i.e. -1, occur), depths over the whole
+// 16-bit range, and poses shifted so that the pixel's point lands within a few float64 ulps of a unit boundary (where the
+// guard must hand over to the exact path).  Returns the number of disagreements; *n_out = pixels whose key is -1.
+long hc_touch_key_stress(unsigned long long seed, long n, long* n_out) {
+  unsigned long long st = seed * 0xA24BAED4963EE407ull + 0x9E3779B9ull;
+  auto rnd = [&]() {
+    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+    return (double)((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+  };
+  long wrong = 0, out = 0;
+  for (long it = 0; it < n; it++) {
+    Camera cam;
+    cam.fx = (float)(20.0 * pow(100.0, rnd())); cam.fy = (float)(20.0 * pow(100.0, rnd()));
+    cam.cx = (float)(rnd() * 1280); cam.cy = (float)(rnd() * 960);
+    cam.icp_trunc = 2.5f; cam.integration_trunc = 2.5f;
+    CameraInv ci;
+    ci.inv_fx = 1.0 / (double)cam.fx; ci.inv_fy = 1.0 / (double)cam.fy; ci.pp_small = 1; ci.pad = 0;
+    double q[4], nq = 0;
+    for (double& c : q) { c = rnd() * 2 - 1; nq += c * c; }
+    nq = sqrt(nq) + 1e-300;
+    for (double& c : q) c /= nq;
+    double T[12] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]), 0,
+                    2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]), 0,
+                    2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2]), 0};
+    const double Rw = rnd() < 0.6 ? 3.0 : (rnd() < 0.5 ? 90.0 : 150.0);
+    for (int r = 0; r < 3; r++) T[4 * r + 3] = (rnd() * 2 - 1) * Rw;
+    const int u = (int)(rnd() * 1280), v = (int)(rnd() * 960);
+    const uint16_t d = (uint16_t)(1 + (int)(rnd() * 65534.99));
+    if (rnd() < 0.5) {                                         // move one axis onto a unit boundary (+- a few ulps)
+      double x, y, z;
+      uvd2xyz(u, v, d, cam, x, y, z);
+      const int r = (int)(rnd() * 3) % 3;
+      const double p = ((T[4 * r] * x + T[4 * r + 1] * y) + T[4 * r + 2] * z) + T[4 * r + 3];
+      const double unit = floor(p / kUnitLength / 64.0 + rnd() * 2 - 1);
+      double target = (unit * 64.0 - 0.5) * kUnitLength;       // voxel index flips here: p / ul + 0.5 == 64 unit
+      for (int b = (int)(rnd() * 7) - 3; b != 0; b += b < 0 ? 1 : -1) target = nextafter(target, b < 0 ? -1e300 : 1e300);
+      T[4 * r + 3] += target - p;
+    }
+    const int a = touch_key(u, v, d, cam, ci, T), b = touch_key_exact(u, v, d, cam, T);
+    wrong += a != b;
+    out += b < 0;
+  }
+  if (n_out) *n_out = out;
+  return wrong;
+}
+
 // band_quotient_core against the IEEE division it replaces on the device, for every float whose magnitude bits lie in
 // [lo, hi], both signs, compared as float64 bit patterns.  Returns the number of mismatches, the first one in *first.
 long hc_band_quotient_check(unsigned lo, unsigned hi, unsigned* first) {

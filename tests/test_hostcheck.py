@@ -48,6 +48,8 @@ def hc():
     for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations"):
         getattr(L, name).restype = C.c_long
         getattr(L, name).argtypes = [vp]
+    L.hc_touch_key_stress.restype = C.c_long
+    L.hc_touch_key_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_sure_stress.restype = C.c_long
     L.hc_sure_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_unit_keys.argtypes = [vp, vp]
@@ -375,6 +377,14 @@ def test_culling_verdict_stress(hc):
     assert sum(w for w, _ in res) == 0, res
     dead = sum(n for _, n in res)
     assert 8000 < dead < 72000, res                          # it decides both ways
+
+
+def test_touch_key_stress(hc):
+    """The guarded division-free unit key of k_prepare against the reference's expression: random cameras, poses up to 150 m
+    out (keys of -1 occur), the whole 16-bit depth range, and points placed within a few float64 ulps of a unit boundary."""
+    n_out = C.c_long(0)
+    assert hc.hc_touch_key_stress(5, 3000000, C.byref(n_out)) == 0
+    assert 100000 < n_out.value < 2500000, n_out.value
 
 
 def test_sure_classification_stress(hc):
