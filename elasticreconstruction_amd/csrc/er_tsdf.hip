@@ -53,6 +53,13 @@ enum { C_NUNITS = 0, C_NBATCH = 1 /* and 6, 7: one per pipeline slot */, C_POOL_
 constexpr int kDepth = ER_PIPE_DEPTH;    // batches in flight: voxel pass of n, pre-passes of n+1 and n+2
 constexpr int kAux = ER_AUX_STREAMS;     // pre-pass streams (batch b runs on stream b mod kAux)
 static_assert(kDepth >= 2 && kDepth <= 3 && kAux >= 1 && kAux <= 2 && kAux < kDepth, "pipeline shape");
+// Occupancy throttle of the pre-pass kernels: a dynamic LDS allocation they never touch limits how many of their workgroups a
+// CU holds (160 KB per CU), which leaves issue slots to k_integrate -- the kernel on the critical (main) stream -- while the
+// two pre-pass streams, which have slack, take a little longer (A/B: profiles/r02u_ab_prepass_throttle.txt).
+#ifndef ER_PRE_LDS
+#define ER_PRE_LDS 0
+#endif
+constexpr unsigned kPrePassLds = ER_PRE_LDS;
 constexpr int kNbatchSlot[3] = {C_NBATCH, C_NBATCH1, C_NBATCH2};
 constexpr int kZeroFlagSlot[2] = {C_ZERO_WRITE, C_ZERO_WRITE1};
 
@@ -949,7 +956,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   int* nbatch = h->counters + kNbatchSlot[p];
 
 #ifndef ER_INT_BLOCKS_PER_CU
-#define ER_INT_BLOCKS_PER_CU 8
+#define ER_INT_BLOCKS_PER_CU 10
 #endif
   const int wide_grid = h->n_cu * ER_INT_BLOCKS_PER_CU;
   uint32_t* zsrc = nullptr;
@@ -989,7 +996,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     zsrc = h->zbuf[a];
   }
 
-  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
+  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), kPrePassLds, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
                      h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
@@ -1289,7 +1296,7 @@ static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::
 #endif
   {
     // (staging the lattice in LDS for this kernel was measured as well: slower, profiles/r02d_ab_lds_lattice.txt)
-    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
+    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), kPrePassLds, X, RA);
   }
   hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(256), 0, X, RA);      // (one small workgroup: it has to find room next to two busy kernels)
   ER_HIP_TRY(hipGetLastError());
