@@ -280,7 +280,7 @@ constexpr int kTileKeys = 96;
 
 // Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
 // returned 0) appends the unit to the batch list.  The pool slot of a unit that is new to the volume is handed out
-// by k_plan on the main stream (the pre-passes of two batches run concurrently; the main stream is in order).
+// by k_integrate itself (unit_slot below): the pre-passes of two batches run concurrently, the voxel passes run in order.
 //
 // Unit-shard mode (the bit-exact multi-GPU alternative): with shard.y > 1 GPUs every GPU runs the pre-pass of
 // ALL frames but only owns -- allocates, integrates, reports -- the units with unit_owner(key) == shard.x.  Units are
@@ -398,28 +398,13 @@ struct Plan {
 
 __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, const int* __restrict__ nbatch,
                                               const unsigned long long* __restrict__ ht_mask, int* __restrict__ plan_entry,
-                                              Plan* __restrict__ plan, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
-                                              int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
+                                              Plan* __restrict__ plan) {
   __shared__ int hist[65];
   __shared__ int start[66];
   const int n = *nbatch;                            // <= hash capacity = size of plan_entry
   for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < n; t += blockDim.x) {
-    const int e = batch[t];
-    atomicAdd(&hist[__popcll(ht_mask[e])], 1);
-    // data_.find( key ) == end, TSDFVolume.cpp:55: a unit that is new to the volume gets its pool slot here -- on the main
-    // stream, one batch after the other, every unit once per batch list (pool memory is zero-filled up front)
-    if (ht_slot[e] < 0) {
-      const int s = atomicAdd(&counters[C_NUNITS], 1);
-      if (s < max_units) {
-        ht_slot[e] = s;
-        unit_key[s] = ht_key[e];
-      } else {
-        atomicOr(&counters[C_POOL_OVERFLOW], 1);
-      }
-    }
-  }
+  for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&hist[__popcll(ht_mask[batch[t]])], 1);
   __syncthreads();
   if (threadIdx.x == 0) {
     int acc = 0;
@@ -457,14 +442,44 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 #ifndef ER_INT_MINBLOCKS
 #define ER_INT_MINBLOCKS 1
 #endif
+// Pool slot of hash entry e for a wave of k_integrate; hands the slot out on the unit's first ever visit (data_.find( key ) ==
+// end, TSDFVolume.cpp:55; pool memory is zero-filled up front).  Voxel passes run one after the other on the main stream, so
+// only waves of THIS launch can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes
+// it; the others poll until it appears (the winner is a running wave, so they never wait for a workgroup that has not been
+// scheduled).  -3 = pool exhausted (reported by the host).  Wave-uniform: lane 0 acts, the result is broadcast.
+__device__ __noinline__ int unit_slot_acquire(int e, int key, int* __restrict__ ht_slot, int* __restrict__ unit_key, int max_units,
+                                              int* __restrict__ counters) {
+  int slot = -2;
+  if ((threadIdx.x & 63) == 0) {
+    if (atomicCAS(&ht_slot[e], -1, -2) == -1) {
+      const int s = atomicAdd(&counters[C_NUNITS], 1);
+      if (s < max_units) {
+        unit_key[s] = key;
+        __threadfence();
+        slot = s;
+      } else {
+        atomicOr(&counters[C_POOL_OVERFLOW], 1);
+        slot = -3;
+      }
+      atomicExch(&ht_slot[e], slot);
+    } else {
+      do {
+        slot = __hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (slot == -2) __builtin_amdgcn_s_sleep(8);
+      } while (slot == -2);
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(slot);
+}
+
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 template <bool kSure>
 __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
-    float2* __restrict__ pool, const int* __restrict__ ht_key, const int* __restrict__ ht_slot,
+    float2* __restrict__ pool, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, const Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
+    int tiles_x, int tiles_y, Camera cam, int cols, int rows, int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
@@ -484,9 +499,10 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     const int j0 = (item & 3) * 16;
     const int jlane = lane >> 4, jstep = 4, k0 = wave * 16, klane = lane & 15, jspan = 16, kspan = 16;
 #endif
-    const int slot = __builtin_amdgcn_readfirstlane(ht_slot[e]);
-    if (slot < 0) continue;                                             // pool overflow: reported by the host
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
+    int slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (slot < 0 && slot != -3) slot = unit_slot_acquire(e, key, ht_slot, unit_key, max_units, counters);   // first visit of the unit
+    if (slot < 0) continue;                                             // pool overflow: reported by the host
     unsigned long long m = uniform_u64(ht_mask[e]);
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
@@ -821,8 +837,10 @@ struct er_tsdf_s {
   uint16_t* depth_stage[kDepth] = {};              // host frames of the batch in flight, by pipeline slot
   uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
-  int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr, *plan_entry = nullptr;
-  Plan* plan = nullptr;
+  int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
+  int* plan_entry[kDepth] = {};
+  Plan* plan[kDepth] = {};
+  bool reset_pending[kDepth] = {};                  // k_reset of the slot's last batch has not been launched yet
   size_t key_scratch_cap = 0;
   // profiling
   bool profiling = false;
@@ -914,7 +932,22 @@ struct Staging {
   int gi[ER_MAX_BATCH];
 };
 
+// k_reset of a batch (clears the frame masks of its unit list, accounts the unit visits) is deferred: it runs on the pre-pass
+// stream of the batch that reuses the slot, off the main stream, whose per-batch chain is then ONE kernel.  Whoever needs the
+// accounts or leaves the pipeline (synchronise, profile read-out) flushes the pending ones on the main stream.
+int flush_resets(er_tsdf_t h) {
+  for (int q = 0; q < kDepth; q++)
+    if (h->reset_pending[q]) {
+      hipLaunchKernelGGL(k_reset, dim3(1), dim3(kBlock), 0, h->stream, h->batch[q], h->counters + kNbatchSlot[q], h->ht_mask[q], h->stats);
+      ER_HIP_TRY(hipGetLastError());
+      ER_HIP_TRY(hipEventRecord(h->int_done[q], h->stream));            // the slot's next user waits for this reset as well
+      h->reset_pending[q] = false;
+    }
+  return 0;
+}
+
 int sync_all(er_tsdf_t h) {
+  if (flush_resets(h)) return 1;
   if (h->copy_stream) ER_HIP_TRY(hipStreamSynchronize(h->copy_stream));
   for (int a = 0; a < kAux; a++) ER_HIP_TRY(hipStreamSynchronize(h->aux_stream[a]));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -924,8 +957,8 @@ int sync_all(er_tsdf_t h) {
 // One batch (<= ER_MAX_BATCH frames).  depth_dev: n * pixels uint16 on device (must be complete: the
 // pre-pass runs on the handle's auxiliary stream, which does not wait for the caller's stream).
 // Pipeline over three in-order streams, batch state triple-buffered by slot p = batch mod 3:
-//   aux stream b mod 2: [H2D constants] -> k_reproject_* -> k_prepare(p)        -> event pre_done[p]
-//   main stream       : wait pre_done[p] -> k_plan -> k_integrate(p) -> k_reset(p)  -> event int_done[p]
+//   aux stream b mod 2: wait int_done[p] -> [k_reset(p) of batch n-3] -> [H2D constants] -> k_reproject_* -> k_prepare(p) -> k_plan(p) -> event pre_done[p]
+//   main stream       : wait pre_done[p] -> k_integrate(p) -> event int_done[p]            (ONE kernel per batch: it is the critical path)
 // so the pre-passes of batches n+1 and n+2 (latency / float64 bound, each a serial chain of launches) overlap each other and
 // k_integrate of batch n (float32 VALU bound).  Round 1 ran one pre-pass stream (+23 % over no overlap); since the compact
 // patches of round 2 made k_integrate shorter than the pre-pass chain, the second pre-pass stream keeps the chip busy while
@@ -984,6 +1017,11 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   }
   // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
   if (h->used[p]) ER_HIP_TRY(hipStreamWaitEvent(X, h->int_done[p], 0));     // k_integrate of batch n-3 still reads dstage[p] / scaled[p] / masks[p]
+  if (h->reset_pending[p]) {
+    hipLaunchKernelGGL(k_reset, dim3(1), dim3(kBlock), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->stats);
+    ER_HIP_TRY(hipGetLastError());
+    h->reset_pending[p] = false;
+  }
   ER_HIP_TRY(hipMemcpyAsync(h->dstage[p], st, sizeof(Staging), hipMemcpyHostToDevice, X));
   ER_HIP_TRY(hipEventRecord(h->consts_done[p], X));
   if (warp) {
@@ -1000,13 +1038,11 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
                      h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry[p], h->plan[p]);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
   ER_HIP_TRY(hipStreamWaitEvent(S, h->pre_done[p], 0));
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, S, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry, h->plan, h->ht_key, h->ht_slot,
-                     h->unit_key, h->max_units, h->counters);
-  ER_HIP_TRY(hipGetLastError());
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (h->profiling) {
     ER_HIP_TRY(hipEventCreate(&e0));
@@ -1019,15 +1055,15 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   const bool sure = false;
 #endif
   hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
-                     h->ht_mask[p], h->plan_entry, h->plan, h->frames[p], h->scaled[p], h->tile_max[p], (h->cols + kTile - 1) / kTile,
-                     (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows);
+                     h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], (h->cols + kTile - 1) / kTile,
+                     (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows, h->unit_key, h->max_units, h->counters);
   if (h->profiling) {
     ER_HIP_TRY(hipEventRecord(e1, S));
     h->events.emplace_back(e0, e1);
   }
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(kBlock), 0, S, h->batch[p], nbatch, h->ht_mask[p], h->stats);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->int_done[p], S));
+  h->reset_pending[p] = true;                               // (launched by the slot's next user, or by flush_resets)
   h->used[p] = true;
   h->frames_done += n;
   return 0;
@@ -1125,8 +1161,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
-  ER_ALLOC(h->plan_entry, (size_t)cap * sizeof(int));
-  ER_ALLOC(h->plan, sizeof(Plan));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan_entry[q], (size_t)cap * sizeof(int));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan[q], sizeof(Plan));
 #undef ER_ALLOC
   hipStream_t s = h->stream;
   bool ok = hipMemsetAsync(h->pool, 0, (size_t)max_units * er::kUnitVox * sizeof(float2), s) == hipSuccess &&
@@ -1162,9 +1198,10 @@ int er_tsdf_destroy(er_tsdf_t h) {
     if (h->aux_stream[a]) (void)hipStreamSynchronize(h->aux_stream[a]);
   std::vector<void*> ptrs = {h->pool, h->ht_key, h->ht_slot, h->unit_key, h->counters, h->stats, h->lambda, h->T12, h->seg12, h->madj12,
                              h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->ctr4_dev[0], h->ctr4_dev[1], h->key_scratch,
-                             h->slot_scratch, h->plan_entry, h->plan};
+                             h->slot_scratch};
   for (int q = 0; q < kDepth; q++)
-    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q]})
+    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q],
+                    (void*)h->plan_entry[q], (void*)h->plan[q]})
       ptrs.push_back(x);
   for (int q = 0; q < kAux; q++) {
     ptrs.push_back(h->zbuf[q]);
@@ -1411,7 +1448,7 @@ int er_tsdf_reset(er_tsdf_t h) {
   for (int q = 0; q < kDepth; q++) ER_HIP_TRY(hipMemsetAsync(h->ht_mask[q], 0, (size_t)h->ht_cap * sizeof(unsigned long long), s));
   ER_HIP_TRY(hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s));
   ER_HIP_TRY(hipStreamSynchronize(s));
-  for (int q = 0; q < kDepth; q++) h->used[q] = false;
+  for (int q = 0; q < kDepth; q++) h->used[q] = h->reset_pending[q] = false;
   h->batch_no = 0;
   return 0;
 }
@@ -1591,7 +1628,7 @@ int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const
 int er_tsdf_set_profiling(er_tsdf_t h, int enable) {
   if (!h) return er::fail("er_tsdf_set_profiling: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
-  if (drain_events(h)) return 1;
+  if (flush_resets(h) || drain_events(h)) return 1;         // (pending resets would add their unit visits after the counters are cleared)
   h->profiling = enable != 0;
   h->ms_total = 0.0;
   h->launches = 0;
@@ -1604,6 +1641,7 @@ int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate
                         long* unit_visits) {
   if (!h) return er::fail("er_tsdf_get_profile: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
+  if (flush_resets(h)) return 1;
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   if (drain_events(h)) return 1;
   unsigned long long st[4] = {0, 0, 0, 0};
