@@ -295,17 +295,20 @@ long hc_inside_stress(unsigned long long seed, long n, long* n_inside) {
     }
     if (!ok) continue;
     const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
-    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~3;
+    // patch shape: the 16 x 16 (j, k) square k_integrate gives a wave (odd iterations) or the round-1 strip of 4 rows x 64
+    const bool square = (it & 1) != 0;
+    const int jn = square ? 16 : 4, kn = square ? 16 : 64;
+    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
     const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
     std::vector<float> tile_max((size_t)tiles_x * tiles_y, 1.0e4f);   // "depth everywhere": the culling half never fires
     bool inside = false;
     const float g0 = grid_coord(i, xs);
-    if (!patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs), f, cam, cols, rows,
+    if (!patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kn - 1, zs), f, cam, cols, rows,
                           tile_max.data(), tiles_x, tiles_y, &inside) || !inside)
       continue;
     ins++;
-    for (int j = j0; j < j0 + 4; j++)
-      for (int k = 0; k < 64; k++) {
+    for (int j = j0; j < j0 + jn; j++)
+      for (int k = k0; k < k0 + kn; k++) {
         const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
         unsigned ref_pixel = 0;
         const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
@@ -384,15 +387,17 @@ long hc_cull_stress(unsigned long long seed, long n, long* n_dead) {
         m = std::max(m, d);
       }
     const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
-    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~3;
+    const bool square = (it & 1) != 0;                         // 16 x 16 square (round 2) or 4 x 64 strip (round 1)
+    const int jn = square ? 16 : 4, kn = square ? 16 : 64;
+    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
     const float g0 = grid_coord(i, xs);
     bool inside = false;
-    if (patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + 3, ys), grid_coord(0, zs), grid_coord(63, zs), f, cam, cols, rows,
+    if (patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kn - 1, zs), f, cam, cols, rows,
                          tile_max.data(), tiles_x, tiles_y, &inside))
       continue;
     dead++;
-    for (int j = j0; j < j0 + 4; j++)
-      for (int k = 0; k < 64; k++) {
+    for (int j = j0; j < j0 + jn; j++)
+      for (int k = k0; k < k0 + kn; k++) {
         float S = 0.25f, W = 3.0f;
         if (voxel_update(S, W, g0, grid_coord(j, ys), grid_coord(k, zs), f, cam, cols, rows, img.data())) wrong++;
       }
