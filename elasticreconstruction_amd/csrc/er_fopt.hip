@@ -818,6 +818,28 @@ int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* 
 }
 
 // ---- on-device solve -------------------------------------------------------------------------------------------------
+// rocSOLVER's potrf has been seen to report a non-positive pivot (info 1096..1125 of 1125) for a matrix that IS positive
+// definite -- the same assembled matrix factors on the host -- when several PROCESSES use the GPU at once: 3-6 of 120-160 runs
+// of bin/FragmentOptimizer with four copies running concurrently, none in 40 runs alone (scripts/gpu_fopt_flake.py,
+// ER_FOPT_DIAG=1).  The assembly is cheap (a few ms), so the factor entry points assemble and factor again (at most
+// kFactorAttempts times, with a note on stderr) before they report the system as not positive definite.
+constexpr int kNotPositiveDefinite = 2;
+constexpr int kFactorAttempts = 3;
+
+}  // extern "C" (a template cannot have C linkage)
+template <typename Attempt>
+static int factor_with_retry(const char* what, Attempt attempt) {
+  int rc = 1;
+  for (int a = 0; a < kFactorAttempts; a++) {
+    rc = attempt();
+    if (rc != kNotPositiveDefinite) return rc;
+    if (a + 1 < kFactorAttempts)
+      fprintf(stderr, "liber_hip: %s: %s -- assembling and factoring again (attempt %d of %d)\n", what, er_last_error(), a + 2, kFactorAttempts);
+  }
+  return 1;
+}
+extern "C" {
+
 static int factor_common(er_fopt_t h, double* A, long n) {
   if (rocsolver_load(h->roc, h->stream)) return 1;
   if (!h->d_info) ER_HIP_TRY(hipMalloc((void**)&h->d_info, sizeof(int)));
@@ -827,11 +849,42 @@ static int factor_common(er_fopt_t h, double* A, long n) {
   }
   if (n > 2147483647L) return er::fail("system too large for rocSOLVER (%ld unknowns)", n);
   ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)n * sizeof(double)));
+  // ER_FOPT_DIAG=1 (debugging aid): keep a host copy of the assembled matrix and, if rocSOLVER reports a non-positive pivot,
+  // factor that copy on the host -- tells a wrong matrix (assembly) from a wrong factorisation.
+  std::vector<double> diag_copy;
+  if (getenv("ER_FOPT_DIAG")) {
+    diag_copy.resize((size_t)n * n);
+    ER_HIP_TRY(hipMemcpyAsync(diag_copy.data(), A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
   if (h->roc.dpotrf(h->roc.handle, kFillLower, (int)n, A, (int)n, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed");
   int info = 0;
   ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
-  if (info != 0) return er::fail("the assembled system is not positive definite (rocsolver_dpotrf info = %d)", info);
+  if (info != 0 && !diag_copy.empty()) {
+    // column-major lower triangle == the row-major upper triangle that was assembled: a(i, j) for j >= i at [i * n + j]
+    std::vector<double>& M = diag_copy;
+    long bad = 0;
+    for (long j = 0; j < n && !bad; j++) {                   // plain right-looking Cholesky on the upper triangle (U^T U)
+      double d = M[(size_t)j * n + j];
+      for (long k = 0; k < j; k++) d -= M[(size_t)k * n + j] * M[(size_t)k * n + j];
+      if (!(d > 0.0)) { bad = j + 1; break; }
+      d = sqrt(d);
+      M[(size_t)j * n + j] = d;
+      for (long c = j + 1; c < n; c++) {
+        double v = M[(size_t)j * n + c];
+        for (long k = 0; k < j; k++) v -= M[(size_t)k * n + j] * M[(size_t)k * n + c];
+        M[(size_t)j * n + c] = v / d;
+      }
+    }
+    er::fail("rocsolver_dpotrf info = %d; host Cholesky of the SAME assembled matrix: %s (pivot %ld)", info,
+             bad ? "ALSO not positive definite -> the matrix is wrong" : "positive definite -> the factorisation is wrong", bad);
+    return kNotPositiveDefinite;
+  }
+  if (info != 0) {
+    er::fail("the assembled system is not positive definite (rocsolver_dpotrf info = %d)", info);
+    return kNotPositiveDefinite;
+  }
   h->d_sys = A;
   h->sys_n = n;
   h->blocked = false;
@@ -839,7 +892,13 @@ static int factor_common(er_fopt_t h, double* A, long n) {
   return 0;
 }
 
+static int factor_slac_once(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score);
+
 int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score) {
+  return factor_with_retry("er_fopt_factor_slac", [&] { return factor_slac_once(h, pose_rot_t, default_weight, dataJb_host, score); });
+}
+
+static int factor_slac_once(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score) {
   if (!h || !pose_rot_t) return er::fail("er_fopt_factor_slac: bad arguments");
   ER_HIP_TRY(hipSetDevice(h->device));
   h->factored = false;
@@ -948,7 +1007,10 @@ static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
     int info = 0;
     ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     ER_HIP_TRY(hipStreamSynchronize(h->stream));
-    if (info != 0) return er::fail("the assembled system is not positive definite (fragment block %d, rocsolver_dpotrf info = %d)", k, info);
+    if (info != 0) {
+      er::fail("the assembled system is not positive definite (fragment block %d, rocsolver_dpotrf info = %d)", k, info);
+      return kNotPositiveDefinite;
+    }
     const std::vector<int>& rows = h->blk_rows[(size_t)k];
     for (int i : rows)                                            // L_ik = A_ik L_kk^-T
       if (h->roc.dtrsm(h->roc.handle, kSideRight, kFillLower, kOpT, kDiagNonUnit, B, B, &one, blk(k, k), B, blk(i, k), B) != 0)
@@ -991,7 +1053,13 @@ static int solve_blocked(er_fopt_t h) {                              // d_rhs <-
   return 0;
 }
 
+static int factor_nonrigid_once(er_fopt_t h, double weight);
+
 int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
+  return factor_with_retry("er_fopt_factor_nonrigid", [&] { return factor_nonrigid_once(h, weight); });
+}
+
+static int factor_nonrigid_once(er_fopt_t h, double weight) {
   if (!h) return er::fail("er_fopt_factor_nonrigid: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
   h->factored = false;

@@ -15,20 +15,32 @@ args = ["--num", "3", "--resolution", "4", "--length", "3.0", "--weight", "1.7",
 bg = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "1", "--cpu-sample", "0", "--icp-pairs", "0",
                         "--no-streamed", "--min-seconds", "60"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(hogs)]
 time.sleep(25)
-ref, bad, worst = None, 0, 0.0
+PAR = int(sys.argv[3]) if len(sys.argv) > 3 else 1           # copies of the program running at the same time (like pytest -n 4)
+from concurrent.futures import ThreadPoolExecutor
 t0 = time.time()
-for i in range(N):
+
+
+def one(i):
+    out = os.path.join(d, "o%d.ctr" % (i % PAR))
     cmd = [BIN] + args + ["--registration", os.path.join(d, "reg_output.log"), "--dir", d + "/", "--rgbdslam", os.path.join(d, "rgbd.log"),
-                          "--interval", "1", "--blacklistpair", "0", "--save_to", os.path.join(d, "o.ctr")]
+                          "--interval", "1", "--blacklistpair", "0", "--save_to", out]
     r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
     if r.returncode != 0:
-        bad += 1
         print("run %d FAILED: %s" % (i, r.stderr.strip()[-200:]), flush=True)
-        continue
-    c = np.loadtxt(os.path.join(d, "o.ctr"))
-    if ref is None:
-        ref = c
-    worst = max(worst, float(np.abs(c - ref).max()))
+        return None
+    return np.loadtxt(out)
+
+
+ref, bad, worst = None, 0, 0.0
+with ThreadPoolExecutor(PAR) as ex:
+    for lo in range(0, N, PAR):
+        for c in ex.map(one, range(lo, min(lo + PAR, N))):
+            if c is None:
+                bad += 1
+                continue
+            if ref is None:
+                ref = c
+            worst = max(worst, float(np.abs(c - ref).max()))
 for p in bg:
     p.kill()
-print("runs %d  failed %d  max |ctr - first| %.3e  (%.1f s, %d background benches)" % (N, bad, worst, time.time() - t0, hogs))
+print("runs %d (%d at a time)  failed %d  max |ctr - first| %.3e  (%.1f s, %d background benches)" % (N, PAR, bad, worst, time.time() - t0, hogs))
