@@ -3,6 +3,8 @@ seeded inputs, against the committed golden digests of the reference build, and 
 sizes -- through size-independent properties.  Bar: BIT-EXACT sdf_/weight_ (float32 bit patterns),
 identical unit key sets; only the multi-GPU frame-split merge is a float-tolerance test (1e-5,
 SURVEY.md 8e: it changes the summation order by construction)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -291,6 +293,43 @@ def test_full_config2_batching_invariance(gpu):
     assert a.sum_weight() == b.sum_weight() == c.sum_weight() > 4e9
     for v in (a, b, c):
         v.close()
+
+
+@pytest.mark.gpu
+def test_full_config2_equals_the_reference_build(gpu):
+    """BASELINE.json configs[1] at FULL size against the REFERENCE's own code: tests/golden/config2_golden.json holds the digest of
+    the volume that /root/reference/Integrate/*.cpp (compiled unmodified, driven through CIntegrateApp::Init / Execute on
+    pose.log / seg.log / .ctr) leaves after all 3000 frames with the control-grid warp (tests/golden/make_golden_config2.py).
+    The frames are re-rendered on the GPU from the committed camera poses (digest checked), integrated in bench.py's steps of
+    150 frames, and unit keys, every sdf_ and every weight_ array must be bit-identical."""
+    import hashlib
+    import json
+    import torch
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    z = np.load(os.path.join(gdir, "config2_inputs.npz"))
+    g = json.load(open(os.path.join(gdir, "config2_golden.json")))
+    n = int(g["frames"])
+    depth = synth.render_depth(z["world"], device="cuda:0")
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for lo in range(0, n, 250):
+        h.update(synth.to_numpy_u16(depth[lo:lo + 250]).tobytes())
+    assert h.hexdigest() == g["depth_sha256"], "synthetic renderer is not bit-reproducible on this device"
+    sc = dict(depth=depth, traj=z["traj"], pose=z["pose"], seg=z["seg"], grids=z["grids"], interval=int(z["meta"][0]),
+              resolution=int(z["meta"][1]), length=float(z["length"]), n=n)
+    warp = synth.warp_arrays(sc)
+    px = depth.shape[1]
+    vol = TSDFVolume(max_units=640)
+    for lo in range(0, n, 150):
+        hi = lo + 150
+        w = dict(ctr=warp["ctr"], resolution=warp["resolution"], length=warp["length"], grid_index=warp["grid_index"][lo:hi],
+                 seg=warp["seg"][lo:hi], madj=warp["madj"][lo:hi])
+        vol.IntegrateFrames(None, sc["traj"][lo:hi], w, device_ptr=depth.data_ptr() + lo * px * 2)
+    d = helpers.volume_digest(vol)
+    assert d["keys"] == g["volume"]["keys"], "unit key sets differ: %d vs %d units" % (len(d["keys"]), len(g["volume"]["keys"]))
+    assert d["sum_weight"] == g["volume"]["sum_weight"], (d["sum_weight"], g["volume"]["sum_weight"])
+    assert d["sha256"] == g["volume"]["sha256"], "volume differs from the reference build's"
+    vol.close()
 
 
 @pytest.mark.gpu
