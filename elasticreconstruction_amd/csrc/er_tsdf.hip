@@ -275,6 +275,9 @@ __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restric
 // left neighbour's append it to a small LDS list; after the barrier the list is de-duplicated and only
 // the DISTINCT keys of the tile go to the global hash map.  Without this every wave hammered the same
 // few hash entries with device-scope atomics at the same moment (measured: 90 % of wave time waiting).
+// Frames of the scaled-depth buffer are kScaledPad floats apart beyond their pixels; the pad stays 0.0f for ever (zero-filled at
+// create, never written): a voxel whose projection misses the image gathers from it instead of taking a predicated load.
+constexpr int kScaledPad = 64;
 constexpr int kTile = 32;
 constexpr int kTileKeys = 96;
 
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     int key = -1;
     if (x < cols && y < rows) {
       const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
-      scaled[(size_t)f * pixels + y * cols + x] = sc;
+      scaled[(size_t)f * (pixels + kScaledPad) + y * cols + x] = sc;
       wmax = fmaxf(wmax, sc);
       if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
         key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
@@ -532,18 +535,19 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
     }
-    while (m) {
-      const int f = __builtin_ctzll(m);
-      m &= m - 1;
+    // Frame loop in two halves: project() computes the pixel under every voxel of the four register rows and issues the depth
+    // gathers, finish() does the arithmetic that needs the samples.  -DER_FRAME_PIPELINE software-pipelines the loop over two
+    // frames (the gathers of frame n+1 in flight during the update of frame n; the waits become "all but the newest four
+    // loads"): measured, no gain -- 124.9 k vs 125.4 k frames/s, 108 VGPRs instead of 98 (profiles/r02x_ab_frame_pipeline.txt) --
+    // so the sequential order is the default.  Frames reach every voxel in ascending order either way.
+    auto project = [&](int f, float (&dp)[kRows]) {
       const FrameXform fx = frames[f];
-      const float* __restrict__ sc = scaled + (size_t)f * pixels;
-      // phase 1: project every row and issue its depth gather; phase 2: the arithmetic that needs the sample (the gathers'
-      // L2 latency overlaps the other rows' work: k_integrate 0.418 -> 0.390 ms, profiles/r01_ab_variants.txt run 11)
-      float dp[kRows];
+      const float* __restrict__ sc = scaled + (size_t)f * (pixels + kScaledPad);
+      unsigned pix[kRows];
 #ifndef ER_NO_INSIDE_PATH
       if ((m_in >> f) & 1ull) {                                          // wave-uniform
 #pragma unroll
-        for (int r = 0; r < kRows; r++) dp[r] = sc[voxel_project_inside(g0, g1[r], g2, fx, cam, cols, rows)];
+        for (int r = 0; r < kRows; r++) pix[r] = voxel_project_inside(g0, g1[r], g2, fx, cam, cols, rows);
       } else
 #endif
       {
@@ -551,32 +555,40 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
         for (int r = 0; r < kRows; r++) {
           unsigned pixel;
           const bool ok = voxel_project(g0, g1[r], g2, fx, cam, cols, rows, pixel);
-          dp[r] = ok ? sc[pixel] : 0.0f;                                 // dp = 0 fails ":82 dp > 0.001" like the reference's early out
+          pix[r] = ok ? pixel : (unsigned)pixels;                        // the frame's zero pad: dp = 0 fails ":82 dp > 0.001" like the reference's early out
         }
       }
+      // kRows UNCONDITIONAL gathers in straight-line code after the branches, nothing that depends on them here: the wait in
+      // finish() is then "all but the newest kRows loads" on every path (predicated loads or loads inside the branches make the
+      // count path-dependent and the compiler falls back to waiting for everything)
+#pragma unroll
+      for (int r = 0; r < kRows; r++) dp[r] = sc[pix[r]];
+    };
+    auto finish = [&](int f, const float (&dp)[kRows]) {
+      const FrameXform& fx = frames[f];                                  // (only the camera centre: three scalar loads)
       float d2[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0, g1[r], g2, fx);
       if (kSure) {
-      // Sure path (er_tsdf_math.h: voxel_classify): if every lane of the four rows is provably in free space (tsdf = 1) or
-      // provably behind the surface (no update) and every free lane holds S == 1 or W == 0, the whole update of this frame is
-      // "W += 1, S = 1" on the free lanes -- no square root, no band quotient, no division.  ~60 % of the (patch, frame)
-      // visits of configs[1] (every row that does not cross a surface); one wave-uniform branch per frame.
-      bool fre[kRows], need = false;
-#pragma unroll
-      for (int r = 0; r < kRows; r++) {
-        bool behind;
-        voxel_classify(dp[r], d2[r], fre[r], behind);
-        need = need | !(fre[r] | behind) | (fre[r] & !voxel_free_trivial(S[r], W[r]));
-      }
-      if (__ballot(need) == 0ull) {
+        // Sure path (er_tsdf_math.h: voxel_classify): if every lane of the four rows is provably in free space (tsdf = 1) or
+        // provably behind the surface (no update) and every free lane holds S == 1 or W == 0, the whole update of this frame is
+        // "W += 1, S = 1" on the free lanes -- no square root, no band quotient, no division.  78 % of the (patch, frame)
+        // visits of the golden scene; one wave-uniform branch per frame.
+        bool fre[kRows], need = false;
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
-          S[r] = fre[r] ? 1.0f : S[r];
-          W[r] = fre[r] ? W[r] + 1.0f : W[r];
+          bool behind;
+          voxel_classify(dp[r], d2[r], fre[r], behind);
+          need = need | !(fre[r] | behind) | (fre[r] & !voxel_free_trivial(S[r], W[r]));
         }
-        continue;
-      }
+        if (__ballot(need) == 0ull) {
+#pragma unroll
+          for (int r = 0; r < kRows; r++) {
+            S[r] = fre[r] ? 1.0f : S[r];
+            W[r] = fre[r] ? W[r] + 1.0f : W[r];
+          }
+          return;
+        }
       }
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
@@ -592,7 +604,41 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
         (void)upd;
 #endif
       }
+    };
+#ifndef ER_FRAME_PIPELINE
+    while (m) {
+      const int f = __builtin_ctzll(m);
+      m &= m - 1;
+      float dp[kRows];
+      project(f, dp);
+      finish(f, dp);
     }
+#else
+    if (m) {
+      float dpA[kRows], dpB[kRows];
+      int fa = __builtin_ctzll(m), fb;
+      m &= m - 1;
+      project(fa, dpA);
+      for (;;) {                                                         // every exit is wave-uniform
+        if (!m) {
+          finish(fa, dpA);
+          break;
+        }
+        fb = __builtin_ctzll(m);
+        m &= m - 1;
+        project(fb, dpB);                                                // gathers of the NEXT frame in flight ...
+        finish(fa, dpA);                                                 // ... while this frame's samples are consumed
+        if (!m) {
+          finish(fb, dpB);
+          break;
+        }
+        fa = __builtin_ctzll(m);
+        m &= m - 1;
+        project(fa, dpA);
+        finish(fb, dpB);
+      }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < kRows; r++)
       if (W[r] != W0[r]) slab[r * jstep * kUnitRes] = make_float2(S[r], W[r]);
@@ -1149,7 +1195,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->stats, 4 * sizeof(unsigned long long));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->batch[q], (size_t)cap * sizeof(int));
   ER_ALLOC(h->lambda, px * sizeof(float));
-  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->scaled[q], B * px * sizeof(float));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->scaled[q], B * (px + kScaledPad) * sizeof(float));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->zbuf[q], B * px * sizeof(uint32_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->lastzero[q], B * px * sizeof(uint32_t));
@@ -1170,7 +1216,9 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
             hipMemsetAsync(h->ht_slot, 0xFF, (size_t)cap * sizeof(int), s) == hipSuccess &&
             hipMemsetAsync(h->counters, 0, C_COUNT * sizeof(int), s) == hipSuccess &&
             hipMemsetAsync(h->stats, 0, 4 * sizeof(unsigned long long), s) == hipSuccess;
-  for (int q = 0; q < kDepth; q++) ok = ok && hipMemsetAsync(h->ht_mask[q], 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess;
+  for (int q = 0; q < kDepth; q++)
+    ok = ok && hipMemsetAsync(h->ht_mask[q], 0, (size_t)cap * sizeof(unsigned long long), s) == hipSuccess &&
+         hipMemsetAsync(h->scaled[q], 0, B * (px + kScaledPad) * sizeof(float), s) == hipSuccess;   // (the pads stay zero)
   for (int q = 0; q < kAux; q++)
     ok = ok && hipMemsetAsync(h->lastzero[q], 0, B * px * sizeof(uint32_t), s) == hipSuccess &&
          hipMemsetAsync(h->zbuf[q], 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
