@@ -443,6 +443,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=200, help="frames timed on the CPU reference (0 = skip)")
     ap.add_argument("--host-input", action="store_true",
                     help="hand the depth frames over as (pageable) HOST memory in the headline loop; never the headline configuration")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket every n-th k_integrate launch of the timed passes with HIP events (1 = every launch: costs ~2 %% of the rate; 0 = none)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra pass that streams the frames from page-locked host memory")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
@@ -563,7 +565,7 @@ def main():
             dt = float(t.item())
         return dt, nu
 
-    vol.set_profiling(True)
+    vol.set_profiling(max(args.event_stride, 0))
     pass_s, n_union = [], 0
     while True:
         dt, n_union = timed_pass(depth_host)
@@ -678,9 +680,11 @@ def main():
         if use_dist:
             out["config"]["merge_union_units"] = n_union
             out["config"]["merge_impl"] = args.merge_impl
-        launches = max(prof["launches"], 1)
-        ms_launch = prof["integrate_ms"] / launches
-        frames_per_launch = n_frames * n_pass / float(launches)
+        timed_launches = max(prof["launches"], 1)                 # every --event-stride-th launch of the timed passes carries HIP events
+        ms_launch = prof["integrate_ms"] / timed_launches
+        per_step = -(-S // 64)                                     # er_tsdf_integrate_frames: ceil(S / 64) launches of equal size per step
+        launches = n_pass * K * per_step
+        frames_per_launch = S / float(per_step)
         if prof["integrate_ms"] > 0:
             bytes_pass = 16.0 * sum_w + FRAME_BYTES_FIXED * n_frames + (2 * FRAME_BYTES_RAW * n_frames if warp_on else 0)
             per_launch = bytes_pass * n_pass / launches
@@ -709,6 +713,7 @@ def main():
                                if traffic else None,
                                "hbm_physical_frac": phys,
                                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms_launch, "launches": launches,
+                               "launches_timed": timed_launches, "event_stride": args.event_stride,
                                "frames_per_launch": frames_per_launch,
                                "voxel_updates_per_pass": sum_w, "unit_visits": prof["unit_visits"],
                                "note": ("rank 0 kernel; voxel updates = job total / ranks; " if world > 1 else "") +

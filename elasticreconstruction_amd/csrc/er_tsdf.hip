@@ -889,7 +889,8 @@ struct er_tsdf_s {
   bool reset_pending[kDepth] = {};                  // k_reset of the slot's last batch has not been launched yet
   size_t key_scratch_cap = 0;
   // profiling
-  bool profiling = false;
+  int prof_stride = 0;                              // 0 = off, n = time every n-th k_integrate launch
+  long prof_tick = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double ms_total = 0.0;
   long launches = 0, frames_done = 0;
@@ -1090,7 +1091,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 
   ER_HIP_TRY(hipStreamWaitEvent(S, h->pre_done[p], 0));
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (h->profiling) {
+  const bool timed = h->prof_stride > 0 && (h->prof_tick++ % h->prof_stride) == 0;
+  if (timed) {
     ER_HIP_TRY(hipEventCreate(&e0));
     ER_HIP_TRY(hipEventCreate(&e1));
     ER_HIP_TRY(hipEventRecord(e0, S));
@@ -1103,7 +1105,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], (h->cols + kTile - 1) / kTile,
                      (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows, h->unit_key, h->max_units, h->counters);
-  if (h->profiling) {
+  if (timed) {
     ER_HIP_TRY(hipEventRecord(e1, S));
     h->events.emplace_back(e0, e1);
   }
@@ -1677,7 +1679,8 @@ int er_tsdf_set_profiling(er_tsdf_t h, int enable) {
   if (!h) return er::fail("er_tsdf_set_profiling: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
   if (flush_resets(h) || drain_events(h)) return 1;         // (pending resets would add their unit visits after the counters are cleared)
-  h->profiling = enable != 0;
+  h->prof_stride = enable > 0 ? enable : 0;
+  h->prof_tick = 0;
   h->ms_total = 0.0;
   h->launches = 0;
   h->frames_done = 0;

@@ -194,7 +194,8 @@ class TSDFVolume:
 
     # -- profiling --------------------------------------------------------------------------------
     def set_profiling(self, enable):
-        _ffi.check(self._lib.er_tsdf_set_profiling(self._h, 1 if enable else 0), "er_tsdf_set_profiling")
+        """True / 1: time every k_integrate launch; n > 1: every n-th launch; False / 0: off."""
+        _ffi.check(self._lib.er_tsdf_set_profiling(self._h, int(enable)), "er_tsdf_set_profiling")
 
     def get_profile(self):
         ms, ln, fr, uv = C.c_double(0), C.c_long(0), C.c_long(0), C.c_long(0)

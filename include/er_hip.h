@@ -168,7 +168,9 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units);
 /* Contiguous frame block [lo, hi) of `rank` (IntegrateApp.cpp:190-226 is the loop being split). */
 void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi);
 
-/* Kernel timing (HIP events on the handle's stream around every IntegrateVolumeUnit launch). */
+/* Kernel timing: HIP events on the handle's stream around every `enable`-th IntegrateVolumeUnit launch (1 = every launch, 0 = off;
+ * each timed launch puts two more packets on the stream, about 2 % of the frame rate when every launch is timed).  get_profile
+ * returns the sum and the number of the TIMED launches, all frames and all unit visits since set_profiling. */
 int er_tsdf_set_profiling(er_tsdf_t h, int enable);
 int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate_launches, long* frames,
                         long* unit_visits);
