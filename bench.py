@@ -445,6 +445,8 @@ def main():
                     help="hand the depth frames over as (pageable) HOST memory in the headline loop; never the headline configuration")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket every n-th k_integrate launch of the timed passes with HIP events (1 = every launch: costs ~2 %% of the rate; 0 = none)")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra untimed pass that runs k_integrate alone (profiler runs: keeps "
+                                                            "the kernel-trace average comparable with roofline.avg_launch_ms)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra pass that streams the frames from page-locked host memory")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
@@ -583,7 +585,7 @@ def main():
     # so the kernel runs alone on the chip.  In the timed passes it shares the SIMDs with the pre-passes of the next two
     # batches, which is faster for the job and slower for the kernel; both durations are reported.
     alone = None
-    if rank == 0 and world == 1 and not args.host_input:
+    if rank == 0 and world == 1 and not args.host_input and not args.no_alone:
         vol.reset()
         vol.set_profiling(True)
         for lo in range(0, n_frames, I):

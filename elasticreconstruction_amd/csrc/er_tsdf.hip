@@ -443,7 +443,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 }
 
 #ifndef ER_INT_MINBLOCKS
-#define ER_INT_MINBLOCKS 1
+#define ER_INT_MINBLOCKS 5                // 5 workgroups of 4 waves per CU = 5 waves per SIMD: keeps the kernel at <= 96 VGPRs
+                                          // (98 would round up to 104 and cost the fifth wave: 125.2 k vs 126.9 k frames/s)
 #endif
 // Pool slot of hash entry e for a wave of k_integrate; hands the slot out on the unit's first ever visit (data_.find( key ) ==
 // end, TSDFVolume.cpp:55; pool memory is zero-filled up front).  Voxel passes run one after the other on the main stream, so
@@ -489,18 +490,27 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
   const int n_items = plan->n_units * (kUnitRes * 4);
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int e = plan_entry[item >> 8];
+#if defined(ER_ROW_PATCH)
+    // (round-1 mapping, kept for A/B: the wave owns 4 whole rows of 64 voxels of one slab, lane = k)
     const int i = (item >> 2) & 63;
-#ifdef ER_ROW_PATCH
-    // (round-1 mapping, kept for A/B: the wave owns 4 whole rows of 64 voxels, lane = k)
     const int j0 = (item & 3) * 16 + wave * kRows;
-    const int jlane = 0, jstep = 1, k0 = 0, klane = lane, jspan = kRows, kspan = kUnitRes;
-#else
-    // The wave owns a COMPACT 16 x 16 (j, k) square of the slab: register row r holds rows j0 + 4 r .. + 3, 16 voxels of k each
-    // (lane = 16 jj + kk), so every access is four fully used 128-byte lines.  A 9.4 cm square instead of a 2.3 x 37.5 cm strip:
-    // a tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and
-    // far fewer patches that cross a surface (the sure path below applies to most visits).
+    const int jlane = 0, jstep = 1, istep = 0, k0 = 0, klane = lane, jspan = kRows, kspan = kUnitRes, ispan = 1;
+#elif defined(ER_SQUARE_PATCH)
+    // (first compact shape of round 2, kept for A/B: a 16 x 16 (j, k) square of one slab; register row r holds rows j0 + 4 r .. + 3,
+    //  16 voxels of k each, lane = 16 jj + kk)
+    const int i = (item >> 2) & 63;
     const int j0 = (item & 3) * 16;
-    const int jlane = lane >> 4, jstep = 4, k0 = wave * 16, klane = lane & 15, jspan = 16, kspan = 16;
+    const int jlane = lane >> 4, jstep = 4, istep = 0, k0 = wave * 16, klane = lane & 15, jspan = 16, kspan = 16, ispan = 1;
+#else
+    // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
+    // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs
+    // x 16 x 16 voxels.  2.3 x 4.7 x 4.7 cm instead of the round-1 strip of 2.3 x 37.5 cm: a tighter pixel hull for the culling
+    // and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and far fewer patches that cross a surface
+    // (the sure path below applies to most visits).  Measured: strip 114.8 k -> 16 x 16 square 123.6 k -> box +1 % more
+    // (profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt).
+    const int i = ((item >> 4) & 15) * 4;
+    const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
+    const int jlane = lane >> 3, jstep = 0, istep = 1, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7, jspan = 8, kspan = 8, ispan = 4;
 #endif
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
     int slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -509,15 +519,18 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     unsigned long long m = uniform_u64(ht_mask[e]);
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
-    const float g0 = grid_coord(i, xs);
     const float g2 = grid_coord(k0 + klane, zs);
     float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + (j0 + jlane) * kUnitRes + k0 + klane;
-    float S[kRows], W[kRows], W0[kRows], g1[kRows];
+    float S[kRows], W[kRows], W0[kRows], g0[kRows], g1[kRows];           // (box: g0 per register row, g1 per lane; square / strip: the reverse)
 #pragma unroll
-    for (int r = 0; r < kRows; r++) g1[r] = grid_coord(j0 + jlane + r * jstep, ys);
+    for (int r = 0; r < kRows; r++) {
+      g0[r] = grid_coord(i + r * istep, xs);
+      g1[r] = grid_coord(j0 + jlane + r * jstep, ys);
+    }
+    const int row_stride = jstep * kUnitRes + istep * kUnitRes * kUnitRes;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {                                   // loads in flight while the culling preamble computes
-      const float2 v = slab[r * jstep * kUnitRes];                      // (loading only the surviving patches, after the culling,
+      const float2 v = slab[r * row_stride];                      // (loading only the surviving patches, after the culling,
       S[r] = v.x;                                                       //  was measured: no change, the kernel is VALU-bound --
       W[r] = v.y;                                                       //  profiles/r02f_ab_k_integrate_variants.txt)
       W0[r] = v.y;
@@ -530,8 +543,9 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     {
       bool keep = ((m >> lane) & 1ull) != 0ull, inside = false;
       if (keep)
-        keep = patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs),
-                                frames[lane], cam, cols, rows, tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside);
+        keep = patch_may_update_box(grid_coord(i, xs), grid_coord(i + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
+                                    grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), frames[lane], cam, cols, rows,
+                                    tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside);
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
     }
@@ -547,14 +561,14 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
 #ifndef ER_NO_INSIDE_PATH
       if ((m_in >> f) & 1ull) {                                          // wave-uniform
 #pragma unroll
-        for (int r = 0; r < kRows; r++) pix[r] = voxel_project_inside(g0, g1[r], g2, fx, cam, cols, rows);
+        for (int r = 0; r < kRows; r++) pix[r] = voxel_project_inside(g0[r], g1[r], g2, fx, cam, cols, rows);
       } else
 #endif
       {
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
           unsigned pixel;
-          const bool ok = voxel_project(g0, g1[r], g2, fx, cam, cols, rows, pixel);
+          const bool ok = voxel_project(g0[r], g1[r], g2, fx, cam, cols, rows, pixel);
           pix[r] = ok ? pixel : (unsigned)pixels;                        // the frame's zero pad: dp = 0 fails ":82 dp > 0.001" like the reference's early out
         }
       }
@@ -568,7 +582,7 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       const FrameXform& fx = frames[f];                                  // (only the camera centre: three scalar loads)
       float d2[kRows];
 #pragma unroll
-      for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0, g1[r], g2, fx);
+      for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0[r], g1[r], g2, fx);
       if (kSure) {
         // Sure path (er_tsdf_math.h: voxel_classify): if every lane of the four rows is provably in free space (tsdf = 1) or
         // provably behind the surface (no update) and every free lane holds S == 1 or W == 0, the whole update of this frame is
@@ -641,7 +655,7 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
 #endif
 #pragma unroll
     for (int r = 0; r < kRows; r++)
-      if (W[r] != W0[r]) slab[r * jstep * kUnitRes] = make_float2(S[r], W[r]);
+      if (W[r] != W0[r]) slab[r * row_stride] = make_float2(S[r], W[r]);
   }
 }
 

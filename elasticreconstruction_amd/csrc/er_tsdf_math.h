@@ -409,11 +409,18 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 // NaNs anywhere make a comparison false and the verdict false.  tests/hostcheck cross-checks every "inside" voxel of the golden
 // and fuzz scenes against voxel_project itself.
 //
-ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
-                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
+// The patch may also be a BOX [g0lo,g0hi] x [g1lo,g1hi] x [g2lo,g2hi] (eight corners): every argument above only uses that the
+// patch is convex with its extreme points among the tested corners -- t2 is affine (its extremes over the box are at corners),
+// a convex body in front of the camera projects into the convex hull of its corners, P is projective-linear on it -- and the
+// error sums A_k take the largest coordinate magnitudes of the patch.
+ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
+                                int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
   *inside = false;
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
+  const int n0 = g0hi != g0lo ? 2 : 1;
+  for (int o = 0; o < n0; o++)
   for (int a = 0; a < 2; a++) {
+    const float g0 = o ? g0hi : g0lo;
     const float g1 = a ? g1hi : g1lo;
     for (int b = 0; b < 2; b++) {
       const float g2 = b ? g2hi : g2lo;
@@ -457,13 +464,13 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
-  const float dx = g0 - f.tx;
+  const float dx = f.tx < g0lo ? g0lo - f.tx : (f.tx > g0hi ? f.tx - g0hi : 0.0f);
   const float dy = f.ty < g1lo ? g1lo - f.ty : (f.ty > g1hi ? f.ty - g1hi : 0.0f);
   const float dz = f.tz < g2lo ? g2lo - f.tz : (f.tz > g2hi ? f.tz - g2hi : 0.0f);
   const float dmin = sqrtf((dx * dx + dy * dy) + dz * dz);
   if (dmax_tile - dmin < -(float)kTsdfTrunc - 1e-4f) return false;   // every voxel is behind the surface by more than trunc
   {
-    const float a0 = fabsf(g0), G1 = fmaxf(fabsf(g1lo), fabsf(g1hi)), G2 = fmaxf(fabsf(g2lo), fabsf(g2hi));
+    const float a0 = fmaxf(fabsf(g0lo), fabsf(g0hi)), G1 = fmaxf(fabsf(g1lo), fabsf(g1hi)), G2 = fmaxf(fabsf(g2lo), fabsf(g2hi));
     const float e0 = 0x1p-21f * (((fabsf(f.mi[0]) * a0 + fabsf(f.mi[1]) * G1) + fabsf(f.mi[2]) * G2) + fabsf(f.mi[3]));
     const float e1 = 0x1p-21f * (((fabsf(f.mi[4]) * a0 + fabsf(f.mi[5]) * G1) + fabsf(f.mi[6]) * G2) + fabsf(f.mi[7]));
     const float e2 = 0x1p-21f * (((fabsf(f.mi[8]) * a0 + fabsf(f.mi[9]) * G1) + fabsf(f.mi[10]) * G2) + fabsf(f.mi[11]));
@@ -476,6 +483,12 @@ ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float 
               (umin >= 0.5f) & (umax <= (float)cols - 1.5f) & (vmin >= 0.5f) & (vmax <= (float)rows - 1.5f);
   }
   return true;
+}
+
+// The planar patch (x = g0) k_integrate gives a wave by default.
+ER_HD bool patch_may_update(float g0, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
+                            int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
+  return patch_may_update_box(g0, g0, g1lo, g1hi, g2lo, g2hi, f, c, cols, rows, tile_max, tiles_x, tiles_y, inside);
 }
 
 // ---- A6/A7: one source pixel of Reproject, IntegrateApp.cpp:250-259 ------------------------------

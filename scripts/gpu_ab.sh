@@ -8,5 +8,5 @@ echo "pytest exit $? after ${SECONDS}s" >> gpurun_out/pytest_gpu_$TAG.log; tail 
 echo "== t=${SECONDS}s A/B"
 bash scripts/ab_libs.sh $REPS "$@" > gpurun_out/ab_$TAG.txt 2>&1; cat gpurun_out/ab_$TAG.txt
 echo "== t=${SECONDS}s stats"
-bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --min-seconds 0.01 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -8
+bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --min-seconds 0.01 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -8
 echo "== done t=${SECONDS}s"

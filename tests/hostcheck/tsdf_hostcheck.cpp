@@ -14,6 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
+static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 0 = the 16 x 16 square (-DER_SQUARE_PATCH)
 struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0; };
 
 static bool inverse4(const double* m, double* out);
@@ -150,16 +151,20 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
     if (u.frames.empty()) continue;
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
-    for (int i = 0; i < 64; i++)
-      for (int jk = 0; jk < 16; jk++) {
-        const int j0 = (jk >> 2) * 16, k0 = (jk & 3) * 16;
-        // the same (16 x 16 voxel square of slab i, frame) culling k_integrate applies before its frame loop
+    // patch shape of a wave: 1 = the 4 x 8 x 8 box (k_integrate's default), 0 = the 16 x 16 (j, k) square of one slab (-DER_SQUARE_PATCH)
+    const int n_patches = g_patch_shape ? 16 * 64 : 64 * 16;
+    for (int pi = 0; pi < n_patches; pi++) {
+      {
+        int i0, j0, k0, ni, nj, nk;
+        if (g_patch_shape) { i0 = (pi >> 6) * 4; j0 = ((pi >> 3) & 7) * 8; k0 = (pi & 7) * 8; ni = 4; nj = 8; nk = 8; }
+        else { i0 = pi >> 4; j0 = ((pi >> 2) & 3) * 16; k0 = (pi & 3) * 16; ni = 1; nj = 16; nk = 16; }
+        // the same (patch, frame) culling k_integrate applies before its frame loop
         std::vector<int> frames;
         std::vector<char> in;
         for (int f : u.frames) {
           bool inside = false;
-          if (patch_may_update(grid_coord(i, xs), grid_coord(j0, ys), grid_coord(j0 + 15, ys), grid_coord(k0, zs), grid_coord(k0 + 15, zs),
-                               fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside)) {
+          if (patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + ni - 1, xs), grid_coord(j0, ys), grid_coord(j0 + nj - 1, ys), grid_coord(k0, zs),
+                                   grid_coord(k0 + nk - 1, zs), fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside)) {
             frames.push_back(f);
             in.push_back(inside);
             kept++;
@@ -168,16 +173,21 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
             culled++;
           }
         }
+        auto voxel_of = [&](int t, int& i, int& j, int& k) {
+          if (g_patch_shape) { i = i0 + (t >> 6); j = j0 + ((t >> 3) & 7); k = k0 + (t & 7); }
+          else { i = i0; j = j0 + (t >> 4); k = k0 + (t & 15); }
+        };
         // frame-major over the patch, like the wave of k_integrate: all 256 lanes against frame q, then the next frame
-        const float g0 = grid_coord(i, xs);
         float dpv[256], d2v[256];
         bool frev[256], behv[256];
         for (size_t q = 0; q < frames.size(); q++) {
           const int f = frames[q];
           bool need = false, unsure_any = false;
           for (int t = 0; t < 256; t++) {
-            const int j = j0 + (t >> 4), k = k0 + (t & 15), l = (i * 64 + j) * 64 + k;
-            const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
+            int i, j, k;
+            voxel_of(t, i, j, k);
+            const int l = (i * 64 + j) * 64 + k;
+            const float g0 = grid_coord(i, xs), g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
             float dp = 0.0f;                                // k_integrate: dp = 0 where the projection fails
             if (in[q]) {                                    // k_integrate's shortcut, cross-checked against the full test
               const unsigned pixel = voxel_project_inside(g0, g1, g2, fx[f], v->cam, v->cols, v->rows);
@@ -209,7 +219,9 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           v->sure += !need;
           v->unsure_pf += unsure_any;
           for (int t = 0; t < 256; t++) {
-            const int j = j0 + (t >> 4), k = k0 + (t & 15), l = (i * 64 + j) * 64 + k;
+            int i, j, k;
+            voxel_of(t, i, j, k);
+            const int l = (i * 64 + j) * 64 + k;
             float S2 = u.sdf[l], W2 = u.w[l];
             voxel_finish_d2(S2, W2, dpv[t], d2v[t]);
             if (behv[t] || (frev[t] && voxel_free_trivial(u.sdf[l], u.w[l]))) {
@@ -222,12 +234,14 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           }
         }
       }
+    }
   }
   v->culled += culled;
   v->kept += kept;
   return 0;
 }
 
+void hc_set_patch_shape(int shape) { g_patch_shape = shape; }
 long hc_sure(void* h) { return static_cast<HcVolume*>(h)->sure; }
 long hc_visited(void* h) { return static_cast<HcVolume*>(h)->visited; }
 long hc_unsure_pf(void* h) { return static_cast<HcVolume*>(h)->unsure_pf; }

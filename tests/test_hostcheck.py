@@ -48,6 +48,8 @@ def hc():
     for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations"):
         getattr(L, name).restype = C.c_long
         getattr(L, name).argtypes = [vp]
+    L.hc_set_patch_shape.restype = None
+    L.hc_set_patch_shape.argtypes = [C.c_int]
     L.hc_touch_key_stress.restype = C.c_long
     L.hc_touch_key_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_sure_stress.restype = C.c_long
@@ -123,7 +125,18 @@ def test_device_math_rigid_matches_golden(hc):
     assert hc.hc_inside_violations(v.h) == 0 and inside > 0.4 * kept
 
 
-def test_device_math_warp_matches_golden(hc):
+@pytest.mark.parametrize("shape", [0, 1])
+def test_device_math_warp_matches_golden(hc, shape):
+    """shape 1: the 4 x 8 x 8 box k_integrate gives a wave (patch_may_update_box with eight corners); shape 0: the 16 x 16 square
+    of one slab (-DER_SQUARE_PATCH on the device).  Same golden digests either way: the culling and both shortcuts are exact."""
+    hc.hc_set_patch_shape(shape)
+    try:
+        _warp_matches_golden(hc)
+    finally:
+        hc.hc_set_patch_shape(1)
+
+
+def _warp_matches_golden(hc):
     sc = helpers.golden_warp()
     g = helpers.golden()["warp"]
     depth = synth.to_numpy_u16(sc["depth"])
