@@ -13,15 +13,18 @@
 //   scaled    float[64][rows*cols]            scaled depth of every frame of the batch in flight
 //   zbuf      uint32[64][rows*cols]           Reproject's z-buffer (atomicMin; 0xFFFFFFFF = empty)
 //
-// Launch sequence for a batch of <= 64 frames (er_tsdf_integrate_frames):
+// Launch sequence for a batch of <= 64 frames (er_tsdf_integrate_frames); three batches are in flight (run_batch):
+//  pre-pass stream (batch b on stream b mod 2):
+//   k_reset        clears the frame masks of the slot's previous batch (deferred from the main stream)
 //   [k_reproject_scatter -> k_reproject_fix]          per SOURCE pixel: warp + scatter-min   (A6/A7)
 //   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
-//                  allocates the unit on first ever touch, appends it to the batch list
+//                  appends the unit to the batch list
 //   k_plan         sorts the batch's units by cost (frames in the mask) for a balanced static deal
-//   k_integrate    per (unit, i-slab, quarter): each voxel is loaded ONCE, run against every frame (A4)
-//                  whose bit is set IN FRAME ORDER, stored once -> bit-identical to the
-//                  reference's frame-by-frame loop with 1/batch of its HBM traffic
-//   k_reset        clears the masks of the batch list
+//  main stream:
+//   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every   (A4)
+//                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
+//                  frame-by-frame loop with 1/batch of its HBM traffic; hands out the pool slot of a unit
+//                  on its first ever visit
 // All kernels are HBM/latency/VALU work on scattered voxels and pixels: no MFMA.
 #include "er_common.h"
 #include "er_tsdf_math.h"
@@ -428,13 +431,14 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
-// Work item = (unit, i-slab, quarter) = 16 rows x 64 voxels for one 256-thread workgroup; each wave owns
-// kRows = 4 rows.  lane = k, so one voxel row is a 512-byte coalesced float2 access; the rows stay in
-// registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform loop: the
-// frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
-// Items are dealt round-robin in cost order (k_plan).  Schedules measured on MI355X (profiles/
-// r01_ab_variants.txt, ms per 50-frame launch): whole slabs 0.565; these quarter slabs 0.497 (VALU 90 %
-// busy, L2 hit rate 91 %); XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25.
+// Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in
+// kRows = 4 register rows of 64 -- since round 2 a 4 x 8 x 8 box (see the mapping below; round 1: four rows of 64 voxels,
+// lane = k).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
+// loop: the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
+// Items are dealt round-robin in cost order (k_plan).  Schedules measured on MI355X in round 1 (profiles/
+// r01_ab_variants.txt, ms per 50-frame launch): whole slabs 0.565; quarter slabs 0.497 (VALU 90 %
+// busy, L2 hit rate 91 %); XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25; round 2: a global work queue
+// (profiles/r02z_ab_dynamic_items.txt).
 #ifdef ER_STATS
 __device__ unsigned long long g_stats[4];
 #endif
@@ -1038,7 +1042,7 @@ int sync_all(er_tsdf_t h) {
 }
 
 // One batch (<= ER_MAX_BATCH frames).  depth_dev: n * pixels uint16 on device (must be complete: the
-// pre-pass runs on the handle's auxiliary stream, which does not wait for the caller's stream).
+// pre-passes run on the handle's auxiliary streams, which do not wait for the caller's stream).
 // Pipeline over three in-order streams, batch state triple-buffered by slot p = batch mod 3:
 //   aux stream b mod 2: wait int_done[p] -> [k_reset(p) of batch n-3] -> [H2D constants] -> k_reproject_* -> k_prepare(p) -> k_plan(p) -> event pre_done[p]
 //   main stream       : wait pre_done[p] -> k_integrate(p) -> event int_done[p]            (ONE kernel per batch: it is the critical path)

@@ -68,7 +68,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
 int er_tsdf_destroy(er_tsdf_t h);
 
 /* Run the handle's voxel pass and every other call on an existing hipStream_t (e.g. torch's current stream).
- * NULL = the handle's own stream.  (The pre-pass always uses an internal auxiliary stream.) */
+ * NULL = the handle's own stream.  (The pre-passes always use two internal auxiliary streams.) */
 int er_tsdf_set_stream(er_tsdf_t h, void* hip_stream);
 int er_tsdf_synchronize(er_tsdf_t h);
 
