@@ -28,16 +28,20 @@ def pair_shard(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def union_keys(local_keys, dist, device):
-    """Union of the per-rank touched unit keys (sorted int32 numpy).  The ranks first AGREE on the padded length
-    (all_reduce(MAX) of the local counts), then exchange the keys in ONE fixed-size all-gather (padded with -1): tensor
-    shapes are identical on every rank whatever each rank touched."""
+def union_keys(local_keys, dist, device, pad_to=None):
+    """Union of the per-rank touched unit keys (sorted int32 numpy) in ONE fixed-size all-gather (padded with -1): tensor shapes
+    are identical on every rank whatever each rank touched.  pad_to = a length every rank knows without talking (the volume's
+    max_units: a rank cannot hold more keys than that); without it the ranks first AGREE on the padded length with an
+    all_reduce(MAX) of the local counts -- one more collective."""
     import torch
     world = dist.get_world_size()
     keys = np.ascontiguousarray(local_keys, np.int32)
-    cnt = torch.tensor([keys.size], dtype=torch.int64, device=device)
-    dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-    max_keys = max(int(cnt.item()), 1)
+    if pad_to is not None and keys.size <= int(pad_to):
+        max_keys = max(int(pad_to), 1)
+    else:
+        cnt = torch.tensor([keys.size], dtype=torch.int64, device=device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+        max_keys = max(int(cnt.item()), 1)
     pad = torch.full((max_keys,), -1, dtype=torch.int32)
     if keys.size:
         pad[:keys.size] = torch.from_numpy(keys)
@@ -57,7 +61,7 @@ def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
     is SAFE for any stream set-up: the volume's streams are drained after the export and torch's current stream (the one
     the collective is ordered on) is drained before the import -- two host waits, once per job."""
     import torch
-    union = union_keys(vol.unit_keys(), dist, device)
+    union = union_keys(vol.unit_keys(), dist, device, pad_to=getattr(vol, "max_units", None))
     if union.size == 0:
         return 0
     buf = torch.empty((union.size, 2, 64 ** 3), dtype=torch.float32, device=device)

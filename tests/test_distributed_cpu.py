@@ -73,6 +73,8 @@ def _worker(rank, world, port, q):
     local_keys = vol.unit_keys()
     import copy
     vol_ar = copy.deepcopy(vol)
+    vol_ar.max_units = 256                       # the all_reduce variant takes the one-collective key union (padded to max_units),
+                                                 # the reduce variant below the two-collective one (no max_units attribute)
     n_union = parallel.merge_volumes(vol, dist, torch.device("cpu"))                       # reduce to rank 0
     n_union_ar = parallel.merge_volumes(vol_ar, dist, torch.device("cpu"), mode="all_reduce")
     same = n_union == n_union_ar and all(np.array_equal(vol_ar.units[k][1], vol.units[k][1]) for k in vol.units) if rank == 0 else True
