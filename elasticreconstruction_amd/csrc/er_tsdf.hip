@@ -162,73 +162,68 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   reproject_scatter_px(A, f, u, v, 0);
 }
 
-// Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1").  A workgroup owns a 64 x 16 pixel tile of one frame, each
-// thread 4 pixels of one column.  The frame's control lattice is staged in LDS as one 16-byte vertex each (all pixels of a
-// tile fall into one or two lattice cells, so the 8 vertex reads per pixel are LDS broadcasts instead of 24 global gathers).
-//   tier 1  every pixel: float64 lattice coordinates (no guard needed: they only feed the estimate), float32 trilinear sum,
-//           float32 projection, and the per-pixel proof that the three roundings and every range test of the reference are
-//           decided by the estimate -> scatter (or drop) at once;
-//   tier 2  the few per cent it cannot decide are appended to an LDS list and then run through the exact chain
-//           (reproject_scatter_px) by the first threads of the workgroup: ~50 of 1024 pixels -> one wave instead of sixteen.
+// Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1"), as TWO kernels with one source pixel per thread each:
+//   k_reproject_tier  every pixel: float64 lattice coordinates (no guard needed: they only feed the estimate), float32 trilinear
+//                     sum over 16-byte vertices, float32 projection, and the per-pixel proof that the three roundings and every
+//                     range test of the reference are decided by the estimate -> scatter (or drop) at once; each wave leaves the
+//                     64-bit mask of the pixels it could NOT decide (a few per cent);
+//   k_reproject_tail  gathers the set bits of 64 such masks per wave into an LDS list (wave scan, no atomics) and runs the listed
+//                     pixels through the exact chain (reproject_scatter_px) with all lanes busy.
 // Results are the reference's for every pixel either way (tests: hostcheck replay on the CPU, golden digests and fuzz on the GPU).
-#ifndef ER_RT_PIX
-#define ER_RT_PIX 4                      // pixels per thread (one column of the tile)
-#endif
-constexpr int kRtW = 64, kRtPix = ER_RT_PIX, kRtH = 4 * kRtPix;
-
-__global__ __launch_bounds__(kBlock) void k_reproject_tiered(ReprojArgs A, const ReprojFast* __restrict__ fast, const Vert4* __restrict__ ctr4) {
-  extern __shared__ Vert4 s_ctr[];
-  __shared__ unsigned short s_unsure[kRtW * kRtH];
-  __shared__ int s_n;
-  const int f = blockIdx.z, tid = threadIdx.x;
-  const int n1 = A.res + 1, verts = n1 * n1 * n1;
-  const Vert4* __restrict__ g4 = ctr4 + (size_t)A.grid_index[f] * verts;
-  for (int i = tid; i < verts; i += kBlock) s_ctr[i] = g4[i];
-  if (tid == 0) s_n = 0;
-  const ReprojFast& F = fast[f];                                        // wave-uniform: scalar loads
-  const int lx = tid & 63, ly0 = (tid >> 6) * kRtPix;
-  const int u = blockIdx.x * kRtW + lx, v0 = blockIdx.y * kRtH + ly0;
+// History: v1 / v2 (round 2 calls b, c) kept the undecided pixels of a 64 x 16 tile in an LDS list and ran four pixels per
+// thread with the lattice staged in LDS: 111 VGPRs, a barrier per tile -- slower than the exact kernel.  v3 appended the undecided
+// pixels to ONE global list with an atomic per wave: 200 k same-address atomics per batch across 8 XCDs = 5x slower job.
+__global__ __launch_bounds__(kBlock) void k_reproject_tier(ReprojArgs A, const ReprojFast* __restrict__ fast, const Vert4* __restrict__ ctr4,
+                                                           unsigned long long* __restrict__ masks) {
+  const int f = blockIdx.z, lane = threadIdx.x & 63;
+  const int u = blockIdx.x * 64 + lane;
+  const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const bool live = u < A.cols && v < A.rows;
   const int pixels = A.cols * A.rows;
-  const uint16_t* __restrict__ src = A.depth + (size_t)f * pixels;
-  int d[kRtPix];
-#pragma unroll
-  for (int j = 0; j < kRtPix; j++) {                                    // clamped address + select: no branches around the loads
-    const int t = src[min(v0 + j, A.rows - 1) * A.cols + min(u, A.cols - 1)];
-    d[j] = (u < A.cols && v0 + j < A.rows) ? t : 0;
+  const int p = v * A.cols + u;
+  const uint16_t d = live ? A.depth[(size_t)f * pixels + p] : (uint16_t)0;
+  int cls = kReprojReject, cell = 0;
+  uint16_t dd = 0;
+  if (d != 0) {                                                          // UVD2XYZ false otherwise
+    const ReprojFast& F = fast[f];                                       // wave-uniform: scalar loads
+    const int n1 = A.res + 1;
+    const double up = (double)((float)u - A.cam.cx), vp = (double)((float)v - A.cam.cy);   // UVD2XYZ: int - float in float32, then promoted
+    const double g[3] = {fma(F.gb[0], vp, fma(F.ga[0], up, F.gc[0])), fma(F.gb[1], vp, fma(F.ga[1], up, F.gc[1])),
+                         fma(F.gb[2], vp, fma(F.ga[2], up, F.gc[2]))};
+    cls = reproject_fast(d, g, F, A.cam, ctr4 + (size_t)A.grid_index[f] * (n1 * n1 * n1), n1, A.cols, cell, dd);
+    if (cls == kReprojAccept) scatter_px(A, f, p, cell, dd, 0);
   }
-  // stage A for every pixel of the thread
-  RtPix P[kRtPix];
-  {
-    const double up = (double)((float)u - A.cam.cx);                    // UVD2XYZ: int - float in float32, then promoted
-    const double gu[3] = {fma(F.ga[0], up, F.gc[0]), fma(F.ga[1], up, F.gc[1]), fma(F.ga[2], up, F.gc[2])};
-#pragma unroll
-    for (int j = 0; j < kRtPix; j++) {
-      const double vp = (double)((float)(v0 + j) - A.cam.cy);
-      const double g[3] = {fma(F.gb[0], vp, gu[0]), fma(F.gb[1], vp, gu[1]), fma(F.gb[2], vp, gu[2])};
-      rt_stage_a(d[j], g, F, n1, P[j]);
-    }
+  const unsigned long long mb = __ballot(cls == kReprojUnsure);
+  if (lane == 0) masks[(((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = mb;
+}
+
+// n_waves = frames * gy * gx * 4 masks (one per wave of k_reproject_tier, in its launch order); gx, gy = its grid.
+__global__ __launch_bounds__(kBlock) void k_reproject_tail(ReprojArgs A, const unsigned long long* __restrict__ masks, int n_waves, int gx, int gy) {
+  __shared__ unsigned short s_list[kBlock / 64][64 * 64];               // per wave: (source wave within the group) << 6 | pixel bit
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int group = (blockIdx.x * (kBlock / 64) + wv) * 64;             // first source wave of this wave's group
+  const int src = group + lane;
+  unsigned long long m = src < n_waves ? masks[src] : 0ull;
+  int cnt = __popcll(m), off = cnt;
+  for (int sft = 1; sft < 64; sft <<= 1) {                               // inclusive wave scan of the counts
+    const int t = __shfl_up(off, sft);
+    if (lane >= sft) off += t;
   }
-  __syncthreads();                                                      // the lattice is in LDS
-  // stages C and E two pixels at a time: 16 LDS vertex reads in flight, registers for two pixels' vertices only
-#pragma unroll
-  for (int j = 0; j < kRtPix; j++) {
-    float pos[3];
-    rt_stage_c(P[j], s_ctr, n1, pos);
-    int cell, dd;
-    const int cls = rt_stage_e(d[j] != 0, P[j], pos, F, A.cam.cx, A.cam.cy, A.cols, cell, dd);
-    if (cls == kReprojAccept) {
-      scatter_px(A, f, (v0 + j) * A.cols + u, cell, (uint16_t)dd, 0);
-    } else if (cls == kReprojUnsure) {
-#ifndef ER_RT_NO_TIER2
-      s_unsure[atomicAdd(&s_n, 1)] = (unsigned short)((ly0 + j) * kRtW + lx);
-#endif
-    }
+  const int total = __shfl(off, 63);
+  off -= cnt;
+  unsigned short* __restrict__ list = s_list[wv];
+  while (m) {
+    const int bit = __builtin_ctzll(m);
+    m &= m - 1;
+    list[off++] = (unsigned short)((lane << 6) | bit);
   }
-  __syncthreads();
-  const int n = s_n;
-  for (int i = tid; i < n; i += kBlock) {
-    const int q = s_unsure[i];
-    reproject_scatter_px(A, f, blockIdx.x * kRtW + (q & 63), blockIdx.y * kRtH + (q >> 6), 0);
+  __syncthreads();                                                       // (the list of a wave is read by its own lanes only: this orders its LDS writes and reads)
+  for (int t = lane; t < total; t += 64) {
+    const int e = list[t];
+    const int w = group + (e >> 6);                                      // source wave -> (frame, tile row, tile column, row in the tile)
+    const int row = w & 3, tile = w >> 2;
+    const int bx = tile % gx, by = (tile / gx) % gy, f = tile / (gx * gy);
+    reproject_scatter_px(A, f, bx * 64 + (e & 63), by * 4 + row, 0);
   }
 }
 
@@ -922,6 +917,7 @@ struct er_tsdf_s {
   std::vector<double> grid_cmax, grid_dmax;                 // per lattice: max |component|, max lattice-edge component (host)
   uint16_t* depth_stage[kDepth] = {};              // host frames of the batch in flight, by pipeline slot
   uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
+  void* rlist[kAux] = {};                           // tier 1's masks of undecided source pixels (ER_REPROJECT_TIERED), one buffer per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
   int* plan_entry[kDepth] = {};
@@ -939,7 +935,7 @@ struct er_tsdf_s {
 hipStream_t er::tsdf_stream(er_tsdf_s* h) { return h->stream; }
 int er::tsdf_device(er_tsdf_s* h) { return h->device; }
 
-static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X);
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X, int aux);
 
 namespace {
 
@@ -1117,7 +1113,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
                         verts * 3, h->zbuf[a], h->lastzero[a], h->counters + kZeroFlagSlot[a]};
-    if (launch_reproject(h, RA, n, reinterpret_cast<const er::ReprojFast*>(dst + offsetof(Staging, fast)), X)) return 1;
+    if (launch_reproject(h, RA, n, reinterpret_cast<const er::ReprojFast*>(dst + offsetof(Staging, fast)), X, a)) return 1;
     zsrc = h->zbuf[a];
   }
 
@@ -1241,6 +1237,10 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->zbuf[q], B * px * sizeof(uint32_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->lastzero[q], B * px * sizeof(uint32_t));
+#ifdef ER_REPROJECT_TIERED
+  for (int q = 0; q < kAux; q++)                              // one 64-bit mask per 64 source pixels (rows of 64, ragged right edge included)
+    ER_ALLOC(h->rlist[q], B * (size_t)((cols + 63) / 64) * ((rows + 3) / 4) * 4 * sizeof(unsigned long long));
+#endif
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
   for (int q = 0; q < kDepth; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
@@ -1296,6 +1296,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   for (int q = 0; q < kAux; q++) {
     ptrs.push_back(h->zbuf[q]);
     ptrs.push_back(h->lastzero[q]);
+    ptrs.push_back(h->rlist[q]);
   }
   for (int q = 0; q < kDepth; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
@@ -1412,19 +1413,21 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
   return 0;
 }
 
-// Reproject of n frames into zbuf (tiered when the lattice fits LDS, else the all-exact kernel) + the replay launch.
-static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X) {
+// Reproject of n frames into zbuf: the all-exact kernel, or (-DER_REPROJECT_TIERED) tier 1 + the exact tail; then the replay launch.
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X, int aux) {
 #ifdef ER_REPROJECT_TIERED
-  const size_t lds = (size_t)(RA.res + 1) * (RA.res + 1) * (RA.res + 1) * sizeof(er::Vert4);             // measured slower than the all-exact kernel (profiles/r02c_ab_tiered_reproject_v2.txt): off by default
-  if (lds <= 48 * 1024 && dev_fast) {
-    hipLaunchKernelGGL(k_reproject_tiered, dim3((h->cols + kRtW - 1) / kRtW, (h->rows + kRtH - 1) / kRtH, n), dim3(kBlock), lds, X, RA, dev_fast,
-                       h->ctr4);
+  if (dev_fast && h->rlist[aux]) {
+    const int gx = (h->cols + 63) / 64, gy = (h->rows + 3) / 4, n_waves = n * gy * gx * 4;
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(h->rlist[aux]);
+    hipLaunchKernelGGL(k_reproject_tier, dim3(gx, gy, n), dim3(kBlock), 0, X, RA, dev_fast, h->ctr4, masks);
+    hipLaunchKernelGGL(k_reproject_tail, dim3((n_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, X, RA, masks, n_waves, gx, gy);
   } else
 #endif
   {
     // (staging the lattice in LDS for this kernel was measured as well: slower, profiles/r02d_ab_lds_lattice.txt)
     hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), kPrePassLds, X, RA);
   }
+  (void)aux;
   hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(256), 0, X, RA);      // (one small workgroup: it has to find room next to two busy kernels)
   ER_HIP_TRY(hipGetLastError());
   return 0;
@@ -1458,7 +1461,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
     er::reproj_fast_setup(seg16, madj, h->cam, h->cols, h->rows, resolution, grid_ul, h->grid_cmax[0], h->grid_dmax[0], st->fast[0]);
     ER_HIP_TRY(hipMemcpyAsync(dev_fast, &st->fast[0], sizeof(er::ReprojFast), hipMemcpyHostToDevice, h->stream));
 #endif
-    if (launch_reproject(h, RA, 1, dev_fast, h->stream)) return 1;
+    if (launch_reproject(h, RA, 1, dev_fast, h->stream, 0)) return 1;
   }
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf[0],
                      h->depth_stage[0], total);
