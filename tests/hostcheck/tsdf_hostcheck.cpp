@@ -309,21 +309,21 @@ long hc_inside_stress(unsigned long long seed, long n, long* n_inside) {
     }
     if (!ok) continue;
     const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
-    // patch shape: the 16 x 16 (j, k) square k_integrate gives a wave (odd iterations) or the round-1 strip of 4 rows x 64
-    const bool square = (it & 1) != 0;
-    const int jn = square ? 16 : 4, kn = square ? 16 : 64;
-    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
+    // patch shape, in turn: the 4 x 8 x 8 box k_integrate gives a wave, the 16 x 16 (j, k) square, the round-1 strip of 4 rows x 64
+    const int shape = (int)(it % 3);
+    const int in_ = shape == 0 ? 4 : 1, jn = shape == 0 ? 8 : (shape == 1 ? 16 : 4), kn = shape == 0 ? 8 : (shape == 1 ? 16 : 64);
+    const int i0 = (vi[0] % 64) & ~(in_ - 1), j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
     const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
     std::vector<float> tile_max((size_t)tiles_x * tiles_y, 1.0e4f);   // "depth everywhere": the culling half never fires
     bool inside = false;
-    const float g0 = grid_coord(i, xs);
-    if (!patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kn - 1, zs), f, cam, cols, rows,
-                          tile_max.data(), tiles_x, tiles_y, &inside) || !inside)
+    if (!patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + in_ - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs),
+                              grid_coord(k0 + kn - 1, zs), f, cam, cols, rows, tile_max.data(), tiles_x, tiles_y, &inside) || !inside)
       continue;
     ins++;
+    for (int i = i0; i < i0 + in_; i++)
     for (int j = j0; j < j0 + jn; j++)
       for (int k = k0; k < k0 + kn; k++) {
-        const float g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
+        const float g0 = grid_coord(i, xs), g1 = grid_coord(j, ys), g2 = grid_coord(k, zs);
         unsigned ref_pixel = 0;
         const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
         const unsigned pixel = voxel_project_inside(g0, g1, g2, f, cam, cols, rows);
@@ -401,19 +401,19 @@ long hc_cull_stress(unsigned long long seed, long n, long* n_dead) {
         m = std::max(m, d);
       }
     const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
-    const bool square = (it & 1) != 0;                         // 16 x 16 square (round 2) or 4 x 64 strip (round 1)
-    const int jn = square ? 16 : 4, kn = square ? 16 : 64;
-    const int i = vi[0] % 64, j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
-    const float g0 = grid_coord(i, xs);
+    const int shape = (int)(it % 3);                           // 4 x 8 x 8 box (the default), 16 x 16 square, 4 x 64 strip (round 1)
+    const int in_ = shape == 0 ? 4 : 1, jn = shape == 0 ? 8 : (shape == 1 ? 16 : 4), kn = shape == 0 ? 8 : (shape == 1 ? 16 : 64);
+    const int i0 = (vi[0] % 64) & ~(in_ - 1), j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
     bool inside = false;
-    if (patch_may_update(g0, grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs), grid_coord(k0 + kn - 1, zs), f, cam, cols, rows,
-                         tile_max.data(), tiles_x, tiles_y, &inside))
+    if (patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + in_ - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs),
+                             grid_coord(k0 + kn - 1, zs), f, cam, cols, rows, tile_max.data(), tiles_x, tiles_y, &inside))
       continue;
     dead++;
+    for (int i = i0; i < i0 + in_; i++)
     for (int j = j0; j < j0 + jn; j++)
       for (int k = k0; k < k0 + kn; k++) {
         float S = 0.25f, W = 3.0f;
-        if (voxel_update(S, W, g0, grid_coord(j, ys), grid_coord(k, zs), f, cam, cols, rows, img.data())) wrong++;
+        if (voxel_update(S, W, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), f, cam, cols, rows, img.data())) wrong++;
       }
   }
   if (n_dead) *n_dead = dead;
