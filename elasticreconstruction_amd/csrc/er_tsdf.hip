@@ -312,10 +312,10 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max, int2 shard) {
+    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
-  __shared__ float s_wmax[kPrepThreads / 64];
+  __shared__ float s_wmax[kPrepThreads / 64], s_wlo[kPrepThreads / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
   const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;      // ty in [0, 8)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       lam[q] = lambda[p];
     }
   }
-  float wmax = 0.0f;
+  float wmax = 0.0f, wlo = 3.0e38f;
 #pragma unroll
   for (int q = 0; q < kPrepPix; q++) {
     const int y = blockIdx.y * kTile + ty + q * (kTile / kPrepPix);
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
       scaled[(size_t)f * (pixels + kScaledPad) + y * cols + x] = sc;
       wmax = fmaxf(wmax, sc);
+      wlo = fminf(wlo, sc);                                             // over EVERY pixel of the tile: 0 as soon as one carries no usable depth
       if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
         key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
         if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);
@@ -369,14 +370,25 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       }
     }
   }
-  // max of the scaled depth over the tile (consumed by patch_may_update in k_integrate)
-  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmax;
+  // max and min of the scaled depth over the tile (consumed by patch_may_update_box in k_integrate: culling / the full verdict)
+  for (int off = 32; off > 0; off >>= 1) {
+    wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+    wlo = fminf(wlo, __shfl_xor(wlo, off));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_wmax[threadIdx.x >> 6] = wmax;
+    s_wlo[threadIdx.x >> 6] = wlo;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float m = 0.0f;
-    for (int w = 0; w < kPrepThreads / 64; w++) m = fmaxf(m, s_wmax[w]);
-    tile_max[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = m;
+    float m = 0.0f, lo = 3.0e38f;
+    for (int w = 0; w < kPrepThreads / 64; w++) {
+      m = fmaxf(m, s_wmax[w]);
+      lo = fminf(lo, s_wlo[w]);
+    }
+    const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    tile_max[t] = m;
+    tile_lo[t] = lo;
   }
   const int n = min(s_n, kTileKeys);
   if ((int)threadIdx.x < n) {
@@ -484,19 +496,22 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    int tiles_x, int tiles_y, Camera cam, int cols, int rows, int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
+    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows, int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
   const int n_items = plan->n_units * (kUnitRes * 4);
-#ifndef ER_DYNAMIC_ITEMS
-  // Static round-robin deal of the cost-sorted items.  -DER_DYNAMIC_ITEMS turns it into a work queue (every workgroup claims the
-  // next item with one atomic when it is done with its own: longest-processing-time-first).  Measured: the kernel itself gets
-  // 13 % faster (0.316 vs 0.365 ms per launch in the pipeline, no idle tail) and the JOB 5 % slower (122.3 k vs 128.7 k frames/s,
-  // profiles/r02z_ab_dynamic_items.txt): the idle tail of the voxel pass is where the two pre-pass streams get their share of the
-  // SIMDs, and they are the other half of the critical path.
+#ifdef ER_STATIC_ITEMS
+  // (static round-robin deal of the cost-sorted items, kept for A/B)
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
 #else
+  // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
+  // its own (one atomic per item and workgroup; the grid is 4 persistent workgroups per CU): longest-processing-time-
+  // first scheduling.  The culling and the full / sure shortcuts make the real cost of an item unpredictable, and with a static
+  // deal the kernel lasted as long as its unluckiest workgroup: taking 22 % of the instructions out of the kernel (the full
+  // path) did not shorten it at all.  History: with the static deal the queue made the kernel 13 % faster and the JOB 5 %
+  // slower (the idle tail was where the pre-pass streams got their share of the SIMDs); together with the full path it is
+  // +2.6 % for the job and -20 % for the kernel (profiles/r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt).
   __shared__ int s_item;
   for (;;) {
     __syncthreads();                                                     // everybody is done with the previous s_item
@@ -560,15 +575,24 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
 #elif defined(ER_PROBE_HALF_FRAMES)
     m &= 0x5555555555555555ull;
 #endif
-    unsigned long long m_in;
+    // Third verdict (m_full): the frame updates EVERY voxel of the patch with tsdf = 1 -- proven from the tile minima of the depth
+    // under the patch's pixel hull -- so the frame needs no projection, no depth sample and no arithmetic at all: W += 1, and S
+    // stays / becomes exactly 1 wherever S == 1 or W == 0 (most of the frustum is such free space).
+    unsigned long long m_in, m_full;
     {
-      bool keep = ((m >> lane) & 1ull) != 0ull, inside = false;
+      bool keep = ((m >> lane) & 1ull) != 0ull, inside = false, full = false;
       if (keep)
         keep = patch_may_update_box(grid_coord(i, xs), grid_coord(i + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
                                     grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), frames[lane], cam, cols, rows,
-                                    tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside);
+                                    tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside,
+                                    tile_lo + (size_t)lane * tiles_x * tiles_y, &full);
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
+#ifndef ER_NO_FULL_PATH
+      m_full = __ballot(keep && full);
+#else
+      m_full = 0ull;
+#endif
     }
     // Frame loop in two halves: project() computes the pixel under every voxel of the four register rows and issues the depth
     // gathers, finish() does the arithmetic that needs the samples.  -DER_FRAME_PIPELINE software-pipelines the loop over two
@@ -642,6 +666,34 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     };
 #ifndef ER_FRAME_PIPELINE
     while (m) {
+      {
+        // a run of consecutive FULL frames (in the mask's order): n updates with tsdf = 1 of every voxel of the patch
+        const unsigned long long nf = m & ~m_full;
+        const unsigned long long run = nf ? (m & ((nf & (0ull - nf)) - 1ull)) : m;
+        if (run) {                                                       // wave-uniform
+          const int n = __popcll(run);
+          m &= ~run;
+          bool nontrivial = false;
+#pragma unroll
+          for (int r = 0; r < kRows; r++) nontrivial = nontrivial | !(voxel_free_trivial(S[r], W[r]) & (W[r] < 8388608.0f));
+          if (__ballot(nontrivial) == 0ull) {                            // (S W + 1) / (W + 1) == 1 exactly, W + n exact below 2^24
+#pragma unroll
+            for (int r = 0; r < kRows; r++) {
+              S[r] = 1.0f;
+              W[r] = W[r] + (float)n;
+            }
+          } else {                                                       // a voxel that was inside the truncation band before: the n divisions, in order
+            for (int q = 0; q < n; q++) {
+#pragma unroll
+              for (int r = 0; r < kRows; r++) {
+                S[r] = div_inrange(S[r] * W[r] + 1.0f, W[r] + 1.0f);
+                W[r] = W[r] + 1.0f;
+              }
+            }
+          }
+          continue;
+        }
+      }
       const int f = __builtin_ctzll(m);
       m &= m - 1;
       float dp[kRows];
@@ -896,7 +948,7 @@ struct er_tsdf_s {
   bool used[kDepth] = {};
   int* batch[kDepth] = {};
   unsigned long long* ht_mask[kDepth] = {};
-  float *scaled[kDepth] = {}, *tile_max[kDepth] = {};
+  float *scaled[kDepth] = {}, *tile_max[kDepth] = {}, *tile_lo[kDepth] = {};
   er::FrameXform* frames[kDepth] = {};              // = &dstage[q]->fx
   void* dstage[kDepth] = {};                        // device twin of the pinned per-batch constants (struct Staging)
   hipEvent_t pre_done[kDepth] = {}, int_done[kDepth] = {};
@@ -1072,7 +1124,13 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   int* nbatch = h->counters + kNbatchSlot[p];
 
 #ifndef ER_INT_BLOCKS_PER_CU
+#ifdef ER_STATIC_ITEMS
 #define ER_INT_BLOCKS_PER_CU 10
+#else
+#define ER_INT_BLOCKS_PER_CU 4             // persistent workgroups fed by the queue; 4 of the 5 that fit a CU, so that the pre-pass
+                                          // kernels find register space next to them: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s
+                                          // (k_integrate 0.284 / 0.298 / 0.354 ms per launch; profiles/r02G_ab_full_path_and_queue.txt)
+#endif
 #endif
   const int wide_grid = h->n_cu * ER_INT_BLOCKS_PER_CU;
   uint32_t* zsrc = nullptr;
@@ -1120,7 +1178,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), kPrePassLds, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
-                     h->tile_max[p], make_int2(h->shard_rank, h->shard_world));
+                     h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world));
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry[p], h->plan[p]);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
@@ -1139,7 +1197,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   const bool sure = false;
 #endif
   hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
-                     h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], (h->cols + kTile - 1) / kTile,
+                     h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], (h->cols + kTile - 1) / kTile,
                      (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows, h->unit_key, h->max_units, h->counters);
   if (timed) {
     ER_HIP_TRY(hipEventRecord(e1, S));
@@ -1249,6 +1307,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->grid_index, B * sizeof(int));
   ER_ALLOC(h->dsum, sizeof(double));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_lo[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan_entry[q], (size_t)cap * sizeof(int));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan[q], sizeof(Plan));
 #undef ER_ALLOC
@@ -1290,7 +1349,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
                              h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->ctr4_dev[0], h->ctr4_dev[1], h->key_scratch,
                              h->slot_scratch};
   for (int q = 0; q < kDepth; q++)
-    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q],
+    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q],
                     (void*)h->plan_entry[q], (void*)h->plan[q]})
       ptrs.push_back(x);
   for (int q = 0; q < kAux; q++) {

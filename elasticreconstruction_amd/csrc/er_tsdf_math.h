@@ -413,9 +413,25 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 // patch is convex with its extreme points among the tested corners -- t2 is affine (its extremes over the box are at corners),
 // a convex body in front of the camera projects into the convex hull of its corners, P is projective-linear on it -- and the
 // error sums A_k take the largest coordinate magnitudes of the patch.
+//
+// *full (third verdict, optional; needs tile_lo = per 32 x 32 tile the minimum of the scaled depth over ALL its pixels, written by
+// k_prepare next to tile_max): true only if the frame updates EVERY voxel of the patch with tsdf = 1, so that k_integrate needs
+// neither the projection nor the depth sample nor any arithmetic of the update:
+//   * the patch is "inside" (above): every voxel projects into the image, onto a pixel of the tiles under the corner hull
+//     (the computed pixel lies within 0.75 px of the corner hull; the tile range takes 1.5 px);
+//   * lo = min of tile_lo over those tiles > 0.001: every pixel a voxel can sample carries a usable depth (":82 dp > 0.001"
+//     passes), and dp >= lo;
+//   * with D = distance from the camera centre to the FARTHEST corner of the patch (dist <= D for every voxel; the float32
+//     evaluations of D here and of dist in the update are within 4e-7 D of the true values):  lo - D > trunc + 1e-4 + 1e-6 D
+//     =>  sdf = RN(dp - dist) > trunc for every voxel: ":87" passes and ":88" yields exactly 1.
+// The update of such a (voxel, frame) is S = (S W + 1) / (W + 1), W = W + 1 -- exactly (1, W + 1) when S == 1 or W == 0.
+// NaNs fail a comparison and the verdict.  tests/hostcheck replays it against the full update for every voxel it covers.
 ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
-                                int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside) {
+                                int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
+                                const float* __restrict__ tile_lo = nullptr, bool* full = nullptr) {
   *inside = false;
+  if (full) *full = false;
+  float lo_tile = 0.0f;                                   // min of the scaled depth over every pixel a voxel can sample (0: unknown)
   float umin = 3.0e38f, umax = -3.0e38f, vmin = 3.0e38f, vmax = -3.0e38f, t2min = 3.0e38f, t2max = -3.0e38f;
   const int n0 = g0hi != g0lo ? 2 : 1;
   for (int o = 0; o < n0; o++)
@@ -457,10 +473,14 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
     const int x0 = (int)fmaxf(umin - 1.5f, 0.0f) >> 5, x1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> 5;
     const int y0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> 5, y1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> 5;
     if ((x1 - x0 + 1) * (y1 - y0 + 1) <= 48) {
-      float m = 0.0f;
+      float m = 0.0f, lo = 3.0e38f;
       for (int ty = y0; ty <= y1; ty++)
-        for (int tx = x0; tx <= x1; tx++) m = fmaxf(m, tile_max[ty * tiles_x + tx]);
+        for (int tx = x0; tx <= x1; tx++) {
+          m = fmaxf(m, tile_max[ty * tiles_x + tx]);
+          if (tile_lo) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
+        }
       dmax_tile = m;
+      if (tile_lo) lo_tile = lo;
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
@@ -481,6 +501,12 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
     const float sv = 1.0625f * (fabsf(c.fy) * e1 + va * e2) / tau + 0x1p-20f * ((va + fabsf(c.cy)) + 1.0f);
     *inside = (tau >= 0x1p-20f) & (t2max + 2.0f * e2 <= 0x1p20f) & (e2 * 4096.0f <= tau) & (su <= 0.125f) & (sv <= 0.125f) &
               (umin >= 0.5f) & (umax <= (float)cols - 1.5f) & (vmin >= 0.5f) & (vmax <= (float)rows - 1.5f);
+  }
+  if (full && *inside && lo_tile > 0.001f) {
+    const float ex = fmaxf(fabsf(g0lo - f.tx), fabsf(g0hi - f.tx)), ey = fmaxf(fabsf(g1lo - f.ty), fabsf(g1hi - f.ty)),
+                ez = fmaxf(fabsf(g2lo - f.tz), fabsf(g2hi - f.tz));
+    const float dfar = sqrtf((ex * ex + ey * ey) + ez * ez);
+    *full = lo_tile - dfar > ((float)kTsdfTrunc + 1e-4f) + 1e-6f * dfar;      // (NaN / inf: false)
   }
   return true;
 }

@@ -15,7 +15,7 @@ using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
 static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 0 = the 16 x 16 square (-DER_SQUARE_PATCH)
-struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -139,10 +139,12 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
   // tile maxima of the scaled depth, as k_prepare writes them (32 x 32 pixel tiles)
   const int tiles_x = (v->cols + 31) / 32, tiles_y = (v->rows + 31) / 32;
   std::vector<std::vector<float>> tile_max(n, std::vector<float>((size_t)tiles_x * tiles_y, 0.f));
+  std::vector<std::vector<float>> tile_lo(n, std::vector<float>((size_t)tiles_x * tiles_y, 3.0e38f));   // min over ALL pixels of the tile
   for (int f = 0; f < n; f++)
     for (int p = 0; p < px; p++) {
       const size_t t = (size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32;
       tile_max[f][t] = std::max(tile_max[f][t], scaled[f][p]);
+      tile_lo[f][t] = std::min(tile_lo[f][t], scaled[f][p]);
     }
   long culled = 0, kept = 0;
   for (auto& kv : v->units) {
@@ -160,15 +162,18 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
         else { i0 = pi >> 4; j0 = ((pi >> 2) & 3) * 16; k0 = (pi & 3) * 16; ni = 1; nj = 16; nk = 16; }
         // the same (patch, frame) culling k_integrate applies before its frame loop
         std::vector<int> frames;
-        std::vector<char> in;
+        std::vector<char> in, ful;
         for (int f : u.frames) {
-          bool inside = false;
+          bool inside = false, full = false;
           if (patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + ni - 1, xs), grid_coord(j0, ys), grid_coord(j0 + nj - 1, ys), grid_coord(k0, zs),
-                                   grid_coord(k0 + nk - 1, zs), fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside)) {
+                                   grid_coord(k0 + nk - 1, zs), fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside,
+                                   tile_lo[f].data(), &full)) {
             frames.push_back(f);
             in.push_back(inside);
+            ful.push_back(full);
             kept++;
             v->inside += inside;
+            v->full_pf += full;
           } else {
             culled++;
           }
@@ -224,6 +229,16 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
             const int l = (i * 64 + j) * 64 + k;
             float S2 = u.sdf[l], W2 = u.w[l];
             voxel_finish_d2(S2, W2, dpv[t], d2v[t]);
+            if (ful[q]) {
+              // k_integrate's FULL path: no projection, no sample, no arithmetic -- the update must be the tsdf = 1 update of a voxel
+              // that projects inside the image onto a usable depth: (1, W + 1) for trivial voxels, (S W + 1) / (W + 1) otherwise
+              const float S0 = u.sdf[l], W0 = u.w[l];
+              const float S3 = voxel_free_trivial(S0, W0) ? 1.0f : (S0 * W0 + 1.0f) / (W0 + 1.0f), W3 = W0 + 1.0f;
+              unsigned rp = 0;
+              if (!in[q] || !voxel_project(grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), fx[f], v->cam, v->cols, v->rows, rp) ||
+                  !(scaled[f][rp] > 0.001f) || memcmp(&S3, &S2, 4) != 0 || memcmp(&W3, &W2, 4) != 0)
+                v->full_violations++;
+            }
             if (behv[t] || (frev[t] && voxel_free_trivial(u.sdf[l], u.w[l]))) {
               const float S3 = frev[t] ? 1.0f : u.sdf[l], W3 = frev[t] ? u.w[l] + 1.0f : u.w[l];
               if (memcmp(&S3, &S2, 4) != 0 || memcmp(&W3, &W2, 4) != 0 || (frev[t] && behv[t])) v->sure_violations++;
@@ -244,6 +259,8 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
 void hc_set_patch_shape(int shape) { g_patch_shape = shape; }
 long hc_sure(void* h) { return static_cast<HcVolume*>(h)->sure; }
 long hc_visited(void* h) { return static_cast<HcVolume*>(h)->visited; }
+long hc_full(void* h) { return static_cast<HcVolume*>(h)->full_pf; }
+long hc_full_violations(void* h) { return static_cast<HcVolume*>(h)->full_violations; }
 long hc_unsure_pf(void* h) { return static_cast<HcVolume*>(h)->unsure_pf; }
 long hc_sure_violations(void* h) { return static_cast<HcVolume*>(h)->sure_violations; }
 long hc_culled(void* h) { return static_cast<HcVolume*>(h)->culled; }
@@ -417,6 +434,99 @@ long hc_cull_stress(unsigned long long seed, long n, long* n_dead) {
       }
   }
   if (n_dead) *n_dead = dead;
+  return wrong;
+}
+
+// Stress of the FULL verdict of patch_may_update_box: random cameras / poses / patches (box, square, strip in turn) and depth
+// images whose tiles lie around and BEHIND the patch's own distance (so that "in front of the surface by more than the
+// truncation" is decided both ways), with and without holes.  Whenever the verdict says "full", every voxel of the patch is
+// updated from several (S, W) states -- fresh, S == 1, arbitrary -- by the full voxel_update and by the shortcut
+// ((1, W + 1) for trivial voxels, (S W + 1) / (W + 1) otherwise): the float bits must agree.  Returns the disagreements.
+long hc_full_stress(unsigned long long seed, long n, long* n_full) {
+  unsigned long long st = seed * 0xD1B54A32D192ED03ull + 0x13579BDFull;
+  auto rnd = [&]() {
+    st ^= st >> 12; st ^= st << 25; st ^= st >> 27;
+    return (double)((st * 0x2545F4914F6CDD1Dull) >> 11) * (1.0 / 9007199254740992.0);
+  };
+  long wrong = 0, nfull = 0;
+  std::vector<float> img, tile_max, tile_lo;
+  for (long it = 0; it < n; it++) {
+    const int cols = 64 + (int)(rnd() * 577), rows = 64 + (int)(rnd() * 417);
+    Camera cam;
+    cam.fx = (float)(100.0 * pow(8.0, rnd()));
+    cam.fy = (float)(100.0 * pow(8.0, rnd()));
+    cam.cx = (float)(rnd() * cols);
+    cam.cy = (float)(rnd() * rows);
+    cam.icp_trunc = 2.5f; cam.integration_trunc = 60.0f;
+    double q[4], nq = 0;
+    for (double& c : q) { c = rnd() * 2 - 1; nq += c * c; }
+    nq = sqrt(nq) + 1e-300;
+    for (double& c : q) c /= nq;
+    const double Rm[9] = {1 - 2 * (q[2] * q[2] + q[3] * q[3]), 2 * (q[1] * q[2] - q[0] * q[3]), 2 * (q[1] * q[3] + q[0] * q[2]),
+                          2 * (q[1] * q[2] + q[0] * q[3]), 1 - 2 * (q[1] * q[1] + q[3] * q[3]), 2 * (q[2] * q[3] - q[0] * q[1]),
+                          2 * (q[1] * q[3] - q[0] * q[2]), 2 * (q[2] * q[3] + q[0] * q[1]), 1 - 2 * (q[1] * q[1] + q[2] * q[2])};
+    const double Rw = rnd() < 0.7 ? 3.0 : 40.0;
+    const double t[3] = {(rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw, (rnd() * 2 - 1) * Rw};
+    FrameXform f;
+    for (int r = 0; r < 3; r++) {
+      for (int c = 0; c < 3; c++) f.mi[r * 4 + c] = (float)Rm[c * 3 + r];
+      f.mi[r * 4 + 3] = (float)(-(Rm[0 * 3 + r] * t[0] + Rm[1 * 3 + r] * t[1] + Rm[2 * 3 + r] * t[2]));
+    }
+    f.tx = (float)t[0]; f.ty = (float)t[1]; f.tz = (float)t[2]; f.pad = 0.f;
+    const double pu = (0.1 + 0.8 * rnd()) * cols, pv = (0.1 + 0.8 * rnd()) * rows;     // mostly well inside the image
+    const double D = 0.3 * pow(30.0, rnd());
+    const double pc[3] = {(pu - cam.cx) / cam.fx * D, (pv - cam.cy) / cam.fy * D, D};
+    double pw[3];
+    for (int r = 0; r < 3; r++) pw[r] = Rm[r * 3] * pc[0] + Rm[r * 3 + 1] * pc[1] + Rm[r * 3 + 2] * pc[2] + t[r];
+    int vi[3];
+    bool ok = true;
+    for (int r = 0; r < 3; r++) {
+      vi[r] = (int)floor(pw[r] / kUnitLength) + 256 * 64;
+      ok = ok && vi[r] >= 0 && vi[r] < 512 * 64;
+    }
+    if (!ok) continue;
+    const double dist = sqrt(pc[0] * pc[0] + pc[1] * pc[1] + pc[2] * pc[2]);
+    const int tiles_x = (cols + 31) / 32, tiles_y = (rows + 31) / 32;
+    img.assign((size_t)cols * rows, 0.f);
+    tile_max.assign((size_t)tiles_x * tiles_y, 0.f);
+    tile_lo.assign((size_t)tiles_x * tiles_y, 3.0e38f);
+    // the surface: behind the patch by 0 .. 0.6 m (the verdict needs > trunc + the patch's own extent), tile to tile +- 5 cm,
+    // pixel noise +- 5 mm; holes in one image out of three
+    const double behind = rnd() * 0.6, hole_p = (it % 3 == 0) ? 0.002 : 0.0;
+    std::vector<float> tile_depth((size_t)tiles_x * tiles_y);
+    for (float& d : tile_depth) d = (float)(dist + behind + (rnd() * 2 - 1) * 0.05);
+    for (int y = 0; y < rows; y++)
+      for (int x = 0; x < cols; x++) {
+        float d = tile_depth[(size_t)(y / 32) * tiles_x + x / 32] + (float)((rnd() * 2 - 1) * 0.005);
+        if (rnd() < hole_p || d < 0.f) d = 0.f;
+        img[(size_t)y * cols + x] = d;
+        const size_t tt = (size_t)(y / 32) * tiles_x + x / 32;
+        tile_max[tt] = std::max(tile_max[tt], d);
+        tile_lo[tt] = std::min(tile_lo[tt], d);
+      }
+    const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
+    const int shape = (int)((it / 3) % 3);                     // 4 x 8 x 8 box (the default), 16 x 16 square, 4 x 64 strip (round 1)
+    const int in_ = shape == 0 ? 4 : 1, jn = shape == 0 ? 8 : (shape == 1 ? 16 : 4), kn = shape == 0 ? 8 : (shape == 1 ? 16 : 64);
+    const int i0 = (vi[0] % 64) & ~(in_ - 1), j0 = (vi[1] % 64) & ~(jn - 1), k0 = (vi[2] % 64) & ~(kn - 1);
+    bool inside = false, full = false;
+    if (!patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + in_ - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jn - 1, ys), grid_coord(k0, zs),
+                              grid_coord(k0 + kn - 1, zs), f, cam, cols, rows, tile_max.data(), tiles_x, tiles_y, &inside, tile_lo.data(), &full) ||
+        !full)
+      continue;
+    nfull++;
+    const float states[5][2] = {{0.f, 0.f}, {1.f, 7.f}, {1.f, 16777216.f}, {0.25f, 3.f}, {-0.6f, 1000.f}};
+    for (int i = i0; i < i0 + in_; i++)
+      for (int j = j0; j < j0 + jn; j++)
+        for (int k = k0; k < k0 + kn; k++)
+          for (int qq = 0; qq < 5; qq++) {
+            const float S0 = states[qq][0], W0 = states[qq][1];
+            float S2 = S0, W2 = W0;
+            const bool upd = voxel_update(S2, W2, grid_coord(i, xs), grid_coord(j, ys), grid_coord(k, zs), f, cam, cols, rows, img.data());
+            const float S3 = voxel_free_trivial(S0, W0) ? 1.0f : (S0 * W0 + 1.0f) / (W0 + 1.0f), W3 = W0 + 1.0f;
+            if (!upd || memcmp(&S3, &S2, 4) != 0 || memcmp(&W3, &W2, 4) != 0) wrong++;
+          }
+  }
+  if (n_full) *n_full = nfull;
   return wrong;
 }
 

@@ -45,13 +45,15 @@ def hc():
     L.hc_inside.argtypes = [vp]
     L.hc_inside_violations.restype = C.c_long
     L.hc_inside_violations.argtypes = [vp]
-    for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations"):
+    for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations", "hc_full", "hc_full_violations"):
         getattr(L, name).restype = C.c_long
         getattr(L, name).argtypes = [vp]
     L.hc_set_patch_shape.restype = None
     L.hc_set_patch_shape.argtypes = [C.c_int]
     L.hc_touch_key_stress.restype = C.c_long
     L.hc_touch_key_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
+    L.hc_full_stress.restype = C.c_long
+    L.hc_full_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_sure_stress.restype = C.c_long
     L.hc_sure_stress.argtypes = [C.c_ulonglong, C.c_long, C.POINTER(C.c_long)]
     L.hc_unit_keys.argtypes = [vp, vp]
@@ -123,6 +125,8 @@ def test_device_math_rigid_matches_golden(hc):
     inside = hc.hc_inside(v.h)
     print("patch-frames: %d culled, %d kept, %d of them inside (%.0f %%)" % (culled, kept, inside, 100.0 * inside / kept))
     assert hc.hc_inside_violations(v.h) == 0 and inside > 0.4 * kept
+    assert hc.hc_full_violations(v.h) == 0
+    print("full (patch, frame) visits: %d of %d kept (%.1f %%)" % (hc.hc_full(v.h), kept, 100.0 * hc.hc_full(v.h) / max(kept, 1)))
 
 
 @pytest.mark.parametrize("shape", [0, 1])
@@ -156,6 +160,9 @@ def _warp_matches_golden(hc):
     assert hc.hc_sure_violations(v.h) == 0 and hc.hc_sure(v.h) > 0.25 * hc.hc_visited(v.h), (hc.hc_sure(v.h), hc.hc_visited(v.h))
     print("sure (patch, frame) visits: %d of %d (%.1f %%); with an unsure lane: %d" %
           (hc.hc_sure(v.h), hc.hc_visited(v.h), 100.0 * hc.hc_sure(v.h) / hc.hc_visited(v.h), hc.hc_unsure_pf(v.h)))
+    # the FULL verdict (every voxel of the patch updated with tsdf = 1: no projection, no sample): checked voxel by voxel
+    assert hc.hc_full_violations(v.h) == 0
+    print("full (patch, frame) visits: %d of %d kept (%.1f %%)" % (hc.hc_full(v.h), hc.hc_kept(v.h), 100.0 * hc.hc_full(v.h) / max(hc.hc_kept(v.h), 1)))
 
 
 def test_device_math_custom_camera_vs_oracle(hc):
@@ -398,6 +405,22 @@ def test_touch_key_stress(hc):
     n_out = C.c_long(0)
     assert hc.hc_touch_key_stress(5, 3000000, C.byref(n_out)) == 0
     assert 100000 < n_out.value < 2500000, n_out.value
+
+
+def test_full_verdict_stress(hc):
+    """patch_may_update_box's third verdict on its own: random cameras, poses, patches (box / square / strip) and depth images
+    whose surface lies around and behind the patch, with and without holes; wherever it says "full", every voxel of the patch
+    must be updated by the full voxel_update exactly like the tsdf = 1 shortcut, from fresh, S == 1 (also W = 2^24) and
+    arbitrary voxel states."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(seed):
+        n_full = C.c_long(0)
+        return hc.hc_full_stress(seed, 2500, C.byref(n_full)), n_full.value
+    with ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(run, range(31, 39)))
+    assert sum(w for w, _ in res) == 0, res
+    assert sum(n for _, n in res) > 2000, res                 # it fires often enough to mean something
 
 
 def test_sure_classification_stress(hc):
