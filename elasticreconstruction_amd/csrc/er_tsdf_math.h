@@ -428,7 +428,7 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 // NaNs fail a comparison and the verdict.  tests/hostcheck replays it against the full update for every voxel it covers.
 ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
                                 int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
-                                const float* __restrict__ tile_lo = nullptr, bool* full = nullptr) {
+                                const float* __restrict__ tile_lo = nullptr, bool* full = nullptr, int lo_shift = 5, int lo_tiles_x = 0) {
   *inside = false;
   if (full) *full = false;
   float lo_tile = 0.0f;                                   // min of the scaled depth over every pixel a voxel can sample (0: unknown)
@@ -477,10 +477,21 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
       for (int ty = y0; ty <= y1; ty++)
         for (int tx = x0; tx <= x1; tx++) {
           m = fmaxf(m, tile_max[ty * tiles_x + tx]);
-          if (tile_lo) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
+          if (tile_lo && lo_shift == 5) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
         }
       dmax_tile = m;
-      if (tile_lo) lo_tile = lo;
+      if (tile_lo && lo_shift == 5) lo_tile = lo;
+      if (tile_lo && lo_shift != 5) {
+        // (experiment, host replay only so far: tile_lo at a finer granularity of 2^lo_shift pixels, lo_tiles_x tiles per row -- the
+        //  warp's scatter holes then spoil fewer verdicts)
+        const int a0 = (int)fmaxf(umin - 1.5f, 0.0f) >> lo_shift, a1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> lo_shift;
+        const int b0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> lo_shift, b1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> lo_shift;
+        if ((a1 - a0 + 1) * (b1 - b0 + 1) <= 64) {
+          for (int ty = b0; ty <= b1; ty++)
+            for (int tx = a0; tx <= a1; tx++) lo = fminf(lo, tile_lo[ty * lo_tiles_x + tx]);
+          lo_tile = lo;
+        }
+      }
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch

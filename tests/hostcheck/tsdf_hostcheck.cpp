@@ -14,6 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
+static int g_lo_shift = 5;             // granularity of tile_lo in the replay (5 = the 32-pixel tiles k_prepare writes)
 static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 0 = the 16 x 16 square (-DER_SQUARE_PATCH)
 struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0; };
 
@@ -139,12 +140,14 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
   // tile maxima of the scaled depth, as k_prepare writes them (32 x 32 pixel tiles)
   const int tiles_x = (v->cols + 31) / 32, tiles_y = (v->rows + 31) / 32;
   std::vector<std::vector<float>> tile_max(n, std::vector<float>((size_t)tiles_x * tiles_y, 0.f));
-  std::vector<std::vector<float>> tile_lo(n, std::vector<float>((size_t)tiles_x * tiles_y, 3.0e38f));   // min over ALL pixels of the tile
+  const int lts = 1 << g_lo_shift, lo_tx = (v->cols + lts - 1) / lts, lo_ty = (v->rows + lts - 1) / lts;
+  std::vector<std::vector<float>> tile_lo(n, std::vector<float>((size_t)lo_tx * lo_ty, 3.0e38f));   // min over ALL pixels of the tile
   for (int f = 0; f < n; f++)
     for (int p = 0; p < px; p++) {
       const size_t t = (size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32;
       tile_max[f][t] = std::max(tile_max[f][t], scaled[f][p]);
-      tile_lo[f][t] = std::min(tile_lo[f][t], scaled[f][p]);
+      const size_t tl = (size_t)((p / v->cols) >> g_lo_shift) * lo_tx + ((p % v->cols) >> g_lo_shift);
+      tile_lo[f][tl] = std::min(tile_lo[f][tl], scaled[f][p]);
     }
   long culled = 0, kept = 0;
   for (auto& kv : v->units) {
@@ -167,7 +170,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           bool inside = false, full = false;
           if (patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + ni - 1, xs), grid_coord(j0, ys), grid_coord(j0 + nj - 1, ys), grid_coord(k0, zs),
                                    grid_coord(k0 + nk - 1, zs), fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside,
-                                   tile_lo[f].data(), &full)) {
+                                   tile_lo[f].data(), &full, g_lo_shift, lo_tx)) {
             frames.push_back(f);
             in.push_back(inside);
             ful.push_back(full);
@@ -257,6 +260,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
 }
 
 void hc_set_patch_shape(int shape) { g_patch_shape = shape; }
+void hc_set_lo_shift(int shift) { g_lo_shift = shift; }
 long hc_sure(void* h) { return static_cast<HcVolume*>(h)->sure; }
 long hc_visited(void* h) { return static_cast<HcVolume*>(h)->visited; }
 long hc_full(void* h) { return static_cast<HcVolume*>(h)->full_pf; }
