@@ -353,7 +353,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
       scaled[(size_t)f * (pixels + kScaledPad) + y * cols + x] = sc;
       wmax = fmaxf(wmax, sc);
-      wlo = fminf(wlo, sc);                                             // over EVERY pixel of the tile: 0 as soon as one carries no usable depth
+      wlo = fminf(wlo, sc > 0.001f ? sc : 0.0f);                        // over EVERY pixel of the tile: 0 as soon as one carries no usable depth
+                                                                        // (a NaN depth -- degenerate camera -- fails ":82 dp > 0.001" too: it counts as 0, fminf alone would skip it)
       if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
         key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
         if (key < 0) atomicAdd(&counters[C_OUT_OF_RANGE], 1);

@@ -147,7 +147,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
       const size_t t = (size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32;
       tile_max[f][t] = std::max(tile_max[f][t], scaled[f][p]);
       const size_t tl = (size_t)((p / v->cols) >> g_lo_shift) * lo_tx + ((p % v->cols) >> g_lo_shift);
-      tile_lo[f][tl] = std::min(tile_lo[f][tl], scaled[f][p]);
+      tile_lo[f][tl] = std::min(tile_lo[f][tl], scaled[f][p] > 0.001f ? scaled[f][p] : 0.0f);   // as k_prepare: NaN / unusable -> 0
     }
   long culled = 0, kept = 0;
   for (auto& kv : v->units) {
@@ -506,7 +506,7 @@ long hc_full_stress(unsigned long long seed, long n, long* n_full) {
         img[(size_t)y * cols + x] = d;
         const size_t tt = (size_t)(y / 32) * tiles_x + x / 32;
         tile_max[tt] = std::max(tile_max[tt], d);
-        tile_lo[tt] = std::min(tile_lo[tt], d);
+        tile_lo[tt] = std::min(tile_lo[tt], d > 0.001f ? d : 0.0f);
       }
     const float xs = unit_shift(vi[0] / 64), ys = unit_shift(vi[1] / 64), zs = unit_shift(vi[2] / 64);
     const int shape = (int)((it / 3) % 3);                     // 4 x 8 x 8 box (the default), 16 x 16 square, 4 x 64 strip (round 1)
