@@ -203,6 +203,27 @@ class CorresApp:
             inside &= (p[a] >= 0) & (p[a] <= self.length_)
         return float(inside.sum()) / res / res / res
 
+    def InitialPairs(self, filename, num):
+        """The --traj/--num branch of LoadData (CorresApp.cpp:40-69): fragment poses from every interval_-th camera pose,
+        consecutive fragments always paired, the others when their cubes overlap by more than 30 %.  Host-only."""
+        temp = formats.load_log(filename)
+        self.corres_traj_ = []
+        self.num_ = num
+        base = np.eye(4)
+        base[0, 3] = self.length_ / 2.0
+        base[1, 3] = self.length_ / 2.0
+        base[2, 3] = -0.3
+        baseinv = _inverse(base)
+        leftbase = mat4_mul(base, _inverse(temp[0].T))
+        ipose = [mat4_mul(mat4_mul(leftbase, temp[i * self.interval_].T), baseinv) for i in range(num)]
+        for i in range(num - 1):
+            self.corres_traj_.append(formats.FramedTransformation(i, i + 1, num, mat4_mul(_inverse(ipose[i]), ipose[i + 1])))
+            for j in range(i + 2, num):
+                trans = mat4_mul(_inverse(ipose[i]), ipose[j])
+                if self.GetVolumeOverlapRatio(trans) > 0.3:
+                    self.corres_traj_.append(formats.FramedTransformation(i, j, num, trans))
+        return self.corres_traj_
+
     # ---- CorresApp.cpp:31-110 --------------------------------------------------------------------
     def LoadData(self, filename, num):
         cut = max(filename.rfind("\\"), -1)
@@ -210,22 +231,7 @@ class CorresApp:
             cut = filename.rfind("/")
         self.m_pDirName = filename[:cut + 1]
         if num > 0:
-            temp = formats.load_log(filename)
-            self.corres_traj_ = []
-            self.num_ = num
-            base = np.eye(4)
-            base[0, 3] = self.length_ / 2.0
-            base[1, 3] = self.length_ / 2.0
-            base[2, 3] = -0.3
-            baseinv = _inverse(base)
-            leftbase = mat4_mul(base, _inverse(temp[0].T))
-            ipose = [mat4_mul(mat4_mul(leftbase, temp[i * self.interval_].T), baseinv) for i in range(num)]
-            for i in range(num - 1):
-                self.corres_traj_.append(formats.FramedTransformation(i, i + 1, num, mat4_mul(_inverse(ipose[i]), ipose[i + 1])))
-                for j in range(i + 2, num):
-                    trans = mat4_mul(_inverse(ipose[i]), ipose[j])
-                    if self.GetVolumeOverlapRatio(trans) > 0.3:
-                        self.corres_traj_.append(formats.FramedTransformation(i, j, num, trans))
+            self.InitialPairs(filename, num)
         else:
             self.corres_traj_ = formats.load_log(filename)
             self.num_ = self.corres_traj_[0].frame

@@ -499,3 +499,159 @@ class RefFopt:
     def update_normals(self, frag, ctr_full):
         c = np.ascontiguousarray(ctr_full, np.float64).reshape(-1)
         self.lib().rfopt_update_normals(self.clouds[frag], _p(c), c.size)
+
+
+class RefCorres:
+    """oracle/_ref/libref_corres*.so: the reference's own CCorresApp (BuildCorrespondence/CorresApp.{h,cpp} compiled in place,
+    unmodified, against oracle/stub_corres) on in-memory clouds.  Registration's pre-check / accept rule, FindCorrespondence, the
+    ratio test and the information matrix run as REFERENCE code; the PCL calls inside them are the stub's (exact kd-tree, PCL 1.7
+    transforms and ICP restated on the reference's vendored Eigen).  Only where /root/reference was present at build time."""
+    _libs = {}
+    REF_BIN = os.path.join(HERE, "_ref", "BuildCorrespondence_ref")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(os.path.join(HERE, "_ref", "libref_corres.so"))
+
+    @classmethod
+    def lib(cls, uncapped=False):
+        if uncapped not in cls._libs:
+            L = _load("_ref/libref_corres_uncapped.so" if uncapped else "_ref/libref_corres.so")
+            L.rcorres_create.restype = _vp
+            L.rcorres_create.argtypes = [C.c_char_p]
+            L.rcorres_destroy.argtypes = [_vp]
+            L.rcorres_set_params.argtypes = [_vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+            L.rcorres_add_cloud.argtypes = [_vp, _vp, _vp, C.c_int]
+            L.rcorres_add_pair.argtypes = [_vp, C.c_int, C.c_int, C.c_int, _vp]
+            L.rcorres_blacklist.argtypes = [_vp, C.c_int]
+            L.rcorres_registration.argtypes = [_vp]
+            L.rcorres_find_correspondence.argtypes = [_vp]
+            L.rcorres_num_pairs.argtypes = [_vp]
+            L.rcorres_get_pair.argtypes = [_vp, C.c_int, _vp, _vp, _vp]
+            L.rcorres_overlap_ratio.restype = C.c_double
+            L.rcorres_overlap_ratio.argtypes = [_vp, C.c_double, _vp]
+            L.rcorres_icp.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, C.c_double, C.c_int, C.c_double, _vp, _vp, _vp, _vp]
+            cls._libs[uncapped] = L
+        return cls._libs[uncapped]
+
+    def __init__(self, out_dir=None, uncapped=False, reg_dist=0.03, dist_thresh=None, reg_ratio=0.25, reg_num=40000,
+                 output_information=True):
+        """out_dir (with trailing slash): where FindCorrespondence writes corres_<i>_<j>.txt; None = save_corres_ off."""
+        self.L = self.lib(uncapped)
+        self._h = _vp(self.L.rcorres_create(out_dir.encode() if out_dir else None))
+        self.L.rcorres_set_params(self._h, float(reg_dist), float(reg_dist / 2.0 if dist_thresh is None else dist_thresh),
+                                  float(reg_ratio), int(reg_num), int(bool(output_information)))
+        self.output_information = bool(output_information)
+
+    def close(self):
+        if self._h:
+            self.L.rcorres_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def add_cloud(self, xyz, nrm):
+        x = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        n = np.ascontiguousarray(nrm, np.float32).reshape(-1, 3)
+        return int(self.L.rcorres_add_cloud(self._h, _p(x), _p(n), x.shape[0]))
+
+    def add_pair(self, id1, id2, frame, T):
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        self.L.rcorres_add_pair(self._h, int(id1), int(id2), int(frame), _p(Tm))
+
+    def blacklist(self, i):
+        self.L.rcorres_blacklist(self._h, int(i))
+
+    def Registration(self):
+        self.L.rcorres_registration(self._h)
+
+    def FindCorrespondence(self):
+        self.L.rcorres_find_correspondence(self._h)
+
+    def pairs(self):
+        """[(id1, id2, frame, T float64 4x4, information 6x6 or None)] = corres_traj_ / corres_info_ as they stand."""
+        out = []
+        for k in range(int(self.L.rcorres_num_pairs(self._h))):
+            ids = np.zeros(3, np.int32)
+            T, info = np.zeros(16), np.zeros(36)
+            self.L.rcorres_get_pair(self._h, k, _p(ids), _p(T), _p(info) if self.output_information else None)
+            out.append((int(ids[0]), int(ids[1]), int(ids[2]), T.reshape(4, 4), info.reshape(6, 6) if self.output_information else None))
+        return out
+
+    def overlap_ratio(self, T, length=3.0):
+        Tm = np.ascontiguousarray(T, np.float64).reshape(16)
+        return float(self.L.rcorres_overlap_ratio(self._h, float(length), _p(Tm)))
+
+    @classmethod
+    def icp(cls, src_xyz, src_nrm, tgt_xyz, tgt_nrm, guess, max_dist=0.03, max_iter=20, eps=1e-6, want_fitness=False):
+        """The stub's PCL 1.7 ICP (kd-tree + vendored Eigen) as CorresApp.cpp:295-306 configures it: (T float32, iterations, converged, fitness)."""
+        L = cls.lib()
+        sx, sn = np.ascontiguousarray(src_xyz, np.float32), np.ascontiguousarray(src_nrm, np.float32)
+        tx, tn = np.ascontiguousarray(tgt_xyz, np.float32), np.ascontiguousarray(tgt_nrm, np.float32)
+        g = np.ascontiguousarray(guess, np.float32).reshape(16)
+        out = np.empty(16, np.float32)
+        it, cv, fit = C.c_int(0), C.c_int(0), C.c_double(0)
+        L.rcorres_icp(_p(sx), _p(sn), sx.shape[0], _p(tx), _p(tn), tx.shape[0], _p(g), float(max_dist), int(max_iter), float(eps),
+                      _p(out), C.byref(it), C.byref(cv), C.byref(fit) if want_fitness else None)
+        return out.reshape(4, 4), it.value, bool(cv.value), (fit.value if want_fitness else None)
+
+
+class RefRansac:
+    """oracle/_ref/libref_ransac.so: the reference's own GlobalRegistration/RansacCurvature.h (getFitness, getInformation,
+    align_redux) included in place behind oracle/ref_ransac_driver.cpp.  Only where /root/reference was present at build time."""
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(os.path.join(HERE, "_ref", "libref_ransac.so"))
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            L = _load("_ref/libref_ransac.so")
+            L.rransac_create.restype = _vp
+            L.rransac_create.argtypes = [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_double, C.c_float, C.c_int]
+            L.rransac_destroy.argtypes = [_vp]
+            L.rransac_fitness.argtypes = [_vp, _vp, _vp, _vp, _vp]
+            L.rransac_align_redux.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+            cls._lib = L
+        return cls._lib
+
+    def __init__(self, src_xyz, src_nrm, tgt_xyz, tgt_nrm, max_corr_dist, inlier_fraction=0.0, inlier_number=1000000):
+        sx, sn = np.ascontiguousarray(src_xyz, np.float32), np.ascontiguousarray(src_nrm, np.float32)
+        tx, tn = np.ascontiguousarray(tgt_xyz, np.float32), np.ascontiguousarray(tgt_nrm, np.float32)
+        self.n = sx.shape[0]
+        self._h = _vp(self.lib().rransac_create(_p(sx), _p(sn), self.n, _p(tx), _p(tn), tx.shape[0], float(max_corr_dist),
+                                                C.c_float(inlier_fraction), int(inlier_number)))
+
+    def close(self):
+        if self._h:
+            self.lib().rransac_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def fitness(self, M):
+        """getFitness with final_transformation_ = M: (inliers, inliers_target, float32 fitness score)."""
+        Mm = np.ascontiguousarray(M, np.float32).reshape(16)
+        a, b = np.empty(max(self.n, 1), np.int32), np.empty(max(self.n, 1), np.int32)
+        f = C.c_float(0)
+        m = int(self.lib().rransac_fitness(self._h, _p(Mm), _p(a), _p(b), C.byref(f)))
+        return a[:m].copy(), b[:m].copy(), float(f.value)
+
+    def align_redux(self, guess):
+        """align_redux( out, guess ) + getInformation(): (converged, inliers_, inliers_target_, information_source_, information_target_)."""
+        g = np.ascontiguousarray(guess, np.float32).reshape(16)
+        a, b = np.empty(max(self.n, 1), np.int32), np.empty(max(self.n, 1), np.int32)
+        i_s, i_t = np.zeros(36), np.zeros(36)
+        m = C.c_int(0)
+        conv = int(self.lib().rransac_align_redux(self._h, _p(g), self.n, C.byref(m), _p(a), _p(b), _p(i_s), _p(i_t)))
+        return bool(conv), a[:m.value].copy(), b[:m.value].copy(), i_s.reshape(6, 6), i_t.reshape(6, 6)

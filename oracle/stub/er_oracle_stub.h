@@ -197,12 +197,23 @@ struct PointXYZRGBNormal {
   PointXYZRGBNormal() : x(0), y(0), z(0), normal_x(0), normal_y(0), normal_z(0), rgb(0), curvature(0) {}   // PCL 1.7 zero-initialises
 };
 
+struct PCLHeader { unsigned seq; unsigned long long stamp; std::string frame_id; PCLHeader() : seq(0), stamp(0) {} };
 template <class PointT> class PointCloud {
  public:
   typedef boost::shared_ptr<PointCloud<PointT> > Ptr;
+  typedef boost::shared_ptr<const PointCloud<PointT> > ConstPtr;
+  PCLHeader header;
   std::vector<PointT> points;
-  void push_back(const PointT& p) { points.push_back(p); }
+  unsigned width, height;
+  bool is_dense;
+  PointCloud() : width(0), height(0), is_dense(true) {}
+  void push_back(const PointT& p) { points.push_back(p); width = (unsigned)points.size(); height = 1; }
   size_t size() const { return points.size(); }
+  bool empty() const { return points.empty(); }
+  void clear() { points.clear(); width = height = 0; }
+  void resize(size_t n) { points.resize(n); width = (unsigned)n; height = 1; }   // RansacCurvature.h:674,761
+  PointT& operator[](size_t i) { return points[i]; }
+  const PointT& operator[](size_t i) const { return points[i]; }
 };
 
 // FragmentOptimizer/OptApp.cpp:921-922 (SavePoints, only with --write_xyzn_sample).  The stand-in stores the same records

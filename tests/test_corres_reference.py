@@ -1,0 +1,234 @@
+"""Path B pinned to the reference's OWN compiled code (CPU, no GPU needed).
+
+oracle/_ref/BuildCorrespondence_ref is /root/reference/BuildCorrespondence/{BuildCorrespondence,CorresApp}.cpp compiled in
+place, unmodified, against oracle/stub_corres (PCD reader, exact kd-tree, PCL 1.7 cloud transforms and ICP restated on the
+reference's vendored Eigen).  These tests check oracle/icp_oracle.cpp -- the restatement every GPU parity test compares with --
+against that program and against the in-process CCorresApp (oracle/_ref/libref_corres.so):
+  * everything OUTSIDE PCL (LoadData incl. the NaN filter and the generated overlap pairs, the Registration pre-check and accept
+    rule, blacklist, redux, FindCorrespondence with NormalDot and the ratio test, the information matrix, Finalize's formats,
+    --reg_dist -> dist_thresh_ = reg_dist / 2) is thereby pinned to reference code;
+  * the PCL 1.7 ICP loop now has two independent statements (uniform grid + hand-written LU in icp_oracle.cpp; kd-tree + Eigen's
+    ATA.inverse() * ATb, Matrix4f products in the stub) which must agree over easy and hard pairs and in every stop branch."""
+import os
+
+import numpy as np
+import pytest
+
+from corres_helpers import REF_BIN, ground_truth, read_outputs, run_program, standard_pairs, write_scene
+from elasticreconstruction_amd import formats, synth
+from elasticreconstruction_amd.icp import CorresApp
+from oracle.pyoracle import IcpOracle, RefCorres
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(REF_BIN) and RefCorres.available()),
+                                reason="oracle/_ref/BuildCorrespondence_ref is built where /root/reference exists")
+
+
+def test_reference_program_equals_the_restatement(tmp_path):
+    """--reg_traj --registration --reg_dist 0.04 --output_information --blacklist on five fragments (ascii, binary and
+    binary_compressed PCDs, NaN normals): a hopeless pair (rejected by the pre-check), two pairs of a blacklisted fragment."""
+    d = str(tmp_path) + "/"
+    fr = write_scene(d)
+    pairs = standard_pairs(fr, d)
+    with open(d + "black.txt", "w") as f:
+        f.write("# comment line\n4\n")
+    run_program(REF_BIN, ["--reg_traj", d + "init.log", "--registration", "--reg_dist", "0.04", "--output_information",
+                          "--blacklist", d + "black.txt", "--save_xyzn"], d)
+    log, info, corr = read_outputs(d, pairs)
+    assert [(t.id1, t.id2) for t in log] == [(t.id1, t.id2) for t in pairs]
+    assert [t.frame == -1 for t in log] == [False, True, False, False, True, True]
+    assert set(corr) == {(0, 1), (1, 2), (2, 3)}
+    # LoadData: the NaN filter and the .xyzn dump (CorresApp.cpp:93-108)
+    xyzn = np.loadtxt(d + "cloud_bin_xyzn_2.xyzn")
+    assert xyzn.shape == (len(fr[2][0]), 6)
+    assert np.abs(xyzn[:, :3] - fr[2][0]).max() < 1e-6 and np.abs(xyzn[:, 3:] - fr[2][1]).max() < 1e-6
+    loaded = formats.load_log(d + "init.log")
+    oc = [IcpOracle(x, n, 0.04) for x, n, _ in fr]
+    for k, t in enumerate(loaded):
+        if t.id1 == 4 or t.id2 == 4:
+            assert np.abs(log[k].T - t.T).max() < 1e-8                         # blacklisted: transform untouched, frame -1
+            continue
+        cnt = oc[t.id2].count_inliers(oc[t.id1], t.T, 0.04)
+        r1, r2 = cnt / oc[t.id1].n, cnt / oc[t.id2].n
+        accept = cnt >= 40000 or (r1 > 0.25 and r2 > 0.25)                      # CorresApp.cpp:266-270
+        assert accept == (log[k].frame != -1)
+        if not accept:
+            assert np.abs(log[k].T - t.T).max() < 1e-8
+            continue
+        To, ito, conv, _ = oc[t.id2].align(oc[t.id1], t.T.astype(np.float32), max_dist=0.04)
+        assert conv and np.abs(log[k].T - To.astype(np.float64)).max() <= 6e-9, np.abs(log[k].T - To).max()   # the file rounds to 8 decimals
+        # FindCorrespondence on the transform the program wrote; --reg_dist 0.04 made dist_thresh_ 0.02 (BuildCorrespondence.cpp:52-55)
+        po, io = oc[t.id2].find_correspondence(oc[t.id1], To.astype(np.float64), 0.02, want_info=True)
+        assert corr[(t.id1, t.id2)] == "".join("%d %d\n" % (a, b) for a, b in po)
+        assert log[k].frame == po.shape[0] and po.shape[0] >= 0.5 * cnt         # ratio test passed (:164)
+        assert info[k].frame == log[k].frame and np.allclose(info[k].info, io, rtol=1e-12, atol=1e-7)
+        assert np.abs(To.astype(np.float64) - ground_truth(fr, t.id1, t.id2)).max() < 2e-3
+
+
+def test_in_process_reference_equals_the_restatement_in_full_precision():
+    """CCorresApp::Registration + FindCorrespondence called in process (no 8-decimal rounding): counts, transforms and
+    information matrices of the restatement against the reference's members (15 k-point fragments are sparse, so reg_dist_ is
+    0.06 and dist_thresh_ 0.03); includes the `Reduced too much` branch with
+    reg_num_ > 0 (frame_ = -1) and with reg_num_ <= 0 (frame_ = corres.size(), CorresApp.cpp:164-173)."""
+    fr = synth.fragment_set(4, 15000, seed=31)
+    pairs = [(0, 1, ground_truth(fr, 0, 1) @ synth.perturbation(1, 2.0, 0.02)),
+             (1, 2, ground_truth(fr, 1, 2) @ synth.perturbation(2, 4.0, 0.04)),
+             (0, 3, ground_truth(fr, 0, 3) @ synth.perturbation(3, 1.0, 0.01))]
+    for reg_num in (40000, 0):
+        app = RefCorres(reg_dist=0.06, reg_num=reg_num)
+        for x, n, _ in fr:
+            app.add_cloud(x, n)
+        for i, j, T in pairs:
+            app.add_pair(i, j, len(fr), T)
+        app.Registration()
+        after_reg = app.pairs()
+        oc = [IcpOracle(x, n, 0.06) for x, n, _ in fr]
+        finals = []
+        for (i, j, T), (ri, rj, rframe, rT, _) in zip(pairs, after_reg):
+            cnt = oc[j].count_inliers(oc[i], T, 0.06)
+            assert (ri, rj, rframe) == (i, j, cnt)                              # frame_ = cnt (:273)
+            To, _, conv, _ = oc[j].align(oc[i], T.astype(np.float32), max_dist=0.06)
+            assert conv and np.abs(rT - To.astype(np.float64)).max() <= 1e-7, np.abs(rT - To).max()
+            finals.append(rT)
+        # a transform that leaves < 50 % of the pre-check count: exercise the ratio branch through the reference's own loop
+        app2 = RefCorres(reg_dist=0.06, reg_num=reg_num)
+        for x, n, _ in fr:
+            app2.add_cloud(x, n)
+        bad = finals[0] @ synth.perturbation(9, 6.0, 0.09)
+        app2.add_pair(0, 1, after_reg[0][2], bad)                               # frame_ as Registration left it
+        app2.add_pair(1, 2, after_reg[1][2], finals[1])
+        app2.FindCorrespondence()
+        got = app2.pairs()
+        for k, (i, j, T) in enumerate(((0, 1, bad), (1, 2, finals[1]))):
+            po, io = oc[j].find_correspondence(oc[i], T, 0.03, want_info=True)
+            ratio = po.shape[0] / after_reg[k][2]
+            assert (ratio < 0.5) == (k == 0), ratio                             # pair 0 takes the `Reduced too much` branch
+            want = po.shape[0] if (ratio >= 0.5 or reg_num <= 0) else -1
+            assert got[k][2] == want, (got[k][2], want, ratio)
+            assert np.allclose(got[k][4], io, rtol=1e-13, atol=1e-9)
+        app.close()
+        app2.close()
+
+
+@pytest.mark.parametrize("rot,trans,max_iter,eps,expect", [
+    (2.0, 0.02, 20, 1e-6, "transform"), (5.0, 0.05, 20, 1e-6, "transform"), (8.0, 0.08, 20, 1e-6, "transform"),
+    (8.0, 0.08, 5, 1e-6, "max_iter"), (2.0, 0.02, 20, 0.0, "mse_or_max"), (2.0, 0.02, 1, 1e-6, "max_iter")])
+def test_two_statements_of_the_pcl_icp_loop_agree(rot, trans, max_iter, eps, expect):
+    """oracle/icp_oracle.cpp against the stub's Eigen / kd-tree statement: identical iteration counts and stop decisions,
+    transforms within 1e-6 (they have been bit-identical so far), over easy pairs, hard pairs (>= 10 iterations), the
+    iteration limit, and the MSE / iteration-limit exits that a zero transformation epsilon forces."""
+    fr = synth.fragment_set(3, 20000, seed=5)
+    gt = ground_truth(fr, 0, 1)
+    g = (gt @ synth.perturbation(3, rot, trans)).astype(np.float32)
+    T1, it1, c1, _ = RefCorres.icp(fr[1][0], fr[1][1], fr[0][0], fr[0][1], g, 0.03, max_iter, eps)
+    a, b = IcpOracle(fr[1][0], fr[1][1], 0.03), IcpOracle(fr[0][0], fr[0][1], 0.03)
+    T2, it2, c2, _ = a.align(b, g, 0.03, max_iter, eps)
+    assert (it1, c1) == (it2, c2) and np.abs(T1 - T2).max() <= 1e-6, (it1, it2, c1, c2, np.abs(T1 - T2).max())
+    if expect == "max_iter":
+        assert it1 == max_iter and c1
+    elif expect == "transform":
+        assert it1 < max_iter and c1 and (rot < 8 or it1 >= 10)
+    else:
+        assert c1 and it1 > 4                                                   # no small-step exit with eps = 0
+    if max_iter >= 20:
+        assert np.abs(T1.astype(np.float64) - gt).max() < 2e-3
+
+
+def test_icp_degenerate_exits_agree():
+    """Fewer than 3 correspondences (clouds 10 m apart): not converged, zero iterations, the guess comes back; identical
+    clouds with an identity guess: one iteration, converged on the transform criterion."""
+    fr = synth.fragment_set(2, 5000, seed=9)
+    far = np.eye(4, dtype=np.float32)
+    far[0, 3] = 10.0
+    a, b = IcpOracle(fr[1][0], fr[1][1], 0.03), IcpOracle(fr[0][0], fr[0][1], 0.03)
+    T1, it1, c1, _ = RefCorres.icp(fr[1][0], fr[1][1], fr[0][0], fr[0][1], far)
+    T2, it2, c2, _ = a.align(b, far)
+    assert (it1, c1, it2, c2) == (0, False, 0, False) and np.array_equal(T1, far) and np.array_equal(T2, far)
+    T1, it1, c1, _ = RefCorres.icp(fr[0][0], fr[0][1], fr[0][0], fr[0][1], np.eye(4, dtype=np.float32))
+    T2, it2, c2, _ = b.align(b, np.eye(4, dtype=np.float32))
+    assert (it1, c1) == (it2, c2) == (1, True) and np.abs(T1 - T2).max() <= 1e-7 and np.abs(T1 - np.eye(4)).max() < 1e-6
+
+
+def test_generated_overlap_pairs(tmp_path):
+    """--traj/--num/--interval/--length: LoadData builds the pair list itself (CorresApp.cpp:40-69, GetVolumeOverlapRatio
+    CorresApp.h:64-81) -- consecutive fragments always, the others when their cubes overlap by more than 30 %.  The Python
+    mirror's host-only InitialPairs must produce the same list; without --registration the program then runs
+    FindCorrespondence on the generated transforms with frame_ = num (ratio test against the fragment count)."""
+    d = str(tmp_path) + "/"
+    fr = write_scene(d, num=10, pts=6000, radius=0.8)         # cubes on a ring, 36 degrees apart: only neighbours overlap by > 30 %
+    B = synth.basepose(3.0)
+    cams = []
+    for i in range(10):
+        for j in range(3):                                     # every 3rd camera pose is a fragment pose (frame = pose x basepose^-1)
+            cams.append(formats.FramedTransformation(3 * i + j, 3 * i + j, 3 * i + j + 1, fr[i][2] @ B @ synth.perturbation(50 + j, 0.2 * j, 0.001 * j)))
+    formats.save_log(d + "traj.log", cams)
+    app = CorresApp()
+    app.length_, app.interval_ = 3.0, 3
+    want = app.InitialPairs(d + "traj.log", 10)
+    ids = [(t.id1, t.id2) for t in want]
+    assert all((i, i + 1) in ids for i in range(9)) and (0, 9) in ids and (0, 2) not in ids and len(ids) == 10, ids   # 0 and 9 are neighbours on the ring
+    run_program(REF_BIN, ["--traj", d + "traj.log", "--num", "10", "--interval", "3", "--length", "3.0", "--output_information"], d)
+    log, info, corr = read_outputs(d, want)
+    assert [(t.id1, t.id2) for t in log] == ids
+    ref = RefCorres()
+    rng = np.random.RandomState(4)
+    for T in [t.T for t in want] + [synth.perturbation(int(rng.randint(1 << 30)), 180, 3.0) for _ in range(200)]:
+        assert ref.overlap_ratio(T) == app.GetVolumeOverlapRatio(T)
+    oc = [IcpOracle(x, n, 0.03) for x, n, _ in fr]
+    for t, w, fi in zip(log, want, info):
+        assert np.abs(t.T - w.T).max() <= 6e-9                 # the generated guess, rounded to 8 decimals by SaveToFile
+        po, io = oc[w.id2].find_correspondence(oc[w.id1], w.T, 0.015, want_info=True)
+        assert corr[(w.id1, w.id2)] == "".join("%d %d\n" % (a, b) for a, b in po)
+        assert t.frame == (po.shape[0] if po.shape[0] / 10.0 >= 0.5 else -1) and fi.frame == t.frame
+        assert np.allclose(fi.info, io, rtol=1e-12, atol=1e-7)
+
+
+def test_redux_replaces_the_transform_of_an_accepted_pair(tmp_path):
+    """--redux: an accepted pair that the redux log names takes the log's transform instead of running ICP (CorresApp.cpp:283-293,
+    GetReduxIndex = i + j * num_); pairs the log does not name are aligned as usual; a rejected pair stays rejected."""
+    d = str(tmp_path) + "/"
+    fr = write_scene(d)
+    pairs = standard_pairs(fr, d)
+    mark = ground_truth(fr, 0, 1) @ synth.perturbation(77, 0.05, 0.0005)
+    formats.save_log(d + "redux.log", [formats.FramedTransformation(0, 1, 5, mark), formats.FramedTransformation(0, 2, 5, np.eye(4)),
+                                       formats.FramedTransformation(4, 0, 5, np.eye(4))])
+    run_program(REF_BIN, ["--reg_traj", d + "init.log", "--registration", "--reg_dist", "0.04", "--redux", d + "redux.log"], d)
+    log = formats.load_log(d + "reg_output.log")
+    oc = [IcpOracle(x, n, 0.04) for x, n, _ in fr]
+    assert np.abs(log[0].T - mark).max() <= 6e-9 and log[0].frame > 0
+    assert log[1].frame == -1 and np.abs(log[1].T - pairs[1].T).max() <= 6e-9          # rejected before the redux lookup
+    for k in (2, 3):
+        To, _, _, _ = oc[pairs[k].id2].align(oc[pairs[k].id1], formats.load_log(d + "init.log")[k].T.astype(np.float32), max_dist=0.04)
+        assert np.abs(log[k].T - To.astype(np.float64)).max() <= 6e-9
+
+
+@pytest.mark.skipif(not __import__("oracle.pyoracle", fromlist=["RefRansac"]).RefRansac.available(), reason="oracle/_ref/libref_ransac.so not built")
+def test_ransac_fitness_and_information_equal_the_reference_header():
+    """GlobalRegistration/RansacCurvature.h included in place -- getFitness (:661-704: inlier lists in point
+    order, float32 running sum / count, FLT_MAX when empty), align_redux (:751-817: accept rule on the inlier fraction / number)
+    and getInformation (:707-733) against oracle/icp_oracle.cpp's icp_ransac_fitness / icp_ransac_inliers."""
+    from oracle.pyoracle import RefRansac
+    fr = synth.fragment_set(2, 12000, seed=41)
+    (x0, n0, _), (x1, n1, _) = fr
+    gt = ground_truth(fr, 0, 1)
+    tgt, src = IcpOracle(x0, n0, 0.05), IcpOracle(x1, n1, 0.05)
+    for M, thr in ((gt.astype(np.float32), 0.05), ((gt @ synth.perturbation(8, 1.0, 0.01)).astype(np.float32), 0.03),
+                   (np.eye(4, dtype=np.float32), 0.05), (synth.perturbation(5, 60, 2.0).astype(np.float32), 0.05)):
+        ref = RefRansac(x1, n1, x0, n0, thr)
+        ins, int_, fit = ref.fitness(M)
+        cnt, fit32, _ = src.ransac_fitness(tgt, M, thr)
+        oi, ot, info_s, info_t = src.ransac_inliers(tgt, M, thr)
+        assert cnt == len(ins) and np.array_equal(oi, ins) and np.array_equal(ot, int_)
+        assert np.float32(fit) == np.float32(fit32)                                 # the same float32 running sum, bit for bit
+        conv, a, b, rs, rt = ref.align_redux(M)
+        assert conv == (len(ins) > 0)                                                # inlier_fraction_ = 0: any inlier set is accepted
+        if conv:
+            assert np.array_equal(a, ins) and np.array_equal(b, int_)
+            assert np.allclose(rs, info_s, rtol=1e-13, atol=1e-9) and np.allclose(rt, info_t, rtol=1e-13, atol=1e-9)
+        ref.close()
+    # accept rule: a fraction the inliers cannot reach and an inlier number they cannot exceed -> not converged
+    ref = RefRansac(x1, n1, x0, n0, 0.05, inlier_fraction=0.999, inlier_number=10 ** 7)
+    assert ref.align_redux(gt.astype(np.float32))[0] is False
+    ref.close()
+    ref = RefRansac(x1, n1, x0, n0, 0.05, inlier_fraction=0.999, inlier_number=100)
+    assert ref.align_redux(gt.astype(np.float32))[0] is True
+    ref.close()

@@ -224,6 +224,41 @@ def test_ransac_fitness_batch_matches_oracle(gpu):
         ransac_fitness_batch(src, tgt, hyps, 0.08)               # radius beyond the target's grid cell
 
 
+def test_ransac_entry_points_equal_the_reference_header(gpu, tmp_path):
+    """er_ransac_fitness_batch / er_ransac_inliers against the reference's OWN RansacCurvature.h (getFitness :661-704,
+    getInformation :707-733, included in place behind oracle/_ref/libref_ransac.so when that library travelled here) and against
+    its committed results (tests/golden/corres_golden.json): inlier lists identical, fitness within 1e-6 of the reference's
+    float32 running sum (the GPU sums in float64), information within 1e-12."""
+    import hashlib
+    from corres_helpers import corres_golden, scene_digest, write_scene
+    from elasticreconstruction_amd.icp import ransac_fitness_batch, ransac_inliers
+    from oracle.pyoracle import RefRansac
+    fr = write_scene(str(tmp_path) + "/")
+    g = corres_golden()
+    golden_ok = scene_digest(fr) == g["scene_digest"]
+    assert golden_ok or RefRansac.available()
+    tgt, src = Cloud(fr[0][0], fr[0][1], 0.05), Cloud(fr[1][0], fr[1][1], 0.05)
+    for r in g["ransac"]:
+        M = np.array(r["M"], np.float32).reshape(4, 4)
+        cnt, fit = ransac_fitness_batch(src, tgt, [M], r["thr"])
+        ins, int_, f, info_s, info_t = ransac_inliers(src, tgt, M, r["thr"])
+        if RefRansac.available():
+            ref = RefRansac(fr[1][0], fr[1][1], fr[0][0], fr[0][1], r["thr"])
+            r_ins, r_int, r_fit = ref.fitness(M)
+            conv, a, b, r_is, r_it = ref.align_redux(M)
+            ref.close()
+            assert int(cnt[0]) == len(r_ins) and np.array_equal(ins, r_ins) and np.array_equal(int_, r_int) and conv
+            assert fit[0] == pytest.approx(r_fit, rel=1e-5) and f == pytest.approx(r_fit, rel=1e-5)
+            assert np.allclose(info_s, r_is, rtol=1e-12, atol=1e-9) and np.allclose(info_t, r_it, rtol=1e-12, atol=1e-9)
+        if golden_ok:
+            assert int(cnt[0]) == r["inliers"]
+            assert hashlib.sha256(ins.astype(np.int32).tobytes()).hexdigest() == r["inliers_sha256"]
+            assert hashlib.sha256(int_.astype(np.int32).tobytes()).hexdigest() == r["inliers_target_sha256"]
+            assert fit[0] == pytest.approx(float(np.frombuffer(bytes.fromhex(r["fitness_f32_hex"]), np.float32)[0]), rel=1e-5)
+            assert np.allclose(info_s.reshape(-1), r["info_source"], rtol=1e-12, atol=1e-9)
+            assert np.allclose(info_t.reshape(-1), r["info_target"], rtol=1e-12, atol=1e-9)
+
+
 def test_config2_size_50_pairs_over_25_distinct_fragments(gpu):
     """BASELINE.json configs[2] at full size: 50 pairs over 25 DISTINCT fragments of 250 k points each, through the reference's
     two loops (Registration: pre-check + ICP; FindCorrespondence + information matrix) as bench.py runs them (the *_batch
