@@ -450,9 +450,9 @@ def main():
     ap.add_argument("--no-streamed", action="store_true", help="skip the extra pass that streams the frames from page-locked host memory")
     ap.add_argument("--force-merge", action="store_true",
                     help="run the frame-split merge (key all-gather + all-reduce) even with one rank: exercises the RCCL path on a 1-GPU box")
-    ap.add_argument("--merge-impl", choices=["torch", "abi"], default="torch",
-                    help="frame-split merge through torch.distributed (parallel.merge_volumes) or through liber_hip.so's own RCCL "
-                         "calls (er_tsdf_allreduce, what bin/Integrate --gpus uses)")
+    ap.add_argument("--merge-impl", choices=["torch", "abi"], default="abi",
+                    help="frame-split merge through liber_hip.so's own RCCL calls (er_tsdf_allreduce: the product path, what "
+                         "bin/Integrate --gpus uses; default) or through torch.distributed (parallel.merge_volumes, the cross-check)")
     ap.add_argument("--icp-pairs", type=int, default=50,
                     help="also time N fragment pairs per GPU through Registration + FindCorrespondence (configs[2] shape) and add an "
                          "'icp' object with BASELINE.json's second figure, pairs/s (0 = skip)")
@@ -526,9 +526,22 @@ def main():
                 vol.IntegrateFrames(None, sc["traj"][lo:hi], warp_slice(lo, hi), device_ptr=depth.data_ptr() + lo * px * 2)
 
     comm = None
+    merge_note = None
     if use_dist and args.merge_impl == "abi":
         from elasticreconstruction_amd import parallel
-        comm = parallel.AbiComm(dist, local)
+        try:
+            comm = parallel.AbiComm(dist, local)
+            failed = 0
+        except Exception as ex:                                          # e.g. librccl.so.1 not loadable from the library
+            comm, failed, merge_note = None, 1, "er_comm_create failed on rank %d: %s" % (rank, ex)
+        flag = torch.tensor([failed], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)                      # the choice of implementation must be the same on every rank
+        if int(flag.item()):
+            if comm is not None:
+                comm.close()
+            comm = None
+            merge_note = merge_note or "er_comm_create failed on another rank"
+            args.merge_impl = "torch"
 
     def merge(vol):
         """Frame-split merge: key all-gather + ONE reduce(sum) to rank 0 over the sdf*w / w planes."""
@@ -681,7 +694,10 @@ def main():
         }
         if use_dist:
             out["config"]["merge_union_units"] = n_union
-            out["config"]["merge_impl"] = args.merge_impl
+            out["config"]["merge_impl"] = args.merge_impl + (" (er_tsdf_allreduce: liber_hip.so's own RCCL calls)" if args.merge_impl == "abi" else " (parallel.merge_volumes over torch.distributed)")
+            out["config"]["rccl_ranks"] = world
+            if merge_note:
+                out["config"]["merge_impl_note"] = merge_note
         timed_launches = max(prof["launches"], 1)                 # every --event-stride-th launch of the timed passes carries HIP events
         ms_launch = prof["integrate_ms"] / timed_launches
         per_step = -(-S // 64)                                     # er_tsdf_integrate_frames: ceil(S / 64) launches of equal size per step

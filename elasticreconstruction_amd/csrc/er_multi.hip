@@ -16,6 +16,8 @@
 // torch.distributed) or er_comm_create_local (one process driving several GPUs from one host thread each).
 #include "er_common.h"
 
+#include "er_merge_protocol.h"
+
 #include "../../include/er_hip.h"
 
 #include <dlfcn.h>
@@ -38,16 +40,25 @@ struct Rccl {
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
+  char why[256] = "librccl.so.1 not found";      // dlerror() of the failed load, read ONCE (a second call returns NULL)
 };
 
-Rccl* rccl() {
+Rccl& rccl_state() {
   static Rccl R;
+  return R;
+}
+const char* rccl_reason() { return rccl_state().why; }
+
+Rccl* rccl() {
+  Rccl& R = rccl_state();
   static std::once_flag once;
-  std::call_once(once, [] {
+  std::call_once(once, [&R] {
     const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (const char* n : names) {
       R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (R.lib) break;
+      const char* e = dlerror();
+      if (e) snprintf(R.why, sizeof R.why, "%s", e);
     }
     if (!R.lib) return;
 #define ER_SYM(field, name) R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.lib, name))
@@ -61,9 +72,11 @@ Rccl* rccl() {
     ER_SYM(GetErrorString, "ncclGetErrorString");
 #undef ER_SYM
     R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllReduce && R.Reduce && R.AllGather && R.GetErrorString;
+    if (!R.ok) snprintf(R.why, sizeof R.why, "librccl.so.1 lacks one of the eight nccl* entry points");
   });
   return R.ok ? &R : nullptr;
 }
+
 
 #define ER_NCCL_TRY(R, expr)                                                                        \
   do {                                                                                              \
@@ -83,6 +96,83 @@ struct er_comm_s {
   size_t ikeys_cap = 0;
 };
 
+
+namespace {
+
+// er::MergeTransport over one RCCL communicator; small host arrays are staged through the communicator's device scratch.
+struct RcclTransport : er::MergeTransport {
+  Rccl* R;
+  er_comm_t c;
+  hipStream_t S;
+  RcclTransport(Rccl* r, er_comm_t comm, hipStream_t s) : R(r), c(comm), S(s) {}
+  int rank() const override { return c->rank; }
+  int world() const override { return c->world; }
+  int scratch(size_t ints) {
+    if (c->ikeys_cap >= ints) return 0;
+    if (c->ikeys) (void)hipFree(c->ikeys);
+    c->ikeys = nullptr;
+    c->ikeys_cap = 0;
+    const size_t cap = std::max<size_t>(ints, 64);
+    ER_HIP_TRY(hipMalloc((void**)&c->ikeys, cap * sizeof(int)));
+    c->ikeys_cap = cap;
+    return 0;
+  }
+  int allreduce_max(int* v, int n) override {
+    if (scratch(2 * (size_t)n)) return 1;
+    ER_HIP_TRY(hipMemcpyAsync(c->ikeys, v, (size_t)n * sizeof(int), hipMemcpyHostToDevice, S));
+    ER_NCCL_TRY(R, R->AllReduce(c->ikeys, c->ikeys + n, (size_t)n, ncclInt32, ncclMax, c->comm, S));
+    ER_HIP_TRY(hipMemcpyAsync(v, c->ikeys + n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, S));
+    ER_HIP_TRY(hipStreamSynchronize(S));
+    return 0;
+  }
+  int allgather(const int* mine, int n, int* all) override {
+    if (scratch((size_t)n * ((size_t)c->world + 1))) return 1;
+    ER_HIP_TRY(hipMemcpyAsync(c->ikeys, mine, (size_t)n * sizeof(int), hipMemcpyHostToDevice, S));
+    ER_NCCL_TRY(R, R->AllGather(c->ikeys, c->ikeys + n, (size_t)n, ncclInt32, c->comm, S));
+    ER_HIP_TRY(hipMemcpyAsync(all, c->ikeys + n, (size_t)n * c->world * sizeof(int), hipMemcpyDeviceToHost, S));
+    ER_HIP_TRY(hipStreamSynchronize(S));
+    return 0;
+  }
+  int reduce_sum(float* planes, size_t count, int root) override {
+    if (root < 0)
+      ER_NCCL_TRY(R, R->AllReduce(planes, planes, count, ncclFloat32, ncclSum, c->comm, S));   // the only data-path collective
+    else
+      ER_NCCL_TRY(R, R->Reduce(planes, planes, count, ncclFloat32, ncclSum, root, c->comm, S));
+    return 0;
+  }
+};
+
+// er::MergeVolume over an er_tsdf_t; the planes live in the communicator's grow-only device buffer.
+struct DeviceVolume : er::MergeVolume {
+  er_tsdf_t h;
+  er_comm_t c;
+  DeviceVolume(er_tsdf_t vol, er_comm_t comm) : h(vol), c(comm) {}
+  size_t unit_voxels() const override { return ER_UNIT_VOX; }
+  int touched_keys(std::vector<int>& keys) override {
+    if (er_tsdf_synchronize(h)) return 1;                       // the volume's own streams are drained once per job
+    int n = 0;
+    if (er_tsdf_unit_count(h, &n)) return 1;                    // fails when the unit pool / hash table overflowed
+    keys.assign((size_t)std::max(n, 1), -1);
+    if (n > 0 && er_tsdf_unit_keys(h, keys.data())) return 1;
+    keys.resize((size_t)n);
+    return 0;
+  }
+  int export_planes(const int* uk, int nu, float** planes) override {
+    if (c->buf_units < (size_t)nu) {
+      if (c->buf) (void)hipFree(c->buf);
+      c->buf = nullptr;
+      c->buf_units = 0;
+      ER_HIP_TRY(hipMalloc((void**)&c->buf, (size_t)nu * 2 * ER_UNIT_VOX * sizeof(float)));
+      c->buf_units = (size_t)nu;
+    }
+    *planes = c->buf;
+    return er_tsdf_export_weighted(h, uk, nu, c->buf);          // on the volume's stream, like the collectives
+  }
+  int import_planes(const int* uk, int nu, const float* planes) override { return er_tsdf_import_weighted(h, uk, nu, planes); }
+};
+
+}  // namespace
+
 static_assert(ER_COMM_ID_BYTES == sizeof(ncclUniqueId), "ER_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
 
 extern "C" {
@@ -90,7 +180,7 @@ extern "C" {
 int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]) {
   if (!id) return er::fail("er_comm_unique_id: NULL argument");
   Rccl* R = rccl();
-  if (!R) return er::fail("er_comm_unique_id: librccl.so.1 could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing");
+  if (!R) return er::fail("er_comm_unique_id: librccl.so.1 could not be loaded (%s)", rccl_reason());
   ncclUniqueId u;
   ER_NCCL_TRY(R, R->GetUniqueId(&u));
   memcpy(id, &u, sizeof u);
@@ -102,7 +192,7 @@ int er_comm_create(const unsigned char id[ER_COMM_ID_BYTES], int rank, int world
   *out = nullptr;
   if (world < 1 || rank < 0 || rank >= world) return er::fail("er_comm_create: rank %d not in [0,%d)", rank, world);
   Rccl* R = rccl();
-  if (!R) return er::fail("er_comm_create: librccl.so.1 could not be loaded");
+  if (!R) return er::fail("er_comm_create: librccl.so.1 could not be loaded (%s)", rccl_reason());
   ER_HIP_TRY(hipSetDevice(device));
   ncclUniqueId u;
   memcpy(&u, id, sizeof u);
@@ -123,7 +213,7 @@ int er_comm_create_local(int n, const int* devices, er_comm_t* out) {
   if (n < 1 || !devices || !out) return er::fail("er_comm_create_local: bad arguments");
   for (int i = 0; i < n; i++) out[i] = nullptr;
   Rccl* R = rccl();
-  if (!R) return er::fail("er_comm_create_local: librccl.so.1 could not be loaded");
+  if (!R) return er::fail("er_comm_create_local: librccl.so.1 could not be loaded (%s)", rccl_reason());
   std::vector<ncclComm_t> comms((size_t)n, nullptr);
   ER_NCCL_TRY(R, R->CommInitAll(comms.data(), n, devices));
   for (int i = 0; i < n; i++) {
@@ -151,76 +241,27 @@ int er_comm_destroy(er_comm_t c) {
 int er_comm_rank(er_comm_t c) { return c ? c->rank : -1; }
 int er_comm_world(er_comm_t c) { return c ? c->world : -1; }
 
-// The frame-split merge (see the file header).  Every rank of the communicator calls it once, each from its own host
-// thread / process; root < 0 leaves the merged volume on every rank, otherwise only on `root`.
+// The frame-split merge (see the file header): er_merge_protocol.h's steps over RCCL and the device-resident volume.  Every
+// rank of the communicator calls it once, each from its own host thread / process; root < 0 leaves the merged volume on
+// every rank, otherwise only on `root`.  A rank-local failure (unit pool / hash table overflow, allocation) is carried through
+// the first collective as a status, so ALL ranks return nonzero together instead of the healthy ones waiting for ever.
 int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   if (!h || !c) return er::fail("er_tsdf_allreduce: NULL argument");
   if (root >= c->world) return er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
   if (er::tsdf_device(h) != c->device) return er::fail("er_tsdf_allreduce: the volume lives on device %d, the communicator on %d", er::tsdf_device(h), c->device);
   Rccl* R = rccl();
-  if (!R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded");
+  if (!R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded (%s)", rccl_reason());
   ER_HIP_TRY(hipSetDevice(c->device));
-  if (er_tsdf_synchronize(h)) return 1;                         // the volume's own two streams are drained once per job
-  hipStream_t S = er::tsdf_stream(h);
-  // ---- 1. agree on the padded key count, exchange the keys -------------------------------------
-  int n_local = 0;
-  if (er_tsdf_unit_count(h, &n_local)) return 1;
-  std::vector<int> keys((size_t)std::max(n_local, 1), -1);
-  if (n_local > 0 && er_tsdf_unit_keys(h, keys.data())) return 1;
-  if (c->ikeys_cap < 2) {
-    if (c->ikeys) (void)hipFree(c->ikeys);
-    c->ikeys = nullptr;
-    ER_HIP_TRY(hipMalloc((void**)&c->ikeys, 64 * sizeof(int)));
-    c->ikeys_cap = 64;
+  RcclTransport t(R, c, er::tsdf_stream(h));
+  DeviceVolume v(h, c);
+  const int r = er::merge_protocol(t, v, root, union_units);
+  if (r == er::MERGE_OK) {
+    ER_HIP_TRY(hipStreamSynchronize(er::tsdf_stream(h)));
+    return 0;
   }
-  ER_HIP_TRY(hipMemcpyAsync(c->ikeys, &n_local, sizeof(int), hipMemcpyHostToDevice, S));
-  ER_NCCL_TRY(R, R->AllReduce(c->ikeys, c->ikeys + 1, 1, ncclInt32, ncclMax, c->comm, S));
-  int max_keys = 0;
-  ER_HIP_TRY(hipMemcpyAsync(&max_keys, c->ikeys + 1, sizeof(int), hipMemcpyDeviceToHost, S));
-  ER_HIP_TRY(hipStreamSynchronize(S));
-  if (union_units) *union_units = 0;
-  if (max_keys <= 0) return 0;                                  // nobody touched anything
-  const size_t need = (size_t)max_keys * ((size_t)c->world + 1);
-  if (c->ikeys_cap < need) {
-    (void)hipFree(c->ikeys);
-    c->ikeys = nullptr;
-    c->ikeys_cap = 0;
-    ER_HIP_TRY(hipMalloc((void**)&c->ikeys, need * sizeof(int)));
-    c->ikeys_cap = need;
-  }
-  std::vector<int> padded((size_t)max_keys, -1);
-  std::copy(keys.begin(), keys.begin() + n_local, padded.begin());
-  int* d_mine = c->ikeys;
-  int* d_all = c->ikeys + max_keys;
-  ER_HIP_TRY(hipMemcpyAsync(d_mine, padded.data(), (size_t)max_keys * sizeof(int), hipMemcpyHostToDevice, S));
-  ER_NCCL_TRY(R, R->AllGather(d_mine, d_all, (size_t)max_keys, ncclInt32, c->comm, S));
-  std::vector<int> all((size_t)max_keys * c->world);
-  ER_HIP_TRY(hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int), hipMemcpyDeviceToHost, S));
-  ER_HIP_TRY(hipStreamSynchronize(S));
-  std::sort(all.begin(), all.end());
-  all.erase(std::unique(all.begin(), all.end()), all.end());
-  all.erase(std::remove_if(all.begin(), all.end(), [](int k) { return k < 0; }), all.end());
-  const int nu = (int)all.size();
-  if (union_units) *union_units = nu;
-  if (nu == 0) return 0;
-  // ---- 2. planes of the union, ONE reduction, import ---------------------------------------------
-  if (c->buf_units < (size_t)nu) {
-    if (c->buf) (void)hipFree(c->buf);
-    c->buf = nullptr;
-    c->buf_units = 0;
-    ER_HIP_TRY(hipMalloc((void**)&c->buf, (size_t)nu * 2 * ER_UNIT_VOX * sizeof(float)));
-    c->buf_units = (size_t)nu;
-  }
-  if (er_tsdf_export_weighted(h, all.data(), nu, c->buf)) return 1;       // on S
-  const size_t count = (size_t)nu * 2 * ER_UNIT_VOX;
-  if (root < 0)
-    ER_NCCL_TRY(R, R->AllReduce(c->buf, c->buf, count, ncclFloat32, ncclSum, c->comm, S));     // the only data-path collective
-  else
-    ER_NCCL_TRY(R, R->Reduce(c->buf, c->buf, count, ncclFloat32, ncclSum, root, c->comm, S));
-  if (root < 0 || root == c->rank)
-    if (er_tsdf_import_weighted(h, all.data(), nu, c->buf)) return 1;     // on S, after the reduction
-  ER_HIP_TRY(hipStreamSynchronize(S));
-  return 0;
+  if (r == er::MERGE_PEER_FAILURE)
+    return er::fail("er_tsdf_allreduce: another rank of the communicator failed before the merge (its own er_last_error() says why); nothing was merged");
+  return 1;                                                     // local / transport failure: the message is already recorded
 }
 
 void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi) {

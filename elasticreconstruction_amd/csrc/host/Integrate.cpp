@@ -426,7 +426,8 @@ int main(int argc, char* argv[]) {
     }
     if (wrc[(size_t)g] == 0 && !w.Flush()) wrc[(size_t)g] = 1;
     if (wrc[(size_t)g] == 0 && (er_tsdf_synchronize(w.volume_) != 0 || !w.CheckStatus(true))) wrc[(size_t)g] = 1;
-    // every rank of the communicator must take part in the collective, failed or not (a rank that failed contributes what it has)
+    // every rank of the communicator must take part in the merge, failed or not: a rank whose unit pool / hash table overflowed
+    // reports that through the merge's first collective and ALL ranks return an error together (er_merge_protocol.h) -- nobody hangs
     if (merge) {
       int nu = 0;
       if (er_tsdf_allreduce(w.volume_, comms[(size_t)g], 0, &nu) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); wrc[(size_t)g] = 1; }

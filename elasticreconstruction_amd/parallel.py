@@ -28,20 +28,31 @@ def pair_shard(n_pairs, rank, world):
     return list(range(rank, n_pairs, world))
 
 
-def union_keys(local_keys, dist, device, pad_to=None):
-    """Union of the per-rank touched unit keys (sorted int32 numpy) in ONE fixed-size all-gather (padded with -1): tensor shapes
-    are identical on every rank whatever each rank touched.  pad_to = a length every rank knows without talking (the volume's
-    max_units: a rank cannot hold more keys than that); without it the ranks first AGREE on the padded length with an
-    all_reduce(MAX) of the local counts -- one more collective."""
+class MergeError(RuntimeError):
+    """The frame-split merge was abandoned by ALL ranks together because one of them failed locally."""
+
+
+def _agree_max(values, dist, device):
+    """all_reduce(MAX) of a few host ints (control plane of the merge)."""
+    import torch
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.cpu()]
+
+
+def union_keys(local_keys, dist, device, status=0):
+    """Union of the per-rank touched unit keys (sorted int32 numpy): the ranks first AGREE on the padded length -- one
+    all_reduce(MAX) of {key count, status} -- then exchange the keys in ONE fixed-size all-gather (padded with -1), so every
+    rank issues the same collectives with the same shapes whatever it touched (csrc/er_merge_protocol.h, steps 2-3).
+    status != 0 on any rank makes every rank raise MergeError after the first collective."""
     import torch
     world = dist.get_world_size()
     keys = np.ascontiguousarray(local_keys, np.int32)
-    if pad_to is not None and keys.size <= int(pad_to):
-        max_keys = max(int(pad_to), 1)
-    else:
-        cnt = torch.tensor([keys.size], dtype=torch.int64, device=device)
-        dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
-        max_keys = max(int(cnt.item()), 1)
+    max_keys, any_failed = _agree_max([keys.size, 1 if status else 0], dist, device)
+    if any_failed:
+        raise MergeError("a rank failed before the merge (its unit pool or hash table overflowed?); nothing was merged")
+    if max_keys <= 0:
+        return np.zeros(0, np.int32)
     pad = torch.full((max_keys,), -1, dtype=torch.int32)
     if keys.size:
         pad[:keys.size] = torch.from_numpy(keys)
@@ -53,23 +64,44 @@ def union_keys(local_keys, dist, device, pad_to=None):
 
 
 def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
-    """Frame-split merge.  mode "reduce" (default): ONE reduce(sum) to `root` -- the "final reduce of per-GPU TSDF
+    """Frame-split merge over torch.distributed -- the cross-check of the product path (er_tsdf_allreduce, same protocol:
+    csrc/er_merge_protocol.h).  mode "reduce" (default): ONE reduce(sum) to `root` -- the "final reduce of per-GPU TSDF
     volume-unit weights" of BASELINE.json; afterwards `root` holds the complete volume (the other ranks keep
     their partial volumes).  mode "all_reduce": every rank ends with the complete volume (about 1.75x the
     link traffic of the reduce on a ring).  Returns the union size.
+    A rank-local failure (vol.unit_keys() / export raising, e.g. "raise max_units") is carried through the next collective
+    as a status: every rank raises MergeError together instead of the healthy ones blocking in the reduction.
     sync_stream: callable that orders the communication stream after the volume's kernels and vice versa.  None (default)
     is SAFE for any stream set-up: the volume's streams are drained after the export and torch's current stream (the one
     the collective is ordered on) is drained before the import -- two host waits, once per job."""
     import torch
-    union = union_keys(vol.unit_keys(), dist, device, pad_to=getattr(vol, "max_units", None))
+    local_error = None
+    try:
+        keys = vol.unit_keys()
+    except Exception as ex:                                   # unit pool / hash table overflow on THIS rank
+        keys, local_error = np.zeros(0, np.int32), ex
+    try:
+        union = union_keys(keys, dist, device, status=1 if local_error else 0)
+    except MergeError:
+        if local_error:
+            raise local_error
+        raise
     if union.size == 0:
         return 0
-    buf = torch.empty((union.size, 2, 64 ** 3), dtype=torch.float32, device=device)
-    vol.export_weighted(union, buf.data_ptr())
-    if sync_stream:
-        sync_stream()
-    else:
-        vol.synchronize()                                    # k_export_weighted has written buf
+    buf = None
+    try:
+        buf = torch.empty((union.size, 2, 64 ** 3), dtype=torch.float32, device=device)
+        vol.export_weighted(union, buf.data_ptr())
+        if sync_stream:
+            sync_stream()
+        else:
+            vol.synchronize()                                # k_export_weighted has written buf
+    except Exception as ex:
+        local_error = ex
+    if _agree_max([1 if local_error else 0], dist, device)[0]:
+        if local_error:
+            raise local_error
+        raise MergeError("a rank failed while exporting its planes; nothing was merged")
     if mode == "all_reduce":
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # the ONLY data-path collective of the pipeline
     else:

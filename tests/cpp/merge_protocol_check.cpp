@@ -1,0 +1,207 @@
+// merge_protocol_check.cpp -- CPU test of elasticreconstruction_amd/csrc/er_merge_protocol.h, the protocol behind
+// er_tsdf_allreduce: the SAME header that er_multi.hip runs over RCCL runs here over host threads with a shared-memory
+// transport and host-array volumes (tiny units), world = 1, 2, 3.  Cases: uneven key counts, an empty rank, every rank empty,
+// root = 0 / 1 / 2 / all-reduce (root < 0), a rank whose key query fails (unit pool overflow) and a rank whose export fails:
+// in the failure cases EVERY rank must come back nonzero -- none may wait in a collective for ever (the run itself is the hang test,
+// tests/test_distributed_cpu.py gives it a timeout).  Prints "OK <cases>" and exits 0 on success.
+#include "er_merge_protocol.h"
+
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+const size_t VOX = 8;   // voxels per unit in this test
+
+struct Shared {          // one per communicator
+  int world;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  std::vector<const int*> iptr;
+  std::vector<float*> fptr;
+  std::vector<int> ibuf;
+  std::vector<float> fbuf;
+  explicit Shared(int w) : world(w), iptr((size_t)w), fptr((size_t)w) {}
+  // classic generation barrier; `last` runs inside the critical section of the last arriver
+  template <class F> void barrier(F last) {
+    std::unique_lock<std::mutex> lk(m);
+    const int gen = generation;
+    if (++arrived == world) {
+      last();
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
+struct ThreadTransport : er::MergeTransport {
+  Shared& s;
+  int r;
+  ThreadTransport(Shared& sh, int rank_) : s(sh), r(rank_) {}
+  int rank() const override { return r; }
+  int world() const override { return s.world; }
+  int allreduce_max(int* v, int n) override {
+    s.iptr[(size_t)r] = v;
+    s.barrier([&] {
+      s.ibuf.assign((size_t)n, -2147483647 - 1);
+      for (int q = 0; q < s.world; q++)
+        for (int i = 0; i < n; i++) s.ibuf[(size_t)i] = std::max(s.ibuf[(size_t)i], s.iptr[(size_t)q][i]);
+    });
+    for (int i = 0; i < n; i++) v[i] = s.ibuf[(size_t)i];
+    s.barrier([] {});                                    // nobody overwrites ibuf before everyone has read it
+    return 0;
+  }
+  int allgather(const int* mine, int n, int* all) override {
+    s.iptr[(size_t)r] = mine;
+    s.barrier([&] {
+      s.ibuf.resize((size_t)n * s.world);
+      for (int q = 0; q < s.world; q++) std::copy(s.iptr[(size_t)q], s.iptr[(size_t)q] + n, s.ibuf.begin() + (size_t)q * n);
+    });
+    std::copy(s.ibuf.begin(), s.ibuf.end(), all);
+    s.barrier([] {});
+    return 0;
+  }
+  int reduce_sum(float* planes, size_t count, int root) override {
+    s.fptr[(size_t)r] = planes;
+    s.barrier([&] {
+      s.fbuf.assign(count, 0.f);
+      for (int q = 0; q < s.world; q++)                  // rank order: a fixed summation order, like a ring would give
+        for (size_t i = 0; i < count; i++) s.fbuf[i] += s.fptr[(size_t)q][i];
+    });
+    if (root < 0 || root == r) std::copy(s.fbuf.begin(), s.fbuf.end(), planes);
+    s.barrier([] {});
+    return 0;
+  }
+};
+
+struct HostVolume : er::MergeVolume {
+  std::map<int, std::vector<float>> sdf, w;              // key -> VOX values
+  std::vector<float> planes;
+  bool fail_keys = false, fail_export = false;
+  size_t unit_voxels() const override { return VOX; }
+  int touched_keys(std::vector<int>& keys) override {
+    if (fail_keys) return 1;
+    keys.clear();
+    for (auto& kv : sdf) keys.push_back(kv.first);
+    return 0;
+  }
+  int export_planes(const int* uk, int nu, float** out) override {
+    if (fail_export) return 1;
+    planes.assign((size_t)nu * 2 * VOX, 0.f);
+    for (int u = 0; u < nu; u++) {
+      auto it = sdf.find(uk[u]);
+      if (it == sdf.end()) continue;                     // a unit this rank never touched contributes zeros
+      for (size_t i = 0; i < VOX; i++) {
+        planes[((size_t)u * 2) * VOX + i] = it->second[i] * w[uk[u]][i];
+        planes[((size_t)u * 2 + 1) * VOX + i] = w[uk[u]][i];
+      }
+    }
+    *out = planes.data();
+    return 0;
+  }
+  int import_planes(const int* uk, int nu, const float* p) override {
+    for (int u = 0; u < nu; u++) {
+      std::vector<float>&S = sdf[uk[u]], &W = w[uk[u]];
+      S.assign(VOX, 0.f);
+      W.assign(VOX, 0.f);
+      for (size_t i = 0; i < VOX; i++) {
+        const float ww = p[((size_t)u * 2 + 1) * VOX + i];
+        W[i] = ww;
+        S[i] = ww > 0.f ? p[((size_t)u * 2) * VOX + i] / ww : 0.f;
+      }
+    }
+    return 0;
+  }
+};
+
+unsigned rng_state = 12345u;
+float frand() { rng_state = rng_state * 1664525u + 1013904223u; return (float)((rng_state >> 8) & 0xffff) / 65536.0f; }
+
+struct Case { int world, root; std::vector<int> nkeys; int fail_keys_rank, fail_export_rank; };
+
+int run_case(const Case& c, int id) {
+  const int W = c.world;
+  std::vector<HostVolume> vols((size_t)W);
+  // expected result of the sequential algebra: w = sum w_g, sdf = sum sdf_g w_g / w  (rank order)
+  std::map<int, std::vector<double>> sw, ww;
+  for (int r = 0; r < W; r++) {
+    for (int k = 0; k < c.nkeys[(size_t)r]; k++) {
+      const int key = 1000 + ((k * 7 + r * 3) % 23) * (r % 2 ? 1 : 2);   // overlapping but different key sets per rank
+      if (vols[(size_t)r].sdf.count(key)) continue;
+      std::vector<float> S(VOX), Wt(VOX);
+      for (size_t i = 0; i < VOX; i++) { Wt[i] = (float)(int)(frand() * 40.f); S[i] = Wt[i] > 0 ? frand() * 2.f - 1.f : 0.f; }
+      vols[(size_t)r].sdf[key] = S;
+      vols[(size_t)r].w[key] = Wt;
+    }
+    vols[(size_t)r].fail_keys = r == c.fail_keys_rank;
+    vols[(size_t)r].fail_export = r == c.fail_export_rank;
+  }
+  for (int r = 0; r < W; r++)
+    for (auto& kv : vols[(size_t)r].sdf) {
+      auto& a = sw[kv.first]; auto& b = ww[kv.first];
+      a.resize(VOX, 0.0); b.resize(VOX, 0.0);
+      for (size_t i = 0; i < VOX; i++) { a[i] += (double)(kv.second[i] * vols[(size_t)r].w[kv.first][i]); b[i] += vols[(size_t)r].w[kv.first][i]; }
+    }
+  std::vector<HostVolume> before = vols;
+  Shared sh(W);
+  std::vector<int> rc((size_t)W, -1), nu((size_t)W, -1);
+  std::vector<std::thread> th;
+  for (int r = 0; r < W; r++)
+    th.emplace_back([&, r] {
+      ThreadTransport t(sh, r);
+      rc[(size_t)r] = er::merge_protocol(t, vols[(size_t)r], c.root, &nu[(size_t)r]);
+    });
+  for (auto& t : th) t.join();
+  const bool expect_fail = c.fail_keys_rank >= 0 || c.fail_export_rank >= 0;
+  for (int r = 0; r < W; r++) {
+    if (expect_fail) {
+      const bool me = r == c.fail_keys_rank || r == c.fail_export_rank;
+      const int want = me ? er::MERGE_LOCAL_FAILURE : er::MERGE_PEER_FAILURE;
+      // with only an export failure armed the union may be empty (nothing touched): then nobody fails -- not a case we build
+      if (rc[(size_t)r] != want) { fprintf(stderr, "case %d rank %d: rc %d, want %d\n", id, r, rc[(size_t)r], want); return 1; }
+      // nothing was merged anywhere
+      if (vols[(size_t)r].sdf != before[(size_t)r].sdf || vols[(size_t)r].w != before[(size_t)r].w) { fprintf(stderr, "case %d rank %d: volume changed by a failed merge\n", id, r); return 1; }
+      continue;
+    }
+    if (rc[(size_t)r] != er::MERGE_OK || nu[(size_t)r] != (int)sw.size()) { fprintf(stderr, "case %d rank %d: rc %d union %d want %zu\n", id, r, rc[(size_t)r], nu[(size_t)r], sw.size()); return 1; }
+    const bool receives = c.root < 0 || c.root == r;
+    if (!receives) {
+      if (vols[(size_t)r].sdf != before[(size_t)r].sdf) { fprintf(stderr, "case %d rank %d: non-root volume changed\n", id, r); return 1; }
+      continue;
+    }
+    if (vols[(size_t)r].sdf.size() != sw.size()) { fprintf(stderr, "case %d rank %d: %zu units after the merge, want %zu\n", id, r, vols[(size_t)r].sdf.size(), sw.size()); return 1; }
+    for (auto& kv : sw)
+      for (size_t i = 0; i < VOX; i++) {
+        const double Wd = ww[kv.first][i], Sd = Wd > 0 ? kv.second[i] / Wd : 0.0;
+        if ((double)vols[(size_t)r].w[kv.first][i] != Wd) { fprintf(stderr, "case %d rank %d key %d: weight %g want %g\n", id, r, kv.first, vols[(size_t)r].w[kv.first][i], Wd); return 1; }
+        if (std::fabs((double)vols[(size_t)r].sdf[kv.first][i] - Sd) > 1e-5) { fprintf(stderr, "case %d rank %d key %d: sdf off by %g\n", id, r, kv.first, std::fabs(vols[(size_t)r].sdf[kv.first][i] - Sd)); return 1; }
+      }
+  }
+  return 0;
+}
+
+}  // namespace
+
+int main() {
+  const std::vector<Case> cases = {
+      {1, 0, {5}, -1, -1},               {2, 0, {7, 3}, -1, -1},          {2, 1, {0, 9}, -1, -1},      // an empty rank, root != 0
+      {2, -1, {4, 11}, -1, -1},          {3, 2, {12, 0, 5}, -1, -1},      {3, -1, {1, 2, 20}, -1, -1},
+      {3, 0, {0, 0, 0}, -1, -1},         {2, 0, {23, 23}, -1, -1},                                      // nobody touched anything; identical sets
+      {2, 0, {6, 6}, 1, -1},             {3, -1, {6, 2, 9}, 0, -1},       {3, 1, {6, 2, 9}, -1, 2},    // key query / export failure on one rank
+      {2, -1, {0, 4}, -1, 0},
+  };
+  int id = 0;
+  for (const Case& c : cases)
+    if (run_case(c, id++)) return 1;
+  printf("OK %zu\n", cases.size());
+  return 0;
+}

@@ -73,11 +73,24 @@ def _worker(rank, world, port, q):
     local_keys = vol.unit_keys()
     import copy
     vol_ar = copy.deepcopy(vol)
-    vol_ar.max_units = 256                       # the all_reduce variant takes the one-collective key union (padded to max_units),
-                                                 # the reduce variant below the two-collective one (no max_units attribute)
     n_union = parallel.merge_volumes(vol, dist, torch.device("cpu"))                       # reduce to rank 0
     n_union_ar = parallel.merge_volumes(vol_ar, dist, torch.device("cpu"), mode="all_reduce")
     same = n_union == n_union_ar and all(np.array_equal(vol_ar.units[k][1], vol.units[k][1]) for k in vol.units) if rank == 0 else True
+    # a rank-local failure must become a COLLECTIVE one: rank 1's key query raises like an overflowed unit pool;
+    # rank 0 must come back with MergeError instead of blocking in the reduction, rank 1 with its own error
+    class Broken(HostVolume):
+        def unit_keys(self):
+            raise RuntimeError("TSDF unit pool exhausted (test)")
+    probe = Broken() if rank == 1 else copy.deepcopy(vol)
+    try:
+        parallel.merge_volumes(probe, dist, torch.device("cpu"))
+        kind = "none"
+    except parallel.MergeError:
+        kind = "peer"
+    except RuntimeError:
+        kind = "local"
+    kinds = [None] * world
+    dist.all_gather_object(kinds, kind)
     # pair sharding: every pair exactly once, results back in order
     mine = {p: (p, rank) for p in parallel.pair_shard(7, rank, world)}
     gathered = parallel.gather_pair_results(mine, 7, dist)
@@ -91,7 +104,7 @@ def _worker(rank, world, port, q):
             sf, wf = full.units[int(k)]
             wbad += int((w != wf).sum())
             worst = max(worst, float(np.abs(s - sf).max()))
-        q.put(dict(ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys), modes_agree=bool(same),
+        q.put(dict(failure_kinds=kinds, ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys), modes_agree=bool(same),
                    pairs=[g[0] for g in gathered], owners=[g[1] for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
@@ -111,6 +124,7 @@ def test_frame_split_merge_and_pair_shard_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert res["failure_kinds"] == ["peer", "local"], res["failure_kinds"]
     assert res["ok_keys"], "union of the per-rank unit keys != single-volume keys"
     assert res["wbad"] == 0, "merged weights must be exact (integer-valued floats)"
     assert res["worst"] <= 1e-5, "merged tsdf off by %.3g" % res["worst"]
@@ -148,3 +162,23 @@ def test_c_abi_shard_helpers_match_the_python_protocol():
         region = np.array([[x, y, z] for x in range(252, 260) for y in range(252, 260) for z in range(252, 260)])
         cnt = np.bincount(region.sum(1) % world, minlength=world)
         assert cnt.max() - cnt.min() <= 64
+
+
+def test_c_merge_protocol_world_1_2_3_on_threads(tmp_path):
+    """The protocol of er_tsdf_allreduce (csrc/er_merge_protocol.h -- the very header er_multi.hip runs over RCCL) on host
+    threads with a shared-memory transport, world = 1 / 2 / 3: uneven key counts, empty ranks, root 0 / 1 / 2 / all-reduce, and
+    the collective-failure rule (a rank whose unit pool overflowed or whose export failed makes EVERY rank return an error after
+    the same collective -- no rank is left waiting; the timeout is the hang detector).  Also under ThreadSanitizer when g++ has it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "merge_protocol_check.cpp")
+    inc = os.path.join(root, "elasticreconstruction_amd", "csrc")
+    exe = str(tmp_path / "merge_protocol_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-Wall", "-Werror", "-I" + inc, src, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.startswith("OK "), r.stdout + r.stderr
+    tsan = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I" + inc, src, "-o", exe + "_tsan"],
+                          capture_output=True, text=True)
+    if tsan.returncode == 0:
+        r = subprocess.run([exe + "_tsan"], capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout + r.stderr

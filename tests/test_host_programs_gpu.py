@@ -350,8 +350,10 @@ def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
         assert f1.read() == f2.read()
 
 
-def test_abi_allreduce_two_virtual_ranks_in_one_process(gpu):
-    """er_tsdf_allreduce on a one-rank communicator must be the identity up to re-rounding, and er_frame_block must tile."""
+def test_abi_allreduce_on_a_one_rank_communicator_is_the_identity(gpu):
+    """er_tsdf_allreduce through RCCL with ONE rank (RCCL refuses two ranks on one GPU, and this box has one): export ->
+    all-reduce -> import must be the identity up to re-rounding, and er_frame_block must tile.  The protocol with world = 2 / 3
+    runs on the CPU: tests/test_distributed_cpu.py::test_c_merge_protocol_world_1_2_3_on_threads (the same header)."""
     import ctypes as C
     from elasticreconstruction_amd import _ffi, parallel
     from elasticreconstruction_amd.tsdf import TSDFVolume
