@@ -31,7 +31,8 @@ import sys
 import tempfile
 import time
 
-# before the HIP runtime initialises (torch.cuda below): one hardware queue per stream of the TSDF pipeline, see er_common.cpp
+# OPT-IN, before the HIP runtime initialises (torch.cuda below): one hardware queue per stream of the TSDF pipeline (what
+# er_request_hw_queues / elasticreconstruction_amd.request_hw_queues do; include/er_hip.h).  Never overrides the user's value.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -7,12 +7,16 @@ liber_hip.so); this package is the host-side mirror of the reference's classes o
 There is no CPU fallback: importing works anywhere, but every operation needs the built
 extension and a HIP device.
 """
-import os as _os
+from ._ffi import ErError, LIB_PATH, lib  # noqa: F401
 
-# One hardware queue per stream of the TSDF pipeline (csrc/er_common.cpp); read by the HIP runtime at its first call, so it
-# only takes effect when this package is imported before the process touches the GPU.  Never overrides the user's value.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from ._ffi import ErError, LIB_PATH, lib  # noqa: E402,F401
+def request_hw_queues(n=8):
+    """OPT-IN (er_request_hw_queues, include/er_hip.h): one hardware queue per stream of the TSDF pipeline.  The HIP runtime reads
+    GPU_MAX_HW_QUEUES at its first call, so this only takes effect before the process touches the GPU (before torch.cuda is
+    used); it never overrides a value the user exported.  Importing the package does NOT set it; bench.py calls this first."""
+    import os
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(n)))
+    return int(os.environ["GPU_MAX_HW_QUEUES"])
 
-__all__ = ["ErError", "LIB_PATH", "lib"]
+
+__all__ = ["ErError", "LIB_PATH", "lib", "request_hw_queues"]

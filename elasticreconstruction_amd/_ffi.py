@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ER_HIP_LIB") or os.path.join(_HERE, "liber_hip.so")
 
 # Every symbol include/er_hip.h declares (tests/test_abi.py checks header == this list == the .so).
 SYMBOLS = [
-    "er_last_error", "er_device_count", "er_abi_version", "er_host_alloc", "er_host_free", "er_host_copy_h2d",
+    "er_last_error", "er_device_count", "er_abi_version", "er_request_hw_queues", "er_host_alloc", "er_host_free", "er_host_copy_h2d",
     "er_tsdf_create", "er_tsdf_destroy", "er_tsdf_set_stream", "er_tsdf_synchronize",
     "er_tsdf_wait_event", "er_tsdf_reset", "er_tsdf_status", "er_tsdf_set_unit_shard", "er_unit_owner",
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",

@@ -7,12 +7,11 @@
 
 // HIP multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams that share a queue
 // run in order.  A TSDF volume drives four streams (voxel pass, two pre-passes, host-frame copies) next to the caller's own,
-// and their overlap is the point (er_tsdf.hip: run_batch).  The variable is read when the HIP runtime initialises, i.e. at the
-// process's first HIP call: setting it here -- never overriding the user's value -- covers every program that has not touched
-// HIP before it loads this library; programs that have (a Python process that used torch.cuda first) set it themselves
-// (bench.py, elasticreconstruction_amd/__init__.py).
-__attribute__((constructor)) static void er_request_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-
+// and their overlap is the point (er_tsdf.hip: run_batch; measured 125.5 k frames/s with 8 queues, 106.0 k with 4).  The
+// variable is read when the HIP runtime initialises, i.e. at the process's first HIP call, and it changes the queue set-up of
+// EVERY GPU user of the process -- so the library does not touch it behind the host's back: a host opts in by calling
+// er_request_hw_queues() before its first HIP call (bin/Integrate, bin/BuildCorrespondence and bench.py do), or exports the
+// variable itself.
 namespace er {
 
 char* error_buffer() {
@@ -40,7 +39,15 @@ int er_device_count(void) {
   return n;
 }
 
-int er_abi_version(void) { return 2; }
+int er_abi_version(void) { return 3; }
+
+int er_request_hw_queues(int n) {
+  char v[16];
+  snprintf(v, sizeof v, "%d", n > 0 ? n : 8);
+  setenv("GPU_MAX_HW_QUEUES", v, 0);                      // never overrides the user's value
+  const char* now = getenv("GPU_MAX_HW_QUEUES");
+  return now ? atoi(now) : 0;
+}
 
 void* er_host_alloc(size_t bytes) {
   void* p = nullptr;

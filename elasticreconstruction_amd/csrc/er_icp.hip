@@ -1096,7 +1096,8 @@ int align_start(IcpWs* w, AlignJob& j, er_cloud_t src, er_cloud_t tgt, const flo
   j.src = src;
   j.tgt = tgt;
   memcpy(j.fin, guess, sizeof j.fin);                        // final_transformation_ = guess
-  if (src->n == 0 || tgt->n == 0 || P.max_iter <= 0) {       // fewer than 3 correspondences by construction: nothing to enqueue
+  if (src->n == 0 || tgt->n == 0) {                          // fewer than 3 correspondences by construction: nothing to enqueue
+                                                             // (max_iter <= 0 still runs ONE iteration, like PCL's do { } while loop)
     j.iter = 0;
     j.conv = false;
     if (P.want_fitness) return align_enqueue_fitness(w, j, P);

@@ -399,6 +399,7 @@ struct App {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
 

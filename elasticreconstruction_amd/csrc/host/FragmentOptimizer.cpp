@@ -630,7 +630,8 @@ int print_help() {
 
 }  // namespace
 
-int main(int argc, char* argv[]) {                     // FragmentOptimizer.cpp:40-93
+int main(int argc, char* argv[]) {
+  er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)                     // FragmentOptimizer.cpp:40-93
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
   COptApp app;

@@ -313,6 +313,7 @@ bool SaveWorldSharded(std::vector<App>& apps, const std::string& filename) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
 

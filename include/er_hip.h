@@ -38,6 +38,11 @@ extern "C" {
 const char* er_last_error(void);
 int er_device_count(void);                       /* number of visible HIP devices (0 if none) */
 int er_abi_version(void);
+/* OPT-IN, call before the process's first HIP call: asks the HIP runtime for n hardware queues (GPU_MAX_HW_QUEUES, default 4;
+ * n <= 0 means 8) without overriding a value the user exported; returns the value in force.  A TSDF volume overlaps four
+ * streams and runs ~15 % slower when two of them share a queue.  The library never sets this on its own (it would change the
+ * queue set-up of every GPU user of the process): the drop-in programs and bench.py call it first thing in main(). */
+int er_request_hw_queues(int n);
 
 /* Page-locked host memory.  Every "host" pointer of this ABI may be ordinary (pageable) memory; result buffers
  * that come from er_host_alloc are written by asynchronous device-to-host copies without a staging pass. */

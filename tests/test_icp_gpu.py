@@ -136,6 +136,21 @@ def test_corres_app_pipeline_matches_reference_flow(gpu, tmp_path):
     assert not os.path.exists(d + "corres_0_2.txt") and not os.path.exists(d + "corres_2_3.txt")
 
 
+def test_icp_iteration_limits_follow_pcl_do_while(gpu):
+    """max_iter = 1 and max_iter = 0 both run exactly ONE iteration and report converged (PCL's do { ... } while( !converged )
+    with `iterations >= max_iterations`), max_iter = 3 stops at 3; checked against the restatement, which is
+    itself checked against the stub's second statement (tests/test_corres_reference.py)."""
+    (x0, n0), (x1, n1), P = make_pair(n=30000, rot=4.0, trans=0.04)
+    tgt, src = Cloud(x0, n0, 0.03), Cloud(x1, n1, 0.03)
+    otgt, osrc = IcpOracle(x0, n0, 0.03), IcpOracle(x1, n1, 0.03)
+    g = np.eye(4, dtype=np.float32)
+    for max_iter, want_iter in ((1, 1), (0, 1), (-5, 1), (3, 3)):
+        Tg, itg, cg, _ = icp_align(src, tgt, g, max_iter=max_iter)
+        To, ito, co, _ = osrc.align(otgt, g, max_iter=max_iter)
+        assert (itg, cg) == (ito, co) == (want_iter, True), (max_iter, itg, cg, ito, co)
+        assert np.abs(Tg - To).max() <= TOL_T
+
+
 def test_batch_entry_points_equal_single_calls(gpu):
     """er_*_batch pipelines pairs over several streams/workspaces; the results must be those of the single-pair calls
     (integers and index lists exact; transforms bit-identical: same kernels, same float64 atomics order is NOT
