@@ -19,7 +19,7 @@
 //   [k_reproject_scatter -> k_reproject_fix]          per SOURCE pixel: warp + scatter-min   (A6/A7)
 //   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
 //                  appends the unit to the batch list
-//   k_plan         sorts the batch's units by cost (frames in the mask) for a balanced static deal
+//   k_plan         sorts the batch's units by cost (frames in the mask) and resets the work queue k_integrate claims its items from
 //  main stream:
 //   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every   (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
@@ -47,22 +47,9 @@ constexpr uint32_t kZEmpty = 0xFFFFFFFFu;
 // counters[] slots
 enum { C_NUNITS = 0, C_NBATCH = 1 /* and 6, 7: one per pipeline slot */, C_POOL_OVERFLOW = 2, C_TABLE_FULL = 3, C_OUT_OF_RANGE = 4,
        C_ZERO_WRITE = 5 /* and 8: one per pre-pass stream */, C_NBATCH1 = 6, C_NBATCH2 = 7, C_ZERO_WRITE1 = 8, C_COUNT = 12 };
-#ifndef ER_PIPE_DEPTH
-#define ER_PIPE_DEPTH 3                  // (2 with ER_AUX_STREAMS 1 = the round-1 pipeline, kept for A/B)
-#endif
-#ifndef ER_AUX_STREAMS
-#define ER_AUX_STREAMS 2
-#endif
-constexpr int kDepth = ER_PIPE_DEPTH;    // batches in flight: voxel pass of n, pre-passes of n+1 and n+2
-constexpr int kAux = ER_AUX_STREAMS;     // pre-pass streams (batch b runs on stream b mod kAux)
-static_assert(kDepth >= 2 && kDepth <= 3 && kAux >= 1 && kAux <= 2 && kAux < kDepth, "pipeline shape");
-// Occupancy throttle of the pre-pass kernels: a dynamic LDS allocation they never touch limits how many of their workgroups a
-// CU holds (160 KB per CU), which leaves issue slots to k_integrate -- the kernel on the critical (main) stream -- while the
-// two pre-pass streams, which have slack, take a little longer (A/B: profiles/r02u_ab_prepass_throttle.txt).
-#ifndef ER_PRE_LDS
-#define ER_PRE_LDS 0
-#endif
-constexpr unsigned kPrePassLds = ER_PRE_LDS;
+constexpr int kDepth = 3;                // batches in flight: voxel pass of n, pre-passes of n+1 and n+2 (depth 2 with one pre-pass
+constexpr int kAux = 2;                  // stream = the round-1 pipeline: profiles/r02n_ab_pipeline_depth_hw_queues.txt); pre-pass streams:
+                                         // batch b runs on stream b mod kAux
 constexpr int kNbatchSlot[3] = {C_NBATCH, C_NBATCH1, C_NBATCH2};
 constexpr int kZeroFlagSlot[2] = {C_ZERO_WRITE, C_ZERO_WRITE1};
 
@@ -162,85 +149,17 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   reproject_scatter_px(A, f, u, v, 0);
 }
 
-// Reproject in two tiers (er_tsdf_math.h, "Reproject, tier 1"), as TWO kernels with one source pixel per thread each:
-//   k_reproject_tier  every pixel: float64 lattice coordinates (no guard needed: they only feed the estimate), float32 trilinear
-//                     sum over 16-byte vertices, float32 projection, and the per-pixel proof that the three roundings and every
-//                     range test of the reference are decided by the estimate -> scatter (or drop) at once; each wave leaves the
-//                     64-bit mask of the pixels it could NOT decide (a few per cent);
-//   k_reproject_tail  gathers the set bits of 64 such masks per wave into an LDS list (wave scan, no atomics) and runs the listed
-//                     pixels through the exact chain (reproject_scatter_px) with all lanes busy.
-// Results are the reference's for every pixel either way (tests: hostcheck replay on the CPU, golden digests and fuzz on the GPU).
-// History: v1 / v2 (round 2 calls b, c) kept the undecided pixels of a 64 x 16 tile in an LDS list and ran four pixels per
-// thread with the lattice staged in LDS: 111 VGPRs, a barrier per tile -- slower than the exact kernel.  v3 appended the undecided
-// pixels to ONE global list with an atomic per wave: 200 k same-address atomics per batch across 8 XCDs = 5x slower job.
-__global__ __launch_bounds__(kBlock) void k_reproject_tier(ReprojArgs A, const ReprojFast* __restrict__ fast, const Vert4* __restrict__ ctr4,
-                                                           unsigned long long* __restrict__ masks) {
-  const int f = blockIdx.z, lane = threadIdx.x & 63;
-  const int u = blockIdx.x * 64 + lane;
-  const int v = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const bool live = u < A.cols && v < A.rows;
-  const int pixels = A.cols * A.rows;
-  const int p = v * A.cols + u;
-  const uint16_t d = live ? A.depth[(size_t)f * pixels + p] : (uint16_t)0;
-  int cls = kReprojReject, cell = 0;
-  uint16_t dd = 0;
-  if (d != 0) {                                                          // UVD2XYZ false otherwise
-    const ReprojFast& F = fast[f];                                       // wave-uniform: scalar loads
-    const int n1 = A.res + 1;
-    const double up = (double)((float)u - A.cam.cx), vp = (double)((float)v - A.cam.cy);   // UVD2XYZ: int - float in float32, then promoted
-    const double g[3] = {fma(F.gb[0], vp, fma(F.ga[0], up, F.gc[0])), fma(F.gb[1], vp, fma(F.ga[1], up, F.gc[1])),
-                         fma(F.gb[2], vp, fma(F.ga[2], up, F.gc[2]))};
-    cls = reproject_fast(d, g, F, A.cam, ctr4 + (size_t)A.grid_index[f] * (n1 * n1 * n1), n1, A.cols, cell, dd);
-    if (cls == kReprojAccept) scatter_px(A, f, p, cell, dd, 0);
-  }
-  const unsigned long long mb = __ballot(cls == kReprojUnsure);
-  if (lane == 0) masks[(((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = mb;
-}
-
-// n_waves = frames * gy * gx * 4 masks (one per wave of k_reproject_tier, in its launch order); gx, gy = its grid.
-__global__ __launch_bounds__(kBlock) void k_reproject_tail(ReprojArgs A, const unsigned long long* __restrict__ masks, int n_waves, int gx, int gy) {
-  __shared__ unsigned short s_list[kBlock / 64][64 * 64];               // per wave: (source wave within the group) << 6 | pixel bit
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int group = (blockIdx.x * (kBlock / 64) + wv) * 64;             // first source wave of this wave's group
-  const int src = group + lane;
-  unsigned long long m = src < n_waves ? masks[src] : 0ull;
-  int cnt = __popcll(m), off = cnt;
-  for (int sft = 1; sft < 64; sft <<= 1) {                               // inclusive wave scan of the counts
-    const int t = __shfl_up(off, sft);
-    if (lane >= sft) off += t;
-  }
-  const int total = __shfl(off, 63);
-  off -= cnt;
-  unsigned short* __restrict__ list = s_list[wv];
-  while (m) {
-    const int bit = __builtin_ctzll(m);
-    m &= m - 1;
-    list[off++] = (unsigned short)((lane << 6) | bit);
-  }
-  __syncthreads();                                                       // (the list of a wave is read by its own lanes only: this orders its LDS writes and reads)
-  for (int t = lane; t < total; t += 64) {
-    const int e = list[t];
-    const int w = group + (e >> 6);                                      // source wave -> (frame, tile row, tile column, row in the tile)
-    const int row = w & 3, tile = w >> 2;
-    const int bx = tile % gx, by = (tile / gx) % gy, f = tile / (gx * gy);
-    reproject_scatter_px(A, f, bx * 64 + (e & 63), by * 4 + row, 0);
-  }
-}
-
-// float[3] vertices -> one 16-byte Vert4 each (tier 1's LDS / 16-byte-load layout).
-__global__ void k_expand_ctr(const float* __restrict__ ctr, Vert4* __restrict__ out, long n) {
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  out[t] = Vert4{ctr[3 * t], ctr[3 * t + 1], ctr[3 * t + 2], 0.0f};
-}
-
 // The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch that
 // returns at once unless a zero write was flagged -- it practically never is (a warped depth below 0.5 mm) -- and
 // otherwise lets a single workgroup run the three passes in order: cells that saw a zero write forget everything;
 // every source pixel is scattered again under the replay rule (only writes that come after the cell's last zero
 // write count); lastzero and the flag are re-armed.  Slow (one workgroup) by design: keeping it to one launch saves
-// three idle launches per batch on the pre-pass stream.
-__global__ __launch_bounds__(256) void k_reproject_fix(ReprojArgs A) {
+// three idle launches per batch on the pre-pass stream.  Round 3: a single wave with a capped register budget (the replay may
+// spill, it never runs in practice) -- as a 256-thread workgroup with 83 VGPRs the launch waited 46 us on average (max 237 us,
+// profiles/r03a_kernel_stats.csv) for FOUR free wave slots of that size on one CU next to the persistent k_integrate workgroups
+// and the other stream's pre-pass, on the serial pre-pass chain of every batch.
+constexpr int kFixThreads = 64;
+__global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_num_vgpr(48))) void k_reproject_fix(ReprojArgs A) {
   if (*A.zero_flag == 0) return;
   const long total = (long)A.n_frames * A.cols * A.rows;
   for (long t = threadIdx.x; t < total; t += blockDim.x)
@@ -402,8 +321,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
 
 // ------------------------------------------------------------------------------------------------
 // Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
-// batch list sorted by DESCENDING cost = popcount(frame mask), so that the static round-robin deal in
-// k_integrate hands every workgroup one item from each cost tier (longest-processing-time order).
+// batch list sorted by DESCENDING cost = popcount(frame mask) -- the order in which the persistent workgroups of k_integrate
+// claim their items from the work queue (longest-processing-time first) -- and the queue head reset to 0.
 constexpr int kRows = 4;
 
 struct Plan {
@@ -443,23 +362,16 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // kRows = 4 register rows of 64 -- since round 2 a 4 x 8 x 8 box (see the mapping below; round 1: four rows of 64 voxels,
 // lane = k).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
 // loop: the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
-// Items are dealt round-robin in cost order (k_plan).  Schedules measured on MI355X in round 1 (profiles/
-// r01_ab_variants.txt, ms per 50-frame launch): whole slabs 0.565; quarter slabs 0.497 (VALU 90 %
-// busy, L2 hit rate 91 %); XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25; round 2: a global work queue
-// (profiles/r02z_ab_dynamic_items.txt).
-#ifdef ER_STATS
-__device__ unsigned long long g_stats[4];
-#endif
-
+// Items come from a work queue in cost order (k_plan).  Schedules measured on MI355X (profiles/r01_ab_variants.txt,
+// r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt; ms per 50-frame launch in round 1): whole slabs 0.565; quarter
+// slabs dealt round-robin 0.497; XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25; the global queue below.
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
   return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFull));
 }
 
-#ifndef ER_INT_MINBLOCKS
-#define ER_INT_MINBLOCKS 5                // 5 workgroups of 4 waves per CU = 5 waves per SIMD: keeps the kernel at <= 96 VGPRs
+constexpr int kIntMinBlocks = 5;          // 5 workgroups of 4 waves per CU = 5 waves per SIMD: keeps the kernel at <= 96 VGPRs
                                           // (98 would round up to 104 and cost the fifth wave: 125.2 k vs 126.9 k frames/s)
-#endif
 // Pool slot of hash entry e for a wave of k_integrate; hands the slot out on the unit's first ever visit (data_.find( key ) ==
 // end, TSDFVolume.cpp:55; pool memory is zero-filled up front).  Voxel passes run one after the other on the main stream, so
 // only waves of THIS launch can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes
@@ -493,7 +405,7 @@ __device__ __noinline__ int unit_slot_acquire(int e, int key, int* __restrict__ 
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 template <bool kSure>
-__global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
+__global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     float2* __restrict__ pool, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
     const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
@@ -502,10 +414,6 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
   const int n_items = plan->n_units * (kUnitRes * 4);
-#ifdef ER_STATIC_ITEMS
-  // (static round-robin deal of the cost-sorted items, kept for A/B)
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-#else
   // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
   // its own (one atomic per item and workgroup; the grid is 4 persistent workgroups per CU): longest-processing-time-
   // first scheduling.  The culling and the full / sure shortcuts make the real cost of an item unpredictable, and with a static
@@ -520,30 +428,17 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
-#endif
     const int e = plan_entry[item >> 8];
-#if defined(ER_ROW_PATCH)
-    // (round-1 mapping, kept for A/B: the wave owns 4 whole rows of 64 voxels of one slab, lane = k)
-    const int i = (item >> 2) & 63;
-    const int j0 = (item & 3) * 16 + wave * kRows;
-    const int jlane = 0, jstep = 1, istep = 0, k0 = 0, klane = lane, jspan = kRows, kspan = kUnitRes, ispan = 1;
-#elif defined(ER_SQUARE_PATCH)
-    // (first compact shape of round 2, kept for A/B: a 16 x 16 (j, k) square of one slab; register row r holds rows j0 + 4 r .. + 3,
-    //  16 voxels of k each, lane = 16 jj + kk)
-    const int i = (item >> 2) & 63;
-    const int j0 = (item & 3) * 16;
-    const int jlane = lane >> 4, jstep = 4, istep = 0, k0 = wave * 16, klane = lane & 15, jspan = 16, kspan = 16, ispan = 1;
-#else
     // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
     // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs
-    // x 16 x 16 voxels.  2.3 x 4.7 x 4.7 cm instead of the round-1 strip of 2.3 x 37.5 cm: a tighter pixel hull for the culling
-    // and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and far fewer patches that cross a surface
-    // (the sure path below applies to most visits).  Measured: strip 114.8 k -> 16 x 16 square 123.6 k -> box +1 % more
-    // (profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt).
+    // x 16 x 16 voxels.  2.3 x 4.7 x 4.7 cm instead of the round-1 strip of 2.3 x 37.5 cm (four whole rows of 64 voxels): a
+    // tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and far
+    // fewer patches that cross a surface (the sure path below applies to most visits).  Measured: strip 114.8 k -> 16 x 16
+    // square of one slab 123.6 k -> box +1 % more (profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt).
     const int i = ((item >> 4) & 15) * 4;
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
-    const int jlane = lane >> 3, jstep = 0, istep = 1, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7, jspan = 8, kspan = 8, ispan = 4;
-#endif
+    const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
+    constexpr int jspan = 8, kspan = 8, ispan = 4;
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
     int slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (slot < 0 && slot != -3) slot = unit_slot_acquire(e, key, ht_slot, unit_key, max_units, counters);   // first visit of the unit
@@ -553,13 +448,11 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     const float g2 = grid_coord(k0 + klane, zs);
     float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + (j0 + jlane) * kUnitRes + k0 + klane;
-    float S[kRows], W[kRows], W0[kRows], g0[kRows], g1[kRows];           // (box: g0 per register row, g1 per lane; square / strip: the reverse)
+    float S[kRows], W[kRows], W0[kRows], g0[kRows];                      // g0 per register row (wave-uniform), g1 / g2 per lane
+    const float g1 = grid_coord(j0 + jlane, ys);
 #pragma unroll
-    for (int r = 0; r < kRows; r++) {
-      g0[r] = grid_coord(i + r * istep, xs);
-      g1[r] = grid_coord(j0 + jlane + r * jstep, ys);
-    }
-    const int row_stride = jstep * kUnitRes + istep * kUnitRes * kUnitRes;
+    for (int r = 0; r < kRows; r++) g0[r] = grid_coord(i + r, xs);
+    constexpr int row_stride = kUnitRes * kUnitRes;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {                                   // loads in flight while the culling preamble computes
       const float2 v = slab[r * row_stride];                      // (loading only the surviving patches, after the culling,
@@ -571,11 +464,6 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
     // provably cannot update any voxel of the patch leave the mask (er_tsdf_math.h: patch_may_update).
     // The same test also tells which of the remaining frames see the WHOLE patch inside the image and clear of the camera
     // plane (m_in): for those the per-voxel range tests are proven true and the loop below skips them.
-#if defined(ER_PROBE_SKIP_INTEGRATE)      // timing probes (WRONG results): how fast is the job without / with half of the voxel pass?
-    m = 0ull;
-#elif defined(ER_PROBE_HALF_FRAMES)
-    m &= 0x5555555555555555ull;
-#endif
     // Third verdict (m_full): the frame updates EVERY voxel of the patch with tsdf = 1 -- proven from the tile minima of the depth
     // under the patch's pixel hull -- so the frame needs no projection, no depth sample and no arithmetic at all: W += 1, and S
     // stays / becomes exactly 1 wherever S == 1 or W == 0 (most of the frustum is such free space).
@@ -589,11 +477,7 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
                                     tile_lo + (size_t)lane * tiles_x * tiles_y, &full);
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
-#ifndef ER_NO_FULL_PATH
       m_full = __ballot(keep && full);
-#else
-      m_full = 0ull;
-#endif
     }
     // Frame loop in two halves: project() computes the pixel under every voxel of the four register rows and issues the depth
     // gathers, finish() does the arithmetic that needs the samples.  -DER_FRAME_PIPELINE software-pipelines the loop over two
@@ -604,17 +488,15 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       const FrameXform fx = frames[f];
       const float* __restrict__ sc = scaled + (size_t)f * (pixels + kScaledPad);
       unsigned pix[kRows];
-#ifndef ER_NO_INSIDE_PATH
       if ((m_in >> f) & 1ull) {                                          // wave-uniform
 #pragma unroll
-        for (int r = 0; r < kRows; r++) pix[r] = voxel_project_inside(g0[r], g1[r], g2, fx, cam, cols, rows);
+        for (int r = 0; r < kRows; r++) pix[r] = voxel_project_inside(g0[r], g1, g2, fx, cam, cols, rows);
       } else
-#endif
       {
 #pragma unroll
         for (int r = 0; r < kRows; r++) {
           unsigned pixel;
-          const bool ok = voxel_project(g0[r], g1[r], g2, fx, cam, cols, rows, pixel);
+          const bool ok = voxel_project(g0[r], g1, g2, fx, cam, cols, rows, pixel);
           pix[r] = ok ? pixel : (unsigned)pixels;                        // the frame's zero pad: dp = 0 fails ":82 dp > 0.001" like the reference's early out
         }
       }
@@ -628,7 +510,7 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       const FrameXform& fx = frames[f];                                  // (only the camera centre: three scalar loads)
       float d2[kRows];
 #pragma unroll
-      for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0[r], g1[r], g2, fx);
+      for (int r = 0; r < kRows; r++) d2[r] = voxel_dist2(g0[r], g1, g2, fx);
       if (kSure) {
         // Sure path (er_tsdf_math.h: voxel_classify): if every lane of the four rows is provably in free space (tsdf = 1) or
         // provably behind the surface (no update) and every free lane holds S == 1 or W == 0, the whole update of this frame is
@@ -653,19 +535,9 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
 #pragma unroll
       for (int r = 0; r < kRows; r++) {
         const bool upd = voxel_finish_d2(S[r], W[r], dp[r], d2[r]);
-#ifdef ER_STATS
-        const unsigned long long b = __ballot(upd);
-        if (lane == 0) {
-          atomicAdd(&g_stats[0], 1ull);
-          if (b) atomicAdd(&g_stats[1], 1ull);
-          atomicAdd(&g_stats[2], (unsigned long long)__popcll(b));
-        }
-#else
         (void)upd;
-#endif
       }
     };
-#ifndef ER_FRAME_PIPELINE
     while (m) {
       {
         // a run of consecutive FULL frames (in the mask's order): n updates with tsdf = 1 of every voxel of the patch
@@ -701,32 +573,6 @@ __global__ __launch_bounds__(kBlock, ER_INT_MINBLOCKS) void k_integrate(
       project(f, dp);
       finish(f, dp);
     }
-#else
-    if (m) {
-      float dpA[kRows], dpB[kRows];
-      int fa = __builtin_ctzll(m), fb;
-      m &= m - 1;
-      project(fa, dpA);
-      for (;;) {                                                         // every exit is wave-uniform
-        if (!m) {
-          finish(fa, dpA);
-          break;
-        }
-        fb = __builtin_ctzll(m);
-        m &= m - 1;
-        project(fb, dpB);                                                // gathers of the NEXT frame in flight ...
-        finish(fa, dpA);                                                 // ... while this frame's samples are consumed
-        if (!m) {
-          finish(fb, dpB);
-          break;
-        }
-        fa = __builtin_ctzll(m);
-        m &= m - 1;
-        project(fa, dpA);
-        finish(fb, dpB);
-      }
-    }
-#endif
 #pragma unroll
     for (int r = 0; r < kRows; r++)
       if (W[r] != W0[r]) slab[r * row_stride] = make_float2(S[r], W[r]);
@@ -956,21 +802,17 @@ struct er_tsdf_s {
   void* pinned[kDepth] = {};                              // host staging of the per-batch constants
   int ht_cap = 0, ht_shift = 0;
   float *lambda = nullptr, *ctr = nullptr;
-  er::Vert4* ctr4 = nullptr;                                // the same lattices, one 16-byte vertex each (tier 1 of Reproject)
   // The caller's lattices, double-buffered by call parity on the host (page-locked staging) AND on the device, so that the
   // upload of call c (copy stream) never waits for the pre-passes of call c-1 that still read the other buffer.
   float* ctr_pinned[2] = {nullptr, nullptr};
   float* ctr_dev[2] = {nullptr, nullptr};
-  er::Vert4* ctr4_dev[2] = {nullptr, nullptr};
   size_t ctr_pinned_cap[2] = {0, 0}, ctr_dev_cap[2] = {0, 0};
   hipEvent_t ctr_ev[2] = {nullptr, nullptr};                // upload of the buffer done
   hipEvent_t ctr_rd[2][kAux] = {};                          // last pre-pass reader of the buffer, per pre-pass stream
   bool ctr_rd_set[2] = {false, false};
   int ctr_parity = 0, ctr_cur = 0;
-  std::vector<double> grid_cmax, grid_dmax;                 // per lattice: max |component|, max lattice-edge component (host)
   uint16_t* depth_stage[kDepth] = {};              // host frames of the batch in flight, by pipeline slot
   uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
-  void* rlist[kAux] = {};                           // tier 1's masks of undecided source pixels (ER_REPROJECT_TIERED), one buffer per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
   int* plan_entry[kDepth] = {};
@@ -988,7 +830,7 @@ struct er_tsdf_s {
 hipStream_t er::tsdf_stream(er_tsdf_s* h) { return h->stream; }
 int er::tsdf_device(er_tsdf_s* h) { return h->device; }
 
-static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X, int aux);
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, hipStream_t X);
 
 namespace {
 
@@ -1061,7 +903,6 @@ int sorted_units(er_tsdf_t h, std::vector<int>& keys, std::vector<int>& slots) {
 // Host staging layout of one batch's constants inside the pinned buffer of its parity.
 struct Staging {
   er::FrameXform fx[ER_MAX_BATCH];
-  er::ReprojFast fast[ER_MAX_BATCH];
   double t12[ER_MAX_BATCH * 12];
   double seg[ER_MAX_BATCH * 16];
   double madj[ER_MAX_BATCH * 12];
@@ -1124,16 +965,10 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipStream_t X = h->aux_stream[a], S = h->stream;
   int* nbatch = h->counters + kNbatchSlot[p];
 
-#ifndef ER_INT_BLOCKS_PER_CU
-#ifdef ER_STATIC_ITEMS
-#define ER_INT_BLOCKS_PER_CU 10
-#else
-#define ER_INT_BLOCKS_PER_CU 4             // persistent workgroups fed by the queue; 4 of the 5 that fit a CU, so that the pre-pass
+  constexpr int kIntBlocksPerCu = 4;       // persistent workgroups fed by the queue; 4 of the 5 that fit a CU, so that the pre-pass
                                           // kernels find register space next to them: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s
                                           // (k_integrate 0.284 / 0.298 / 0.354 ms per launch; profiles/r02G_ab_full_path_and_queue.txt)
-#endif
-#endif
-  const int wide_grid = h->n_cu * ER_INT_BLOCKS_PER_CU;
+  const int wide_grid = h->n_cu * kIntBlocksPerCu;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);
   const double* dev_t12 = reinterpret_cast<const double*>(dst + offsetof(Staging, t12));
@@ -1151,10 +986,6 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
       const int g = warp->grid_index[frame0 + f];
       if (g < 0 || g >= warp->num_grids) return er::fail("frame %d: control grid index %d out of [0,%d)", frame0 + f, g, warp->num_grids);
       st->gi[f] = g;
-#ifdef ER_REPROJECT_TIERED
-      er::reproj_fast_setup(&st->seg[f * 16], &st->madj[f * 12], h->cam, h->cols, h->rows, warp->resolution,
-                            warp->length / (float)warp->resolution, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g], st->fast[f]);
-#endif
     }
   }
   // all per-batch constants travel in ONE copy (every launch or copy on this stream costs ~5 us of the pre-pass chain)
@@ -1172,11 +1003,11 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
                         verts * 3, h->zbuf[a], h->lastzero[a], h->counters + kZeroFlagSlot[a]};
-    if (launch_reproject(h, RA, n, reinterpret_cast<const er::ReprojFast*>(dst + offsetof(Staging, fast)), X, a)) return 1;
+    if (launch_reproject(h, RA, n, X)) return 1;
     zsrc = h->zbuf[a];
   }
 
-  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), kPrePassLds, X,
+  hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
                      h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world));
@@ -1192,11 +1023,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipEventCreate(&e1));
     ER_HIP_TRY(hipEventRecord(e0, S));
   }
-#ifndef ER_NO_SURE_PATH
   const bool sure = h->cam.integration_trunc < 64.0f;                   // voxel_classify's bound on the scaled depth (false for NaN)
-#else
-  const bool sure = false;
-#endif
   hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], (h->cols + kTile - 1) / kTile,
                      (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows, h->unit_key, h->max_units, h->counters);
@@ -1215,13 +1042,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 }  // namespace
 
 static hipError_t aux_create(hipStream_t* s) {
-#ifdef ER_AUX_PRIO
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, ER_AUX_PRIO > 0 ? hi : lo);
-#else
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-#endif
 }
 
 extern "C" {
@@ -1296,10 +1117,6 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->zbuf[q], B * px * sizeof(uint32_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->lastzero[q], B * px * sizeof(uint32_t));
-#ifdef ER_REPROJECT_TIERED
-  for (int q = 0; q < kAux; q++)                              // one 64-bit mask per 64 source pixels (rows of 64, ragged right edge included)
-    ER_ALLOC(h->rlist[q], B * (size_t)((cols + 63) / 64) * ((rows + 3) / 4) * 4 * sizeof(unsigned long long));
-#endif
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
   for (int q = 0; q < kDepth; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
@@ -1347,7 +1164,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   for (int a = 0; a < kAux; a++)
     if (h->aux_stream[a]) (void)hipStreamSynchronize(h->aux_stream[a]);
   std::vector<void*> ptrs = {h->pool, h->ht_key, h->ht_slot, h->unit_key, h->counters, h->stats, h->lambda, h->T12, h->seg12, h->madj12,
-                             h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->ctr4_dev[0], h->ctr4_dev[1], h->key_scratch,
+                             h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->key_scratch,
                              h->slot_scratch};
   for (int q = 0; q < kDepth; q++)
     for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q],
@@ -1356,7 +1173,6 @@ int er_tsdf_destroy(er_tsdf_t h) {
   for (int q = 0; q < kAux; q++) {
     ptrs.push_back(h->zbuf[q]);
     ptrs.push_back(h->lastzero[q]);
-    ptrs.push_back(h->rlist[q]);
   }
   for (int q = 0; q < kDepth; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
@@ -1412,10 +1228,10 @@ int er_tsdf_scale_depth(er_tsdf_t h, const uint16_t* depth_host, float* scaled_h
   return 0;
 }
 
-// num_grids lattices of (res+1)^3 x 3 floats -> device (float[3] for the exact chain, Vert4 for tier 1) + their host-side bounds.
+// num_grids lattices of (res+1)^3 x 3 floats -> device.
 // The copy runs on the pre-pass stream of the call's first batch into the device buffer of this call's parity (so it never
 // waits for the previous call's pre-passes, which read the other buffer); the other pre-pass stream (and `also`, if given)
-// waits for it.  Sets h->ctr / h->ctr4 to the buffer the kernels of this call read.
+// waits for it.  Sets h->ctr to the buffer the kernels of this call read.
 static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hipStream_t also) {
   const size_t verts = (size_t)(res + 1) * (res + 1) * (res + 1);
   const size_t floats = verts * 3 * (size_t)num_grids;
@@ -1424,16 +1240,11 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
   if (floats > h->ctr_dev_cap[q]) {
     if (sync_all(h)) return 1;                       // nobody may still be reading the old buffer
     if (h->ctr_dev[q]) (void)hipFree(h->ctr_dev[q]);
-    if (h->ctr4_dev[q]) (void)hipFree(h->ctr4_dev[q]);
     h->ctr_dev[q] = nullptr;
-    h->ctr4_dev[q] = nullptr;
     h->ctr_dev_cap[q] = 0;
     ER_HIP_TRY(hipMalloc((void**)&h->ctr_dev[q], floats * sizeof(float)));
-    ER_HIP_TRY(hipMalloc((void**)&h->ctr4_dev[q], (floats / 3) * sizeof(er::Vert4)));
     h->ctr_dev_cap[q] = floats;
   }
-  h->grid_cmax.assign((size_t)num_grids, 0.0);
-  h->grid_dmax.assign((size_t)num_grids, 0.0);
   // The lattices travel through a page-locked block of the handle: the copy is then truly asynchronous (a copy from the
   // caller's pageable memory would make the host wait for everything queued on this stream at every call) and the caller's
   // memory is free again when the call returns.
@@ -1457,38 +1268,21 @@ static int upload_ctr(er_tsdf_t h, const float* ctr, int res, int num_grids, hip
     for (int a = 0; a < kAux; a++)
       if (a != a0) ER_HIP_TRY(hipStreamWaitEvent(C, h->ctr_rd[q][a], 0));
   ER_HIP_TRY(hipMemcpyAsync(h->ctr_dev[q], h->ctr_pinned[q], floats * sizeof(float), hipMemcpyHostToDevice, C));
-#ifdef ER_REPROJECT_TIERED               // the float32 tier's inputs: lattice bounds (host) and the 16-byte vertex copy (device)
-  for (int g = 0; g < num_grids; g++) er::lattice_bounds(ctr + (size_t)g * verts * 3, res, h->grid_cmax[(size_t)g], h->grid_dmax[(size_t)g]);
-  const long nv = (long)(floats / 3);
-  hipLaunchKernelGGL(k_expand_ctr, dim3((unsigned)((nv + kBlock - 1) / kBlock)), dim3(kBlock), 0, C, h->ctr_dev[q], h->ctr4_dev[q], nv);
-  ER_HIP_TRY(hipGetLastError());
-#endif
   ER_HIP_TRY(hipEventRecord(h->ctr_ev[q], C));
   for (int a = 0; a < kAux; a++)
     if (a != a0) ER_HIP_TRY(hipStreamWaitEvent(h->aux_stream[a], h->ctr_ev[q], 0));
   if (also) ER_HIP_TRY(hipStreamWaitEvent(also, h->ctr_ev[q], 0));
   h->ctr = h->ctr_dev[q];
-  h->ctr4 = h->ctr4_dev[q];
   h->ctr_cur = q;
   return 0;
 }
 
 // Reproject of n frames into zbuf: the all-exact kernel, or (-DER_REPROJECT_TIERED) tier 1 + the exact tail; then the replay launch.
-static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, const er::ReprojFast* dev_fast, hipStream_t X, int aux) {
-#ifdef ER_REPROJECT_TIERED
-  if (dev_fast && h->rlist[aux]) {
-    const int gx = (h->cols + 63) / 64, gy = (h->rows + 3) / 4, n_waves = n * gy * gx * 4;
-    unsigned long long* masks = reinterpret_cast<unsigned long long*>(h->rlist[aux]);
-    hipLaunchKernelGGL(k_reproject_tier, dim3(gx, gy, n), dim3(kBlock), 0, X, RA, dev_fast, h->ctr4, masks);
-    hipLaunchKernelGGL(k_reproject_tail, dim3((n_waves + kBlock - 1) / kBlock), dim3(kBlock), 0, X, RA, masks, n_waves, gx, gy);
-  } else
-#endif
-  {
-    // (staging the lattice in LDS for this kernel was measured as well: slower, profiles/r02d_ab_lds_lattice.txt)
-    hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), kPrePassLds, X, RA);
-  }
-  (void)aux;
-  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(256), 0, X, RA);      // (one small workgroup: it has to find room next to two busy kernels)
+static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, hipStream_t X) {
+  // (staging the lattice in LDS for this kernel was measured: slower, profiles/r02d_ab_lds_lattice.txt; a float32 tier with a
+  //  per-pixel proof in front of the exact chain, four designs: slower, profiles/r02b / r02c / r02z_ab_tiered_reproject_*.txt)
+  hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
+  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(kFixThreads), 0, X, RA);   // ONE WAVE: it has to find room next to three busy kernels
   ER_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1514,15 +1308,7 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const long total = (long)px;
   const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
                       verts * 3, h->zbuf[0], h->lastzero[0], h->counters + kZeroFlagSlot[0]};
-  {
-    er::ReprojFast* dev_fast = reinterpret_cast<er::ReprojFast*>(static_cast<char*>(h->dstage[0]) + offsetof(Staging, fast));
-#ifdef ER_REPROJECT_TIERED
-    Staging* st = static_cast<Staging*>(h->pinned[0]);                    // idle: sync_all above
-    er::reproj_fast_setup(seg16, madj, h->cam, h->cols, h->rows, resolution, grid_ul, h->grid_cmax[0], h->grid_dmax[0], st->fast[0]);
-    ER_HIP_TRY(hipMemcpyAsync(dev_fast, &st->fast[0], sizeof(er::ReprojFast), hipMemcpyHostToDevice, h->stream));
-#endif
-    if (launch_reproject(h, RA, 1, dev_fast, h->stream, 0)) return 1;
-  }
+  if (launch_reproject(h, RA, 1, h->stream)) return 1;
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf[0],
                      h->depth_stage[0], total);
   ER_HIP_TRY(hipGetLastError());
@@ -1807,17 +1593,5 @@ int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate
   return 0;
 }
 
-#ifdef ER_STATS
-// Debug build only (-DER_STATS): row-frames visited / row-frames with >= 1 update / voxel updates.
-int er_debug_stats(unsigned long long out[4], int reset) {
-  ER_HIP_TRY(hipDeviceSynchronize());
-  ER_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), 4 * sizeof(unsigned long long)));
-  if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
-    ER_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof z));
-  }
-  return 0;
-}
-#endif
 
 }  // extern "C"

@@ -69,7 +69,7 @@ ER_HD float div1000_core(float x) {
 }
 
 ER_HD float scale_depth_px(uint16_t d, float lambda, float integration_trunc) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV) && !defined(ER_PLAIN_CONST_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   float res = div1000_core((float)d * lambda);
 #else
   float res = ((float)d * lambda) / 1000.f;
@@ -161,7 +161,7 @@ ER_HD float grid_coord(int i, float shift) { return (float)((double)i * kUnitLen
 // (tests/hostcheck) the plain operators are used.  Measured: k_integrate 0.50 -> 0.43 ms per 50-frame launch
 // (v_rcp/v_sqrt issue at half rate on MI355X, every other f32/f64 VALU op at full rate: scripts/ubench).
 ER_HD void div2_inrange(float n0, float n1, float d, float& q0, float& q1) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.0f), r, r);
   float m = n0 * r;
@@ -177,7 +177,7 @@ ER_HD void div2_inrange(float n0, float n1, float d, float& q0, float& q1) {
 }
 
 ER_HD float div_inrange(float n, float d) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.0f), r, r);
   float m = n * r;
@@ -190,7 +190,7 @@ ER_HD float div_inrange(float n, float d) {
 
 // Three quotients by one denominator (ControlGrid::GetCoordinate's pt / unit_length_, ControlGrid.h:46-48).
 ER_HD void div3_inrange(float n0, float n1, float n2, float d, float& q0, float& q1, float& q2) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   float r = __builtin_amdgcn_rcpf(d);
   r = fmaf(fmaf(-d, r, 1.0f), r, r);
   float m = n0 * r;
@@ -210,7 +210,7 @@ ER_HD void div3_inrange(float n0, float n1, float n2, float d, float& q0, float&
 }
 
 ER_HD float sqrt_inrange(float x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   float s = __builtin_amdgcn_sqrtf(x);                       // <= 1 ulp
   const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
   const float r1 = fmaf(-sm, s, x), r2 = fmaf(-sp, s, x);    // residuals against the two neighbours
@@ -237,7 +237,7 @@ ER_HD double band_quotient_core(float sdf) {
 }
 
 ER_HD double band_quotient(float sdf) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_PLAIN_DIV) && !defined(ER_PLAIN_CONST_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   return band_quotient_core(sdf);
 #else
   return (double)sdf / kTsdfTrunc;
@@ -443,7 +443,7 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
       const float t2 = ((f.mi[8] * g0 + f.mi[9] * g1) + f.mi[10] * g2) + f.mi[11];
       const float t0 = ((f.mi[0] * g0 + f.mi[1] * g1) + f.mi[2] * g2) + f.mi[3];
       const float t1 = ((f.mi[4] * g0 + f.mi[5] * g1) + f.mi[6] * g2) + f.mi[7];
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(ER_CULL_IEEE_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
       // The corner projections feed conservative tests only (margins of 1.5 px; the "inside" slack budgets 16u where 3.3u + 4u
       // are needed), so the 1-ulp hardware reciprocal replaces the two IEEE divisions: 8 fewer division sequences per
       // (patch, frame).  Validated: the whole -m gpu parity suite is bit-exact with it (profiles/r02a_ab_fast_cull.txt),
@@ -591,20 +591,13 @@ ER_HD double round_pixel(double e, double f, double e2, double rcp_e2, double cc
   return floor((e * f / e2 + cc) + 0.5);
 }
 
-struct alignas(16) Vert4 { float x, y, z, w; };     // one lattice vertex padded to 16 bytes (one LDS / 16-byte read per vertex)
-
-// The lattice as ControlGrid keeps it (3 floats per vertex) or as Vert4 (tier 1's 16-byte vertices).  Vertices are addressed by
-// UNSIGNED BYTE offsets from the (wave-uniform) lattice pointer: one 32-bit add per vertex and a scalar-base load, instead of
-// a sign extension, a multiplication by the vertex size and a 64-bit add each.
+// The lattice as ControlGrid keeps it (3 floats per vertex).  Vertices are addressed by UNSIGNED BYTE offsets from the
+// (wave-uniform) lattice pointer: one 32-bit add per vertex and a scalar-base load, instead of a sign extension, a multiplication
+// by the vertex size and a 64-bit add each.
 ER_HD unsigned lattice_stride(const float*) { return 12u; }
-ER_HD unsigned lattice_stride(const Vert4*) { return 16u; }
 ER_HD void lattice_vertex(const float* __restrict__ ctr, unsigned byte_off, float v[3]) {
   const float* p = reinterpret_cast<const float*>(reinterpret_cast<const char*>(ctr) + byte_off);
   v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
-}
-ER_HD void lattice_vertex(const Vert4* __restrict__ ctr, unsigned byte_off, float v[3]) {
-  const Vert4 t = *reinterpret_cast<const Vert4*>(reinterpret_cast<const char*>(ctr) + byte_off);
-  v[0] = t.x; v[1] = t.y; v[2] = t.z;
 }
 
 // seg: rows 0..2 of the float64 4x4 followed by the three rounding bounds of cube_coords (15 doubles used, stride 16);
@@ -677,227 +670,8 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   return true;
 }
 
-// ---- Reproject, tier 1: a float32 ESTIMATE of the warp with a rigorous error bound --------------------------------------
-// Only three integers of Reproject are observable per source pixel: the target pixel (uu, vv) = two roundings, and the
-// millimetre depth dd = one rounding (IntegrateApp.cpp:256-263).  reproject_px above evaluates the reference's whole chain
-// exactly (~235 VALU instructions per 64 pixels, most of them float64).  The tier below estimates the same three values with
-// ~100 cheaper instructions and PROVES, per pixel, whether the estimate is far enough from every decision boundary (lattice
-// range test, z > 0, the three roundings, the image-range test) for the integers to be the reference's; pixels it cannot
-// decide (a few per cent) are handed to reproject_px.  Nothing here has to reproduce an intermediate value of the reference.
-//
-// Notation: u32 = 2^-24; a = pt / unit_length_ (lattice coordinates, ControlGrid.h:44-48); for the lattice of a fragment
-// Cmax = max |vertex component|, Dmax = max component of the difference of two lattice-adjacent vertices.
-// (A) lattice coordinates.  Reference: q = seg * UVD2XYZ in float64 (error < 1e-12 relative to the magnitudes involved),
-//     pt = fl32(q), a_ref = fl32(pt / ul): |a_ref - q/ul| <= 2 u32 |a| (1 + u32).  Here: a~ = d (ga u' + gb v' + gc) + gs in
-//     float64 with host-folded coefficients (error < 1e-9 lattice units, enforced by the host: `ok`).  For |a| <= res + 2:
-//         |a~ - a_ref| <= eps_a = 2.001 u32 (res + 2) + 2e-9.
-//     a~ in [eps_a, res - eps_a] on every axis  =>  the reference accepts the point; a~ < -eps_a or > res + eps_a on some axis
-//     =>  it rejects it; otherwise undecided.
-// (B) trilinear position.  The interpolant is continuous across cells and, inside a cell, d pos / d a_k is a convex
-//     combination of four lattice edges, so moving the evaluation point by delta costs <= sum_k |delta_k| Dmax per component
-//     even when floor() lands in the neighbouring cell.  The reference's own float32 evaluation (weights with relative error
-//     <= 5.001 u32 each: three factors, two products; then 8 products, 7 sums; ControlGrid.h:69-87) deviates from the exact interpolant by <= 13.01 u32 Cmax, and
-//     so does the fused evaluation here (r~ rounded to float32: part of delta).  Hence per component
-//         |pos~ - pos_ref| <= eps_pos = 3 (eps_a + u32) Dmax + 27 u32 Cmax.
-// (C) e = madj * (pos, 1): float64 in the reference (exact to 1e-15), three float32 fmas here with float32 coefficients
-//     (rows 0 / 1 pre-scaled by fx / fy):  |e~_r - s_r e_r| <= s_r eps_e,  eps_e = L1 eps_pos + 4.01 u32 (L1 Cmax' + |m_r|)
-//     with L1 = max_r sum_c |M_rc| and Cmax' = Cmax + eps_pos.
-// (D) projection.  With P = fx e0 / e2 (= u - cx):  e~0 / e~2 - P = (delta0 - P delta2) / e~2; the hardware reciprocal adds
-//     <= 2.5 u32 |P|, the final fma u32 |u|, adding 0.5 another u32 |u|.  The tier only DECIDES pixels whose estimate lies
-//     inside the image (|P| <= pmax), with e~2 >= e2_min = 64 eps_e (so 1 / e2 is within 1.6 % of 1 / e~2):
-//         |u~ - u_ref| <= t1 / e~2 + t2,   t1 = 1.04 (f eps_e + (pmax + 2) eps_e),  t2 = 5 u32 (pmax + |c| + 2)
-//     (f = max(fx, fy), c = cx or cy).  Depth: |1000 e~2 - 1000 e2| <= 1000 eps_e (1.02) + 2 u32 (1000 e~2).
-// A rounding floor(x + 0.5) is decided when the fractional part of x~ + 0.5 keeps more than the tolerance away from 0 and 1;
-// then the integer tests against the image bounds are exact as well.  Every constant is rounded UP on the host
-// (reproj_fast_setup); tests/hostcheck replays the tier on the CPU against reproject_px for every pixel of the golden and
-// fuzzed scenes and records the worst observed error as a fraction of its tolerance.
-struct ReprojFast {
-  double ga[3], gb[3], gc[3], gs[3];   // a_k = d * (ga_k u' + gb_k v' + gc_k) + gs_k, d = raw depth in millimetres
-  float m[12];                         // madj rows 0, 1 scaled by fx, fy; row 2 plain
-  float eps_a, res_hi;                 // lattice range guard: accept inside [eps_a, res_hi], reject outside [-eps_a, res + eps_a]
-  float res_rej;
-  float t1, t2;                        // pixel tolerance = t1 * rcp(e2) + t2
-  float td1;                           // depth tolerance (mm) = td1 + 2 u32 * (1000 e2)
-  float e2_min;
-  float ulim, vlim;                    // min(640, cols), min(480, rows) (reproject_px)
-  int ok;                              // 0: tier disabled for this frame (every pixel goes to the exact path)
-  int pad;
-};
-
-enum { kReprojReject = 0, kReprojAccept = 1, kReprojUnsure = 2 };
-
-// Host side: Cmax / Dmax of one lattice ((res+1)^3 vertices of 3 floats, vertex i + j n1 + k n1^2).  Non-finite -> inf.
-inline void lattice_bounds(const float* ctr, int res, double& cmax, double& dmax) {
-  const int n1 = res + 1, n2 = n1 * n1;
-  cmax = dmax = 0.0;
-  for (int k = 0; k < n1; k++)
-    for (int j = 0; j < n1; j++)
-      for (int i = 0; i < n1; i++) {
-        const int v = i + j * n1 + k * n2;
-        for (int a = 0; a < 3; a++) {
-          const double x = (double)ctr[3 * v + a];
-          if (!std::isfinite(x)) { cmax = dmax = HUGE_VAL; return; }
-          cmax = fmax(cmax, fabs(x));
-          if (i + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + 1) + a] - x));
-          if (j + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + n1) + a] - x));
-          if (k + 1 < n1) dmax = fmax(dmax, fabs((double)ctr[3 * (v + n2) + a] - x));
-        }
-      }
-}
-
-// Host side: constants of one frame.  seg / madj: rows 0..2 of the float64 matrices; cmax / dmax: the lattice bounds above.
-inline void reproj_fast_setup(const double* seg, const double* madj, const Camera& c, int cols, int rows, int res, float grid_ul,
-                              double cmax, double dmax, ReprojFast& F) {
-  memset(&F, 0, sizeof F);
-  const double u32 = 1.0 / 16777216.0;
-  const double ul = (double)grid_ul, fx = (double)c.fx, fy = (double)c.fy;
-  const double umax = fmax(fabs(0.0 - (double)c.cx), fabs((double)(cols - 1) - (double)c.cx)) + 1.0;
-  const double vmax = fmax(fabs(0.0 - (double)c.cy), fabs((double)(rows - 1) - (double)c.cy)) + 1.0;
-  double worst_mag = 0.0;
-  for (int k = 0; k < 3; k++) {
-    F.ga[k] = seg[4 * k] / (fx * ul * 1000.0);
-    F.gb[k] = seg[4 * k + 1] / (fy * ul * 1000.0);
-    F.gc[k] = seg[4 * k + 2] / (ul * 1000.0);
-    F.gs[k] = seg[4 * k + 3] / ul;
-    worst_mag = fmax(worst_mag, 65535.0 * (fabs(F.ga[k]) * umax + fabs(F.gb[k]) * vmax + fabs(F.gc[k])) + fabs(F.gs[k]));
-  }
-  const double eps_a = 2.001 * u32 * (double)(res + 2) + 2e-9;
-  const double eps_pos = 3.0 * (eps_a + u32) * dmax + 27.0 * u32 * cmax + 1e-30;
-  double l1 = 0.0, mabs = 0.0;
-  for (int r = 0; r < 3; r++) {
-    l1 = fmax(l1, fabs(madj[4 * r]) + fabs(madj[4 * r + 1]) + fabs(madj[4 * r + 2]));
-    mabs = fmax(mabs, fabs(madj[4 * r + 3]));
-  }
-  const double eps_e = l1 * eps_pos + 4.01 * u32 * (l1 * (cmax + eps_pos) + mabs);
-  const double ulim = cols < 640 ? (double)cols : 640.0, vlim = rows < 480 ? (double)rows : 480.0;
-  const double pmax = fmax(fmax(fabs((double)c.cx), fabs(ulim - (double)c.cx)), fmax(fabs((double)c.cy), fabs(vlim - (double)c.cy))) + 1.0;
-  const double f = fmax(fabs(fx), fabs(fy)), cc = fmax(fabs((double)c.cx), fabs((double)c.cy));
-  const double t1 = 1.04 * (f * eps_e + (pmax + 2.0) * eps_e), t2 = 5.0 * u32 * (pmax + cc + 2.0);
-  const double up = 1.0 + 1e-6;                                    // float conversion rounds to nearest: push every bound up
-  for (int q = 0; q < 4; q++) {
-    F.m[q] = (float)(madj[q] * fx);
-    F.m[4 + q] = (float)(madj[4 + q] * fy);
-    F.m[8 + q] = (float)madj[8 + q];
-  }
-  F.eps_a = (float)(eps_a * up);
-  F.res_hi = (float)(((double)res - eps_a) / up);
-  F.res_rej = (float)(((double)res + eps_a) * up);
-  F.t1 = (float)(t1 * up);
-  F.t2 = (float)(t2 * up);
-  F.td1 = (float)((1000.0 * eps_e * 1.02 + 1e-9) * up);
-  F.e2_min = (float)(64.0 * eps_e * up);
-  F.ulim = (float)ulim;
-  F.vlim = (float)vlim;
-  // The analysis needs finite, sane magnitudes: float64 evaluation error of a~ below 1e-9 lattice units (20 roundings of
-  // magnitude worst_mag), coefficients that fit float32 comfortably, a lattice spacing in range, a tolerance that can ever pass.
-  const bool sane = std::isfinite(worst_mag) && worst_mag * 20.0 * 1.2e-16 < 1e-9 && std::isfinite(cmax) && std::isfinite(dmax) &&
-                    cmax < 1e6 && std::isfinite(eps_e) && std::isfinite(t1) && std::isfinite(pmax) && pmax < 1e6 && f < 1e6 &&
-                    ul > 1e-6 && ul < 1e6 && res >= 1 && res < 4096 && t2 < 0.25 && mabs < 1e6;
-  F.ok = sane ? 1 : 0;
-}
-
-// Tier 1 in three branch-free stages, so that a thread can run each stage for ALL its pixels before the next one (the frame
-// constants of a stage are then fetched once per thread, and the LDS reads of several pixels are in flight together):
-//   rt_stage_a   lattice coordinates -> cell + residuals + range verdict                       (float64, (A) above)
-//   rt_stage_c   trilinear sum over the 8 vertices of the (clamped) cell                        (float32, (B))
-//   rt_stage_e   e = madj * pos, projection, the three roundings with their tolerances          (float32, (C), (D))
-// Nothing branches on data: undecidable or irrelevant pixels run the same arithmetic on clamped indices and are sorted out
-// by the flags at the end.  NaNs fail every compare and end up "unsure".
-struct RtPix {
-  float r0, r1, r2;      // residuals inside the cell
-  int base;              // index of the cell's corner vertex (clamped into the lattice)
-  bool in, out;          // inside the lattice for sure / outside for sure
-};
-
-// clamp(x, lo, hi) in ONE instruction on the device (v_med3_f32; a NaN comes out as lo or hi, never as NaN)
-ER_HD float rt_med3(float x, float lo, float hi) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_fmed3f(x, lo, hi);
-#else
-  return x != x ? lo : fminf(fmaxf(x, lo), hi);
-#endif
-}
-
-// g[3] = ga u' + gb v' + gc of this pixel (float64, u' = (double)((float)u - cx) as in UVD2XYZ); n1 = res + 1.
-ER_HD void rt_stage_a(int d, const double g[3], const ReprojFast& F, int n1, RtPix& P) {
-  const double dz = (double)d;
-  const double a0 = fma(dz, g[0], F.gs[0]), a1 = fma(dz, g[1], F.gs[1]), a2 = fma(dz, g[2], F.gs[2]);
-  const double amin = fmin(fmin(a0, a1), a2), amax = fmax(fmax(a0, a1), a2);
-  const bool in = (amin >= (double)F.eps_a) & (amax <= (double)F.res_hi);
-  const bool out = (amin < -(double)F.eps_a) | (amax > (double)F.res_rej);
-  const double f0 = floor(a0), f1 = floor(a1), f2 = floor(a2);
-  P.r0 = (float)(a0 - f0);
-  P.r1 = (float)(a1 - f1);
-  P.r2 = (float)(a2 - f2);
-  const float res1 = (float)(n1 - 2);                                    // res - 1: the cell index is clamped into the lattice
-  const int c0 = (int)rt_med3((float)f0, 0.0f, res1), c1 = (int)rt_med3((float)f1, 0.0f, res1), c2 = (int)rt_med3((float)f2, 0.0f, res1);
-  P.base = c0 + (c1 + c2 * n1) * n1;
-  P.in = in;
-  P.out = out;
-}
-
-ER_HD void rt_stage_c(const RtPix& P, const Vert4* __restrict__ ctr4, int n1, float pos[3]) {
-  const int n2 = n1 * n1;
-  const Vert4* __restrict__ cb = ctr4 + P.base;
-  const Vert4 c0 = cb[0], c1 = cb[n2], c2 = cb[n1], c3 = cb[n1 + n2], c4 = cb[1], c5 = cb[1 + n2], c6 = cb[1 + n1], c7 = cb[1 + n1 + n2];
-  const float r0 = P.r0, r1 = P.r1, r2 = P.r2;
-  const float w0 = 1.0f - r0, w1 = 1.0f - r1, w2 = 1.0f - r2;
-  const float w01 = w0 * w1, w0r = w0 * r1, rw1 = r0 * w1, r01 = r0 * r1;
-  const float v0 = w01 * w2, v1 = w01 * r2, v2 = w0r * w2, v3 = w0r * r2, v4 = rw1 * w2, v5 = rw1 * r2, v6 = r01 * w2, v7 = r01 * r2;
-  float px = v0 * c0.x, py = v0 * c0.y, pz = v0 * c0.z;
-  px = fmaf(v1, c1.x, px); py = fmaf(v1, c1.y, py); pz = fmaf(v1, c1.z, pz);
-  px = fmaf(v2, c2.x, px); py = fmaf(v2, c2.y, py); pz = fmaf(v2, c2.z, pz);
-  px = fmaf(v3, c3.x, px); py = fmaf(v3, c3.y, py); pz = fmaf(v3, c3.z, pz);
-  px = fmaf(v4, c4.x, px); py = fmaf(v4, c4.y, py); pz = fmaf(v4, c4.z, pz);
-  px = fmaf(v5, c5.x, px); py = fmaf(v5, c5.y, py); pz = fmaf(v5, c5.z, pz);
-  px = fmaf(v6, c6.x, px); py = fmaf(v6, c6.y, py); pz = fmaf(v6, c6.z, pz);
-  px = fmaf(v7, c7.x, px); py = fmaf(v7, c7.y, py); pz = fmaf(v7, c7.z, pz);
-  pos[0] = px; pos[1] = py; pos[2] = pz;
-}
-
-// valid = the source pixel carries a depth (UVD2XYZ true).  Returns the class; cell / dd are meaningful for kReprojAccept.
-ER_HD int rt_stage_e(bool valid, const RtPix& P, const float pos[3], const ReprojFast& F, float cxf, float cyf, int cols, int& cell, int& dd,
-                     float* dbg = nullptr) {
-  const float e0 = fmaf(F.m[0], pos[0], fmaf(F.m[1], pos[1], fmaf(F.m[2], pos[2], F.m[3])));
-  const float e1 = fmaf(F.m[4], pos[0], fmaf(F.m[5], pos[1], fmaf(F.m[6], pos[2], F.m[7])));
-  const float e2 = fmaf(F.m[8], pos[0], fmaf(F.m[9], pos[1], fmaf(F.m[10], pos[2], F.m[11])));
-#if defined(__HIP_DEVICE_COMPILE__)
-  const float rc = __builtin_amdgcn_rcpf(e2);                            // <= 1 ulp
-#else
-  const float rc = 1.0f / e2;
-#endif
-  const float xu = fmaf(e0, rc, cxf) + 0.5f, xv = fmaf(e1, rc, cyf) + 0.5f;
-  const float xd = fmaf(e2, 1000.0f, 0.5f);
-  const float fu = floorf(xu), fv = floorf(xv), fd = floorf(xd);
-  const float tol = fmaf(F.t1, rc, F.t2), told = fmaf(xd, 0x1p-23f, F.td1);
-  if (dbg) { dbg[0] = xu; dbg[1] = xv; dbg[2] = xd; dbg[3] = tol; dbg[4] = told; }   // (tests: estimates and their tolerances)
-  // a rounding is decided <=> the fractional part keeps the tolerance away from both ends:  | frac - 0.5 | < 0.5 - tol
-  const bool su = fabsf((xu - fu) - 0.5f) < 0.5f - tol, sv = fabsf((xv - fv) - 0.5f) < 0.5f - tol, sd = fabsf((xd - fd) - 0.5f) < 0.5f - told;
-  // estimates outside the image by more than a pixel are not priced by t1 / t2 (|P| <= pmax was assumed): undecided
-  const bool near_img = (fu >= -1.0f) & (fu <= F.ulim) & (fv >= -1.0f) & (fv <= F.vlim);
-  const bool in_img = (fu >= 0.0f) & (fu < F.ulim) & (fv >= 0.0f) & (fv < F.vlim);    // XYZ2UVD's range test, exact on decided integers
-  const bool zpos = e2 >= F.e2_min, zneg = e2 < -F.e2_min;                            // z > 0 / z <= 0 for sure (XYZ2UVD)
-  const bool lat_in = P.in, lat_out = P.out;
-  const bool decided_px = zpos & su & sv & sd & (fd < 65535.0f) & near_img;
-  const bool accept = valid & (F.ok != 0) & lat_in & decided_px & in_img;
-  const bool reject = !valid | ((F.ok != 0) & (lat_out | (lat_in & (zneg | (decided_px & !in_img)))));
-  // only read when the pixel is accepted (then fd is in [0, 65535) and fu, fv are inside the image)
-  dd = accept ? (int)fd : 0;
-  cell = accept ? (int)fv * cols + (int)fu : 0;
-  return accept ? kReprojAccept : (reject ? kReprojReject : kReprojUnsure);
-}
-
-// The three stages for one pixel (tests/hostcheck; the kernel interleaves the stages of its pixels instead).
-ER_HD int reproject_fast(uint16_t d, const double g[3], const ReprojFast& F, const Camera& c, const Vert4* __restrict__ ctr4, int n1,
-                         int cols, int& cell, uint16_t& dd, float* dbg = nullptr) {
-  RtPix P;
-  float pos[3];
-  rt_stage_a((int)d, g, F, n1, P);
-  rt_stage_c(P, ctr4, n1, pos);
-  int ddi = 0;
-  const int cls = rt_stage_e(d != 0, P, pos, F, c.cx, c.cy, cols, cell, ddi, dbg);
-  dd = (uint16_t)ddi;
-  return cls;
-}
+// (A float32 ESTIMATE of the warp with a per-pixel proof in front of this exact chain was built and validated four times in
+//  round 2 and was slower every time -- hipcc needs ~180 VALU instructions for the estimate plus its proof against 231 for the
+//  exact chain; records: profiles/r02b_ab_tiered_reproject_v1.txt, r02c_*, r02z_ab_tiered_reproject_v3_v4.txt.  The code left with round 3.)
 
 }  // namespace er

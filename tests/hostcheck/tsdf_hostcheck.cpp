@@ -57,63 +57,6 @@ void hc_reproject(void* h, uint16_t* depth, const float* ctr, int res, float len
   }
 }
 
-// The tiered Reproject of k_reproject_tiered replayed on the CPU: every source pixel goes through tier 1 (reproject_fast, the
-// float32 estimate with its error bound); its accept / reject verdicts are CROSS-CHECKED against the exact chain
-// (reproject_px) -- same verdict, same target cell, same depth -- and undecided pixels take the exact chain, as on the
-// device.  stats[0..3] = accepted, rejected, undecided, violations.  The depth image that comes out is what the device
-// produces, so the caller can compare it with the oracle as well.
-static double g_tier_worst = 0.0;     // worst observed |estimate - reference value| / tolerance over all accepted pixels
-double hc_tier_worst(int reset) { const double w = g_tier_worst; if (reset) g_tier_worst = 0.0; return w; }
-
-void hc_reproject_tiered(void* h, uint16_t* depth, const float* ctr, int res, float length, const double* seg, const double* madj,
-                         long* stats) {
-  HcVolume* v = static_cast<HcVolume*>(h);
-  const int n = v->cols * v->rows;
-  std::vector<uint16_t> src(depth, depth + n);
-  std::fill(depth, depth + n, (uint16_t)0);
-  const float grid_ul = length / (float)res;
-  double seg16[16] = {0};
-  memcpy(seg16, seg, 12 * sizeof(double));
-  cube_coord_deltas(seg16, v->cam, v->cols, v->rows, seg16 + 12);
-  double cmax, dmax;
-  lattice_bounds(ctr, res, cmax, dmax);
-  ReprojFast F;
-  reproj_fast_setup(seg, madj, v->cam, v->cols, v->rows, res, grid_ul, cmax, dmax, F);
-  const int n1 = res + 1, verts = n1 * n1 * n1;
-  std::vector<Vert4> c4((size_t)verts);
-  for (int q = 0; q < verts; q++) c4[(size_t)q] = Vert4{ctr[3 * q], ctr[3 * q + 1], ctr[3 * q + 2], 0.f};
-  for (int p = 0; p < n; p++) {
-    if (src[p] == 0) continue;
-    const int u = p % v->cols, vv = p / v->cols;
-    const double up = (double)((float)u - v->cam.cx), vp = (double)((float)vv - v->cam.cy);
-    double g[3];
-    for (int k = 0; k < 3; k++) g[k] = fma(F.gb[k], vp, fma(F.ga[k], up, F.gc[k]));
-    int cell_f = -1, cell_x = -1;
-    uint16_t dd_f = 0, dd_x = 0;
-    float dbg[5] = {0, 0, 0, 1, 1};
-    double ex[3] = {0, 0, 0};
-    const int cls = reproject_fast(src[p], g, F, v->cam, c4.data(), n1, v->cols, cell_f, dd_f, dbg);
-    const bool ok_x = reproject_px(u, vv, src[p], v->cam, v->cami, v->cols, v->rows, seg16, madj, ctr, res, grid_ul, cell_x, dd_x, ex);
-    if (cls == kReprojAccept) {
-      // how much of its tolerance did the estimate use?  (reference values in float64 from the exact chain)
-      const double ur = ex[0] * (double)v->cam.fx / ex[2] + (double)v->cam.cx + 0.5, vr = ex[1] * (double)v->cam.fy / ex[2] + (double)v->cam.cy + 0.5;
-      const double dr = ex[2] * 1000.0 + 0.5;
-      g_tier_worst = std::max(g_tier_worst, std::max(std::max(fabs(ur - dbg[0]), fabs(vr - dbg[1])) / dbg[3], fabs(dr - dbg[2]) / dbg[4]));
-      stats[0]++;
-      if (!ok_x || cell_x != cell_f || dd_x != dd_f) stats[3]++;
-    } else if (cls == kReprojReject) {
-      stats[1]++;
-      if (ok_x) stats[3]++;
-    } else {
-      stats[2]++;
-    }
-    const bool ok = cls == kReprojUnsure ? ok_x : cls == kReprojAccept;
-    const int cell = cls == kReprojUnsure ? cell_x : cell_f;
-    const uint16_t dd = cls == kReprojUnsure ? dd_x : dd_f;
-    if (ok && (depth[cell] == 0 || depth[cell] > dd)) depth[cell] = dd;
-  }
-}
-
 // Batch semantics of k_prepare + k_integrate: masks first, then per voxel all frames in order.
 int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, const double* Tinv) {
   HcVolume* v = static_cast<HcVolume*>(h);

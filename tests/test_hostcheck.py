@@ -32,9 +32,6 @@ def hc():
     L.hc_destroy.argtypes = [vp]
     L.hc_scale_depth.argtypes = [vp, vp, vp]
     L.hc_reproject.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp, vp]
-    L.hc_reproject_tiered.argtypes = [vp, vp, vp, C.c_int, C.c_float, vp, vp, vp]
-    L.hc_tier_worst.restype = C.c_double
-    L.hc_tier_worst.argtypes = [C.c_int]
     L.hc_integrate_frames.argtypes = [vp, C.c_int, vp, vp, vp]
     L.hc_unit_count.argtypes = [vp]
     L.hc_culled.restype = C.c_long
@@ -79,16 +76,6 @@ class HcVolume:
         s, m = np.ascontiguousarray(seg, np.float64), np.ascontiguousarray(madj, np.float64)
         self.L.hc_reproject(self.h, d.ctypes.data_as(vp), g.ctypes.data_as(vp), res, C.c_float(length), s.ctypes.data_as(vp), m.ctypes.data_as(vp))
         return d
-
-    def reproject_tiered(self, depth, ctr, res, length, seg, madj):
-        """k_reproject_tiered's arithmetic: (depth image, [accepted, rejected, undecided, violations])."""
-        d = np.array(depth, np.uint16)
-        g = np.ascontiguousarray(ctr, np.float32)
-        s, m = np.ascontiguousarray(seg, np.float64), np.ascontiguousarray(madj, np.float64)
-        st = np.zeros(4, np.int64)
-        self.L.hc_reproject_tiered(self.h, d.ctypes.data_as(vp), g.ctypes.data_as(vp), res, C.c_float(length), s.ctypes.data_as(vp),
-                                   m.ctypes.data_as(vp), st.ctypes.data_as(vp))
-        return d, st
 
     def scale(self, depth):
         d = np.ascontiguousarray(depth, np.uint16)
@@ -286,80 +273,6 @@ def test_device_reproject_randomised_grids_vs_oracle(hc):
             assert np.array_equal(mine, np.asarray(want).reshape(-1)), "case %d frame %d: %d pixels differ" % (
                 case, f, int((mine != np.asarray(want).reshape(-1)).sum()))
             assert (mine != 0).sum() > 1000
-
-
-def test_tiered_reproject_golden_scene(hc):
-    """The float32 tier of Reproject (reproject_fast) on the golden warp scene: every verdict it commits to (accept with
-    cell + depth, or reject) equals the exact chain's, the image equals the reference digest, and it decides most pixels."""
-    sc = helpers.golden_warp()
-    g = helpers.golden()["warp"]
-    depth = synth.to_numpy_u16(sc["depth"])
-    warp = synth.warp_arrays(sc)
-    v = HcVolume(hc)
-    hc.hc_tier_worst(1)
-    tot = np.zeros(4, np.int64)
-    for f in range(sc["n"]):
-        d, st = v.reproject_tiered(depth[f], sc["grids"][warp["grid_index"][f]], sc["resolution"], sc["length"], warp["seg"][f], warp["madj"][f])
-        assert helpers.digest(d) == g["reprojected_depth"][f]
-        tot += st
-    assert tot[3] == 0, "%d verdicts of the float32 tier contradict the exact chain" % tot[3]
-    assert tot[2] < 0.08 * tot[:3].sum() and tot[0] > 100000, "the tier decides too few pixels: accepted %d rejected %d undecided %d" % tuple(tot[:3])
-    worst = hc.hc_tier_worst(1)
-    assert worst < 0.5, "an estimate used %.2f of its tolerance: the error bound is not as loose as the derivation says" % worst
-    print("tier 1 on the golden scene: accepted %d, rejected %d, undecided %d (%.2f %%); worst error / tolerance %.3f" % (
-        tot[0], tot[1], tot[2], 100.0 * tot[2] / tot[:3].sum(), worst))
-
-
-def test_tiered_reproject_randomised_vs_oracle(hc):
-    """Fuzz of the tier: random cameras, poses, strongly deformed lattices (1-5 cm noise per vertex), lattices far from the
-    origin (large |vertex| -> wide tolerances), resolutions 2..12, holes, salt noise, depths up to 60 m; the image must
-    equal the oracle's and no committed verdict may contradict the exact chain.  Degenerate set-ups (non-finite lattice,
-    absurd magnitudes) must switch the tier off (everything undecided) instead of guessing."""
-    tot = np.zeros(4, np.int64)
-    for case in range(6):
-        rng = np.random.default_rng(7700 + case)
-        cam = np.array([float(rng.uniform(300, 700)), float(rng.uniform(300, 700)), 0.0 if case == 2 else float(rng.uniform(150, 500)),
-                        float(rng.uniform(100, 380)), 2.5, 2.5], np.float32)
-        poses = np.stack([synth.look_at(tuple(rng.uniform(0.5, 2.5, 3)), tuple(rng.uniform(0.2, 2.8, 3))) @
-                          synth.perturbation(int(rng.integers(1 << 30)), 15.0, 0.0) for _ in range(2)])
-        depth = synth.to_numpy_u16(synth.render_depth(poses, cam=tuple(float(c) for c in cam[:4]))).copy()
-        depth[rng.random(depth.shape) < 0.05] = 0
-        salt = rng.random(depth.shape) < 0.004
-        depth[salt] = rng.integers(1, 60000, int(salt.sum()), dtype=np.uint16)
-        res, length = int(rng.integers(2, 13)), 3.0
-        k, j, i = np.meshgrid(np.arange(res + 1), np.arange(res + 1), np.arange(res + 1), indexing="ij")
-        base = np.stack([i.ravel(), j.ravel(), k.ravel()], 1) * (length / res)
-        shift = np.array([0.0, 0.0, 0.0]) if case % 3 else rng.uniform(-40, 40, 3)      # lattice (and its frame) far from the origin
-        grid = (base + shift + rng.normal(0, 0.01 * (1 + 2 * (case % 3)), base.shape)).astype(np.float32)
-        cube = synth.basepose()
-        seg = np.stack([cube @ np.linalg.inv(poses[0]) @ P for P in poses])
-        S = np.eye(4)
-        S[:3, 3] = -shift
-        madj = np.stack([np.linalg.inv(poses[f]) @ poses[0] @ np.linalg.inv(seg[0]) @ S for f in range(2)])
-        v, ora = HcVolume(hc, cam), OracleVolume(640, 480, cam)
-        for f in range(2):
-            mine, st = v.reproject_tiered(depth[f], grid, res, length, seg[f], madj[f])
-            want = np.asarray(ora.Reproject(depth[f], grid, res, np.float32(length), seg[f], madj[f])).reshape(-1)
-            assert st[3] == 0, "case %d frame %d: %d committed verdicts are wrong" % (case, f, st[3])
-            assert np.array_equal(mine, want), "case %d frame %d: %d pixels differ" % (case, f, int((mine != want).sum()))
-            assert (mine != 0).sum() > 1000
-            tot += st
-    assert tot[0] > 0.2 * tot[:3].sum()
-    # degenerate: a NaN vertex, and a lattice 1e7 m away -> the tier must abstain everywhere
-    sc = helpers.golden_warp()
-    depth = synth.to_numpy_u16(sc["depth"])
-    warp = synth.warp_arrays(sc)
-    v, ora = HcVolume(hc), OracleVolume()
-    for bad in (np.nan, 1e7):
-        grid = sc["grids"][0].copy()
-        grid[5, 1] = bad
-        mine, st = v.reproject_tiered(depth[0], grid, sc["resolution"], sc["length"], warp["seg"][0], warp["madj"][0])
-        want = np.asarray(ora.Reproject(depth[0], grid, sc["resolution"], np.float32(sc["length"]), warp["seg"][0], warp["madj"][0])).reshape(-1)
-        assert st[0] == 0 and st[3] == 0 and np.array_equal(mine, want)
-    worst = hc.hc_tier_worst(1)
-    assert worst < 0.5, "an estimate used %.2f of its tolerance" % worst
-    print("tier 1 fuzz: accepted %d, rejected %d, undecided %d (%.2f %%); worst error / tolerance %.3f" % (
-        tot[0], tot[1], tot[2], 100.0 * tot[2] / tot[:3].sum(), worst))
 
 
 def test_inside_verdict_stress(hc):
