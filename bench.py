@@ -34,6 +34,7 @@ import time
 # OPT-IN, before the HIP runtime initialises (torch.cuda below): one hardware queue per stream of the TSDF pipeline (what
 # er_request_hw_queues / elasticreconstruction_amd.request_hw_queues do; include/er_hip.h).  Never overrides the user's value.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("ER_ORACLE_QUIET", "1")          # the reference's own code logs through printf / cout: stdout carries ONE JSON line
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -259,9 +260,9 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     dth = time.perf_counter() - t0
     res["ransac_fitness"] = {"hypotheses_per_s": H.shape[0] / dth, "hypotheses": int(H.shape[0]), "source_points": 5000,
                              "target_points": len(clouds[0][0]), "what": "er_ransac_fitness_batch = RansacCurvature::getFitness per hypothesis"}
-    # ---- a HARD pair list: the same fragments, guesses up to 8 deg / 8 cm off -> >= 10 ICP iterations on average,
+    # ---- a HARD pair list: the same fragments, guesses up to 6 deg / 6 cm off (three times the configs[2] perturbation),
     # so the 20-iteration budget, the transform criterion and the iteration limit are all on the timed path ----
-    hard = [(a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(1700 + k, 8.0, 0.08)) for k, (a, b, _) in enumerate(pairs)]
+    hard = [(a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(1700 + k, 6.0, 0.06)) for k, (a, b, _) in enumerate(pairs)]
     run_list(hard)
     hd = []
     for _ in range(3):
@@ -270,7 +271,7 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
         hd.append(time.perf_counter() - t0)
     gt_err = max(float(np.abs(F.astype(np.float64) - np.linalg.inv(clouds[a][1]) @ clouds[b][1]).max()) for F, (a, b, _) in zip(h_fins, hard))
     res["hard_set"] = {"pairs_per_s": n_pairs / float(np.median(hd)), "mean_icp_iterations": float(np.mean(h_iters)), "max_icp_iterations": int(np.max(h_iters)),
-                       "guess": "ground truth o perturbation of <= 8 deg / 8 cm", "max_abs_T_error_vs_ground_truth": gt_err,
+                       "guess": "ground truth o perturbation of <= 6 deg / 6 cm", "max_abs_T_error_vs_ground_truth": gt_err,
                        "nn_queries_per_s": npts * (int(np.sum(h_iters)) + 2 * n_pairs) / float(np.median(hd))}
     if not with_cpu:
         return res

@@ -11,14 +11,16 @@
 //   cell_start   int[cells+1]   uniform grid, cell edge >= the largest search radius, so an exact
 //                               nearest neighbour inside the radius lies in the 3x3x3 neighbourhood;
 //                               cell id = (z*ny + y)*nx + x, so each (z,y) row is ONE contiguous range
-// plus per-pair workspaces (stream, X, match, nd, pair list, sums, pinned result block) borrowed from a per-device
-// pool, so clouds are immutable and any number of pairs can be in flight.
+// plus GROUP workspaces (streams, per-pair descriptors and ICP states, scratch slabs cut into one slice per pair) borrowed from a
+// per-device pool, so clouds are immutable and any number of pair lists can be in flight.
 // Queries run in the SOURCE cloud's own cell-sorted order (thread t takes sorted[t]), so the lanes of a wave
 // walk the same few target cells together (coalesced / broadcast candidate loads); results are written back
-// by original index.  The NN search is block-cooperative (see nn_block); candidates stream from L2 as 16-byte loads:
+// by original index.  The NN search is block-cooperative (see nn_block); candidates stream from L2 as 16-byte loads.
+// Every stage processes a whole GROUP of pairs per launch (blockIdx.y = pair, round 3; "pair groups" below):
 //   k_count_inliers   transform (float64 -> float32) + NN + count           (Registration pre-check)
-//   k_icp_iter        one ICP iteration: [apply last increment] + NN + point-to-plane rows -> 27+2 float64 sums
-//                     (wave shuffle -> LDS -> per-workgroup partial -> fixed-order final sum by the last workgroup)
+//   k_icp_iter        one ICP iteration: [apply guess / last increment] + NN + point-to-plane rows -> 27+2 float64 sums
+//                     (4 points per thread -> wave shuffle -> LDS -> per-workgroup partial)
+//   k_icp_final       one workgroup per pair: fixed-order total, 6x6 solve, increment, PCL's stop rule -- the loop stays on the device
 //   k_find_corr       transform points+normals + NN + distance/normal tests -> match[orig index];
 //                     k_count_blocks (+ information-matrix sums) + k_scan_blocks + k_compact = stable compaction in file order
 // Reductions and scans, not contractions: no MFMA.
@@ -189,33 +191,6 @@ __device__ __forceinline__ void xform_d(const Mat12d& T, float x, float y, float
   oz = (float)(((T.m[8] * dx + T.m[9] * dy) + T.m[10] * dz) + T.m[11]);
 }
 
-// Registration pre-check, CorresApp.cpp:257-264.  A fixed grid strides over the points and issues ONE atomic per
-// workgroup (one per wave serialised thousands of atomics on one word).
-__global__ __launch_bounds__(kBlock) void k_count_inliers(const float4* __restrict__ src_sorted, int n, Mat12d T, Grid g, float radius,
-                                                          double maxd2, int* __restrict__ count) {
-  __shared__ NnShared sh;
-  int local = 0;
-  for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
-    const int k = base + (int)threadIdx.x;
-    float qx = 0.f, qy = 0.f, qz = 0.f, d;
-    if (k < n) {
-      const float4 s = src_sorted[k];
-      xform_d(T, s.x, s.y, s.z, qx, qy, qz);
-    }
-    const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
-    if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
-  }
-  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
-  __shared__ int part[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kBlock / 64; w++) s += part[w];
-    if (s) atomicAdd(count, s);
-  }
-}
-
 // RansacCurvature::getFitness (GlobalRegistration/RansacCurvature.h:661-704) for MANY pose hypotheses of one
 // (source, target) pair: blockIdx.y = hypothesis, blockIdx.x strides over the source points.  Float32 transform
 // ([PCL] transformPointCloud with a Matrix4f), exact NN, inlier iff d < threshold^2 (float compare, :670,:687);
@@ -270,81 +245,42 @@ __global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restr
   }
 }
 
-// The accepted hypothesis once more, this time keeping the lists (RansacCurvature.h:661-704: `inliers`, `inliers_target`):
-// match[original source index] = NN index if d < threshold^2, else -1; acc[20] += d over the inliers.
-__global__ __launch_bounds__(kBlock) void k_ransac_match(const float4* __restrict__ src_sorted, int n, Mat12f M, Grid g, float radius,
-                                                         float max_range, int* __restrict__ match, double* __restrict__ acc) {
-  __shared__ NnShared sh;
-  const int q = blockIdx.x * kBlock + threadIdx.x;
-  float qx = 0.f, qy = 0.f, qz = 0.f, d;
-  int k = 0;
-  if (q < n) {
-    const float4 s = src_sorted[q];
-    k = __float_as_int(s.w);
-    qx = ((M.m[0] * s.x + M.m[1] * s.y) + M.m[2] * s.z) + M.m[3];
-    qy = ((M.m[4] * s.x + M.m[5] * s.y) + M.m[6] * s.z) + M.m[7];
-    qz = ((M.m[8] * s.x + M.m[9] * s.y) + M.m[10] * s.z) + M.m[11];
-  }
-  const int i = nn_block(sh, g, q < n, qx, qy, qz, radius * radius, d);
-  const bool hit = q < n && i >= 0 && d < max_range;
-  if (q < n) match[k] = hit ? i : -1;
-  double v[1] = {hit ? (double)d : 0.0};
-  __syncthreads();
-  block_reduce_atomic<1>(v, acc + 20);
-}
-
-// getInformation's target half (RansacCurvature.h:723-731): the ten distinct terms of sum A^T A (see k_count_blocks) over the
-// matched TARGET points.
-__global__ __launch_bounds__(kBlock) void k_info_matched(const int* __restrict__ match, const float* __restrict__ tgt_xyz, int n,
-                                                         double* __restrict__ info) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  double v[10];
-#pragma unroll
-  for (int i = 0; i < 10; i++) v[i] = 0.0;
-  const int m = k < n ? match[k] : -1;
-  if (m >= 0) {
-    const float tx = tgt_xyz[3 * m], ty = tgt_xyz[3 * m + 1], tz = tgt_xyz[3 * m + 2];
-    const double ax = (double)(2 * tx), ay = (double)(2 * ty), az = (double)(2 * tz);
-    v[0] = ax; v[1] = ay; v[2] = az;
-    v[3] = az * az + ay * ay;
-    v[4] = az * az + ax * ax;
-    v[5] = ay * ay + ax * ax;
-    v[6] = ay * (-ax);
-    v[7] = (-az) * ax;
-    v[8] = az * (-ay);
-    v[9] = 1.0;
-  }
-  block_reduce_atomic<10>(v, info);
-}
-
-// guess * source in float32 (IterativeClosestPoint::transformCloud), or a plain copy for an identity guess.
-__global__ void k_init_x(const float4* __restrict__ src_sorted, float* __restrict__ X, int n, Mat12f M, int apply) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;       // k = position in the source's cell-sorted order
-  if (k >= n) return;
-  const float4 s = src_sorted[k];
-  const float x = s.x, y = s.y, z = s.z;
-  if (apply) {
-    X[3 * k] = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
-    X[3 * k + 1] = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
-    X[3 * k + 2] = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
-  } else {
-    X[3 * k] = x;
-    X[3 * k + 1] = y;
-    X[3 * k + 2] = z;
-  }
-}
+// ---- pair groups -------------------------------------------------------------------------------------------------------
+// The reference's two loops run over a LIST of fragment pairs (CorresApp.cpp:121,220: #pragma omp parallel for).  Here a whole
+// group of pairs goes through every stage in ONE launch: blockIdx.y = pair, blockIdx.x = a slice of that pair's source points.
+// A 250 k-point pair alone is ~1000 workgroups of latency-bound exact-NN work -- half of what the 256 CUs hold -- and every
+// launch, memset and small copy costs 5-20 us of an otherwise idle stream; 50 pairs per launch fill the chip and turn the
+// host side into a handful of calls per stage (round 2: ~30 launches and ~7 copies PER PAIR over four streams).
+// PairDev = what the kernels need to know about one pair of the group; read with scalar loads (blockIdx.y is wave-uniform).
+struct PairDev {
+  const float4* src_sorted;      // source, cell-sorted {x, y, z, original index}
+  const float* src_xyz;          // source, file order (information matrix, CorresApp.cpp:192-196)
+  const float* src_nrm;
+  const float* tgt_xyz;
+  const float* tgt_nrm;
+  Grid g;                        // the target's uniform grid
+  Mat12d T;                      // transform of the pre-check / FindCorrespondence (Matrix4d, rows 0..2)
+  float* X;                      // [3 n]   ICP: the source as the loop transforms it (cell-sorted order)
+  int* match;                    // [n]     FindCorrespondence: NN index or -1, file order
+  int* block_count;              // [nb]
+  int* block_offset;             // [nb]
+  int* pairs;                    // [2 n]   compacted (target index, source index) list
+  double* partial;               // [nbi][32] per-workgroup sums of one ICP iteration
+  int n, nb, nbi, pad;           // source points, ceil(n / 256), ceil(n / (256 kIcpPts))
+};
 
 // ---- the ICP loop's state lives on the device ------------------------------------------------------------------------
 // pcl::IterativeClosestPoint::align's loop variables (final_transformation_, the last increment, the previous MSE, the
-// iteration counter and the convergence flags).  k_icp_final updates them from the iteration's sums -- 6x6 solve, increment,
-// PCL's stop rule -- and k_icp_iter reads the increment (and the `done` flag) from here, so a whole chunk of iterations is
-// enqueued without a host round trip; launches that find `done` set return at once.
+// iteration counter and the convergence flags), one per pair of the group.  k_icp_final updates them from the iteration's sums
+// -- 6x6 solve, increment, PCL's stop rule -- and k_icp_iter reads the increment (and the `done` flag) from here, so a whole
+// chunk of iterations is enqueued without a host round trip; workgroups that find `done` set return at once.
 struct IcpDev {
-  float fin[16];           // final_transformation_
+  float fin[16];           // final_transformation_ (= the guess before the first iteration)
   float delta[16];         // last increment (identity before the first solve)
   float prev_delta[16];
   double prev_mse;
   int iter, done, conv, apply;   // apply: the next k_icp_iter multiplies X by delta first
+  int init_apply, pad[3];        // iteration 0 reads the source itself and applies the guess unless it is the identity
 };
 
 struct IcpParams {
@@ -511,57 +447,106 @@ __device__ void dev_icp_decide(const double* acc, IcpDev* st, IcpParams P) {
   if (stop) st->done = 1;
 }
 
-// One ICP iteration in one launch:
-//   X <- delta * X (the previous iteration's increment, float32); correspondence estimation (exact NN, kept if
-//   d^2 <= max_dist^2); the sums of TransformationEstimationPointToPlaneLLS over the kept correspondences:
-//   acc[0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
-// Reduction: thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in `partial`; k_icp_final adds
-// the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from run to run (they
-// still differ from a sequential CPU sum in the last bits).
-__global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int n, const IcpDev* __restrict__ st, Grid g, float radius,
-                                                     double maxd2, const float* __restrict__ tgt_xyz, const float* __restrict__ tgt_nrm,
-                                                     double* __restrict__ partial) {
+
+constexpr int kIcpPts = 4;                 // source points per thread of k_icp_iter (the 29 cross-lane sums are paid once per workgroup)
+
+// Registration pre-check, CorresApp.cpp:257-264, for a group of pairs: counts[pair] = #{k : d2 < reg_dist^2}.  blockIdx.x
+// strides over the pair's points; ONE atomic per workgroup.
+__global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restrict__ P, float radius, double maxd2, int* __restrict__ counts) {
   __shared__ NnShared sh;
-  if (st->done) return;                                      // the loop has ended: this launch of the chunk is a no-op
-  const int apply = st->apply;                               // wave-uniform (scalar loads)
-  const float* __restrict__ dm = st->delta;
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  if (k < n) {
-    sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
-    if (apply) {
-      const float x = sx, y = sy, z = sz;
-      sx = ((dm[0] * x + dm[1] * y) + dm[2] * z) + dm[3];
-      sy = ((dm[4] * x + dm[5] * y) + dm[6] * z) + dm[7];
-      sz = ((dm[8] * x + dm[9] * y) + dm[10] * z) + dm[11];
-      X[3 * k] = sx;
-      X[3 * k + 1] = sy;
-      X[3 * k + 2] = sz;
+  const PairDev& p = P[blockIdx.y];
+  const int n = p.n;
+  if ((int)blockIdx.x * kBlock >= n) return;                 // (wave-uniform: whole workgroups beyond a short pair's points)
+  int local = 0;
+  for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const int k = base + (int)threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f, d;
+    if (k < n) {
+      const float4 s = p.src_sorted[k];
+      xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
     }
+    const int i = nn_block(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
-  float d;
-  const int i = nn_block(sh, g, k < n, sx, sy, sz, radius * radius, d);
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
+  __shared__ int part[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 0; w < kBlock / 64; w++) s += part[w];
+    if (s) atomicAdd(&counts[blockIdx.y], s);
+  }
+}
+
+// One ICP iteration of every ACTIVE pair of the group in one launch (blockIdx.y -> active[y] = the pair's slot):
+//   iteration 0: X <- guess * source (IterativeClosestPoint::transformCloud, float32; a plain copy for an identity guess);
+//   later:       X <- delta * X (the previous iteration's increment, float32);
+//   correspondence estimation (exact NN, kept if d^2 <= max_dist^2); the sums of TransformationEstimationPointToPlaneLLS over
+//   the kept correspondences: acc[0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
+// A thread takes kIcpPts points (slices of kBlock consecutive points: the NN search is a workgroup-cooperative step per slice)
+// and adds their rows up privately; then thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in
+// `partial`; k_icp_final adds the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from
+// run to run (they still differ from a sequential CPU sum in the last bits).
+__global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__ P, const int* __restrict__ active, const IcpDev* __restrict__ S,
+                                                     float radius, double maxd2) {
+  __shared__ NnShared sh;
+  const int slot = active[blockIdx.y];
+  const PairDev& p = P[slot];
+  const IcpDev& st = S[slot];
+  if (st.done || (int)blockIdx.x >= p.nbi) return;           // the loop has ended / a shorter pair: wave-uniform exits
+  const int n = p.n;
+  const bool first = st.iter == 0;
+  const int apply = first ? st.init_apply : st.apply;        // wave-uniform (scalar loads)
+  const float* __restrict__ dm = first ? st.fin : st.delta;
+  float* __restrict__ X = p.X;
   double v[29];
 #pragma unroll
   for (int t = 0; t < 29; t++) v[t] = 0.0;
-  if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
-    const float dx = tgt_xyz[3 * i], dy = tgt_xyz[3 * i + 1], dz = tgt_xyz[3 * i + 2];
-    const float nx = tgt_nrm[3 * i], ny = tgt_nrm[3 * i + 1], nz = tgt_nrm[3 * i + 2];
-    v[27] = (double)d;
-    v[28] = 1.0;
-    if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
-      const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
-      const double b = (double)(nx * sz - nz * sx);
-      const double c = (double)(ny * sx - nx * sy);
-      const double dnx = nx, dny = ny, dnz = nz;
-      v[0] = a * a;  v[1] = a * b;  v[2] = a * c;  v[3] = a * dnx;  v[4] = a * dny;  v[5] = a * dnz;
-      v[6] = b * b;  v[7] = b * c;  v[8] = b * dnx; v[9] = b * dny; v[10] = b * dnz;
-      v[11] = c * c; v[12] = c * dnx; v[13] = c * dny; v[14] = c * dnz;
-      v[15] = dnx * dnx; v[16] = dnx * dny; v[17] = dnx * dnz;
-      v[18] = dny * dny; v[19] = dny * dnz;
-      v[20] = dnz * dnz;
-      const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-      v[21] = a * e; v[22] = b * e; v[23] = c * e; v[24] = dnx * e; v[25] = dny * e; v[26] = dnz * e;
+  for (int c = 0; c < kIcpPts; c++) {
+    const int k = (blockIdx.x * kIcpPts + c) * kBlock + threadIdx.x;
+    if ((blockIdx.x * kIcpPts + c) * kBlock >= n) break;     // wave-uniform
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (k < n) {
+      if (first) {
+        const float4 s = p.src_sorted[k];
+        sx = s.x, sy = s.y, sz = s.z;
+      } else {
+        sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
+      }
+      if (apply) {
+        const float x = sx, y = sy, z = sz;
+        sx = ((dm[0] * x + dm[1] * y) + dm[2] * z) + dm[3];
+        sy = ((dm[4] * x + dm[5] * y) + dm[6] * z) + dm[7];
+        sz = ((dm[8] * x + dm[9] * y) + dm[10] * z) + dm[11];
+      }
+      if (apply || first) {
+        X[3 * k] = sx;
+        X[3 * k + 1] = sy;
+        X[3 * k + 2] = sz;
+      }
+    }
+    float d;
+    const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
+    if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
+      const float dx = p.tgt_xyz[3 * i], dy = p.tgt_xyz[3 * i + 1], dz = p.tgt_xyz[3 * i + 2];
+      const float nx = p.tgt_nrm[3 * i], ny = p.tgt_nrm[3 * i + 1], nz = p.tgt_nrm[3 * i + 2];
+      v[27] += (double)d;
+      v[28] += 1.0;
+      if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
+        const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
+        const double b = (double)(nx * sz - nz * sx);
+        const double cc = (double)(ny * sx - nx * sy);
+        const double dnx = nx, dny = ny, dnz = nz;
+        v[0] += a * a;  v[1] += a * b;  v[2] += a * cc;  v[3] += a * dnx;  v[4] += a * dny;  v[5] += a * dnz;
+        v[6] += b * b;  v[7] += b * cc;  v[8] += b * dnx; v[9] += b * dny; v[10] += b * dnz;
+        v[11] += cc * cc; v[12] += cc * dnx; v[13] += cc * dny; v[14] += cc * dnz;
+        v[15] += dnx * dnx; v[16] += dnx * dny; v[17] += dnx * dnz;
+        v[18] += dny * dny; v[19] += dny * dnz;
+        v[20] += dnz * dnz;
+        const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
+        v[21] += a * e; v[22] += b * e; v[23] += cc * e; v[24] += dnx * e; v[25] += dny * e; v[26] += dnz * e;
+      }
     }
   }
   // workgroup partial
@@ -578,17 +563,20 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(float* __restrict__ X, int 
     double q = 0.0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; w++) q += part[w][threadIdx.x];
-    partial[(size_t)blockIdx.x * 32 + threadIdx.x] = q;
+    p.partial[(size_t)blockIdx.x * 32 + threadIdx.x] = q;
   }
 }
 
-// Second half of the reduction: ONE workgroup adds the per-workgroup partial vectors in a fixed order (8 strided
-// slices per value, then the slices in order) -> acc[0..28].  A separate launch on purpose: finishing inside
-// k_icp_iter ("last workgroup done" ticket + __threadfence) costs an L2 write-back per workgroup on this
-// multi-XCD part (measured: 100-600 us per launch instead of ~25).
-__global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__ partial, int nparts, double* __restrict__ acc,
-                                                      IcpDev* __restrict__ st, IcpParams P) {
+// Second half of the reduction, one workgroup PER ACTIVE PAIR: adds the pair's per-workgroup partial vectors in a fixed order
+// (8 strided slices per value, then the slices in order) and decides -- 6x6 solve, increment, stop rule: the loop never leaves
+// the device.  A separate launch on purpose: finishing inside k_icp_iter ("last workgroup done" ticket + __threadfence) costs
+// an L2 write-back per workgroup on this multi-XCD part (measured in round 1: 100-600 us per launch instead of ~25).
+__global__ __launch_bounds__(kBlock) void k_icp_final(const PairDev* __restrict__ P, const int* __restrict__ active, IcpDev* __restrict__ S, IcpParams prm) {
+  const int slot = active[blockIdx.x];
+  IcpDev* st = S + slot;
   if (st->done) return;
+  const double* __restrict__ partial = P[slot].partial;
+  const int nparts = P[slot].nbi;
   const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;   // 32 x 8
   double q = 0.0;
   if (val < 29) {
@@ -603,78 +591,105 @@ __global__ __launch_bounds__(kBlock) void k_icp_final(const double* __restrict__
     double r = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 8; sl++) r += fin[sl][threadIdx.x];
-    acc[threadIdx.x] = r;
     tot[threadIdx.x] = r;
   }
   __syncthreads();
-  if (threadIdx.x == 0) dev_icp_decide(tot, st, P);          // solve, increment, stop rule: the loop never leaves the device
+  if (threadIdx.x == 0) dev_icp_decide(tot, st, prm);
 }
 
-// getFitnessScore-style diagnostic: squared NN distance of final * source inside the search radius (-1 = none).
-__global__ __launch_bounds__(kBlock) void k_fitness_nn(const float4* __restrict__ src_sorted, int n, Mat12f M, Grid g, float radius,
-                                                       float* __restrict__ nd) {
+// getFitnessScore-style diagnostic (logging only, CorresApp.cpp:307): per pair the sum and the number of the squared NN
+// distances of final * source inside the search radius -> fit[2 pair], fit[2 pair + 1].
+__global__ __launch_bounds__(kBlock) void k_fitness(const PairDev* __restrict__ P, const IcpDev* __restrict__ S, float radius, double* __restrict__ fit) {
   __shared__ NnShared sh;
-  const int k = blockIdx.x * kBlock + threadIdx.x;
-  float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (k < n) {
-    const float4 s = src_sorted[k];
-    const float x = s.x, y = s.y, z = s.z;
-    qx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
-    qy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
-    qz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
-  }
-  float d;
-  const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
-  if (k < n) nd[k] = (i >= 0 && (double)d <= (double)radius * (double)radius) ? d : -1.0f;
-}
-
-__global__ __launch_bounds__(kBlock) void k_fitness_sum(const float* __restrict__ nd, int n, double* __restrict__ acc) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const PairDev& p = P[blockIdx.y];
+  const int n = p.n;
+  if ((int)blockIdx.x * kBlock >= n) return;
+  const float* __restrict__ M = S[blockIdx.y].fin;
   double v[2] = {0.0, 0.0};
-  if (k < n && nd[k] >= 0.0f) {
-    v[0] = (double)nd[k];
-    v[1] = 1.0;
+  for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
+    const int k = base + (int)threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f, d;
+    if (k < n) {
+      const float4 s = p.src_sorted[k];
+      qx = ((M[0] * s.x + M[1] * s.y) + M[2] * s.z) + M[3];
+      qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
+      qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
+    }
+    const int i = nn_block(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius) {
+      v[0] += (double)d;
+      v[1] += 1.0;
+    }
   }
-  block_reduce_atomic<2>(v, acc);
+  __syncthreads();
+  block_reduce_atomic<2>(v, fit + 2 * (size_t)blockIdx.y);
 }
 
-// FindCorrespondence, CorresApp.cpp:144-161: match[original index] = NN index
-// passing the distance and normal tests, else -1.
-__global__ __launch_bounds__(kBlock) void k_find_corr(const float4* __restrict__ src_sorted, const float* __restrict__ nrm, int n,
-                                                      Mat12d T, Grid g, const float* __restrict__ tgt_nrm, float radius,
-                                                      double dist2, double normal_cos, int* __restrict__ match) {
+// FindCorrespondence, CorresApp.cpp:144-161: match[original index] = NN index passing the distance and normal tests, else -1.
+__global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict__ P, float radius, double dist2, double normal_cos) {
   __shared__ NnShared sh;
+  const PairDev& p = P[blockIdx.y];
+  const int n = p.n;
+  if ((int)blockIdx.x >= p.nb) return;
   const int q = blockIdx.x * kBlock + threadIdx.x;             // q = position in the source's cell-sorted order
   float qx = 0.f, qy = 0.f, qz = 0.f, d;
   int k = 0;
   if (q < n) {
-    const float4 s = src_sorted[q];
+    const float4 s = p.src_sorted[q];
     k = __float_as_int(s.w);                                   // original (file-order) index of this source point
-    xform_d(T, s.x, s.y, s.z, qx, qy, qz);
+    xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
   }
-  const int i = nn_block(sh, g, q < n, qx, qy, qz, radius * radius, d);
+  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
   if (q >= n) return;
   int m = -1;
   if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {         // :154
-    const double nx = nrm[3 * k], ny = nrm[3 * k + 1], nz = nrm[3 * k + 2];
-    const float tnx = (float)((T.m[0] * nx + T.m[1] * ny) + T.m[2] * nz);                     // n' = R n (double -> float)
-    const float tny = (float)((T.m[4] * nx + T.m[5] * ny) + T.m[6] * nz);
-    const float tnz = (float)((T.m[8] * nx + T.m[9] * ny) + T.m[10] * nz);
+    const double nx = p.src_nrm[3 * k], ny = p.src_nrm[3 * k + 1], nz = p.src_nrm[3 * k + 2];
+    const float tnx = (float)((p.T.m[0] * nx + p.T.m[1] * ny) + p.T.m[2] * nz);              // n' = R n (double -> float)
+    const float tny = (float)((p.T.m[4] * nx + p.T.m[5] * ny) + p.T.m[6] * nz);
+    const float tnz = (float)((p.T.m[8] * nx + p.T.m[9] * ny) + p.T.m[10] * nz);
     // NormalDot, CorresApp.h:58-60: float32 products/sums, compared as double
-    const float dot = (tgt_nrm[3 * i] * tnx + tgt_nrm[3 * i + 1] * tny) + tgt_nrm[3 * i + 2] * tnz;
+    const float dot = (p.tgt_nrm[3 * i] * tnx + p.tgt_nrm[3 * i + 1] * tny) + p.tgt_nrm[3 * i + 2] * tnz;
     if ((double)dot > normal_cos) m = i;                                                       // :155
   }
-  match[k] = m;
+  p.match[k] = m;
+}
+
+// The accepted RANSAC hypothesis once more, this time keeping the lists (RansacCurvature.h:661-704: `inliers`, `inliers_target`):
+// match[original source index] = NN index if d < threshold^2, else -1; acc[20] += d over the inliers.  (One pair: P[0].)
+__global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restrict__ P, Mat12f M, float radius, float max_range, double* __restrict__ acc) {
+  __shared__ NnShared sh;
+  const PairDev& p = P[0];
+  const int n = p.n;
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  float qx = 0.f, qy = 0.f, qz = 0.f, d;
+  int k = 0;
+  if (q < n) {
+    const float4 s = p.src_sorted[q];
+    k = __float_as_int(s.w);
+    qx = ((M.m[0] * s.x + M.m[1] * s.y) + M.m[2] * s.z) + M.m[3];
+    qy = ((M.m[4] * s.x + M.m[5] * s.y) + M.m[6] * s.z) + M.m[7];
+    qz = ((M.m[8] * s.x + M.m[9] * s.y) + M.m[10] * s.z) + M.m[11];
+  }
+  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
+  const bool hit = q < n && i >= 0 && d < max_range;
+  if (q < n) p.match[k] = hit ? i : -1;
+  double v[1] = {hit ? (double)d : 0.0};
+  __syncthreads();
+  block_reduce_atomic<1>(v, acc + 20);
 }
 
 // Matches per block of 256 consecutive ORIGINAL indices (the order of the output list) and, optionally, the
-// information matrix of CorresApp.cpp:186-208 over the matched, UNtransformed source points:
-// info[0..2] = sum 2sx,2sy,2sz; [3..5] = sum (4sz^2+4sy^2),(4sz^2+4sx^2),(4sy^2+4sx^2);
-// [6..8] = sum -4sysx, -4szsx, -4szsy; [9] = count   (the distinct terms of sum A^T A, A = [I | 2*skew-like(s)])
-__global__ __launch_bounds__(kBlock) void k_count_blocks(const int* __restrict__ match, const float* __restrict__ xyz, int n,
-                                                         int* __restrict__ block_count, double* __restrict__ info, int want_info) {
+// information matrix of CorresApp.cpp:186-208 over the matched, UNtransformed source points (target points: RansacCurvature.h
+// :723-731 with which = 1):  info[0..2] = sum 2sx,2sy,2sz; [3..5] = sum (4sz^2+4sy^2),(4sz^2+4sx^2),(4sy^2+4sx^2);
+// [6..8] = sum -4sysx, -4szsx, -4szsy; [9] = count   (the distinct terms of sum A^T A, A = [I | 2*skew-like(s)]); info is
+// kAcc doubles per pair (source terms at 0, target terms at 10).
+__global__ __launch_bounds__(kBlock) void k_count_blocks(const PairDev* __restrict__ P, double* __restrict__ info, int want_source, int want_target) {
+  const PairDev& p = P[blockIdx.y];
+  const int n = p.n;
+  if ((int)blockIdx.x >= p.nb) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool hit = k < n && match[k] >= 0;
+  const int m = k < n ? p.match[k] : -1;
+  const bool hit = m >= 0;
   const unsigned long long b = __ballot(hit);
   __shared__ int wcnt[kBlock / 64];
   if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(b);
@@ -682,14 +697,16 @@ __global__ __launch_bounds__(kBlock) void k_count_blocks(const int* __restrict__
   if (threadIdx.x == 0) {
     int s = 0;
     for (int w = 0; w < kBlock / 64; w++) s += wcnt[w];
-    block_count[blockIdx.x] = s;
+    p.block_count[blockIdx.x] = s;
   }
-  if (want_info) {
+  for (int which = 0; which < 2; which++) {
+    if (!(which ? want_target : want_source)) continue;        // uniform
     double v[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) v[i] = 0.0;
     if (hit) {                                                                                 // :192-204
-      const float sx = xyz[3 * k], sy = xyz[3 * k + 1], sz = xyz[3 * k + 2];
+      const float* __restrict__ s = which ? p.tgt_xyz + 3 * (size_t)m : p.src_xyz + 3 * (size_t)k;
+      const float sx = s[0], sy = s[1], sz = s[2];
       const double ax = (double)(2 * sx), ay = (double)(2 * sy), az = (double)(2 * sz);
       v[0] = ax; v[1] = ay; v[2] = az;
       v[3] = az * az + ay * ay;     // (0*0 + (-2sz)(-2sz)) + (2sy)(2sy)
@@ -701,20 +718,21 @@ __global__ __launch_bounds__(kBlock) void k_count_blocks(const int* __restrict__
       v[9] = 1.0;
     }
     __syncthreads();
-    block_reduce_atomic<10>(v, info);
+    block_reduce_atomic<10>(v, info + (size_t)blockIdx.y * kAcc + 10 * which);
   }
 }
 
-// Exclusive scan of the per-block match counts (a few thousand blocks at most): one workgroup.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const int* __restrict__ block_count, int* __restrict__ block_offset, int nb,
-                                                       int* __restrict__ total) {
+// Exclusive scan of a pair's per-block match counts (a few thousand blocks at most): one workgroup per pair.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const PairDev* __restrict__ P, int* __restrict__ totals) {
   __shared__ int buf[1024];
   __shared__ int carry;
+  const PairDev& p = P[blockIdx.x];
+  const int nb = p.nb;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < nb; base += 1024) {
     const int i = base + (int)threadIdx.x;
-    const int v = i < nb ? block_count[i] : 0;
+    const int v = i < nb ? p.block_count[i] : 0;
     buf[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -723,31 +741,31 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const int* __restrict__ bl
       buf[threadIdx.x] += t;
       __syncthreads();
     }
-    if (i < nb) block_offset[i] = carry + buf[threadIdx.x] - v;
+    if (i < nb) p.block_offset[i] = carry + buf[threadIdx.x] - v;
     __syncthreads();
     if (threadIdx.x == 1023) carry += buf[1023];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 // Stable compaction: pairs (match[k], k) in ascending k (CorresApp.cpp:157, file order of corres_*.txt).
-__global__ __launch_bounds__(kBlock) void k_compact(const int* __restrict__ match, int n, const int* __restrict__ block_offset,
-                                                    int* __restrict__ pairs, int capacity) {
+__global__ __launch_bounds__(kBlock) void k_compact(const PairDev* __restrict__ P) {
+  const PairDev& p = P[blockIdx.y];
+  const int n = p.n;
+  if ((int)blockIdx.x >= p.nb) return;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = k < n ? match[k] : -1;
+  const int m = k < n ? p.match[k] : -1;
   const unsigned long long b = __ballot(m >= 0);
   __shared__ int wcnt[kBlock / 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) wcnt[wave] = __popcll(b);
   __syncthreads();
   if (m >= 0) {
-    int o = block_offset[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+    int o = p.block_offset[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; w++) o += wcnt[w];
-    if (o < capacity) {
-      pairs[2 * o] = m;
-      pairs[2 * o + 1] = k;
-    }
+    p.pairs[2 * o] = m;                                        // (o < n: every match has its own k)
+    p.pairs[2 * o + 1] = k;
   }
 }
 
@@ -871,93 +889,136 @@ struct er_cloud_s {
 namespace {
 Grid grid_of(const er_cloud_s* c) { return c->grid; }
 
-// ---- workspaces --------------------------------------------------------------------------------
-// Everything a pair needs while it is being processed (clouds are immutable and shared): one HIP stream, the
-// per-source-point scratch and a small pinned block the kernels' results are copied into.  Workspaces live in
-// a per-device pool: a single-pair call borrows one, a *_batch call borrows several and software-pipelines
-// its pairs over them so that one pair's host round trip (6x6 solve, convergence test) overlaps the kernels
-// of the others.  The pool is never freed behind the HIP runtime's back (er_icp_release_workspaces does it).
-struct HostBlock {
-  double acc[kAcc];
-  int count[4];
-  IcpDev state;                 // the ICP loop's state: uploaded at the start of a job, read back after every chunk of iterations
-};
-
-struct IcpWs {
+// ---- group workspaces ----------------------------------------------------------------------------
+// Everything a GROUP of pairs needs while it is being processed (clouds are immutable and shared): one compute stream and one
+// copy stream, the per-pair descriptors and ICP states (device + pinned host mirrors), small per-pair result arrays, and slabs of
+// per-source-point scratch cut into one slice per pair.  Groups live in a per-device pool: an API call borrows one (calls from
+// several host threads -- the reference's "#pragma omp parallel for" -- borrow one each and overlap on the GPU) and returns it.
+// The pool is never freed behind the HIP runtime's back (er_icp_release_workspaces does it).
+struct Group {
   int device = 0;
-  size_t cap = 0;               // points
-  hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;
-  float *X = nullptr, *nd = nullptr;
-  int *match = nullptr, *block_count = nullptr, *block_offset = nullptr, *pairs = nullptr, *icount = nullptr;
-  double* acc = nullptr;
-  IcpDev* dstate = nullptr;     // the ICP loop's state on the device
-  double* partial = nullptr;    // one 32-double vector per workgroup of k_icp_iter
-  HostBlock* host = nullptr;    // pinned
-  int* stage = nullptr;         // pinned, cap * 2 ints: pair lists on their way to pageable caller memory (lazy)
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev = nullptr, ev2 = nullptr;
+  std::vector<hipEvent_t> sub_ev;  // one per sub-group of er_find_correspondence_batch (grown on demand)
+  int cap_pairs = 0;
+  size_t cap_points = 0, cap_blocks = 0, cap_parts = 0;
+  // device
+  PairDev* d_pairs = nullptr;
+  IcpDev* d_state = nullptr;
+  int *d_active = nullptr, *d_counts = nullptr, *d_totals = nullptr;
+  double *d_info = nullptr, *d_fit = nullptr;      // kAcc per pair; 2 per pair
+  float* X = nullptr;
+  int *match = nullptr, *pairs = nullptr, *block_count = nullptr, *block_offset = nullptr;
+  double* partial = nullptr;
+  // pinned host mirrors
+  PairDev* h_pairs = nullptr;
+  IcpDev* h_state = nullptr;
+  int *h_active = nullptr, *h_counts = nullptr, *h_totals = nullptr;
+  double *h_info = nullptr, *h_fit = nullptr;
+  int* stage = nullptr;         // pinned: pair lists on their way to pageable caller memory (lazy)
   size_t stage_cap = 0;
 };
 
-void ws_free_buffers(IcpWs* w) {
-  void* ptrs[] = {w->X, w->nd, w->match, w->block_count, w->block_offset, w->pairs, w->partial};
+void group_free_slabs(Group* g) {
+  void* ptrs[] = {g->X, g->match, g->pairs, g->block_count, g->block_offset, g->partial};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  w->partial = nullptr;
-  w->X = w->nd = nullptr;
-  w->match = w->block_count = w->block_offset = w->pairs = nullptr;
-  w->cap = 0;
+  g->X = nullptr;
+  g->match = g->pairs = g->block_count = g->block_offset = nullptr;
+  g->partial = nullptr;
+  g->cap_points = g->cap_blocks = g->cap_parts = 0;
 }
 
-void ws_destroy(IcpWs* w) {
-  if (!w) return;
-  (void)hipSetDevice(w->device);
-  if (w->stream) (void)hipStreamSynchronize(w->stream);
-  ws_free_buffers(w);
-  if (w->icount) (void)hipFree(w->icount);
-  if (w->acc) (void)hipFree(w->acc);
-  if (w->dstate) (void)hipFree(w->dstate);
-  if (w->host) (void)hipHostFree(w->host);
-  if (w->stage) (void)hipHostFree(w->stage);
-  if (w->ev) (void)hipEventDestroy(w->ev);
-  if (w->stream) (void)hipStreamDestroy(w->stream);
-  delete w;
+void group_free_pairs(Group* g) {
+  void* dev[] = {g->d_pairs, g->d_state, g->d_active, g->d_counts, g->d_totals, g->d_info, g->d_fit};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  void* host[] = {g->h_pairs, g->h_state, g->h_active, g->h_counts, g->h_totals, g->h_info, g->h_fit};
+  for (void* p : host)
+    if (p) (void)hipHostFree(p);
+  g->d_pairs = nullptr; g->d_state = nullptr; g->d_active = g->d_counts = g->d_totals = nullptr; g->d_info = g->d_fit = nullptr;
+  g->h_pairs = nullptr; g->h_state = nullptr; g->h_active = g->h_counts = g->h_totals = nullptr; g->h_info = g->h_fit = nullptr;
+  g->cap_pairs = 0;
 }
 
-int ws_reserve(IcpWs* w, size_t n) {
-  n = std::max<size_t>(n, 1);
-  if (n <= w->cap) return 0;
-  ER_HIP_TRY(hipStreamSynchronize(w->stream));
-  ws_free_buffers(w);
-  const size_t cap = n + n / 8;
-  const size_t nb = (cap + kBlock - 1) / kBlock;
-  ER_HIP_TRY(hipMalloc((void**)&w->X, cap * 3 * sizeof(float)));
-  ER_HIP_TRY(hipMalloc((void**)&w->nd, cap * sizeof(float)));
-  ER_HIP_TRY(hipMalloc((void**)&w->match, cap * sizeof(int)));
-  ER_HIP_TRY(hipMalloc((void**)&w->pairs, cap * 2 * sizeof(int)));
-  ER_HIP_TRY(hipMalloc((void**)&w->block_count, nb * sizeof(int)));
-  ER_HIP_TRY(hipMalloc((void**)&w->block_offset, nb * sizeof(int)));
-  ER_HIP_TRY(hipMalloc((void**)&w->partial, nb * 32 * sizeof(double)));
-  w->cap = cap;
+void group_destroy(Group* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+  group_free_slabs(g);
+  group_free_pairs(g);
+  if (g->stage) (void)hipHostFree(g->stage);
+  if (g->ev) (void)hipEventDestroy(g->ev);
+  if (g->ev2) (void)hipEventDestroy(g->ev2);
+  for (hipEvent_t e : g->sub_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  delete g;
+}
+
+int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
+int nparts_of(int n) { return (std::max(n, 1) + kBlock * kIcpPts - 1) / (kBlock * kIcpPts); }
+
+// Room for `pairs` descriptors and, when per-point scratch is needed, for `points` source points in `blocks` / `parts` blocks.
+int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t parts) {
+  if (pairs > g->cap_pairs) {
+    ER_HIP_TRY(hipStreamSynchronize(g->stream));
+    group_free_pairs(g);
+    const size_t c = (size_t)std::max(pairs, 16);
+    ER_HIP_TRY(hipMalloc((void**)&g->d_pairs, c * sizeof(PairDev)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_state, c * sizeof(IcpDev)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_active, c * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_counts, c * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_totals, c * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_info, c * kAcc * sizeof(double)));
+    ER_HIP_TRY(hipMalloc((void**)&g->d_fit, c * 2 * sizeof(double)));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_pairs, c * sizeof(PairDev), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_state, c * sizeof(IcpDev), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_active, c * sizeof(int), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_counts, c * sizeof(int), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_totals, c * sizeof(int), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_info, c * kAcc * sizeof(double), hipHostMallocDefault));
+    ER_HIP_TRY(hipHostMalloc((void**)&g->h_fit, c * 2 * sizeof(double), hipHostMallocDefault));
+    g->cap_pairs = (int)c;
+  }
+  if (points > g->cap_points || blocks > g->cap_blocks || parts > g->cap_parts) {
+    ER_HIP_TRY(hipStreamSynchronize(g->stream));
+    if (g->copy_stream) ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+    const size_t cp = std::max(points + points / 8, g->cap_points), cb = std::max(blocks + blocks / 8, g->cap_blocks),
+                 cq = std::max(parts + parts / 8, g->cap_parts);
+    group_free_slabs(g);
+    ER_HIP_TRY(hipMalloc((void**)&g->X, std::max<size_t>(cp, 1) * 3 * sizeof(float)));
+    ER_HIP_TRY(hipMalloc((void**)&g->match, std::max<size_t>(cp, 1) * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->pairs, std::max<size_t>(cp, 1) * 2 * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->block_count, std::max<size_t>(cb, 1) * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->block_offset, std::max<size_t>(cb, 1) * sizeof(int)));
+    ER_HIP_TRY(hipMalloc((void**)&g->partial, std::max<size_t>(cq, 1) * 32 * sizeof(double)));
+    g->cap_points = cp;
+    g->cap_blocks = cb;
+    g->cap_parts = cq;
+  }
   return 0;
 }
 
-struct WsPool {
+struct GroupPool {
   std::mutex mu;
-  std::vector<IcpWs*> idle;
+  std::vector<Group*> idle;
 };
-WsPool& pool() {
-  static WsPool* p = new WsPool();      // intentionally leaked: must outlive every static destructor
+GroupPool& pool() {
+  static GroupPool* p = new GroupPool();      // intentionally leaked: must outlive every static destructor
   return *p;
 }
 
-IcpWs* ws_acquire(int device, size_t n) {
-  IcpWs* w = nullptr;
+Group* group_acquire(int device) {
+  Group* g = nullptr;
   {
     std::lock_guard<std::mutex> lock(pool().mu);
     auto& v = pool().idle;
     for (size_t i = 0; i < v.size(); i++)
       if (v[i]->device == device) {
-        w = v[i];
+        g = v[i];
         v.erase(v.begin() + (long)i);
         break;
       }
@@ -966,55 +1027,38 @@ IcpWs* ws_acquire(int device, size_t n) {
     er::fail("hipSetDevice(%d) failed", device);
     return nullptr;
   }
-  if (!w) {
-    w = new IcpWs();
-    w->device = device;
-    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&w->ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void**)&w->icount, 4 * sizeof(int)) != hipSuccess || hipMalloc((void**)&w->acc, kAcc * sizeof(double)) != hipSuccess ||
-        hipMalloc((void**)&w->dstate, sizeof(IcpDev)) != hipSuccess ||
-        hipHostMalloc((void**)&w->host, sizeof(HostBlock), hipHostMallocDefault) != hipSuccess) {
+  if (!g) {
+    g = new Group();
+    g->device = device;
+    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev2, hipEventDisableTiming) != hipSuccess) {
       er::fail("ICP workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
-      ws_destroy(w);
+      group_destroy(g);
       return nullptr;
     }
   }
-  if (ws_reserve(w, n)) {
-    ws_destroy(w);
-    return nullptr;
-  }
-  return w;
+  return g;
 }
 
-void ws_release(IcpWs* w) {
-  if (!w) return;
-  std::lock_guard<std::mutex> lock(pool().mu);
-  pool().idle.push_back(w);
-}
-
-struct WsSet {                  // RAII: the workspaces of one API call
-  std::vector<IcpWs*> ws;
-  ~WsSet() {
-    for (IcpWs* w : ws) {
-      if (w->stream) (void)hipStreamSynchronize(w->stream);
-      ws_release(w);
-    }
+struct GroupLease {             // RAII: the group of one API call
+  Group* g = nullptr;
+  ~GroupLease() {
+    if (!g) return;
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    std::lock_guard<std::mutex> lock(pool().mu);
+    pool().idle.push_back(g);
   }
-  int acquire(int device, size_t n, int count) {
-    for (int i = 0; i < count; i++) {
-      IcpWs* w = ws_acquire(device, n);
-      if (!w) return 1;
-      ws.push_back(w);
-    }
-    return 0;
+  int acquire(int device) {
+    g = group_acquire(device);
+    return g ? 0 : 1;
   }
 };
 
-static int lanes_cfg() { const char* e = getenv("ER_ICP_LANES"); int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }
-#define kLanes (lanes_cfg())
-
-int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
-int gblocks_of(int n) { return nblocks_of(n); }                // NN kernels: one query per thread
+// Pairs per group: bounded by the per-point scratch (32 bytes per source point and pair).  ER_ICP_GROUP overrides (tests use small groups).
+static int group_cfg() { const char* e = getenv("ER_ICP_GROUP"); int v = e ? atoi(e) : 64; return v < 1 ? 1 : (v > 1024 ? 1024 : v); }
 
 int check_pair(er_cloud_t src, er_cloud_t tgt, double radius, const char* who) {
   if (!src || !tgt) return er::fail("%s: NULL cloud", who);
@@ -1024,140 +1068,54 @@ int check_pair(er_cloud_t src, er_cloud_t tgt, double radius, const char* who) {
   return 0;
 }
 
-// ---- Registration pre-check ---------------------------------------------------------------------
-int count_enqueue(IcpWs* w, er_cloud_t src, er_cloud_t tgt, const double* T, double max_dist) {
-  Mat12d M;
-  for (int q = 0; q < 12; q++) M.m[q] = T[q];
-  ER_HIP_TRY(hipMemsetAsync(w->icount, 0, sizeof(int), w->stream));
-  if (src->n > 0 && tgt->n > 0) {
-    hipLaunchKernelGGL(k_count_inliers, dim3(std::min(gblocks_of(src->n), 2048)), dim3(kBlock), 0, w->stream, src->sorted, src->n, M,
-                       grid_of(tgt), (float)max_dist, max_dist * max_dist, w->icount);
-    ER_HIP_TRY(hipGetLastError());
+int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double radius, const char* who, int* device) {
+  if (n < 0 || (n > 0 && (!src || !tgt))) return er::fail("%s: bad arguments", who);
+  *device = n > 0 && src[0] ? src[0]->device : 0;
+  for (int i = 0; i < n; i++) {
+    if (check_pair(src[i], tgt[i], radius, who)) return 1;
+    if (src[i]->device != *device) return er::fail("%s: all pairs of one batch must live on one device", who);
   }
-  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[0], w->icount, sizeof(int), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
   return 0;
 }
 
-// ---- ICP as a resumable job ---------------------------------------------------------------------
-struct AlignJob {
-  er_cloud_t src = nullptr, tgt = nullptr;
-  float fin[16];
-  int iter = 0;
-  bool conv = false;
-  double fitness = DBL_MAX;
-  enum { ITERATING, FITNESS, DONE } state = ITERATING;
-};
-
-struct AlignParams {
-  double max_dist, eps;
-  int max_iter, stop_rule;
-  bool want_fitness;
-};
-
-// Iterations enqueued per host visit.  PCL's loop runs 3 iterations on most fragment pairs of the pipeline (the third one
-// meets the stop rule): one chunk usually ends the job; launches of a chunk that come after the stop decision return at once.
-constexpr int kIcpChunk = 3;
-
-// A chunk of ICP iterations with NO host round trip in between: k_icp_iter (apply the last increment, exact NN, point-to-plane
-// sums) + k_icp_final (fixed-order total, 6x6 solve, increment, stop rule -- on the device), then the state comes back once.
-int align_enqueue_chunk(IcpWs* w, AlignJob& j, const AlignParams& P) {
-  const int n = j.src->n;
-  const IcpParams IP{P.eps, P.max_iter, P.stop_rule};
-  for (int c = 0; c < kIcpChunk; c++) {
-    hipLaunchKernelGGL(k_icp_iter, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->X, n, w->dstate, grid_of(j.tgt), (float)P.max_dist,
-                       P.max_dist * P.max_dist, j.tgt->xyz, j.tgt->nrm, w->partial);
-    hipLaunchKernelGGL(k_icp_final, dim3(1), dim3(kBlock), 0, w->stream, w->partial, nblocks_of(n), w->acc, w->dstate, IP);
+// Fills the descriptors of pairs [i0, i0 + m) of the caller's lists into slots 0..m-1 and cuts the scratch slabs (scratch = false:
+// the pre-check needs none).  T16: one row-major float64 4x4 per pair, or NULL.
+int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_cloud_t* tgt, const double* T16, bool scratch) {
+  size_t points = 0, blocks = 0, parts = 0;
+  for (int q = 0; q < m; q++) {
+    const int n = src[i0 + q]->n;
+    points += (size_t)((n + 3) & ~3);                          // slices stay 16-byte aligned
+    blocks += (size_t)nblocks_of(n);
+    parts += (size_t)nparts_of(n);
   }
-  ER_HIP_TRY(hipGetLastError());
-  ER_HIP_TRY(hipMemcpyAsync(&w->host->state, w->dstate, sizeof(IcpDev), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
+  if (group_reserve(g, m, scratch ? points : 0, scratch ? blocks : 0, scratch ? parts : 0)) return 1;
+  size_t op = 0, ob = 0, oq = 0;
+  for (int q = 0; q < m; q++) {
+    const er_cloud_s* s = src[i0 + q];
+    const er_cloud_s* t = tgt[i0 + q];
+    PairDev& P = g->h_pairs[q];
+    memset(&P, 0, sizeof P);
+    P.src_sorted = s->sorted; P.src_xyz = s->xyz; P.src_nrm = s->nrm;
+    P.tgt_xyz = t->xyz; P.tgt_nrm = t->nrm;
+    P.g = grid_of(t);
+    if (T16)
+      for (int c = 0; c < 12; c++) P.T.m[c] = T16[(size_t)(i0 + q) * 16 + c];
+    P.n = s->n; P.nb = nblocks_of(s->n); P.nbi = nparts_of(s->n);
+    if (scratch) {
+      P.X = g->X + 3 * op; P.match = g->match + op; P.pairs = g->pairs + 2 * op;
+      P.block_count = g->block_count + ob; P.block_offset = g->block_offset + ob;
+      P.partial = g->partial + 32 * oq;
+      op += (size_t)((s->n + 3) & ~3); ob += (size_t)P.nb; oq += (size_t)P.nbi;
+    }
+  }
+  ER_HIP_TRY(hipMemcpyAsync(g->d_pairs, g->h_pairs, (size_t)m * sizeof(PairDev), hipMemcpyHostToDevice, g->stream));
   return 0;
 }
 
-int align_enqueue_fitness(IcpWs* w, AlignJob& j, const AlignParams& P) {
-  const int n = j.src->n;
-  Mat12f F;
-  for (int q = 0; q < 12; q++) F.m[q] = j.fin[q];
-  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
-  if (n > 0 && j.tgt->n > 0) {
-    hipLaunchKernelGGL(k_fitness_nn, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, j.src->sorted, n, F, grid_of(j.tgt), (float)P.max_dist, w->nd);
-    hipLaunchKernelGGL(k_fitness_sum, dim3(nblocks_of(n)), dim3(kBlock), 0, w->stream, w->nd, n, w->acc);
-    ER_HIP_TRY(hipGetLastError());
-  }
-  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, 2 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
-  j.state = AlignJob::FITNESS;
-  return 0;
-}
-
-int align_start(IcpWs* w, AlignJob& j, er_cloud_t src, er_cloud_t tgt, const float* guess, const AlignParams& P) {
-  j = AlignJob();
-  j.src = src;
-  j.tgt = tgt;
-  memcpy(j.fin, guess, sizeof j.fin);                        // final_transformation_ = guess
-  if (src->n == 0 || tgt->n == 0) {                          // fewer than 3 correspondences by construction: nothing to enqueue
-                                                             // (max_iter <= 0 still runs ONE iteration, like PCL's do { } while loop)
-    j.iter = 0;
-    j.conv = false;
-    if (P.want_fitness) return align_enqueue_fitness(w, j, P);
-    j.state = AlignJob::DONE;
-    ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
-    return 0;
-  }
-  bool ident = true;
-  for (int i = 0; i < 16; i++) ident = ident && guess[i] == ((i % 5 == 0) ? 1.f : 0.f);
-  // The previous job's state read-back has been consumed (the lane's event was waited for), so the pinned block is free.
-  IcpDev& st = w->host->state;
-  memset(&st, 0, sizeof st);
-  memcpy(st.fin, guess, sizeof st.fin);
-  for (int i = 0; i < 16; i++) st.delta[i] = st.prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
-  st.prev_mse = DBL_MAX;
-  ER_HIP_TRY(hipMemcpyAsync(w->dstate, &st, sizeof st, hipMemcpyHostToDevice, w->stream));
-  Mat12f G;
-  for (int q = 0; q < 12; q++) G.m[q] = guess[q];
-  hipLaunchKernelGGL(k_init_x, dim3(nblocks_of(src->n)), dim3(kBlock), 0, w->stream, src->sorted, w->X, src->n, G, ident ? 0 : 1);
-  ER_HIP_TRY(hipGetLastError());
-  return align_enqueue_chunk(w, j, P);
-}
-
-// The host half of a job: wait for the lane's event; either the loop has ended on the device (collect) or another chunk goes out.
-int align_advance(IcpWs* w, AlignJob& j, const AlignParams& P) {
-  ER_HIP_TRY(hipEventSynchronize(w->ev));
-  if (j.state == AlignJob::DONE) return 0;
-  if (j.state == AlignJob::FITNESS) {
-    const double* acc = w->host->acc;
-    j.fitness = acc[1] > 0 ? acc[0] / acc[1] : DBL_MAX;
-    j.state = AlignJob::DONE;
-    return 0;
-  }
-  const IcpDev& st = w->host->state;
-  if (!st.done) return align_enqueue_chunk(w, j, P);         // (h2d of the state is NOT repeated: it lives on the device)
-  memcpy(j.fin, st.fin, sizeof j.fin);
-  j.iter = st.iter;
-  j.conv = st.conv != 0;
-  if (P.want_fitness) return align_enqueue_fitness(w, j, P);
-  j.state = AlignJob::DONE;
-  return 0;
-}
-
-// ---- FindCorrespondence ---------------------------------------------------------------------------
-int corr_enqueue(IcpWs* w, er_cloud_t src, er_cloud_t tgt, const double* T, double dist, double normal_cos, bool want_info) {
-  const int n = src->n;
-  Mat12d M;
-  for (int q = 0; q < 12; q++) M.m[q] = T[q];
-  const int nb = nblocks_of(n);
-  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
-  hipLaunchKernelGGL(k_find_corr, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, src->sorted, src->nrm, n, M, grid_of(tgt), tgt->nrm,
-                     (float)dist, dist * dist, normal_cos, w->match);
-  hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kBlock), 0, w->stream, w->match, src->xyz, n, w->block_count, w->acc, want_info ? 1 : 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, w->stream, w->block_count, w->block_offset, nb, w->icount + 1);
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kBlock), 0, w->stream, w->match, n, w->block_offset, w->pairs, n);
-  ER_HIP_TRY(hipGetLastError());
-  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[1], w->icount + 1, sizeof(int), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, 10 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
-  return 0;
+int max_points(int i0, int m, const er_cloud_t* src) {
+  int mx = 0;
+  for (int q = 0; q < m; q++) mx = std::max(mx, src[i0 + q]->n);
+  return mx;
 }
 
 bool is_pinned_host(const void* p) {
@@ -1170,7 +1128,7 @@ bool is_pinned_host(const void* p) {
 }
 
 // sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203,
-// RansacCurvature.h:717-721) from its ten distinct terms (k_count_blocks / k_info_matched).
+// RansacCurvature.h:717-721) from its ten distinct terms (k_count_blocks).
 void expand_information(const double* acc, double* I) {
   memset(I, 0, 36 * sizeof(double));
   const double N = acc[9];
@@ -1189,58 +1147,9 @@ void expand_information(const double* acc, double* I) {
   I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
 }
 
-// (Letting k_compact store the list straight into page-locked host memory -- zero-copy -- was tried: one stage
-// fewer, but 3.5 instead of 2.9 ms per 40 pairs.)
-// Stage 2 of a pair (after the lane's kernel event): the pair count is known; start the copy of exactly that many
-// pairs -- straight into the caller's buffer when it is page-locked (er_host_alloc), else into the lane's pinned
-// staging block -- and expand the information matrix.  *staged tells corr_finish whether a host memcpy remains.
-int corr_start_copy(IcpWs* w, int* pairs_host, int capacity, int* n_pairs, double* info36, bool* staged) {
-  ER_HIP_TRY(hipEventSynchronize(w->ev));
-  const int total = w->host->count[1];
-  *n_pairs = total;
-  *staged = false;
-  const int ncopy = std::min(total, capacity);
-  if (ncopy > 0) {
-    int* dst = pairs_host;
-    if (!is_pinned_host(pairs_host)) {
-      if (w->stage_cap < w->cap) {
-        if (w->stage) (void)hipHostFree(w->stage);
-        w->stage = nullptr;
-        w->stage_cap = 0;
-        ER_HIP_TRY(hipHostMalloc((void**)&w->stage, w->cap * 2 * sizeof(int), hipHostMallocDefault));
-        w->stage_cap = w->cap;
-      }
-      dst = w->stage;
-      *staged = true;
-    }
-    ER_HIP_TRY(hipMemcpyAsync(dst, w->pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, w->stream));
-    ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
-  }
-  if (info36) expand_information(w->host->acc, info36);
-  return 0;
-}
-
-// Stage 3: the copy has landed.
-int corr_finish(IcpWs* w, int* pairs_host, int capacity, int total, bool staged) {
-  const int ncopy = std::min(total, capacity);
-  if (ncopy > 0) {
-    ER_HIP_TRY(hipEventSynchronize(w->ev));
-    if (staged) memcpy(pairs_host, w->stage, (size_t)ncopy * 2 * sizeof(int));
-  }
-  return total > capacity ? er::fail("er_find_correspondence: %d pairs exceed the capacity %d", total, capacity) : 0;
-}
-
-int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double radius, const char* who, int* device, size_t* max_n) {
-  if (n < 0 || (n > 0 && (!src || !tgt))) return er::fail("%s: bad arguments", who);
-  *device = n > 0 && src[0] ? src[0]->device : 0;
-  *max_n = 1;
-  for (int i = 0; i < n; i++) {
-    if (check_pair(src[i], tgt[i], radius, who)) return 1;
-    if (src[i]->device != *device) return er::fail("%s: all pairs of one batch must live on one device", who);
-    *max_n = std::max(*max_n, (size_t)src[i]->n);
-  }
-  return 0;
-}
+// Iterations enqueued per host visit.  PCL's loop runs 3 iterations on most fragment pairs of the pipeline (the third one
+// meets the stop rule): one chunk usually ends the job; workgroups of a chunk that come after a pair's stop decision return at once.
+constexpr int kIcpChunk = 3;
 
 }  // namespace
 
@@ -1392,31 +1301,39 @@ int er_cloud_destroy(er_cloud_t c) {
 int er_cloud_size(er_cloud_t c) { return c ? c->n : -1; }
 
 int er_icp_release_workspaces(void) {
-  std::vector<IcpWs*> all;
+  std::vector<Group*> v;
   {
     std::lock_guard<std::mutex> lock(pool().mu);
-    all.swap(pool().idle);
+    v.swap(pool().idle);
   }
-  for (IcpWs* w : all) ws_destroy(w);
+  for (Group* g : v) group_destroy(g);
   return 0;
 }
 
+// Registration pre-check of a pair list (CorresApp.cpp:249-264): one launch per group of pairs.
 int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double max_dist, int* counts) {
   int device;
-  size_t max_n;
   if (n > 0 && (!T || !counts)) return er::fail("er_icp_count_inliers_batch: NULL argument");
-  if (batch_prologue(n, src, tgt, max_dist, "er_icp_count_inliers", &device, &max_n)) return 1;
+  if (batch_prologue(n, src, tgt, max_dist, "er_icp_count_inliers", &device)) return 1;
   if (n == 0) return 0;
-  WsSet set;
-  const int lanes = std::min(n, kLanes);
-  if (set.acquire(device, 1, lanes)) return 1;               // the pre-check needs no per-point scratch
-  for (int i = 0; i < n + lanes; i++) {
-    IcpWs* w = set.ws[(size_t)(i % lanes)];
-    if (i >= lanes) {
-      ER_HIP_TRY(hipEventSynchronize(w->ev));
-      counts[i - lanes] = w->host->count[0];
+  GroupLease L;
+  if (L.acquire(device)) return 1;
+  Group* g = L.g;
+  const int G = group_cfg();
+  for (int i0 = 0; i0 < n; i0 += G) {
+    const int m = std::min(G, n - i0);
+    if (group_describe(g, i0, m, src, tgt, T, false)) return 1;
+    ER_HIP_TRY(hipMemsetAsync(g->d_counts, 0, (size_t)m * sizeof(int), g->stream));
+    const int mx = max_points(i0, m, src);
+    if (mx > 0) {
+      // a few thousand workgroups in flight fill the chip; each strides over its pair's points (one atomic per workgroup)
+      const int bx = std::max(1, std::min(nblocks_of(mx), std::max(64, 8192 / m)));
+      hipLaunchKernelGGL(k_count_inliers, dim3(bx, m), dim3(kBlock), 0, g->stream, g->d_pairs, (float)max_dist, max_dist * max_dist, g->d_counts);
+      ER_HIP_TRY(hipGetLastError());
     }
-    if (i < n && count_enqueue(w, src[i], tgt[i], T + (size_t)i * 16, max_dist)) return 1;
+    ER_HIP_TRY(hipMemcpyAsync(g->h_counts, g->d_counts, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    ER_HIP_TRY(hipStreamSynchronize(g->stream));
+    for (int q = 0; q < m; q++) counts[i0 + q] = (src[i0 + q]->n > 0 && tgt[i0 + q]->n > 0) ? g->h_counts[q] : 0;
   }
   return 0;
 }
@@ -1426,53 +1343,86 @@ int er_icp_count_inliers(er_cloud_t src, er_cloud_t tgt, const double T[16], dou
   return er_icp_count_inliers_batch(1, &src, &tgt, T, max_dist, count);
 }
 
+// icp.align of a pair list (CorresApp.cpp:295-306).  Per group: the states go up once; chunks of kIcpChunk iterations are
+// enqueued for the pairs that are still running -- two launches per iteration for the whole group -- and the states come back
+// once per chunk; the host only compacts the list of running pairs.
 int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const float* guess, double max_dist, int max_iter,
                        double transformation_epsilon, int stop_rule, float* out, int* iterations, int* converged, double* fitness) {
   int device;
-  size_t max_n;
   if (n > 0 && (!guess || !out)) return er::fail("er_icp_align: NULL argument");
-  if (batch_prologue(n, src, tgt, max_dist, "er_icp_align", &device, &max_n)) return 1;
+  if (batch_prologue(n, src, tgt, max_dist, "er_icp_align", &device)) return 1;
   if (n == 0) return 0;
-  const AlignParams P{max_dist, transformation_epsilon, max_iter, stop_rule, fitness != nullptr};
-  WsSet set;
-  const int lanes = std::min(n, kLanes);
-  if (set.acquire(device, max_n, lanes)) return 1;
-  std::vector<AlignJob> job((size_t)lanes);
-  std::vector<int> which((size_t)lanes, -1);
-  int next = 0, done = 0;
-  for (int l = 0; l < lanes; l++) {
-    which[(size_t)l] = next;
-    if (align_start(set.ws[(size_t)l], job[(size_t)l], src[next], tgt[next], guess + (size_t)next * 16, P)) return 1;
-    next++;
-  }
-  // round robin over the lanes: every lane always has work queued, so waiting on one never idles the GPU
-  for (int l = 0; done < n; l = (l + 1) % lanes) {
-    const int i = which[(size_t)l];
-    if (i < 0) continue;
-    AlignJob& j = job[(size_t)l];
-    if (align_advance(set.ws[(size_t)l], j, P)) return 1;
-    if (j.state != AlignJob::DONE) continue;
-    memcpy(out + (size_t)i * 16, j.fin, sizeof j.fin);
-    if (iterations) iterations[i] = j.iter;
-    if (converged) converged[i] = j.conv ? 1 : 0;
-    if (fitness) fitness[i] = j.fitness;
-    done++;
-    which[(size_t)l] = -1;
-    if (next < n) {
-      which[(size_t)l] = next;
-      if (align_start(set.ws[(size_t)l], j, src[next], tgt[next], guess + (size_t)next * 16, P)) return 1;
-      next++;
+  GroupLease L;
+  if (L.acquire(device)) return 1;
+  Group* g = L.g;
+  const IcpParams prm{transformation_epsilon, max_iter, stop_rule};
+  const int G = group_cfg();
+  for (int i0 = 0; i0 < n; i0 += G) {
+    const int m = std::min(G, n - i0);
+    if (group_describe(g, i0, m, src, tgt, nullptr, true)) return 1;
+    int n_active = 0;
+    for (int q = 0; q < m; q++) {
+      IcpDev& st = g->h_state[q];
+      memset(&st, 0, sizeof st);
+      const float* gq = guess + (size_t)(i0 + q) * 16;
+      memcpy(st.fin, gq, sizeof st.fin);                         // final_transformation_ = guess
+      bool ident = true;
+      for (int i = 0; i < 16; i++) {
+        st.delta[i] = st.prev_delta[i] = (i % 5 == 0) ? 1.f : 0.f;
+        ident = ident && gq[i] == ((i % 5 == 0) ? 1.f : 0.f);
+      }
+      st.prev_mse = DBL_MAX;
+      st.init_apply = ident ? 0 : 1;
+      if (src[i0 + q]->n == 0 || tgt[i0 + q]->n == 0) {
+        st.done = 1;                                             // fewer than 3 correspondences by construction: not converged, the guess comes back
+      } else {                                                   // (max_iter <= 0 still runs ONE iteration, like PCL's do { } while loop)
+        g->h_active[n_active++] = q;
+      }
+    }
+    ER_HIP_TRY(hipMemcpyAsync(g->d_state, g->h_state, (size_t)m * sizeof(IcpDev), hipMemcpyHostToDevice, g->stream));
+    while (n_active > 0) {
+      ER_HIP_TRY(hipMemcpyAsync(g->d_active, g->h_active, (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, g->stream));
+      int mxp = 1;
+      for (int a = 0; a < n_active; a++) mxp = std::max(mxp, g->h_pairs[g->h_active[a]].nbi);
+      for (int c = 0; c < kIcpChunk; c++) {
+        hipLaunchKernelGGL(k_icp_iter, dim3(mxp, n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, (float)max_dist,
+                           max_dist * max_dist);
+        hipLaunchKernelGGL(k_icp_final, dim3(n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, prm);
+      }
+      ER_HIP_TRY(hipGetLastError());
+      ER_HIP_TRY(hipMemcpyAsync(g->h_state, g->d_state, (size_t)m * sizeof(IcpDev), hipMemcpyDeviceToHost, g->stream));
+      ER_HIP_TRY(hipStreamSynchronize(g->stream));               // (d_active is free again: the chunk has run)
+      int k = 0;
+      for (int a = 0; a < n_active; a++)
+        if (!g->h_state[g->h_active[a]].done) g->h_active[k++] = g->h_active[a];
+      n_active = k;
+    }
+    if (fitness) {
+      ER_HIP_TRY(hipMemsetAsync(g->d_fit, 0, (size_t)m * 2 * sizeof(double), g->stream));
+      const int mx = max_points(i0, m, src);
+      if (mx > 0) {
+        const int bx = std::max(1, std::min(nblocks_of(mx), std::max(64, 8192 / m)));
+        hipLaunchKernelGGL(k_fitness, dim3(bx, m), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_state, (float)max_dist, g->d_fit);
+        ER_HIP_TRY(hipGetLastError());
+      }
+      ER_HIP_TRY(hipMemcpyAsync(g->h_fit, g->d_fit, (size_t)m * 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+      ER_HIP_TRY(hipStreamSynchronize(g->stream));
+    }
+    for (int q = 0; q < m; q++) {
+      const IcpDev& st = g->h_state[q];
+      memcpy(out + (size_t)(i0 + q) * 16, st.fin, 16 * sizeof(float));
+      if (iterations) iterations[i0 + q] = st.iter;
+      if (converged) converged[i0 + q] = st.conv ? 1 : 0;
+      if (fitness) fitness[i0 + q] = g->h_fit[2 * q + 1] > 0 ? g->h_fit[2 * q] / g->h_fit[2 * q + 1] : DBL_MAX;
     }
   }
   return 0;
 }
 
 int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double max_dist, int max_iter,
-                 double transformation_epsilon, int stop_rule, float out[16], int* iterations, int* converged,
-                 double* fitness) {
+                 double transformation_epsilon, int stop_rule, float out[16], int* iterations, int* converged, double* fitness) {
   if (!guess || !out) return er::fail("er_icp_align: NULL argument");
-  return er_icp_align_batch(1, &src, &tgt, guess, max_dist, max_iter, transformation_epsilon, stop_rule, out, iterations, converged,
-                            fitness);
+  return er_icp_align_batch(1, &src, &tgt, guess, max_dist, max_iter, transformation_epsilon, stop_rule, out, iterations, converged, fitness);
 }
 
 int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const float* M, float corr_dist_threshold, int* inliers,
@@ -1480,9 +1430,9 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
   if (n_hyp < 0 || (n_hyp > 0 && (!M || !inliers))) return er::fail("er_ransac_fitness_batch: bad arguments");
   if (check_pair(src, tgt, (double)corr_dist_threshold, "er_ransac_fitness_batch")) return 1;
   if (n_hyp == 0) return 0;
-  WsSet set;
-  if (set.acquire(src->device, 1, 1)) return 1;
-  IcpWs* w = set.ws[0];
+  GroupLease L;
+  if (L.acquire(src->device)) return 1;
+  Group* w = L.g;
   float* d_hyp = nullptr;
   int* d_cnt = nullptr;
   double* d_sum = nullptr;
@@ -1520,6 +1470,31 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
   return rc;
 }
 
+// Compaction chain of slots [s0, s0 + m) of the group (match already written): per-block counts (+ information terms), per-pair
+// scan, stable compaction; the totals and the information terms come back to the pinned mirrors.  Records `done` on the stream.
+static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done) {
+  hipLaunchKernelGGL(k_count_blocks, dim3(mxb, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0, g->d_info + (size_t)s0 * kAcc, want_source ? 1 : 0,
+                     want_target ? 1 : 0);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, g->stream, g->d_pairs + s0, g->d_totals + s0);
+  hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemcpyAsync(g->h_totals + s0, g->d_totals + s0, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+  ER_HIP_TRY(hipMemcpyAsync(g->h_info + (size_t)s0 * kAcc, g->d_info + (size_t)s0 * kAcc, (size_t)m * kAcc * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  ER_HIP_TRY(hipEventRecord(done, g->stream));
+  return 0;
+}
+
+static int stage_reserve(Group* g, size_t ints) {
+  if (ints <= g->stage_cap) return 0;
+  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+  if (g->stage) (void)hipHostFree(g->stage);
+  g->stage = nullptr;
+  g->stage_cap = 0;
+  ER_HIP_TRY(hipHostMalloc((void**)&g->stage, ints * sizeof(int), hipHostMallocDefault));
+  g->stage_cap = ints;
+  return 0;
+}
+
 int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float corr_dist_threshold, int* pairs_host, int capacity,
                       int* n_inliers, double* fitness, double* info_source36, double* info_target36) {
   if (!M16 || !n_inliers || capacity < 0 || (capacity > 0 && !pairs_host)) return er::fail("er_ransac_inliers: bad arguments");
@@ -1529,73 +1504,119 @@ int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float co
   if (info_source36) memset(info_source36, 0, 36 * sizeof(double));
   if (info_target36) memset(info_target36, 0, 36 * sizeof(double));
   if (src->n == 0 || tgt->n == 0) return 0;
-  WsSet set;
-  if (set.acquire(src->device, (size_t)src->n, 1)) return 1;
-  IcpWs* w = set.ws[0];
+  GroupLease L;
+  if (L.acquire(src->device)) return 1;
+  Group* g = L.g;
+  if (group_describe(g, 0, 1, &src, &tgt, nullptr, true)) return 1;
   const int n = src->n, nb = nblocks_of(n);
   Mat12f M;
   for (int q = 0; q < 12; q++) M.m[q] = M16[q];
-  ER_HIP_TRY(hipMemsetAsync(w->acc, 0, kAcc * sizeof(double), w->stream));
-  hipLaunchKernelGGL(k_ransac_match, dim3(gblocks_of(n)), dim3(kBlock), 0, w->stream, src->sorted, n, M, grid_of(tgt), corr_dist_threshold,
-                     corr_dist_threshold * corr_dist_threshold, w->match, w->acc);
-  hipLaunchKernelGGL(k_count_blocks, dim3(nb), dim3(kBlock), 0, w->stream, w->match, src->xyz, n, w->block_count, w->acc, info_source36 ? 1 : 0);
-  if (info_target36) hipLaunchKernelGGL(k_info_matched, dim3(nb), dim3(kBlock), 0, w->stream, w->match, tgt->xyz, n, w->acc + 10);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, w->stream, w->block_count, w->block_offset, nb, w->icount + 1);
-  hipLaunchKernelGGL(k_compact, dim3(nb), dim3(kBlock), 0, w->stream, w->match, n, w->block_offset, w->pairs, n);
-  ER_HIP_TRY(hipGetLastError());
-  ER_HIP_TRY(hipMemcpyAsync(&w->host->count[1], w->icount + 1, sizeof(int), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipMemcpyAsync(w->host->acc, w->acc, kAcc * sizeof(double), hipMemcpyDeviceToHost, w->stream));
-  ER_HIP_TRY(hipEventRecord(w->ev, w->stream));
-  bool staged = false;
-  if (corr_start_copy(w, pairs_host, capacity, n_inliers, info_source36, &staged)) return 1;
-  if (info_target36) expand_information(w->host->acc + 10, info_target36);
-  if (fitness && *n_inliers > 0) *fitness = w->host->acc[20] / (double)*n_inliers;                  // :697-703
-  return corr_finish(w, pairs_host, capacity, *n_inliers, staged);
+  ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, kAcc * sizeof(double), g->stream));
+  hipLaunchKernelGGL(k_ransac_match, dim3(nb), dim3(kBlock), 0, g->stream, g->d_pairs, M, corr_dist_threshold, corr_dist_threshold * corr_dist_threshold,
+                     g->d_info);
+  if (corr_chain(g, 0, 1, nb, info_source36 != nullptr, info_target36 != nullptr, g->ev)) return 1;
+  ER_HIP_TRY(hipEventSynchronize(g->ev));
+  const int total = g->h_totals[0];
+  *n_inliers = total;
+  if (info_source36) expand_information(g->h_info, info_source36);
+  if (info_target36) expand_information(g->h_info + 10, info_target36);
+  if (fitness && total > 0) *fitness = g->h_info[20] / (double)total;                               // :697-703
+  const int ncopy = std::min(total, capacity);
+  if (ncopy > 0) {
+    const bool direct = is_pinned_host(pairs_host);
+    if (!direct && stage_reserve(g, (size_t)ncopy * 2)) return 1;
+    ER_HIP_TRY(hipMemcpyAsync(direct ? pairs_host : g->stage, g->h_pairs[0].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    ER_HIP_TRY(hipStreamSynchronize(g->stream));
+    if (!direct) memcpy(pairs_host, g->stage, (size_t)ncopy * 2 * sizeof(int));
+  }
+  return total > capacity ? er::fail("er_ransac_inliers: %d pairs exceed the capacity %d", total, capacity) : 0;
 }
 
+// FindCorrespondence of a pair list (CorresApp.cpp:112-210).  A group is described once; its pairs run in SUB-GROUPS of kCorrSub:
+// search + compaction chain of sub-group s+1 are enqueued before the host waits for the totals of sub-group s, and the list copies
+// of s (exactly total pairs each; PCIe-bound: 8 bytes per correspondence) run on the copy stream underneath.
+constexpr int kCorrSub = 16;
 int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist, double normal_cos,
                                  int* const* pairs_host, const int* capacity, int* n_pairs, double* info36) {
   int device;
-  size_t max_n;
   if (n > 0 && (!T || !n_pairs || !pairs_host || !capacity)) return er::fail("er_find_correspondence: NULL argument");
-  if (batch_prologue(n, src, tgt, dist, "er_find_correspondence", &device, &max_n)) return 1;
+  if (batch_prologue(n, src, tgt, dist, "er_find_correspondence", &device)) return 1;
   if (n == 0) return 0;
-  for (int i = 0; i < n; i++)
+  size_t stage_need = 0;
+  std::vector<char> direct((size_t)n, 0);                      // destination is page-locked: the list is copied straight into it
+  for (int i = 0; i < n; i++) {
     if (capacity[i] > 0 && !pairs_host[i]) return er::fail("er_find_correspondence: NULL pair buffer for pair %d", i);
-  WsSet set;
-  const int lanes = std::min(n, kLanes);
-  if (set.acquire(device, max_n, lanes)) return 1;
-  // per lane: IDLE -> KERNELS (search + compaction queued) -> COPY (pair list on its way to the host) -> IDLE
-  enum { IDLE, KERNELS, COPY };
-  struct Lane { int state = IDLE, pair = -1; bool staged = false; };
-  std::vector<Lane> lane((size_t)lanes);
-  int next = 0, done = 0, rc = 0;
-  for (int l = 0; done < n; l = (l + 1) % lanes) {
-    Lane& L = lane[(size_t)l];
-    IcpWs* w = set.ws[(size_t)l];
-    if (L.state == COPY) {
-      if (corr_finish(w, pairs_host[L.pair], capacity[L.pair], n_pairs[L.pair], L.staged)) rc = 1;   // keep draining the other lanes
-      L.state = IDLE;
-      done++;
-    } else if (L.state == KERNELS) {
-      const int k = L.pair;
-      if (corr_start_copy(w, pairs_host[k], capacity[k], &n_pairs[k], info36 ? info36 + (size_t)k * 36 : nullptr, &L.staged)) return 1;
-      L.state = COPY;
-      continue;                                              // the lane's buffers stay busy until the copy is collected
-    }
-    if (L.state == IDLE && next < n) {
-      const int k = next++;
-      if (src[k]->n == 0 || tgt[k]->n == 0) {
-        n_pairs[k] = 0;
-        if (info36) memset(info36 + (size_t)k * 36, 0, 36 * sizeof(double));
-        done++;
-        continue;
-      }
-      if (corr_enqueue(w, src[k], tgt[k], T + (size_t)k * 16, dist, normal_cos, info36 != nullptr)) return 1;
-      L.pair = k;
-      L.state = KERNELS;
+    if (capacity[i] > 0) {
+      direct[(size_t)i] = is_pinned_host(pairs_host[i]) ? 1 : 0;               // (asked once per pair, not again at copy time)
+      if (!direct[(size_t)i]) stage_need += (size_t)std::min(capacity[i], src[i]->n) * 2;
     }
   }
+  GroupLease L;
+  if (L.acquire(device)) return 1;
+  Group* g = L.g;
+  if (stage_need && stage_reserve(g, stage_need)) return 1;
+  std::vector<long> staged((size_t)n, -1);
+  size_t stage_used = 0;
+  const int G = group_cfg();
+  int rc = 0;
+  for (int i0 = 0; i0 < n; i0 += G) {
+    const int m = std::min(G, n - i0);
+    ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));          // the previous group's lists have left the slabs
+    if (group_describe(g, i0, m, src, tgt, T, true)) return 1;
+    ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, (size_t)m * kAcc * sizeof(double), g->stream));
+    const int nsub = (m + kCorrSub - 1) / kCorrSub;
+    while ((int)g->sub_ev.size() < nsub) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return er::fail("er_find_correspondence: hipEventCreate failed");
+      g->sub_ev.push_back(e);
+    }
+    std::vector<hipEvent_t>& evs = g->sub_ev;
+    auto cleanup = [&]() {};
+    auto enqueue = [&](int s) -> int {
+      const int s0 = s * kCorrSub, ms = std::min(kCorrSub, m - s0);
+      int mxb = 1;
+      for (int q = 0; q < ms; q++) mxb = std::max(mxb, g->h_pairs[s0 + q].nb);
+      hipLaunchKernelGGL(k_find_corr, dim3(mxb, ms), dim3(kBlock), 0, g->stream, g->d_pairs + s0, (float)dist, dist * dist, normal_cos);
+      return corr_chain(g, s0, ms, mxb, info36 != nullptr, false, evs[(size_t)s]);
+    };
+    if (enqueue(0)) { cleanup(); return 1; }
+    for (int s = 0; s < nsub; s++) {
+      if (s + 1 < nsub && enqueue(s + 1)) { cleanup(); return 1; }
+      const int s0 = s * kCorrSub, ms = std::min(kCorrSub, m - s0);
+      if (hipEventSynchronize(evs[(size_t)s]) != hipSuccess) { cleanup(); return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError())); }
+      for (int q = 0; q < ms; q++) {
+        const int i = i0 + s0 + q;
+        const bool empty = src[i]->n == 0 || tgt[i]->n == 0;
+        n_pairs[i] = empty ? 0 : g->h_totals[s0 + q];
+        if (empty) g->h_totals[s0 + q] = 0;
+        if (info36) {
+          if (empty) memset(info36 + (size_t)i * 36, 0, 36 * sizeof(double));
+          else expand_information(g->h_info + (size_t)(s0 + q) * kAcc, info36 + (size_t)i * 36);
+        }
+        if (n_pairs[i] > capacity[i]) rc = er::fail("er_find_correspondence: %d pairs exceed the capacity %d", n_pairs[i], capacity[i]);
+      }
+      // copies of this sub-group's lists on the copy stream (its kernels are done: evs[s] has been waited for)
+      ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream, evs[(size_t)s], 0));
+      for (int q = 0; q < ms; q++) {
+        const int i = i0 + s0 + q, ncopy = std::min(n_pairs[i], capacity[i]);
+        if (ncopy <= 0) continue;
+        int* dst = pairs_host[i];
+        if (!direct[(size_t)i]) {
+          staged[(size_t)i] = (long)stage_used;
+          dst = g->stage + stage_used;
+          stage_used += (size_t)ncopy * 2;
+        }
+        if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, g->copy_stream) != hipSuccess) {
+          cleanup();
+          return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError()));
+        }
+      }
+    }
+    cleanup();
+  }
+  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+  for (int i = 0; i < n; i++)
+    if (staged[(size_t)i] >= 0) memcpy(pairs_host[i], g->stage + staged[(size_t)i], (size_t)std::min(n_pairs[i], capacity[i]) * 2 * sizeof(int));
   return rc;
 }
 
