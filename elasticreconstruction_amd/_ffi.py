@@ -17,7 +17,7 @@ SYMBOLS = [
     "er_tsdf_wait_event", "er_tsdf_reset", "er_tsdf_status", "er_tsdf_set_unit_shard", "er_unit_owner",
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
     "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
-    "er_tsdf_extract_world", "er_tsdf_extract_surface", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
+    "er_tsdf_extract_world", "er_tsdf_extract_surface", "er_tsdf_extract_mesh", "er_mc_table", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_destroy", "er_comm_rank", "er_comm_world",
     "er_tsdf_allreduce", "er_frame_block",

@@ -80,15 +80,15 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 struct NnShared {
   unsigned long long best[kBlock];
   float q[3][kBlock];
-  int x01[2][kBlock];
+  int ix[kBlock];                 // the query's own cell column (may be -1 or dim[0]: one cell outside the grid)
   int task_row[kBlock * 8];
   unsigned char task_q[kBlock * 8];
+  unsigned char task_lr[kBlock * 8];   // bit 0: the row's cell x-1 can still hold a closer point, bit 1: cell x+1
   int ntask;
 };
 
-__device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int x0, int x1, float qx, float qy, float qz,
-                                                       unsigned long long key) {
-  const int s0 = g.cell_start[row + x0], s1 = g.cell_start[row + x1 + 1];
+// Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
+__device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
   for (int s = s0; s < s1; s += kUnroll) {
     float4 p[kUnroll];
 #pragma unroll
@@ -105,8 +105,17 @@ __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, i
   return key;
 }
 
+// Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
+__device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
+  return scan_range(g, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, key);
+}
+
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
 // Returns the index (or -1) and the squared distance of the nearest target point.
+// Round 3: the HOME row is no longer scanned as one range of three cells -- the query's own cell first, then the left / right
+// cell only if its face is closer than the best so far -- and the neighbour rows carry the same two flags, so a typical query
+// looks at about half the candidates (a cell is skipped only when every point in it is provably farther than the best: its
+// nearest face already is, with the same 1e-4 relative margin as the row test; ties cannot hide there).
 __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
                                         float& best_d) {
   const int tid = threadIdx.x;
@@ -120,30 +129,47 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     const bool inside = cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
     if (inside) {
       const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-      const int x0 = max(ix - 1, 0), x1 = min(ix + 1, g.dim[0] - 1);
-      if (x0 <= x1) {
-        // distance from q to the lower / upper face of its own cell along y and z (metres)
-        const float ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell, zhi = g.cell - zlo;
+      const int nx = g.dim[0];
+      // distance from q to the lower / upper face of its own cell along x, y and z (metres)
+      const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
+                  zhi = g.cell - zlo;
+      const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
+      if (has_l | has_o | has_r) {
         float bound = limit2 * 1.0001f + 1e-12f;
         if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
-          key = scan_row(g, (iz * g.dim[1] + iy) * g.dim[0], x0, x1, qx, qy, qz, key);
-          bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // neighbours must beat the home row
+          const int row = (iz * g.dim[1] + iy) * nx;
+          if (has_o) {
+            key = scan_row(g, row, ix, ix, qx, qy, qz, key);
+            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
+          }
+          if (has_l && xlo * xlo <= bound) {
+            key = scan_row(g, row, ix - 1, ix - 1, qx, qy, qz, key);
+            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+          }
+          if (has_r && xhi * xhi <= bound) {
+            key = scan_row(g, row, ix + 1, ix + 1, qx, qy, qz, key);
+            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+          }
         }
         sh.q[0][tid] = qx;
         sh.q[1][tid] = qy;
         sh.q[2][tid] = qz;
-        sh.x01[0][tid] = x0;
-        sh.x01[1][tid] = x1;
+        sh.ix[tid] = ix;
 #pragma unroll
         for (int pass = 0; pass < 9; pass++) {
           if (pass == 4) continue;
           const int dy = pass % 3 - 1, dz = pass / 3 - 1;
           const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
           const int y = iy + dy, z = iz + dz;
-          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && ey * ey + ez * ez <= bound) {
-            const int t = atomicAdd(&sh.ntask, 1);
-            sh.task_row[t] = (z * g.dim[1] + y) * g.dim[0];
-            sh.task_q[t] = (unsigned char)tid;
+          const float e2 = ey * ey + ez * ez;
+          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
+            const int lr = ((has_l && xlo * xlo + e2 <= bound) ? 1 : 0) | ((has_r && xhi * xhi + e2 <= bound) ? 2 : 0);
+            if (has_o || lr) {
+              const int t = atomicAdd(&sh.ntask, 1);
+              sh.task_row[t] = (z * g.dim[1] + y) * nx;
+              sh.task_q[t] = (unsigned char)tid;
+              sh.task_lr[t] = (unsigned char)lr;
+            }
           }
         }
       }
@@ -153,8 +179,10 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   __syncthreads();
   const int nt = sh.ntask;
   for (int t = tid; t < nt; t += kBlock) {
-    const int q = sh.task_q[t];
-    const unsigned long long k = scan_row(g, sh.task_row[t], sh.x01[0][q], sh.x01[1][q], sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+    const int q = sh.task_q[t], lr = sh.task_lr[t], ix = sh.ix[q];
+    const int xa = max((lr & 1) ? ix - 1 : ix, 0), xb = min((lr & 2) ? ix + 1 : ix, g.dim[0] - 1);
+    if (xa > xb) continue;
+    const unsigned long long k = scan_row(g, sh.task_row[t], xa, xb, sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
     if (k != kNoHit) atomicMin(&sh.best[q], k);
   }
   __syncthreads();

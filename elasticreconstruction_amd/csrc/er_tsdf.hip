@@ -28,6 +28,7 @@
 // All kernels are HBM/latency/VALU work on scattered voxels and pixels: no MFMA.
 #include "er_common.h"
 #include "er_tsdf_math.h"
+#include "er_mc_table.h"
 
 #include "../../include/er_hip.h"
 
@@ -706,6 +707,119 @@ __global__ __launch_bounds__(64) void k_surface(const float2* __restrict__ pool,
     }
     total += __popcll(bx) + __popcll(by) + __popcll(bz);
   }
+  if (!pass && lane == 0) slab_count[blockIdx.x] = total;
+}
+
+
+// Marching cubes on the resident volume (the triangle connectivity the out-of-repo kinfu "mesh_output" step builds
+// from world.pcd, done where the volume lives).  Cell (i, j, k) of a unit = the eight voxels (i..i+1, j..j+1, k..k+1) -- the last
+// layer of cells reaches into the adjacent units (+x, +y, +z and their combinations, found through the hash map).  A cell
+// yields triangles only if all eight voxels are observed (weight != 0, kinfu's rule); corner c is inside iff sdf < 0; the case
+// table is generated on the host (er_mc_table.h) and staged in LDS.  A vertex on the lattice edge from the lower voxel L to the
+// upper voxel H lies at  pos(L) + (F_L / (F_L - F_H)) * voxel size  along the edge's axis (float32; pos = (float)(global index *
+// 3/512)) -- evaluated from the edge's LOWER end whichever cell asks, so the cells that share the edge produce the same bits and
+// the triangle soup is watertight by vertex equality.  Order: units by ascending key, cells in i, j, k order, triangles in table
+// order; two passes (count, then write at the slab's offset: a stable ballot-prefix compaction) like k_world / k_surface.
+__global__ __launch_bounds__(64) void k_mesh(const float2* __restrict__ pool, const int* __restrict__ slots, const int* __restrict__ keys,
+                                             const int* __restrict__ ht_key, const int* __restrict__ ht_slot, int cap_mask, int shift,
+                                             const unsigned char* __restrict__ table, long* __restrict__ slab_count,
+                                             const long* __restrict__ slab_offset, float* __restrict__ out, int pass) {
+  __shared__ unsigned char s_tab[256 * 16];
+  for (int t = threadIdx.x; t < 256 * 16 / 4; t += 64) reinterpret_cast<unsigned*>(s_tab)[t] = reinterpret_cast<const unsigned*>(table)[t];
+  __syncthreads();
+  const int rank = blockIdx.x >> 6;          // unit in ascending key order
+  const int i = blockIdx.x & 63;
+  const int lane = threadIdx.x;              // = k
+  const int key = keys[rank];
+  const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
+  // the (up to) eight units a slab of cells can touch: [dx][dy][dz]; -1 = that unit does not exist (its voxels count as unobserved)
+  int us[2][2][2];
+  for (int dx = 0; dx < 2; dx++)
+    for (int dy = 0; dy < 2; dy++)
+      for (int dz = 0; dz < 2; dz++) {
+        const bool need = (dx == 0 || i == 63);
+        const bool ok = xi + dx < 512 && yi + dy < 512 && zi + dz < 512;
+        us[dx][dy][dz] = (dx | dy | dz) == 0 ? slots[rank]
+                         : (need && ok ? ht_lookup_slot(ht_key, ht_slot, cap_mask, shift, key + dx * 512 * 512 + dy * 512 + dz) : -1);
+      }
+  const int ia[2] = {i, i == 63 ? 0 : i + 1}, ux[2] = {0, i == 63 ? 1 : 0};      // slab index and unit offset of the two i layers
+  const float2 none = make_float2(0.0f, 0.0f);
+  const float ulf = (float)kUnitLength;
+  const float gx = (float)((double)(i + (xi - 256) * 64) * kUnitLength);
+  const float gz = (float)((double)(lane + (zi - 256) * 64) * kUnitLength);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  long base = pass ? slab_offset[blockIdx.x] : 0;
+  long total = 0;
+  for (int j = 0; j < 64; j++) {
+    // the eight corners of this lane's cell: f[a][b][c] = voxel (i + a, j + b, k + c)
+    float2 f[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int jb = (j + b) & 63, uy = (j + b) >> 6;
+        const int s0 = us[ux[a]][uy][0], s1 = us[ux[a]][uy][1];
+        const size_t ro = (size_t)ia[a] * 4096 + (size_t)jb * 64;
+        const float2 v = s0 >= 0 ? pool[(size_t)s0 * kUnitVox + ro + lane] : none;
+        f[a][b][0] = v;
+        float2 w;
+        w.x = __shfl_down(v.x, 1);
+        w.y = __shfl_down(v.y, 1);
+        if (lane == 63) w = s1 >= 0 ? pool[(size_t)s1 * kUnitVox + ro] : none;
+        f[a][b][1] = w;
+      }
+    bool valid = true;
+    int cs = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const float2 v = f[c & 1][(c >> 1) & 1][c >> 2];
+      valid = valid && v.y != 0.0f;
+      cs |= (v.x < 0.0f ? 1 : 0) << c;
+    }
+    const unsigned char* __restrict__ row = s_tab + cs * 16;
+    int nt = 0;
+    if (valid)
+      while (nt < 5 && row[3 * nt] != 255) nt++;
+    // wave-level exclusive prefix of the triangle counts (k order)
+    int incl = nt;
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int t = __shfl_up(incl, sft);
+      if (lane >= sft) incl += t;
+    }
+    const int wave_total = __shfl(incl, 63);
+    if (pass && nt > 0) {
+      const float gy = (float)((double)(j + (yi - 256) * 64) * kUnitLength);
+      float* __restrict__ o = out + (size_t)(base + total + (incl - nt)) * 9;
+      for (int t = 0; t < 3 * nt; t++) {
+        const int e = row[t];
+        const int axis = e >> 2, u = e & 1, v = (e >> 1) & 1;
+        // lower corner of the edge (coordinate 0 along its axis) and the corner one step up the axis; the eight corner values sit
+        // in registers, so they are picked with select chains, not with a runtime index (that would send them through scratch)
+        const int a0 = axis == 0 ? 0 : u, b0 = axis == 1 ? 0 : (axis == 0 ? u : v), c0 = axis == 2 ? 0 : v;
+        const int cl = a0 | b0 << 1 | c0 << 2, ch = cl | (1 << axis);
+        float2 lo = none, hi = none;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const float2 fv = f[c & 1][(c >> 1) & 1][c >> 2];
+          lo = c == cl ? fv : lo;
+          hi = c == ch ? fv : hi;
+        }
+        const float tt = lo.x / (lo.x - hi.x);
+        // lower end of the edge: lattice position of voxel (i + a0, j + b0, k + c0)
+        float px = a0 ? (float)((double)(i + 1 + (xi - 256) * 64) * kUnitLength) : gx;
+        float py = b0 ? (float)((double)(j + 1 + (yi - 256) * 64) * kUnitLength) : gy;
+        float pz = c0 ? (float)((double)(lane + 1 + (zi - 256) * 64) * kUnitLength) : gz;
+        if (axis == 0) px = px + tt * ulf;
+        if (axis == 1) py = py + tt * ulf;
+        if (axis == 2) pz = pz + tt * ulf;
+        o[3 * t] = px;
+        o[3 * t + 1] = py;
+        o[3 * t + 2] = pz;
+      }
+    }
+    total += wave_total;
+  }
+  (void)lt;
   if (!pass && lane == 0) slab_count[blockIdx.x] = total;
 }
 
@@ -1538,6 +1652,78 @@ done:
   if (d_slots) (void)hipFree(d_slots);
   if (d_cnt) (void)hipFree(d_cnt);
   if (d_off) (void)hipFree(d_off);
+  if (d_out) (void)hipFree(d_out);
+  return rc;
+}
+
+int er_mc_table(unsigned char out[256 * 16]) {
+  if (!out) return er::fail("er_mc_table: NULL argument");
+  memcpy(out, er::mc_table().tri, 256 * 16);
+  return 0;
+}
+
+int er_tsdf_extract_mesh(er_tsdf_t h, float* tri_host, long capacity_triangles, long* n_triangles) {
+  if (!h || !n_triangles) return er::fail("er_tsdf_extract_mesh: NULL argument");
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> keys, slots;
+  if (sorted_units(h, keys, slots)) return 1;
+  const int n = (int)keys.size();
+  *n_triangles = 0;
+  if (n == 0) return 0;
+  const int nslab = n * 64;
+  int *d_keys = nullptr, *d_slots = nullptr;
+  long *d_cnt = nullptr, *d_off = nullptr;
+  unsigned char* d_tab = nullptr;
+  float* d_out = nullptr;
+  int rc = 0;
+  std::vector<long> cnt((size_t)nslab), off((size_t)nslab);
+  long total = 0;
+#define ER_W(expr)                                                                              \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) {                                                                     \
+      rc = er::fail("er_tsdf_extract_mesh: %s failed: %s", #expr, hipGetErrorString(e_));       \
+      goto done;                                                                                \
+    }                                                                                           \
+  } while (0)
+  ER_W(hipMalloc((void**)&d_keys, (size_t)n * sizeof(int)));
+  ER_W(hipMalloc((void**)&d_slots, (size_t)n * sizeof(int)));
+  ER_W(hipMalloc((void**)&d_cnt, (size_t)nslab * sizeof(long)));
+  ER_W(hipMalloc((void**)&d_off, (size_t)nslab * sizeof(long)));
+  ER_W(hipMalloc((void**)&d_tab, 256 * 16));
+  ER_W(hipMemcpyAsync(d_keys, keys.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  ER_W(hipMemcpyAsync(d_slots, slots.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  ER_W(hipMemcpyAsync(d_tab, er::mc_table().tri, 256 * 16, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_mesh, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, h->ht_key, h->ht_slot, h->ht_cap - 1, h->ht_shift, d_tab,
+                     d_cnt, d_off, (float*)nullptr, 0);
+  ER_W(hipGetLastError());
+  ER_W(hipMemcpyAsync(cnt.data(), d_cnt, (size_t)nslab * sizeof(long), hipMemcpyDeviceToHost, h->stream));
+  ER_W(hipStreamSynchronize(h->stream));
+  for (int s = 0; s < nslab; s++) {
+    off[(size_t)s] = total;
+    total += cnt[(size_t)s];
+  }
+  *n_triangles = total;
+  if (tri_host && total > 0) {
+    if (capacity_triangles < total) {
+      rc = er::fail("er_tsdf_extract_mesh: capacity %ld < %ld triangles", capacity_triangles, total);
+      goto done;
+    }
+    ER_W(hipMalloc((void**)&d_out, (size_t)total * 9 * sizeof(float)));
+    ER_W(hipMemcpyAsync(d_off, off.data(), (size_t)nslab * sizeof(long), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_mesh, dim3(nslab), dim3(64), 0, h->stream, h->pool, d_slots, d_keys, h->ht_key, h->ht_slot, h->ht_cap - 1, h->ht_shift, d_tab,
+                       d_cnt, d_off, d_out, 1);
+    ER_W(hipGetLastError());
+    ER_W(hipMemcpyAsync(tri_host, d_out, (size_t)total * 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    ER_W(hipStreamSynchronize(h->stream));
+  }
+#undef ER_W
+done:
+  if (d_keys) (void)hipFree(d_keys);
+  if (d_slots) (void)hipFree(d_slots);
+  if (d_cnt) (void)hipFree(d_cnt);
+  if (d_off) (void)hipFree(d_off);
+  if (d_tab) (void)hipFree(d_tab);
   if (d_out) (void)hipFree(d_out);
   return rc;
 }

@@ -178,6 +178,15 @@ class TSDFVolume:
             _ffi.check(self._lib.er_tsdf_extract_surface(self._h, _ffi.ptr(out), n.value, C.byref(n)), "er_tsdf_extract_surface")
         return out
 
+    def extract_mesh(self):
+        """Marching-cubes triangles of the volume (er_tsdf_extract_mesh) as float32[n, 3, 3] = triangle, vertex, xyz in metres."""
+        n = C.c_long(0)
+        _ffi.check(self._lib.er_tsdf_extract_mesh(self._h, None, 0, C.byref(n)), "er_tsdf_extract_mesh")
+        out = np.empty((n.value, 3, 3), dtype=np.float32)
+        if n.value:
+            _ffi.check(self._lib.er_tsdf_extract_mesh(self._h, _ffi.ptr(out), n.value, C.byref(n)), "er_tsdf_extract_mesh")
+        return out
+
     def SaveWorld(self, filename):
         pts = self.extract_world()
         formats.save_pcd_xyzi(filename, pts)

@@ -136,6 +136,16 @@ int er_tsdf_extract_world(er_tsdf_t h, float* out_host, long capacity, long* cou
  * out_host may be NULL to query the count; capacity is in points. */
 int er_tsdf_extract_surface(er_tsdf_t h, float* out_host, long capacity, long* count);
 
+/* Marching cubes on the resident volume (the triangle connectivity the pipeline's next step -- kinfu's mesh output,
+ * outside the reference repository -- builds from world.pcd).  A cell of 2 x 2 x 2 voxels yields triangles only if all eight are
+ * observed (weight != 0); a corner is inside iff sdf < 0; vertices are the linear zero crossings on the lattice edges, in metres.
+ * tri_host: 9 floats per triangle (three vertices x, y, z; the normal of the winding points towards positive sdf = free space);
+ * order: units by ascending key, cells in i, j, k order, triangles in table order.  Vertices shared by neighbouring cells are
+ * bit-identical, so the soup can be welded by exact comparison.  tri_host == NULL: only counts.  er_mc_table copies the 256 x 16
+ * case table (three edge ids per triangle, 255-terminated; conventions in csrc/er_mc_table.h) -- host only, no GPU needed. */
+int er_tsdf_extract_mesh(er_tsdf_t h, float* tri_host, long capacity_triangles, long* n_triangles);
+int er_mc_table(unsigned char out[256 * 16]);
+
 /* Multi-GPU frame split: for the given key list write sum-ready planes into dev_buf
  * (n_keys * 2 * 64^3 floats: [key][0] = sdf*weight, [key][1] = weight; zeros for keys absent here), and
  * after an external all-reduce(sum) read them back as weight = W, sdf = SW / W. */

@@ -1,0 +1,31 @@
+"""The bench's 50-pair list through the three batch entry points, N times, with wall-clock per phase (for API-trace profiling)."""
+import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from elasticreconstruction_amd import synth
+from elasticreconstruction_amd.icp import Cloud, count_inliers_batch, find_correspondence_batch, icp_align_batch
+n_pairs, n_frag, reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50, 25, int(sys.argv[2]) if len(sys.argv) > 2 else 20
+frs = synth.fragment_set(n_frag, 250000, device="cuda:0")
+clouds = [(Cloud(x, n, 0.03, 0), F) for x, n, F in frs]
+pairs = []
+for k in range(n_pairs):
+    a = k % n_frag
+    b = (a + 1 + (k // n_frag) % 3) % n_frag
+    pairs.append((a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(700 + k, 2.0, 0.02)))
+srcs, tgts = [clouds[b][0] for _, b, _ in pairs], [clouds[a][0] for a, _, _ in pairs]
+Ts = [T for _, _, T in pairs]
+T32 = [T.astype(np.float32) for T in Ts]
+ph = []
+for r in range(reps + 2):
+    t0 = time.perf_counter()
+    cnts = count_inliers_batch(srcs, tgts, Ts, 0.03)
+    t1 = time.perf_counter()
+    fins, iters, _, _ = icp_align_batch(srcs, tgts, T32, 0.03, 20, 1e-6, 0)
+    t2 = time.perf_counter()
+    lists, _ = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in fins], 0.015, 0.8660, True, copy=False)
+    t3 = time.perf_counter()
+    if r >= 2:
+        ph.append((t1 - t0, t2 - t1, t3 - t2))
+ph = np.array(ph) * 1e3
+print("phases ms median", np.median(ph, 0), "min", ph.min(0), "max", ph.max(0), "total median %.2f -> %.0f pairs/s" % (np.median(ph.sum(1)), n_pairs / np.median(ph.sum(1)) * 1e3))

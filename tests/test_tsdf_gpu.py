@@ -521,3 +521,117 @@ def test_zero_crossing_extraction_matches_cpu_restatement(gpu):
     dw = np.minimum(np.abs(got[:, :3] - synth.ROOM_LO), np.abs(got[:, :3] - wall)).min(1)
     assert (dw < 2.0 * ul).mean() > 0.9, "only %.1f %% of the zero crossings lie on a surface" % (100 * (dw < 2.0 * ul).mean())
     vol.close()
+
+
+def _mesh_oracle(units):
+    """numpy restatement of k_mesh (er_tsdf_extract_mesh): the same case table (er_mc_table; its properties are checked on
+    the CPU by tests/test_mc_table.py), cells valid iff all eight voxels are observed, inside iff sdf < 0, vertices
+    pos(L) + (F_L / (F_L - F_H)) * voxel size from the edge's lower voxel in float32; units by ascending key, cells in
+    i, j, k order, triangles in table order.  units: {key: (sdf[262144], weight[262144])}."""
+    import ctypes as C
+    from elasticreconstruction_amd import _ffi
+    tab = np.zeros(256 * 16, np.uint8)
+    assert _ffi.lib().er_mc_table(tab.ctypes.data_as(C.c_void_p)) == 0
+    tab = tab.reshape(256, 16)
+    ul = 3.0 / 512.0
+    ulf = np.float32(ul)
+    out = []
+    for key in sorted(units):
+        xi, yi, zi = key >> 18, (key >> 9) & 511, key & 511
+        S = np.zeros((65, 65, 65), np.float32)
+        W = np.zeros((65, 65, 65), np.float32)
+        for dx in range(2):
+            for dy in range(2):
+                for dz in range(2):
+                    k2 = key + dx * 512 * 512 + dy * 512 + dz
+                    if k2 not in units or xi + dx > 511 or yi + dy > 511 or zi + dz > 511:
+                        continue
+                    s, w = (a.reshape(64, 64, 64) for a in units[k2])
+                    sl = tuple(slice(64, 65) if d else slice(0, 64) for d in (dx, dy, dz))
+                    src = tuple(slice(0, 1) if d else slice(0, 64) for d in (dx, dy, dz))
+                    S[sl], W[sl] = s[src], w[src]
+        corner = lambda A, c: A[(c & 1):(c & 1) + 64, ((c >> 1) & 1):((c >> 1) & 1) + 64, (c >> 2):(c >> 2) + 64]
+        valid = np.ones((64, 64, 64), bool)
+        case = np.zeros((64, 64, 64), np.int32)
+        for c in range(8):
+            valid &= corner(W, c) != 0
+            case |= (corner(S, c) < 0).astype(np.int32) << c
+        ntri = (tab[case][..., 0::3][..., :5] != 255).sum(-1) * valid
+        cells = np.argwhere(ntri > 0)                                        # C order = i, j, k order
+        if not len(cells):
+            continue
+        ci, cj, ck = cells.T
+        cs = case[ci, cj, ck]
+        nt = ntri[ci, cj, ck]
+        verts = np.zeros((len(cells), 15, 3), np.float32)
+        G = [((np.arange(66) + (q - 256) * 64).astype(np.float64) * ul).astype(np.float32) for q in (xi, yi, zi)]
+        for t in range(15):
+            e = tab[cs, t].astype(np.int32)
+            live = 3 * nt > t
+            e = np.where(live, e, 0)
+            axis, u, v = e >> 2, e & 1, (e >> 1) & 1
+            a0 = np.where(axis == 0, 0, u)
+            b0 = np.where(axis == 1, 0, np.where(axis == 0, u, v))
+            c0 = np.where(axis == 2, 0, v)
+            li, lj, lk = ci + a0, cj + b0, ck + c0
+            hi_, hj, hk = li + (axis == 0), lj + (axis == 1), lk + (axis == 2)
+            fl, fh = S[li, lj, lk], S[hi_, hj, hk]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tt = (fl / (fl - fh)).astype(np.float32)
+            p = np.stack([G[0][li], G[1][lj], G[2][lk]], 1)
+            add = (tt * ulf).astype(np.float32)
+            for q in range(3):
+                p[:, q] = np.where(axis == q, (p[:, q] + add).astype(np.float32), p[:, q])
+            verts[:, t] = np.where(live[:, None], p, 0)
+        keep = np.arange(15)[None, :] < (3 * nt)[:, None]
+        out.append(verts[keep].reshape(-1, 3, 3))
+    return np.concatenate(out) if out else np.zeros((0, 3, 3), np.float32)
+
+
+def test_marching_cubes_mesh_matches_cpu_restatement_and_is_watertight(gpu):
+    """er_tsdf_extract_mesh (triangle connectivity): the triangle soup equals the numpy restatement bit for bit
+    (same case table, same float32 vertex expression, same order, cells across unit borders included); welded by exact vertex
+    equality every mesh edge is shared by exactly two triangles with opposite directions except on the border of the observed
+    region; every vertex with two non-zero end values is one of er_tsdf_extract_surface's zero crossings; and the triangles lie
+    on the scene's surfaces.  Scene as in the zero-crossing test: walls exactly between two units."""
+    poses, _ = helpers.golden_rigid()
+    wall = 447.5 * 3.0 / 512.0
+    depth = synth.to_numpy_u16(synth.render_depth(poses, hi=wall, sphere=True))
+    vol = TSDFVolume(max_units=256)
+    vol.IntegrateFrames(depth, poses)
+    got = vol.extract_mesh()
+    units = {int(k): vol.read_unit(k) for k in vol.unit_keys()}
+    want = _mesh_oracle(units)
+    assert got.shape == want.shape and got.shape[0] > 40000, (got.shape, want.shape)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d triangles differ" % int((got != want).any((1, 2)).sum())
+    # weld by exact vertex equality
+    flat = got.reshape(-1, 3)
+    uniq, inv = np.unique(flat.view(np.uint32).reshape(-1, 3), axis=0, return_inverse=True)
+    tri = inv.reshape(-1, 3)
+    e = np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]])
+    e = e[e[:, 0] != e[:, 1]]                                                # (a vertex exactly on a voxel collapses a side)
+    und = np.sort(e, 1)
+    code = und[:, 0].astype(np.int64) * len(uniq) + und[:, 1]
+    vals, cnt = np.unique(code, return_counts=True)
+    assert (cnt <= 2).all(), "an edge is shared by %d triangles" % cnt.max()
+    assert (cnt == 2).mean() > 0.97, "only %.1f %% of the edges are interior" % (100 * (cnt == 2).mean())
+    # orientation: the two triangles of an interior edge traverse it in opposite directions
+    dcode = e[:, 0].astype(np.int64) * len(uniq) + e[:, 1]
+    assert len(np.unique(dcode)) == len(dcode), "a directed edge appears twice: inconsistent winding"
+    # vertices are zero crossings of er_tsdf_extract_surface (those with strictly opposite end signs)
+    surf = vol.extract_surface()[:, :3]
+    sset = set(map(bytes, np.ascontiguousarray(surf).view(np.uint8).reshape(len(surf), 12)))
+    vset = list(map(bytes, np.ascontiguousarray(uniq.view(np.float32)).view(np.uint8).reshape(len(uniq), 12)))
+    hit = sum(1 for b in vset if b in sset)
+    assert hit > 0.95 * len(vset), "%d of %d mesh vertices are zero crossings" % (hit, len(vset))
+    # geometry: on the walls or the sphere within two voxels; normals face the free space (towards the camera side)
+    ul = 3.0 / 512.0
+    cen = got.mean(1)
+    dw = np.minimum(np.abs(cen - synth.ROOM_LO), np.abs(cen - wall)).min(1)
+    ds = np.abs(np.linalg.norm(cen - np.array(synth.SPHERE_C), axis=1) - synth.SPHERE_R)
+    assert (np.minimum(dw, ds) < 2.0 * ul).mean() > 0.9
+    nrm = np.cross(got[:, 1] - got[:, 0], got[:, 2] - got[:, 0])
+    on_sphere = ds < 2.0 * ul
+    out_dir = cen[on_sphere] - np.array(synth.SPHERE_C)
+    assert (np.einsum("ij,ij->i", nrm[on_sphere], out_dir) > 0).mean() > 0.99      # free space is OUTSIDE the sphere
+    vol.close()
