@@ -21,7 +21,7 @@
 //                  appends the unit to the batch list
 //   k_plan         sorts the batch's units by cost (frames in the mask) and resets the work queue k_integrate claims its items from
 //  main stream:
-//   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every   (A4)
+//   k_integrate    per wave an 8 x 8 x 8 cube of a unit: each voxel is loaded ONCE, run against every (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
 //                  frame-by-frame loop with 1/batch of its HBM traffic; hands out the pool slot of a unit
 //                  on its first ever visit
@@ -324,7 +324,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
 // Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
 // batch list sorted by DESCENDING cost = popcount(frame mask) -- the order in which the persistent workgroups of k_integrate
 // claim their items from the work queue (longest-processing-time first) -- and the queue head reset to 0.
-constexpr int kRows = 4;
+constexpr int kRows = 8;                  // register rows per lane of k_integrate: a wave owns an 8 x 8 x 8 cube of voxels
+constexpr int kItemsPerUnit = 128;       // work items per unit: 8 slabs x 16 x 16 voxels per 256-thread workgroup
 
 struct Plan {
   int n_units;
@@ -359,9 +360,9 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
-// Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in
-// kRows = 4 register rows of 64 -- since round 2 a 4 x 8 x 8 box (see the mapping below; round 1: four rows of 64 voxels,
-// lane = k).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
+// Work item = 2048 voxels of a unit for one 256-thread workgroup (128 items per unit); each wave owns 512 of them in
+// kRows = 8 register rows of 64 -- an 8 x 8 x 8 cube (see the mapping below; round 1: four rows of 64 voxels, lane = k; round 2:
+// a 4 x 8 x 8 box).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
 // loop: the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
 // Items come from a work queue in cost order (k_plan).  Schedules measured on MI355X (profiles/r01_ab_variants.txt,
 // r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt; ms per 50-frame launch in round 1): whole slabs 0.565; quarter
@@ -371,8 +372,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
          (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFull));
 }
 
-constexpr int kIntMinBlocks = 5;          // 5 workgroups of 4 waves per CU = 5 waves per SIMD: keeps the kernel at <= 96 VGPRs
-                                          // (98 would round up to 104 and cost the fifth wave: 125.2 k vs 126.9 k frames/s)
+constexpr int kIntMinBlocks = 2;          // register budget: 2 workgroups of 4 waves per CU guaranteed (the kernel needs 144 VGPRs with eight rows
+                                          // per lane; round 2: 96 VGPRs / 5 workgroups with four rows)
 // Pool slot of hash entry e for a wave of k_integrate; hands the slot out on the unit's first ever visit (data_.find( key ) ==
 // end, TSDFVolume.cpp:55; pool memory is zero-filled up front).  Voxel passes run one after the other on the main stream, so
 // only waves of THIS launch can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
-  const int n_items = plan->n_units * (kUnitRes * 4);
+  const int n_items = plan->n_units * kItemsPerUnit;
   // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
   // its own (one atomic per item and workgroup; the grid is 4 persistent workgroups per CU): longest-processing-time-
   // first scheduling.  The culling and the full / sure shortcuts make the real cost of an item unpredictable, and with a static
@@ -429,17 +430,22 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
-    const int e = plan_entry[item >> 8];
-    // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
-    // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs
-    // x 16 x 16 voxels.  2.3 x 4.7 x 4.7 cm instead of the round-1 strip of 2.3 x 37.5 cm (four whole rows of 64 voxels): a
-    // tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, and far
-    // fewer patches that cross a surface (the sure path below applies to most visits).  Measured: strip 114.8 k -> 16 x 16
-    // square of one slab 123.6 k -> box +1 % more (profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt).
-    const int i = ((item >> 4) & 15) * 4;
+    const int e = plan_entry[item >> 7];
+    // The wave owns a COMPACT 8 x 8 x 8 CUBE of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
+    // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 8 slabs
+    // x 16 x 16 voxels.  History of the shape (each step bit-identical by construction: the culling is exact): round 1 a strip of
+    // four whole rows of 64 voxels (2.3 x 37.5 cm) 114.8 k frames/s -> round 2 a 16 x 16 square of one slab 123.6 k -> a 4 x 8 x 8
+    // box +1 % (tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders,
+    // far fewer patches that cross a surface: profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt) -> round 3 the cube:
+    // the per-(patch, frame) work that does not depend on the number of rows (frame constants, loop control, the culling preamble,
+    // the uniform products of the projection) is paid half as often -- 69.2 M instead of 72.6 M wave-instructions per 50-frame
+    // launch -- at 144 VGPRs = 3 waves per SIMD, of which the grid only uses 2: the kernel alone is SLOWER (288 vs 259 us) and the
+    // job faster, 140.7 k vs 136.2 k frames/s, because the SIMDs are shared with the pre-pass kernels and total instructions are
+    // what the chip is short of (profiles/r03i_ab_rows8.txt; 2 rows per lane: 110 k, 16 rows: 117 k).
+    const int i = ((item >> 4) & 7) * 8;
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
     const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
-    constexpr int jspan = 8, kspan = 8, ispan = 4;
+    constexpr int jspan = 8, kspan = 8, ispan = kRows;
     const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
     int slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (slot < 0 && slot != -3) slot = unit_slot_acquire(e, key, ht_slot, unit_key, max_units, counters);   // first visit of the unit
@@ -1079,9 +1085,9 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipStream_t X = h->aux_stream[a], S = h->stream;
   int* nbatch = h->counters + kNbatchSlot[p];
 
-  constexpr int kIntBlocksPerCu = 4;       // persistent workgroups fed by the queue; 4 of the 5 that fit a CU, so that the pre-pass
-                                          // kernels find register space next to them: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s
-                                          // (k_integrate 0.284 / 0.298 / 0.354 ms per launch; profiles/r02G_ab_full_path_and_queue.txt)
+  constexpr int kIntBlocksPerCu = 2;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
+                                           // space next to them (round 2, four rows per lane: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s;
+                                           // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; profiles/r02G_*, r03i_ab_rows8.txt)
   const int wide_grid = h->n_cu * kIntBlocksPerCu;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 validation: the WHOLE -m gpu suite sequentially (as the driver runs it), smoke, default bench line, kernel-trace stats over a
+# Round validation (rounds 2 and 3): the WHOLE -m gpu suite sequentially (as the driver runs it), smoke, default bench line, kernel-trace stats over a
 # whole 3000-frame pass, the PMC passes (separate runs, kernel-trace only), ICP kernel stats.  usage: bash scripts/gpu_round2_final.sh TAG
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; TAG="${1:-r02z}"; mkdir -p gpurun_out
 SECONDS=0

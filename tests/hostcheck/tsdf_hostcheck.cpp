@@ -15,7 +15,7 @@ using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
 static int g_lo_shift = 5;             // granularity of tile_lo in the replay (5 = the 32-pixel tiles k_prepare writes)
-static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 0 = the 16 x 16 square (-DER_SQUARE_PATCH)
+static int g_patch_shape = 2;          // 2 = the 8 x 8 x 8 cube k_integrate gives a wave (default since round 3), 1 = the 4 x 8 x 8 box of round 2, 0 = a 16 x 16 square of one slab
 struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0; };
 
 static bool inverse4(const double* m, double* out);
@@ -99,12 +99,13 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
     if (u.frames.empty()) continue;
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
-    // patch shape of a wave: 1 = the 4 x 8 x 8 box (k_integrate's default), 0 = the 16 x 16 (j, k) square of one slab (-DER_SQUARE_PATCH)
-    const int n_patches = g_patch_shape ? 16 * 64 : 64 * 16;
+    // patch shape of a wave: 2 = the 8 x 8 x 8 cube (k_integrate's default), 1 = the 4 x 8 x 8 box, 0 = the 16 x 16 (j, k) square of one slab
+    const int n_patches = g_patch_shape == 2 ? 8 * 64 : (g_patch_shape ? 16 * 64 : 64 * 16);
     for (int pi = 0; pi < n_patches; pi++) {
       {
         int i0, j0, k0, ni, nj, nk;
-        if (g_patch_shape) { i0 = (pi >> 6) * 4; j0 = ((pi >> 3) & 7) * 8; k0 = (pi & 7) * 8; ni = 4; nj = 8; nk = 8; }
+        if (g_patch_shape == 2) { i0 = (pi >> 6) * 8; j0 = ((pi >> 3) & 7) * 8; k0 = (pi & 7) * 8; ni = 8; nj = 8; nk = 8; }
+        else if (g_patch_shape) { i0 = (pi >> 6) * 4; j0 = ((pi >> 3) & 7) * 8; k0 = (pi & 7) * 8; ni = 4; nj = 8; nk = 8; }
         else { i0 = pi >> 4; j0 = ((pi >> 2) & 3) * 16; k0 = (pi & 3) * 16; ni = 1; nj = 16; nk = 16; }
         // the same (patch, frame) culling k_integrate applies before its frame loop
         std::vector<int> frames;
@@ -128,13 +129,14 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           if (g_patch_shape) { i = i0 + (t >> 6); j = j0 + ((t >> 3) & 7); k = k0 + (t & 7); }
           else { i = i0; j = j0 + (t >> 4); k = k0 + (t & 15); }
         };
-        // frame-major over the patch, like the wave of k_integrate: all 256 lanes against frame q, then the next frame
-        float dpv[256], d2v[256];
-        bool frev[256], behv[256];
+        // frame-major over the patch, like the wave of k_integrate: all lanes x register rows against frame q, then the next frame
+        const int nvox = ni * nj * nk;
+        float dpv[512], d2v[512];
+        bool frev[512], behv[512];
         for (size_t q = 0; q < frames.size(); q++) {
           const int f = frames[q];
           bool need = false, unsure_any = false;
-          for (int t = 0; t < 256; t++) {
+          for (int t = 0; t < nvox; t++) {
             int i, j, k;
             voxel_of(t, i, j, k);
             const int l = (i * 64 + j) * 64 + k;
@@ -169,7 +171,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           v->visited++;
           v->sure += !need;
           v->unsure_pf += unsure_any;
-          for (int t = 0; t < 256; t++) {
+          for (int t = 0; t < nvox; t++) {
             int i, j, k;
             voxel_of(t, i, j, k);
             const int l = (i * 64 + j) * 64 + k;

@@ -116,15 +116,16 @@ def test_device_math_rigid_matches_golden(hc):
     print("full (patch, frame) visits: %d of %d kept (%.1f %%)" % (hc.hc_full(v.h), kept, 100.0 * hc.hc_full(v.h) / max(kept, 1)))
 
 
-@pytest.mark.parametrize("shape", [0, 1])
+@pytest.mark.parametrize("shape", [0, 1, 2])
 def test_device_math_warp_matches_golden(hc, shape):
-    """shape 1: the 4 x 8 x 8 box k_integrate gives a wave (patch_may_update_box with eight corners); shape 0: the 16 x 16 square
-    of one slab (-DER_SQUARE_PATCH on the device).  Same golden digests either way: the culling and both shortcuts are exact."""
+    """shape 2: the 8 x 8 x 8 cube k_integrate gives a wave since round 3 (patch_may_update_box with eight corners); shape 1: the
+    4 x 8 x 8 box of round 2; shape 0: a 16 x 16 square of one slab.  Same golden digests every way: the culling and the shortcuts
+    are exact whatever the patch."""
     hc.hc_set_patch_shape(shape)
     try:
         _warp_matches_golden(hc)
     finally:
-        hc.hc_set_patch_shape(1)
+        hc.hc_set_patch_shape(2)
 
 
 def _warp_matches_golden(hc):

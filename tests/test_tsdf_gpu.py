@@ -624,14 +624,18 @@ def test_marching_cubes_mesh_matches_cpu_restatement_and_is_watertight(gpu):
     vset = list(map(bytes, np.ascontiguousarray(uniq.view(np.float32)).view(np.uint8).reshape(len(uniq), 12)))
     hit = sum(1 for b in vset if b in sset)
     assert hit > 0.95 * len(vset), "%d of %d mesh vertices are zero crossings" % (hit, len(vset))
-    # geometry: on the walls or the sphere within two voxels; normals face the free space (towards the camera side)
+    # geometry: on the walls (or the sphere, when a pose sees it) within two voxels; normals face the free space = the room's interior
     ul = 3.0 / 512.0
     cen = got.mean(1)
-    dw = np.minimum(np.abs(cen - synth.ROOM_LO), np.abs(cen - wall)).min(1)
+    dlo, dhi = np.abs(cen - synth.ROOM_LO), np.abs(cen - wall)
+    dw = np.minimum(dlo, dhi).min(1)
     ds = np.abs(np.linalg.norm(cen - np.array(synth.SPHERE_C), axis=1) - synth.SPHERE_R)
     assert (np.minimum(dw, ds) < 2.0 * ul).mean() > 0.9
     nrm = np.cross(got[:, 1] - got[:, 0], got[:, 2] - got[:, 0])
-    on_sphere = ds < 2.0 * ul
-    out_dir = cen[on_sphere] - np.array(synth.SPHERE_C)
-    assert (np.einsum("ij,ij->i", nrm[on_sphere], out_dir) > 0).mean() > 0.99      # free space is OUTSIDE the sphere
+    flat_wall = (dw < 0.5 * ul) & (ds > 0.2)                                   # clearly on ONE wall, away from the sphere and the corners
+    ax = np.minimum(dlo, dhi)[flat_wall].argmin(1)
+    second = np.sort(np.minimum(dlo, dhi)[flat_wall], 1)[:, 1]
+    inward = np.where(dlo[flat_wall, ax] < dhi[flat_wall, ax], 1.0, -1.0)      # at the low wall the interior lies towards +axis
+    ok = (nrm[flat_wall, ax] * inward > 0)[second > 0.1]
+    assert ok.size > 10000 and ok.mean() > 0.999, "%d wall triangles, %.2f %% face the interior" % (ok.size, 100 * ok.mean())
     vol.close()
