@@ -286,6 +286,7 @@ struct PairDev {
   const float* src_nrm;
   const float* tgt_xyz;
   const float* tgt_nrm;
+  const float4* tgt_xn;          // target, file order, {xyz | normal} records of 32 bytes
   Grid g;                        // the target's uniform grid
   Mat12d T;                      // transform of the pre-check / FindCorrespondence (Matrix4d, rows 0..2)
   float* X;                      // [3 n]   ICP: the source as the loop transforms it (cell-sorted order)
@@ -294,7 +295,7 @@ struct PairDev {
   int* block_offset;             // [nb]
   int* pairs;                    // [2 n]   compacted (target index, source index) list
   double* partial;               // [nbi][32] per-workgroup sums of one ICP iteration
-  int n, nb, nbi, pad;           // source points, ceil(n / 256), ceil(n / (256 kIcpPts))
+  int n, nb, nbi, pts;           // source points, ceil(n / 256), ceil(n / (256 pts)); pts = slices of 256 points per workgroup of k_icp_iter
 };
 
 // ---- the ICP loop's state lives on the device ------------------------------------------------------------------------
@@ -476,7 +477,8 @@ __device__ void dev_icp_decide(const double* acc, IcpDev* st, IcpParams P) {
 }
 
 
-constexpr int kIcpPts = 4;                 // source points per thread of k_icp_iter (the 29 cross-lane sums are paid once per workgroup)
+constexpr int kIcpPtsMax = 8;              // source points per thread of k_icp_iter (the 29 cross-lane sums are paid once per workgroup): the host
+                                           // picks 8 when the group still fills the chip with workgroups, fewer for short lists (PairDev::pts)
 
 // Registration pre-check, CorresApp.cpp:257-264, for a group of pairs: counts[pair] = #{k : d2 < reg_dist^2}.  blockIdx.x
 // strides over the pair's points; ONE atomic per workgroup.
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
 //   later:       X <- delta * X (the previous iteration's increment, float32);
 //   correspondence estimation (exact NN, kept if d^2 <= max_dist^2); the sums of TransformationEstimationPointToPlaneLLS over
 //   the kept correspondences: acc[0..20] upper triangle of AtA row by row, [21..26] Atb, [27] sum of d^2, [28] count.
-// A thread takes kIcpPts points (slices of kBlock consecutive points: the NN search is a workgroup-cooperative step per slice)
+// A thread takes `pts` points (slices of kBlock consecutive points: the NN search is a workgroup-cooperative step per slice)
 // and adds their rows up privately; then thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in
 // `partial`; k_icp_final adds the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from
 // run to run (they still differ from a sequential CPU sum in the last bits).
@@ -531,9 +533,10 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
   double v[29];
 #pragma unroll
   for (int t = 0; t < 29; t++) v[t] = 0.0;
-  for (int c = 0; c < kIcpPts; c++) {
-    const int k = (blockIdx.x * kIcpPts + c) * kBlock + threadIdx.x;
-    if ((blockIdx.x * kIcpPts + c) * kBlock >= n) break;     // wave-uniform
+  const int pts = p.pts;
+  for (int c = 0; c < pts; c++) {
+    const int k = (blockIdx.x * pts + c) * kBlock + threadIdx.x;
+    if ((blockIdx.x * pts + c) * kBlock >= n) break;         // wave-uniform
     float sx = 0.f, sy = 0.f, sz = 0.f;
     if (k < n) {
       if (first) {
@@ -557,8 +560,8 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
     float d;
     const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
-      const float dx = p.tgt_xyz[3 * i], dy = p.tgt_xyz[3 * i + 1], dz = p.tgt_xyz[3 * i + 2];
-      const float nx = p.tgt_nrm[3 * i], ny = p.tgt_nrm[3 * i + 1], nz = p.tgt_nrm[3 * i + 2];
+      const float4 tp = p.tgt_xn[2 * (size_t)i], tn = p.tgt_xn[2 * (size_t)i + 1];
+      const float dx = tp.x, dy = tp.y, dz = tp.z, nx = tn.x, ny = tn.y, nz = tn.z;
       v[27] += (double)d;
       v[28] += 1.0;
       if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
@@ -577,20 +580,31 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
       }
     }
   }
-  // workgroup partial
+  // workgroup partial.  Wave level: a halving butterfly over the 32 value slots (29 used) -- at each step the upper half of the lanes
+  // keeps the upper half of the remaining slots and hands the lower half over (and vice versa): 16 + 8 + 4 + 2 + 1 exchanges and a final
+  // pair add instead of 29 x 6 shuffle-adds; lane l ends up with the wave total of slot l >> 1.  A fixed order: bit-reproducible.
   __shared__ double part[kBlock / 64][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double w[32];
 #pragma unroll
-  for (int t = 0; t < 29; t++) {
-    double q = v[t];
-    for (int off = 32; off > 0; off >>= 1) q += __shfl_down(q, off);
-    if (lane == 0) part[wave][t] = q;
+  for (int t = 0; t < 32; t++) w[t] = t < 29 ? v[t] : 0.0;
+#pragma unroll
+  for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int t = 0; t < half; t++) {
+      const double send = upper ? w[t] : w[t + half];
+      const double keep = upper ? w[t + half] : w[t];
+      w[t] = keep + __shfl_xor(send, mask);
+    }
   }
+  w[0] += __shfl_xor(w[0], 1);
+  if ((lane & 1) == 0) part[wave][lane >> 1] = w[0];
   __syncthreads();
   if (threadIdx.x < 29) {
     double q = 0.0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; w++) q += part[w][threadIdx.x];
+    for (int w2 = 0; w2 < kBlock / 64; w2++) q += part[w2][threadIdx.x];
     p.partial[(size_t)blockIdx.x * 32 + threadIdx.x] = q;
   }
 }
@@ -676,7 +690,8 @@ __global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict_
     const float tny = (float)((p.T.m[4] * nx + p.T.m[5] * ny) + p.T.m[6] * nz);
     const float tnz = (float)((p.T.m[8] * nx + p.T.m[9] * ny) + p.T.m[10] * nz);
     // NormalDot, CorresApp.h:58-60: float32 products/sums, compared as double
-    const float dot = (p.tgt_nrm[3 * i] * tnx + p.tgt_nrm[3 * i + 1] * tny) + p.tgt_nrm[3 * i + 2] * tnz;
+    const float4 tn = p.tgt_xn[2 * (size_t)i + 1];                                              // the matched target normal: one aligned 16-byte load
+    const float dot = (tn.x * tnx + tn.y * tny) + tn.z * tnz;
     if ((double)dot > normal_cos) m = i;                                                       // :155
   }
   p.match[k] = m;
@@ -888,6 +903,15 @@ __global__ __launch_bounds__(kBlock) void k_grid_gather(const float* __restrict_
   sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float((int)i));
 }
 
+// xn[2 i] = {x, y, z, 0}, xn[2 i + 1] = {nx, ny, nz, 0} in file order: the matched target point of k_icp_iter is one aligned
+// 32-byte record = one cache line instead of two 12-byte gathers from two arrays (those were ~30 % of an ICP iteration).
+__global__ __launch_bounds__(kBlock) void k_interleave(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, float4* __restrict__ xn) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  xn[2 * (size_t)i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+  xn[2 * (size_t)i + 1] = make_float4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], 0.f);
+}
+
 // Grow-only scratch of the grid build, one per device, handed out under a mutex (er_cloud_create may be called from
 // several host threads; builds on one device then take turns).
 struct GridScratch {
@@ -909,6 +933,7 @@ struct er_cloud_s {
   int device = 0, n = 0;
   float *xyz = nullptr, *nrm = nullptr;
   float4* sorted = nullptr;
+  float4* xn = nullptr;         // [2n] file order: {x, y, z, 0}, {nx, ny, nz, 0} -- ONE 32-byte gather per matched point in k_icp_iter
   int* cell_start = nullptr;
   Grid grid{};
   float radius_cap = 0.f;       // largest search radius the grid supports
@@ -925,7 +950,7 @@ Grid grid_of(const er_cloud_s* c) { return c->grid; }
 // The pool is never freed behind the HIP runtime's back (er_icp_release_workspaces does it).
 struct Group {
   int device = 0;
-  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;   // two copy streams: list copies alternate between them
   hipEvent_t ev = nullptr, ev2 = nullptr;
   std::vector<hipEvent_t> sub_ev;  // one per sub-group of er_find_correspondence_batch (grown on demand)
   int cap_pairs = 0;
@@ -974,6 +999,7 @@ void group_destroy(Group* g) {
   (void)hipSetDevice(g->device);
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+  if (g->copy_stream2) (void)hipStreamSynchronize(g->copy_stream2);
   group_free_slabs(g);
   group_free_pairs(g);
   if (g->stage) (void)hipHostFree(g->stage);
@@ -983,11 +1009,12 @@ void group_destroy(Group* g) {
     if (e) (void)hipEventDestroy(e);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+  if (g->copy_stream2) (void)hipStreamDestroy(g->copy_stream2);
   delete g;
 }
 
 int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
-int nparts_of(int n) { return (std::max(n, 1) + kBlock * kIcpPts - 1) / (kBlock * kIcpPts); }
+int nparts_of(int n, int pts) { return (std::max(n, 1) + kBlock * pts - 1) / (kBlock * pts); }
 
 // Room for `pairs` descriptors and, when per-point scratch is needed, for `points` source points in `blocks` / `parts` blocks.
 int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t parts) {
@@ -1014,6 +1041,7 @@ int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t part
   if (points > g->cap_points || blocks > g->cap_blocks || parts > g->cap_parts) {
     ER_HIP_TRY(hipStreamSynchronize(g->stream));
     if (g->copy_stream) ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+    if (g->copy_stream2) ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
     const size_t cp = std::max(points + points / 8, g->cap_points), cb = std::max(blocks + blocks / 8, g->cap_blocks),
                  cq = std::max(parts + parts / 8, g->cap_parts);
     group_free_slabs(g);
@@ -1060,6 +1088,7 @@ Group* group_acquire(int device) {
     g->device = device;
     if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&g->copy_stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&g->ev2, hipEventDisableTiming) != hipSuccess) {
       er::fail("ICP workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -1076,6 +1105,7 @@ struct GroupLease {             // RAII: the group of one API call
     if (!g) return;
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
+    if (g->copy_stream2) (void)hipStreamSynchronize(g->copy_stream2);
     std::lock_guard<std::mutex> lock(pool().mu);
     pool().idle.push_back(g);
   }
@@ -1110,11 +1140,15 @@ int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double r
 // the pre-check needs none).  T16: one row-major float64 4x4 per pair, or NULL.
 int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_cloud_t* tgt, const double* T16, bool scratch) {
   size_t points = 0, blocks = 0, parts = 0;
+  // points per thread of k_icp_iter: as many as leave ~4 workgroups per CU in flight (one pair of 250 k points alone: 2 -> 490 workgroups)
+  long all_blocks = 0;
+  for (int q = 0; q < m; q++) all_blocks += nblocks_of(src[i0 + q]->n);
+  const int pts = all_blocks >= 8 * 1024 ? kIcpPtsMax : (all_blocks >= 4 * 1024 ? 4 : (all_blocks >= 1024 ? 2 : 1));
   for (int q = 0; q < m; q++) {
     const int n = src[i0 + q]->n;
     points += (size_t)((n + 3) & ~3);                          // slices stay 16-byte aligned
     blocks += (size_t)nblocks_of(n);
-    parts += (size_t)nparts_of(n);
+    parts += (size_t)nparts_of(n, pts);
   }
   if (group_reserve(g, m, scratch ? points : 0, scratch ? blocks : 0, scratch ? parts : 0)) return 1;
   size_t op = 0, ob = 0, oq = 0;
@@ -1124,11 +1158,11 @@ int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_clou
     PairDev& P = g->h_pairs[q];
     memset(&P, 0, sizeof P);
     P.src_sorted = s->sorted; P.src_xyz = s->xyz; P.src_nrm = s->nrm;
-    P.tgt_xyz = t->xyz; P.tgt_nrm = t->nrm;
+    P.tgt_xyz = t->xyz; P.tgt_nrm = t->nrm; P.tgt_xn = t->xn;
     P.g = grid_of(t);
     if (T16)
       for (int c = 0; c < 12; c++) P.T.m[c] = T16[(size_t)(i0 + q) * 16 + c];
-    P.n = s->n; P.nb = nblocks_of(s->n); P.nbi = nparts_of(s->n);
+    P.n = s->n; P.nb = nblocks_of(s->n); P.nbi = nparts_of(s->n, pts); P.pts = pts;
     if (scratch) {
       P.X = g->X + 3 * op; P.match = g->match + op; P.pairs = g->pairs + 2 * op;
       P.block_count = g->block_count + ob; P.block_offset = g->block_offset + ob;
@@ -1216,11 +1250,12 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
       return 1;                                                                               \
     }                                                                                         \
   } while (0)
-  // one allocation for the three per-point arrays: [xyz 3n | normals 3n | sorted n float4]
-  const size_t off_sorted = (nn * 6 + 3) / 4 * 4;                 // float4 needs 16-byte alignment
-  ER_CALLOC(c->xyz, (off_sorted + nn * 4) * sizeof(float));
+  // one allocation for the per-point arrays: [xyz 3n | normals 3n | sorted n float4 | xn 2n float4]
+  const size_t off_sorted = (nn * 6 + 7) / 8 * 8;                 // float4 needs 16-byte alignment (32 for the xn records)
+  ER_CALLOC(c->xyz, (off_sorted + nn * 4 + nn * 8) * sizeof(float));
   c->nrm = c->xyz + nn * 3;
   c->sorted = reinterpret_cast<float4*>(c->xyz + off_sorted);
+  c->xn = c->sorted + nn;
   if (n > 0) {
     ER_CTRY(hipMemcpyAsync(c->xyz, xyz_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
     ER_CTRY(hipMemcpyAsync(c->nrm, normal_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
@@ -1300,6 +1335,7 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
     tmp = gs.cub_cap;
     ER_CTRY(hipcub::DeviceScan::InclusiveSum(gs.cub, tmp, c->cell_start, c->cell_start, ncell + 1, (hipStream_t) nullptr));
     hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, gs.idx[1], n, c->sorted);
+    hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, c->nrm, n, c->xn);
     ER_CTRY(hipGetLastError());
   }
   ER_CTRY(hipStreamSynchronize(nullptr));          // the caller's host arrays and the shared scratch are free again
@@ -1515,6 +1551,7 @@ static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool w
 static int stage_reserve(Group* g, size_t ints) {
   if (ints <= g->stage_cap) return 0;
   ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
   if (g->stage) (void)hipHostFree(g->stage);
   g->stage = nullptr;
   g->stage_cap = 0;
@@ -1562,8 +1599,9 @@ int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float co
 
 // FindCorrespondence of a pair list (CorresApp.cpp:112-210).  A group is described once; its pairs run in SUB-GROUPS of kCorrSub:
 // search + compaction chain of sub-group s+1 are enqueued before the host waits for the totals of sub-group s, and the list copies
-// of s (exactly total pairs each; PCIe-bound: 8 bytes per correspondence) run on the copy stream underneath.
-constexpr int kCorrSub = 16;
+// of s (exactly total pairs each; PCIe-bound: 8 bytes per correspondence) run underneath on TWO copy streams in turn (one stream
+// leaves ~12 us between consecutive copies: 38 instead of 53 GB/s, profiles/r03l_icp_timeline.txt).
+constexpr int kCorrSub = 8;
 int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double dist, double normal_cos,
                                  int* const* pairs_host, const int* capacity, int* n_pairs, double* info36) {
   int device;
@@ -1590,6 +1628,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
   for (int i0 = 0; i0 < n; i0 += G) {
     const int m = std::min(G, n - i0);
     ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));          // the previous group's lists have left the slabs
+    ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
     if (group_describe(g, i0, m, src, tgt, T, true)) return 1;
     ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, (size_t)m * kAcc * sizeof(double), g->stream));
     const int nsub = (m + kCorrSub - 1) / kCorrSub;
@@ -1625,6 +1664,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       }
       // copies of this sub-group's lists on the copy stream (its kernels are done: evs[s] has been waited for)
       ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream, evs[(size_t)s], 0));
+      ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream2, evs[(size_t)s], 0));
       for (int q = 0; q < ms; q++) {
         const int i = i0 + s0 + q, ncopy = std::min(n_pairs[i], capacity[i]);
         if (ncopy <= 0) continue;
@@ -1634,7 +1674,8 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
           dst = g->stage + stage_used;
           stage_used += (size_t)ncopy * 2;
         }
-        if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, g->copy_stream) != hipSuccess) {
+        if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, (i & 1) ? g->copy_stream2 : g->copy_stream) !=
+            hipSuccess) {
           cleanup();
           return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError()));
         }
@@ -1643,6 +1684,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     cleanup();
   }
   ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
+  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
   for (int i = 0; i < n; i++)
     if (staged[(size_t)i] >= 0) memcpy(pairs_host[i], g->stage + staged[(size_t)i], (size_t)std::min(n_pairs[i], capacity[i]) * 2 * sizeof(int));
   return rc;
