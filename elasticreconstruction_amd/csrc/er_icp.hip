@@ -530,9 +530,15 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
   const int apply = first ? st.init_apply : st.apply;        // wave-uniform (scalar loads)
   const float* __restrict__ dm = first ? st.fin : st.delta;
   float* __restrict__ X = p.X;
-  double v[29];
-#pragma unroll
-  for (int t = 0; t < 29; t++) v[t] = 0.0;
+  // Per slice of 256 points: NN, the point's 29 row values, a wave-level halving butterfly over the 32 value slots (29 used) -- at each
+  // step the upper half of the lanes keeps the upper half of the remaining slots and hands the lower half over (and vice versa):
+  // 16 + 8 + 4 + 2 + 1 exchanges and a final pair add instead of 29 x 6 shuffle-adds; lane l ends up with the wave total of slot
+  // l >> 1 -- and the wave adds it to ITS row of the LDS accumulator.  The row values are live only between the NN search and the
+  // butterfly, so the kernel keeps the register footprint of the plain NN kernels (occupancy is what the latency-bound search
+  // needs: with thread-private float64 sums carried across the slices the kernel held 126 VGPRs = 4 waves per SIMD).
+  __shared__ double part[kBlock / 64][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < 32) part[wave][lane] = 0.0;                     // (each wave only ever touches its own row: no barrier needed until the end)
   const int pts = p.pts;
   for (int c = 0; c < pts; c++) {
     const int k = (blockIdx.x * pts + c) * kBlock + threadIdx.x;
@@ -559,47 +565,42 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
     }
     float d;
     const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
+    double w[32];
+#pragma unroll
+    for (int t = 0; t < 32; t++) w[t] = 0.0;
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
       const float4 tp = p.tgt_xn[2 * (size_t)i], tn = p.tgt_xn[2 * (size_t)i + 1];
       const float dx = tp.x, dy = tp.y, dz = tp.z, nx = tn.x, ny = tn.y, nz = tn.z;
-      v[27] += (double)d;
-      v[28] += 1.0;
+      w[27] = (double)d;
+      w[28] = 1.0;
       if (isfinite(sx) && isfinite(sy) && isfinite(sz) && isfinite(nx) && isfinite(ny) && isfinite(nz)) {
         const double a = (double)(nz * sy - ny * sz);      // float32 expressions widened to double (PCL)
         const double b = (double)(nx * sz - nz * sx);
         const double cc = (double)(ny * sx - nx * sy);
         const double dnx = nx, dny = ny, dnz = nz;
-        v[0] += a * a;  v[1] += a * b;  v[2] += a * cc;  v[3] += a * dnx;  v[4] += a * dny;  v[5] += a * dnz;
-        v[6] += b * b;  v[7] += b * cc;  v[8] += b * dnx; v[9] += b * dny; v[10] += b * dnz;
-        v[11] += cc * cc; v[12] += cc * dnx; v[13] += cc * dny; v[14] += cc * dnz;
-        v[15] += dnx * dnx; v[16] += dnx * dny; v[17] += dnx * dnz;
-        v[18] += dny * dny; v[19] += dny * dnz;
-        v[20] += dnz * dnz;
+        w[0] = a * a;  w[1] = a * b;  w[2] = a * cc;  w[3] = a * dnx;  w[4] = a * dny;  w[5] = a * dnz;
+        w[6] = b * b;  w[7] = b * cc;  w[8] = b * dnx; w[9] = b * dny; w[10] = b * dnz;
+        w[11] = cc * cc; w[12] = cc * dnx; w[13] = cc * dny; w[14] = cc * dnz;
+        w[15] = dnx * dnx; w[16] = dnx * dny; w[17] = dnx * dnz;
+        w[18] = dny * dny; w[19] = dny * dnz;
+        w[20] = dnz * dnz;
         const double e = (double)(nx * dx + ny * dy + nz * dz - nx * sx - ny * sy - nz * sz);
-        v[21] += a * e; v[22] += b * e; v[23] += cc * e; v[24] += dnx * e; v[25] += dny * e; v[26] += dnz * e;
+        w[21] = a * e; w[22] = b * e; w[23] = cc * e; w[24] = dnx * e; w[25] = dny * e; w[26] = dnz * e;
       }
     }
-  }
-  // workgroup partial.  Wave level: a halving butterfly over the 32 value slots (29 used) -- at each step the upper half of the lanes
-  // keeps the upper half of the remaining slots and hands the lower half over (and vice versa): 16 + 8 + 4 + 2 + 1 exchanges and a final
-  // pair add instead of 29 x 6 shuffle-adds; lane l ends up with the wave total of slot l >> 1.  A fixed order: bit-reproducible.
-  __shared__ double part[kBlock / 64][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double w[32];
 #pragma unroll
-  for (int t = 0; t < 32; t++) w[t] = t < 29 ? v[t] : 0.0;
+    for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
+      const bool upper = (lane & mask) != 0;
 #pragma unroll
-  for (int half = 16, mask = 32; half >= 1; half >>= 1, mask >>= 1) {
-    const bool upper = (lane & mask) != 0;
-#pragma unroll
-    for (int t = 0; t < half; t++) {
-      const double send = upper ? w[t] : w[t + half];
-      const double keep = upper ? w[t + half] : w[t];
-      w[t] = keep + __shfl_xor(send, mask);
+      for (int t = 0; t < half; t++) {
+        const double send = upper ? w[t] : w[t + half];
+        const double keep = upper ? w[t + half] : w[t];
+        w[t] = keep + __shfl_xor(send, mask);
+      }
     }
+    w[0] += __shfl_xor(w[0], 1);
+    if ((lane & 1) == 0) part[wave][lane >> 1] += w[0];
   }
-  w[0] += __shfl_xor(w[0], 1);
-  if ((lane & 1) == 0) part[wave][lane >> 1] = w[0];
   __syncthreads();
   if (threadIdx.x < 29) {
     double q = 0.0;
