@@ -16,7 +16,7 @@ using namespace er;
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
 static int g_lo_shift = 5;             // granularity of tile_lo in the replay (5 = the 32-pixel tiles k_prepare writes)
 static int g_patch_shape = 2;          // 2 = the 8 x 8 x 8 cube k_integrate gives a wave (default since round 3), 1 = the 4 x 8 x 8 box of round 2, 0 = a 16 x 16 square of one slab
-struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0; };
+struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0, exact_rows = 0, exact_rows_needing = 0; };
 
 static bool inverse4(const double* m, double* out);
 
@@ -136,6 +136,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
         for (size_t q = 0; q < frames.size(); q++) {
           const int f = frames[q];
           bool need = false, unsure_any = false;
+          bool row_need[8] = {false, false, false, false, false, false, false, false};
           for (int t = 0; t < nvox; t++) {
             int i, j, k;
             voxel_of(t, i, j, k);
@@ -164,6 +165,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
             const bool unsure = !(frev[t] | behv[t]);
             unsure_any |= unsure;
             need |= unsure | (frev[t] & !voxel_free_trivial(u.sdf[l], u.w[l]));
+            row_need[(t >> 6) & 7] |= unsure | (frev[t] & !voxel_free_trivial(u.sdf[l], u.w[l]));
           }
           // k_integrate's "sure" path: taken for the wave when no lane needs the exact update; cross-checked lane by lane
           // against the full update (a provably-behind lane must not change, a provably-free trivial lane becomes (1, W + 1)).
@@ -171,6 +173,8 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           v->visited++;
           v->sure += !need;
           v->unsure_pf += unsure_any;
+          if (need)
+            for (int r = 0; r < nvox / 64; r++) { v->exact_rows++; v->exact_rows_needing += row_need[r]; }
           for (int t = 0; t < nvox; t++) {
             int i, j, k;
             voxel_of(t, i, j, k);
@@ -211,6 +215,8 @@ long hc_visited(void* h) { return static_cast<HcVolume*>(h)->visited; }
 long hc_full(void* h) { return static_cast<HcVolume*>(h)->full_pf; }
 long hc_full_violations(void* h) { return static_cast<HcVolume*>(h)->full_violations; }
 long hc_unsure_pf(void* h) { return static_cast<HcVolume*>(h)->unsure_pf; }
+long hc_exact_rows(void* h) { return static_cast<HcVolume*>(h)->exact_rows; }
+long hc_exact_rows_needing(void* h) { return static_cast<HcVolume*>(h)->exact_rows_needing; }
 long hc_sure_violations(void* h) { return static_cast<HcVolume*>(h)->sure_violations; }
 long hc_culled(void* h) { return static_cast<HcVolume*>(h)->culled; }
 long hc_inside(void* h) { return static_cast<HcVolume*>(h)->inside; }

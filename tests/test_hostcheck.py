@@ -42,7 +42,7 @@ def hc():
     L.hc_inside.argtypes = [vp]
     L.hc_inside_violations.restype = C.c_long
     L.hc_inside_violations.argtypes = [vp]
-    for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations", "hc_full", "hc_full_violations"):
+    for name in ("hc_sure", "hc_visited", "hc_unsure_pf", "hc_sure_violations", "hc_full", "hc_full_violations", "hc_exact_rows", "hc_exact_rows_needing"):
         getattr(L, name).restype = C.c_long
         getattr(L, name).argtypes = [vp]
     L.hc_set_patch_shape.restype = None
@@ -151,6 +151,8 @@ def _warp_matches_golden(hc):
     # the FULL verdict (every voxel of the patch updated with tsdf = 1: no projection, no sample): checked voxel by voxel
     assert hc.hc_full_violations(v.h) == 0
     print("full (patch, frame) visits: %d of %d kept (%.1f %%)" % (hc.hc_full(v.h), hc.hc_kept(v.h), 100.0 * hc.hc_full(v.h) / max(hc.hc_kept(v.h), 1)))
+    print("register rows of the exact-path visits that need the exact update: %d of %d (%.1f %%)" % (
+        hc.hc_exact_rows_needing(v.h), hc.hc_exact_rows(v.h), 100.0 * hc.hc_exact_rows_needing(v.h) / max(hc.hc_exact_rows(v.h), 1)))
 
 
 def test_device_math_custom_camera_vs_oracle(hc):
