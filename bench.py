@@ -480,6 +480,43 @@ def fopt_section(device):
     return res
 
 
+def other_configs(device):
+    """BASELINE.json configs[3] and configs[4] at one GPU's share, each as a CHILD run of this file (its own process, volume and
+    scene; the headline's numbers are final before this starts): short passes, no CPU legs.  A child that fails or overruns leaves
+    its error text here and never touches the headline line."""
+    import subprocess
+    import time
+    res = {"what": "python bench.py --config 4 | 5 --min-seconds 0.2 --cpu-sample 0, run after the headline measurement in child "
+                   "processes; one GPU: configs[3] forces the frame-split merge (er_tsdf_allreduce on a 1-rank communicator)"}
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)), MASTER_PORT="29531")
+    if "HIP_VISIBLE_DEVICES" not in os.environ:
+        env["LOCAL_RANK"] = "0"
+    for cfg in (4, 5):
+        t0 = time.time()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--min-seconds", "0.2", "--cpu-sample", "0",
+                                "--no-alone", "--no-streamed", "--other-configs", "0"], env=env, stdout=subprocess.PIPE,
+                               stderr=subprocess.PIPE, timeout=240)
+            line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                res["configs[%d]" % (cfg - 1)] = {"error": "rc %d: %s" % (p.returncode, p.stderr.decode()[-400:])}
+                continue
+            d = json.loads(line[-1])
+            r = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "scaling": d["scaling"],
+                 "workload": d["config"]["workload"], "frames": d["config"]["frames_per_gpu"],
+                 "volume_units_touched": d["config"].get("volume_units_touched"),
+                 "merge_union_units": d["config"].get("merge_union_units"), "merge_impl": d["config"].get("merge_impl"),
+                 "roofline_frac": (d.get("roofline") or {}).get("frac"), "wall_s": time.time() - t0}
+            i = d.get("icp")
+            if i:
+                r["icp"] = {k: i[k] for k in ("pairs_per_s", "pairs_total", "pairs_this_rank", "accepted_this_rank", "rejected_by_pre_check",
+                                              "parity_checked", "fragments") if k in i}
+            res["configs[%d]" % (cfg - 1)] = r
+        except Exception as ex:                                         # timeout, unparsable output
+            res["configs[%d]" % (cfg - 1)] = {"error": repr(ex)[:400]}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -514,6 +551,9 @@ def main():
     ap.add_argument("--icp-pairs", type=int, default=50,
                     help="also time N fragment pairs per GPU through Registration + FindCorrespondence (configs[2] shape) and add an "
                          "'icp' object with BASELINE.json's second figure, pairs/s (0 = skip)")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="(default run only: --config 2, one GPU, frames resident) also run 'bench.py --config 4' and '--config 5' as child "
+                         "processes after the headline measurement and attach a summary of their JSON lines as 'other_configs' (0 = skip)")
     args = ap.parse_args()
 
     import numpy as np
@@ -846,8 +886,13 @@ def main():
             out["icp"] = icp
             if world == 1 and args.config == 2:
                 out["fragment_optimizer"] = fopt_section(local)
+        if world == 1 and args.config == 2 and args.other_configs and not args.host_input and not args.force_merge:
+            vol.close()
+            vol = None
+            out["other_configs"] = other_configs(local)
         print(json.dumps(out), flush=True)
-    vol.close()
+    if vol is not None:
+        vol.close()
     if comm is not None:
         comm.close()
     if use_dist:

@@ -1162,6 +1162,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 }  // namespace
 
 static hipError_t aux_create(hipStream_t* s) {
+  // (stream priorities for the pre-pass streams, lowest or highest against the voxel stream's default: no effect on the job or on
+  //  k_integrate's time in the pipeline, profiles/r03r_ab_stream_priority.txt)
   return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
 
