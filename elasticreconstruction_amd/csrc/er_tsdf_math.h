@@ -136,6 +136,10 @@ ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const CameraInv& 
   return touch_key_exact(u, v, d, c, T);
 }
 
+// (A float32 first try of this key -- full-rate fused multiply-adds from per-frame constants, a per-pixel error bound as the
+//  guard, this function as the fallback for the 0.1 % of the pixels next to a unit border -- was built, proven and stress-tested
+//  in round 3; it decided 99.9 % of the pixels correctly and changed neither k_prepare's place in the pipeline nor the job:
+//  140.9 k vs 140.8 k frames/s, profiles/r03s_ab_key32_and_fma_probe.txt.  The pre-pass kernels are not what the job waits for.)
 // Owner of a volume unit when the volume is sharded BY UNIT over `world` GPUs (bit-exact alternative):
 // diagonal stripes of the unit lattice, so the ~30-60 units a frustum touches spread evenly over the GPUs.
 ER_HD int unit_owner(int key, int world) {
@@ -252,8 +256,15 @@ ER_HD double band_quotient(float sdf) {
 // (to 1.0 at most) for x in [-0.5, 0).  lim_m_half = (float)lim - 0.5f.  p is only meaningful when true is returned.
 // Checked against the float64 expression for EVERY float by tests/hip/arith_check.hip.
 ER_HD bool pixel_index(float x, float lim_m_half, int& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // v_cvt_rpi_i32_f32: (int)floor(x + 0.5) with the sum NOT rounded to float32 first -- TSDFVolume::round in one instruction
+  // instead of five (floor, subtract, compare, convert, add with carry); 16 of them per (patch, frame) visit of k_integrate.
+  // tests/hip/arith_check.hip compares it with the float64 expression for EVERY float (k_pixel_all).
+  asm("v_cvt_rpi_i32_f32_e32 %0, %1" : "=v"(p) : "v"(x));
+#else
   const float fl = floorf(x);
   p = (int)fl + ((x - fl) >= 0.5f ? 1 : 0);
+#endif
   return (x >= -0.5f) & (x < lim_m_half);
 }
 

@@ -7,7 +7,7 @@ for i in $(seq $reps); do
     v="${vq%@*}"
     if [ "$vq" != "$v" ]; then export GPU_MAX_HW_QUEUES="${vq#*@}"; else unset GPU_MAX_HW_QUEUES; fi
     if [ "$v" = main ]; then unset ER_HIP_LIB; else export ER_HIP_LIB=$PWD/elasticreconstruction_amd/_ab/liber_hip_$v.so; fi
-    python bench.py --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --min-seconds 0.3 2>/dev/null | python -c "
+    python bench.py --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --other-configs 0 --min-seconds 0.3 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
 print('%-10s value %8.0f fps  ms/step %.3f  k_integrate %.3f ms' % ('$vq', d['value'], d['ms_per_step'], r['avg_launch_ms']))"
