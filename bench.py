@@ -217,7 +217,8 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
         dt8 = time.perf_counter() - t0
     # the whole list takes ~10 ms, the same order as one scheduling hiccup on a shared host: median of 7 passes
     dts, phases = [], []
-    run_list(pairs)          # (untimed: the first list pass after the 8-thread run above re-warms the list workspace)
+    for _ in range(4):       # (untimed: after the single-call runs above the first list passes take 10, 10, 6, 6 ms before they settle at
+        run_list(pairs)      #  5.3 ms -- clocks and the list workspace's page-locked arena warm up; every pass is reported in pass_ms)
     for _ in range(7):
         t0 = time.perf_counter()
         cnts, iters, ncs, fins, lists = run_list(pairs)

@@ -19,7 +19,8 @@
 //   [k_reproject_scatter -> k_reproject_fix]          per SOURCE pixel: warp + scatter-min   (A6/A7)
 //   k_prepare      per pixel: ScaleDepth + unit key; marks bit f in the unit's frame mask,   (A3/A5)
 //                  appends the unit to the batch list
-//   k_plan         sorts the batch's units by cost (frames in the mask) and resets the work queue k_integrate claims its items from
+//   k_plan         hands new units their pool slots, writes one record {key, slot, frame mask} per unit of the batch in cost order
+//                  (frames in the mask) and resets the work queue k_integrate claims its items from
 //  main stream:
 //   k_integrate    per wave an 8 x 8 x 8 cube of a unit: each voxel is loaded ONCE, run against every (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
@@ -332,12 +333,54 @@ struct Plan {
   int next;      // work queue of k_integrate: index of the next unclaimed item (reset by k_plan)
 };
 
+// What k_integrate needs to know about one unit of the batch, in ONE 16-byte scalar load (round 3; it used to chase plan entry ->
+// hash key -> pool slot -> frame mask through four dependent loads per item).
+struct PlanRec {
+  int key;                  // hash_key of the unit (TSDFVolume.h:62-64)
+  int slot;                 // pool slot; < 0: the pool is exhausted (reported by the host), the unit is skipped
+  unsigned long long mask;  // frames of the batch that touch the unit
+};
+
+// Pool slot of hash entry e; hands the slot out on the unit's first ever visit (data_.find( key ) == end, TSDFVolume.cpp:55; pool
+// memory is zero-filled up front).  Called by ONE thread per unit from k_plan.  The pre-passes of two batches run concurrently, so
+// two k_plan launches can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes it; the
+// other polls until it appears (the winner is a running thread of a resident single-workgroup kernel, so the wait is bounded).
+// -3 = pool exhausted.  (Rounds 1-2 did this from k_integrate, per wave and item.)
+// Two phases in program order -- winners draw and publish WITHOUT ever waiting, only then do the losers poll -- so that lanes of one
+// wave that lost against the other launch cannot hold up lanes of the same wave that won (a wave runs the two sides of a divergent
+// branch one after the other).
+__device__ int unit_slot_acquire(int e, int key, int* __restrict__ ht_slot, int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
+  int slot = __hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool won = false;
+  if (slot == -1) won = atomicCAS(&ht_slot[e], -1, -2) == -1;
+  if (won) {
+    const int s = atomicAdd(&counters[C_NUNITS], 1);
+    if (s < max_units) {
+      unit_key[s] = key;
+      __threadfence();
+      slot = s;
+    } else {
+      atomicOr(&counters[C_POOL_OVERFLOW], 1);
+      slot = -3;
+    }
+    atomicExch(&ht_slot[e], slot);
+  }
+  if (!won && (slot == -1 || slot == -2)) {
+    do {
+      slot = __hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot == -2) __builtin_amdgcn_s_sleep(8);
+    } while (slot == -2);
+  }
+  return slot;
+}
+
 __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, const int* __restrict__ nbatch,
-                                              const unsigned long long* __restrict__ ht_mask, int* __restrict__ plan_entry,
-                                              Plan* __restrict__ plan) {
+                                              const unsigned long long* __restrict__ ht_mask, const int* __restrict__ ht_key,
+                                              int* __restrict__ ht_slot, int* __restrict__ unit_key, int max_units,
+                                              int* __restrict__ counters, PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan) {
   __shared__ int hist[65];
   __shared__ int start[66];
-  const int n = *nbatch;                            // <= hash capacity = size of plan_entry
+  const int n = *nbatch;                            // <= hash capacity = size of plan_rec
   for (int t = threadIdx.x; t < 65; t += blockDim.x) hist[t] = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < n; t += blockDim.x) atomicAdd(&hist[__popcll(ht_mask[batch[t]])], 1);
@@ -354,7 +397,13 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
   __syncthreads();
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
     const int e = batch[t];
-    plan_entry[atomicAdd(&start[__popcll(ht_mask[e])], 1)] = e;
+    const unsigned long long mask = ht_mask[e];
+    const int key = ht_key[e];
+    PlanRec r;
+    r.key = key;
+    r.slot = unit_slot_acquire(e, key, ht_slot, unit_key, max_units, counters);
+    r.mask = mask;
+    plan_rec[atomicAdd(&start[__popcll(mask)], 1)] = r;                 // position in descending cost order
   }
 }
 
@@ -367,51 +416,19 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // Items come from a work queue in cost order (k_plan).  Schedules measured on MI355X (profiles/r01_ab_variants.txt,
 // r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt; ms per 50-frame launch in round 1): whole slabs 0.565; quarter
 // slabs dealt round-robin 0.497; XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25; the global queue below.
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xFFFFFFFFull));
-}
-
+// Round 3 asked the same two questions of the final kernel (profiles/r03z_queue_variants.txt): one queue per XCD (each unit swept by
+// the 64 workgroups of one XCD, so that its depth tiles stay in that L2) 0.415 ms against 0.263 ms for the global queue; claiming
+// one or two items ahead (to take the claim's latency off the critical path) 0.345 / 0.385 ms.  The global queue, claimed when the
+// workgroup is free, stays.
 constexpr int kIntMinBlocks = 2;          // register budget: 2 workgroups of 4 waves per CU guaranteed (the kernel needs 144 VGPRs with eight rows
                                           // per lane; round 2: 96 VGPRs / 5 workgroups with four rows)
-// Pool slot of hash entry e for a wave of k_integrate; hands the slot out on the unit's first ever visit (data_.find( key ) ==
-// end, TSDFVolume.cpp:55; pool memory is zero-filled up front).  Voxel passes run one after the other on the main stream, so
-// only waves of THIS launch can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes
-// it; the others poll until it appears (the winner is a running wave, so they never wait for a workgroup that has not been
-// scheduled).  -3 = pool exhausted (reported by the host).  Wave-uniform: lane 0 acts, the result is broadcast.
-__device__ __noinline__ int unit_slot_acquire(int e, int key, int* __restrict__ ht_slot, int* __restrict__ unit_key, int max_units,
-                                              int* __restrict__ counters) {
-  int slot = -2;
-  if ((threadIdx.x & 63) == 0) {
-    if (atomicCAS(&ht_slot[e], -1, -2) == -1) {
-      const int s = atomicAdd(&counters[C_NUNITS], 1);
-      if (s < max_units) {
-        unit_key[s] = key;
-        __threadfence();
-        slot = s;
-      } else {
-        atomicOr(&counters[C_POOL_OVERFLOW], 1);
-        slot = -3;
-      }
-      atomicExch(&ht_slot[e], slot);
-    } else {
-      do {
-        slot = __hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (slot == -2) __builtin_amdgcn_s_sleep(8);
-      } while (slot == -2);
-    }
-  }
-  return __builtin_amdgcn_readfirstlane(slot);
-}
-
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 template <bool kSure>
 __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
-    float2* __restrict__ pool, const int* __restrict__ ht_key, int* __restrict__ ht_slot,
-    const unsigned long long* __restrict__ ht_mask, const int* __restrict__ plan_entry, Plan* __restrict__ plan,
+    float2* __restrict__ pool, const PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows, int* __restrict__ unit_key, int max_units, int* __restrict__ counters) {
+    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
@@ -423,6 +440,10 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
   // path) did not shorten it at all.  History: with the static deal the queue made the kernel 13 % faster and the JOB 5 %
   // slower (the idle tail was where the pre-pass streams got their share of the SIMDs); together with the full path it is
   // +2.6 % for the job and -20 % for the kernel (profiles/r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt).
+  // (Measured in round 3, profiles/r03A_ab_item_barrier.txt: bare s_barrier instructions instead of __syncthreads(), which also drains
+  //  vmcnt -- no difference; ONE barrier per item with the claim passed through two alternating LDS words -- 15 % slower: the wave of
+  //  thread 0 then claims while the other waves still work, and a claim that is made before the workgroup is free costs more than the
+  //  barrier it saves, like the look-ahead variants in profiles/r03z_queue_variants.txt.)
   __shared__ int s_item;
   for (;;) {
     __syncthreads();                                                     // everybody is done with the previous s_item
@@ -430,7 +451,7 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
-    const int e = plan_entry[item >> 7];
+    const PlanRec rec = plan_rec[item >> 7];                              // (wave-uniform: one 16-byte scalar load)
     // The wave owns a COMPACT 8 x 8 x 8 CUBE of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
     // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 8 slabs
     // x 16 x 16 voxels.  History of the shape (each step bit-identical by construction: the culling is exact): round 1 a strip of
@@ -446,11 +467,9 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
     const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
     constexpr int jspan = 8, kspan = 8, ispan = kRows;
-    const int key = __builtin_amdgcn_readfirstlane(ht_key[e]);
-    int slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ht_slot[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (slot < 0 && slot != -3) slot = unit_slot_acquire(e, key, ht_slot, unit_key, max_units, counters);   // first visit of the unit
+    const int key = rec.key, slot = rec.slot;
     if (slot < 0) continue;                                             // pool overflow: reported by the host
-    unsigned long long m = uniform_u64(ht_mask[e]);
+    unsigned long long m = rec.mask;
     const int xi = key >> 18, yi = (key >> 9) & 511, zi = key & 511;
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     const float g2 = grid_coord(k0 + klane, zs);
@@ -935,7 +954,7 @@ struct er_tsdf_s {
   uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
-  int* plan_entry[kDepth] = {};
+  PlanRec* plan_rec[kDepth] = {};
   Plan* plan[kDepth] = {};
   bool reset_pending[kDepth] = {};                  // k_reset of the slot's last batch has not been launched yet
   size_t key_scratch_cap = 0;
@@ -1131,7 +1150,8 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
                      h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world));
-  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->plan_entry[p], h->plan[p]);
+  hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->ht_key, h->ht_slot, h->unit_key, h->max_units,
+                     h->counters, h->plan_rec[p], h->plan[p]);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
@@ -1144,9 +1164,9 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     ER_HIP_TRY(hipEventRecord(e0, S));
   }
   const bool sure = h->cam.integration_trunc < 64.0f;                   // voxel_classify's bound on the scaled depth (false for NaN)
-  hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->ht_key, h->ht_slot,
-                     h->ht_mask[p], h->plan_entry[p], h->plan[p], h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], (h->cols + kTile - 1) / kTile,
-                     (h->rows + kTile - 1) / kTile, h->cam, h->cols, h->rows, h->unit_key, h->max_units, h->counters);
+  hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->plan_rec[p], h->plan[p],
+                     h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], (h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile,
+                     h->cam, h->cols, h->rows);
   if (timed) {
     ER_HIP_TRY(hipEventRecord(e1, S));
     h->events.emplace_back(e0, e1);
@@ -1248,7 +1268,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->dsum, sizeof(double));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_lo[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
-  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan_entry[q], (size_t)cap * sizeof(int));
+  for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan_rec[q], (size_t)cap * sizeof(PlanRec));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan[q], sizeof(Plan));
 #undef ER_ALLOC
   hipStream_t s = h->stream;
@@ -1290,7 +1310,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
                              h->slot_scratch};
   for (int q = 0; q < kDepth; q++)
     for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q],
-                    (void*)h->plan_entry[q], (void*)h->plan[q]})
+                    (void*)h->plan_rec[q], (void*)h->plan[q]})
       ptrs.push_back(x);
   for (int q = 0; q < kAux; q++) {
     ptrs.push_back(h->zbuf[q]);

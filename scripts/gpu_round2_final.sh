@@ -9,14 +9,14 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 echo "== t=${SECONDS}s default bench"
 timeout 600 python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; head -c 1200 gpurun_out/bench_default_$TAG.json; echo
 echo "== t=${SECONDS}s stats (same command as the PMC passes: one whole 3000-frame pass + warm-up, no 'alone' pass)"
-bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --min-seconds 0.01 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -8
+bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --other-configs 0 --min-seconds 0.01 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -8
 grep -o '"avg_launch_ms": [0-9.]*' gpurun_out/prof_$TAG/bench.json | head -1
 echo "== t=${SECONDS}s pmc"
 OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 i=0
 for CS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $R/bench.py --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --min-seconds 0.01 > $OUT/run_$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $R/bench.py --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --no-streamed --no-alone --other-configs 0 --min-seconds 0.01 > $OUT/run_$i.log 2>&1
   for f in $(find /tmp/pmc_${TAG}_$i -name "*counter_collection.csv"); do cp "$f" $OUT/pass${i}_counter_collection.csv; done
   echo "pass $i done t=${SECONDS}s"
 done
