@@ -22,7 +22,7 @@
 //   k_plan         hands new units their pool slots, writes one record {key, slot, frame mask} per unit of the batch in cost order
 //                  (frames in the mask) and resets the work queue k_integrate claims its items from
 //  main stream:
-//   k_integrate    per wave an 8 x 8 x 8 cube of a unit: each voxel is loaded ONCE, run against every (A4)
+//   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
 //                  frame-by-frame loop with 1/batch of its HBM traffic; hands out the pool slot of a unit
 //                  on its first ever visit
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
 // Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
 // batch list sorted by DESCENDING cost = popcount(frame mask) -- the order in which the persistent workgroups of k_integrate
 // claim their items from the work queue (longest-processing-time first) -- and the queue head reset to 0.
-constexpr int kRows = 8;                  // register rows per lane of k_integrate: a wave owns an 8 x 8 x 8 cube of voxels
-constexpr int kItemsPerUnit = 128;       // work items per unit: 8 slabs x 16 x 16 voxels per 256-thread workgroup
+constexpr int kRows = 4;                  // register rows per lane of k_integrate: a wave owns a 4 x 8 x 8 box of voxels
+constexpr int kItemsPerUnit = 256;       // work items per unit: 4 slabs x 16 x 16 voxels per 256-thread workgroup
 
 struct Plan {
   int n_units;
@@ -409,9 +409,8 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
-// Work item = 2048 voxels of a unit for one 256-thread workgroup (128 items per unit); each wave owns 512 of them in
-// kRows = 8 register rows of 64 -- an 8 x 8 x 8 cube (see the mapping below; round 1: four rows of 64 voxels, lane = k; round 2:
-// a 4 x 8 x 8 box).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
+// Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in
+// kRows = 4 register rows of 64 -- a 4 x 8 x 8 box (see the mapping below; round 1: four rows of 64 voxels, lane = k).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
 // loop: the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
 // Items come from a work queue in cost order (k_plan).  Schedules measured on MI355X (profiles/r01_ab_variants.txt,
 // r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt; ms per 50-frame launch in round 1): whole slabs 0.565; quarter
@@ -420,8 +419,8 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // the 64 workgroups of one XCD, so that its depth tiles stay in that L2) 0.415 ms against 0.263 ms for the global queue; claiming
 // one or two items ahead (to take the claim's latency off the critical path) 0.345 / 0.385 ms.  The global queue, claimed when the
 // workgroup is free, stays.
-constexpr int kIntMinBlocks = 2;          // register budget: 2 workgroups of 4 waves per CU guaranteed (the kernel needs 144 VGPRs with eight rows
-                                          // per lane; round 2: 96 VGPRs / 5 workgroups with four rows)
+constexpr int kIntMinBlocks = 4;          // register budget: 4 workgroups of 4 waves per CU guaranteed (94 VGPRs with four rows per lane; the
+                                          // eight-row kernel of mid round 3 needed 144)
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 template <bool kSure>
@@ -451,19 +450,20 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
-    const PlanRec rec = plan_rec[item >> 7];                              // (wave-uniform: one 16-byte scalar load)
-    // The wave owns a COMPACT 8 x 8 x 8 CUBE of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments
-    // per access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 8 slabs
-    // x 16 x 16 voxels.  History of the shape (each step bit-identical by construction: the culling is exact): round 1 a strip of
-    // four whole rows of 64 voxels (2.3 x 37.5 cm) 114.8 k frames/s -> round 2 a 16 x 16 square of one slab 123.6 k -> a 4 x 8 x 8
-    // box +1 % (tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders,
-    // far fewer patches that cross a surface: profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt) -> round 3 the cube:
-    // the per-(patch, frame) work that does not depend on the number of rows (frame constants, loop control, the culling preamble,
-    // the uniform products of the projection) is paid half as often -- 69.2 M instead of 72.6 M wave-instructions per 50-frame
-    // launch -- at 144 VGPRs = 3 waves per SIMD, of which the grid only uses 2: the kernel alone is SLOWER (288 vs 259 us) and the
-    // job faster, 140.7 k vs 136.2 k frames/s, because the SIMDs are shared with the pre-pass kernels and total instructions are
-    // what the chip is short of (profiles/r03i_ab_rows8.txt; 2 rows per lane: 110 k, 16 rows: 117 k).
-    const int i = ((item >> 4) & 7) * 8;
+    const PlanRec rec = plan_rec[item >> 8];                              // (wave-uniform: one 16-byte scalar load)
+    // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments per
+    // access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs x 16 x 16
+    // voxels.  History of the shape (each step bit-identical by construction: the culling is exact): round 1 a strip of four whole
+    // rows of 64 voxels (2.3 x 37.5 cm) 114.8 k frames/s -> round 2 a 16 x 16 square of one slab 123.6 k -> the 4 x 8 x 8 box +1 %
+    // (tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, far fewer
+    // patches that cross a surface: profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt) -> round 3 an 8 x 8 x 8 cube with
+    // eight rows per lane (the per-(patch, frame) work that does not depend on the number of rows is paid half as often: 69.2 M
+    // instead of 72.6 M wave-instructions per launch, +3.3 % for the job at 144 VGPRs and two workgroups per CU, profiles/
+    // r03i_ab_rows8.txt) -> and back to the box: wall-clock stamps (profiles/r03C_item_times.txt) showed that a 50-frame launch has
+    // only ~2500 items for 512 workgroups and that the longest ones -- patches crossing the surface, the exact update for every frame
+    // -- last 150-180 us of a 270 us kernel; four rows halve them, and at 94 VGPRs four workgroups per CU hide each other's
+    // latencies: 0.201 ms alone (0.263), 0.233 ms in the pipeline (0.314), 159 k frames/s (151 k), profiles/r03D_ab_rows4_again.txt.
+    const int i = ((item >> 4) & 15) * 4;
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
     const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
     constexpr int jspan = 8, kspan = 8, ispan = kRows;
@@ -1104,9 +1104,10 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipStream_t X = h->aux_stream[a], S = h->stream;
   int* nbatch = h->counters + kNbatchSlot[p];
 
-  constexpr int kIntBlocksPerCu = 2;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
+  constexpr int kIntBlocksPerCu = 4;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
                                            // space next to them (round 2, four rows per lane: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s;
-                                           // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; profiles/r02G_*, r03i_ab_rows8.txt)
+                                           // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; four rows with the plan records: 2 -> 153.3 k,
+                                           // 3 -> 158.5 k, 4 -> 159.2 k, 5 -> 155.2 k; profiles/r02G_*, r03i_ab_rows8.txt, r03D_ab_rows4_again.txt)
   const int wide_grid = h->n_cu * kIntBlocksPerCu;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);

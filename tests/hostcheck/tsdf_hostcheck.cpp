@@ -15,7 +15,7 @@ using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
 static int g_lo_shift = 5;             // granularity of tile_lo in the replay (5 = the 32-pixel tiles k_prepare writes)
-static int g_patch_shape = 2;          // 2 = the 8 x 8 x 8 cube k_integrate gives a wave (default since round 3), 1 = the 4 x 8 x 8 box of round 2, 0 = a 16 x 16 square of one slab
+static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 2 = the 8 x 8 x 8 cube of mid round 3, 0 = a 16 x 16 square of one slab
 struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0, exact_rows = 0, exact_rows_needing = 0; };
 
 static bool inverse4(const double* m, double* out);

@@ -118,14 +118,14 @@ def test_device_math_rigid_matches_golden(hc):
 
 @pytest.mark.parametrize("shape", [0, 1, 2])
 def test_device_math_warp_matches_golden(hc, shape):
-    """shape 2: the 8 x 8 x 8 cube k_integrate gives a wave since round 3 (patch_may_update_box with eight corners); shape 1: the
-    4 x 8 x 8 box of round 2; shape 0: a 16 x 16 square of one slab.  Same golden digests every way: the culling and the shortcuts
-    are exact whatever the patch."""
+    """shape 1: the 4 x 8 x 8 box k_integrate gives a wave (patch_may_update_box with eight corners); shape 2: the 8 x 8 x 8 cube the
+    kernel used for part of round 3; shape 0: a 16 x 16 square of one slab.  Same golden digests every way: the culling and the
+    shortcuts are exact whatever the patch."""
     hc.hc_set_patch_shape(shape)
     try:
         _warp_matches_golden(hc)
     finally:
-        hc.hc_set_patch_shape(2)
+        hc.hc_set_patch_shape(1)
 
 
 def _warp_matches_golden(hc):
