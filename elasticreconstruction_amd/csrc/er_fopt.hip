@@ -385,17 +385,18 @@ __global__ void k_fopt_axpy(double* __restrict__ y, const double* __restrict__ x
   if (t < n) y[t] += x[t];
 }
 
-// rocSOLVER / rocBLAS are loaded on first use (the TSDF and ICP paths never pay for them).  Caveat met on this ROCm: when
-// the host PROGRAM reached HIP through its start-up dependencies (liber_hip.so as DT_NEEDED), a later dlopen of librocsolver
-// hangs in its static initialisation; such programs link librocsolver / librocblas themselves (bin/FragmentOptimizer does),
-// after which the dlopen below only finds the libraries already loaded.  From Python (ctypes) the lazy load works as is.
-struct RocSolver {
-  void *blas = nullptr, *solver = nullptr, *handle = nullptr;
+// rocBLAS (level-3 BLAS for the trailing updates and triangular solves of the Cholesky factorisation below) is loaded on first use:
+// the TSDF and ICP paths never pay for it.  Round 3 dropped rocSOLVER: its potrf reported non-positive pivots for positive definite
+// matrices under multi-process load (round 2 retried around it); the factorisation is now potrf_lower below -- an own 64 x 64
+// diagonal-block kernel + rocblas_dtrsm / dsyrk -- and potrs is two rocblas_dtrsv.  Caveat met on this ROCm: when the host PROGRAM
+// reached HIP through its start-up dependencies (liber_hip.so as DT_NEEDED), a later dlopen of a ROCm math library can hang in its
+// static initialisation; such programs link librocblas themselves (bin/FragmentOptimizer does), after which the dlopen below only
+// finds the library already loaded.  From Python (ctypes) the lazy load works as is.
+struct RocBlas {
+  void *blas = nullptr, *handle = nullptr;
   int (*create_handle)(void**) = nullptr;
   int (*destroy_handle)(void*) = nullptr;
   int (*set_stream)(void*, hipStream_t) = nullptr;
-  int (*dpotrf)(void*, int, int, double*, int, int*) = nullptr;
-  int (*dpotrs)(void*, int, int, int, double*, int, double*, int) = nullptr;
   // block-sparse factorisation of the non-rigid system: level-3 BLAS on fragment blocks
   int (*dtrsm)(void*, int, int, int, int, int, int, const double*, const double*, int, double*, int) = nullptr;
   int (*dgemm)(void*, int, int, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
@@ -406,25 +407,59 @@ struct RocSolver {
 constexpr int kFillLower = 122;                                 // rocblas_fill_lower
 constexpr int kOpN = 111, kOpT = 112, kDiagNonUnit = 131, kSideRight = 142;   // rocblas_operation / diagonal / side
 
-int rocsolver_load(RocSolver& R, hipStream_t stream) {
+// Cholesky factorisation of one diagonal block (jb <= 64, column-major, lower triangle) by ONE workgroup in LDS: right-looking, column by
+// column -- pivot, scale the column, rank-1 update of the trailing triangle.  A non-positive (or NaN) pivot records its 1-based global
+// index in *info (LAPACK's convention; the first one wins) and the block is left as it is; a launch that finds *info set returns at once.
+constexpr int kPotrfNb = 64;
+__global__ __launch_bounds__(256) void k_potrf_block(double* __restrict__ A, long lda, int jb, int j0, int* __restrict__ info) {
+  __shared__ double a[kPotrfNb][kPotrfNb + 1];
+  if (*info != 0) return;
+  const int tid = threadIdx.x;
+  for (int t = tid; t < jb * jb; t += 256) {
+    const int r = t % jb, c = t / jb;
+    a[r][c] = r >= c ? A[(size_t)c * lda + r] : 0.0;
+  }
+  __syncthreads();
+  for (int j = 0; j < jb; j++) {
+    const double d = a[j][j];
+    if (!(d > 0.0)) {                                        // uniform: every thread reads the same LDS word
+      if (tid == 0) atomicCAS(info, 0, j0 + j + 1);
+      return;
+    }
+    const double l = sqrt(d);
+    __syncthreads();                                           // everybody has read a[j][j]
+    if (tid == 0) a[j][j] = l;
+    for (int r = j + 1 + tid; r < jb; r += 256) a[r][j] = a[r][j] / l;
+    __syncthreads();
+    // trailing update of the lower triangle: a[r][c] -= a[r][j] a[c][j] for j < c <= r
+    const int m = jb - j - 1;
+    for (int t = tid; t < m * m; t += 256) {
+      const int r = j + 1 + t % m, c = j + 1 + t / m;
+      if (r >= c) a[r][c] -= a[r][j] * a[c][j];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < jb * jb; t += 256) {
+    const int r = t % jb, c = t / jb;
+    if (r >= c) A[(size_t)c * lda + r] = a[r][c];
+  }
+}
+
+int rocblas_load(RocBlas& R, hipStream_t stream) {
   if (R.handle) return 0;
   R.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
   if (!R.blas) R.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
-  R.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!R.solver) R.solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
-  if (!R.blas || !R.solver) return er::fail("the on-device solve needs librocblas.so and librocsolver.so: %s", dlerror());
+  if (!R.blas) return er::fail("the on-device solve needs librocblas.so: %s", dlerror());
   R.create_handle = reinterpret_cast<int (*)(void**)>(dlsym(R.blas, "rocblas_create_handle"));
   R.destroy_handle = reinterpret_cast<int (*)(void*)>(dlsym(R.blas, "rocblas_destroy_handle"));
   R.set_stream = reinterpret_cast<int (*)(void*, hipStream_t)>(dlsym(R.blas, "rocblas_set_stream"));
-  R.dpotrf = reinterpret_cast<int (*)(void*, int, int, double*, int, int*)>(dlsym(R.solver, "rocsolver_dpotrf"));
-  R.dpotrs = reinterpret_cast<int (*)(void*, int, int, int, double*, int, double*, int)>(dlsym(R.solver, "rocsolver_dpotrs"));
   R.dtrsm = reinterpret_cast<decltype(R.dtrsm)>(dlsym(R.blas, "rocblas_dtrsm"));
   R.dgemm = reinterpret_cast<decltype(R.dgemm)>(dlsym(R.blas, "rocblas_dgemm"));
   R.dsyrk = reinterpret_cast<decltype(R.dsyrk)>(dlsym(R.blas, "rocblas_dsyrk"));
   R.dgemv = reinterpret_cast<decltype(R.dgemv)>(dlsym(R.blas, "rocblas_dgemv"));
   R.dtrsv = reinterpret_cast<decltype(R.dtrsv)>(dlsym(R.blas, "rocblas_dtrsv"));
-  if (!R.create_handle || !R.destroy_handle || !R.set_stream || !R.dpotrf || !R.dpotrs || !R.dtrsm || !R.dgemm || !R.dsyrk || !R.dgemv || !R.dtrsv)
-    return er::fail("rocSOLVER / rocBLAS symbols not found");
+  if (!R.create_handle || !R.destroy_handle || !R.set_stream || !R.dtrsm || !R.dgemm || !R.dsyrk || !R.dgemv || !R.dtrsv)
+    return er::fail("rocBLAS symbols not found");
   if (R.create_handle(&R.handle) != 0 || R.set_stream(R.handle, stream) != 0) {
     R.handle = nullptr;
     return er::fail("rocblas_create_handle failed");
@@ -451,7 +486,7 @@ struct er_fopt_s {
   double *d_diag = nullptr, *d_off = nullptr;
   size_t diag_cap = 0, off_cap = 0;
   // the system kept on the device for er_fopt_solve
-  RocSolver roc;
+  RocBlas roc;
   double *d_sys = nullptr, *d_rhs = nullptr;       // d_sys aliases d_JJ in the SLAC mode, own allocation in the non-rigid mode
   double* d_big = nullptr;
   size_t big_cap = 0;
@@ -818,30 +853,40 @@ int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* 
 }
 
 // ---- on-device solve -------------------------------------------------------------------------------------------------
-// rocSOLVER's potrf has been seen to report a non-positive pivot (info 1096..1125 of 1125) for a matrix that IS positive
-// definite -- the same assembled matrix factors on the host -- when several PROCESSES use the GPU at once: 3-6 of 120-160 runs
-// of bin/FragmentOptimizer with four copies running concurrently, none in 40 runs alone (scripts/gpu_fopt_flake.py,
-// ER_FOPT_DIAG=1).  The assembly is cheap (a few ms), so the factor entry points assemble and factor again (at most
-// kFactorAttempts times, with a note on stderr) before they report the system as not positive definite.
 constexpr int kNotPositiveDefinite = 2;
-constexpr int kFactorAttempts = 3;
 
-}  // extern "C" (a template cannot have C linkage)
-template <typename Attempt>
-static int factor_with_retry(const char* what, Attempt attempt) {
-  int rc = 1;
-  for (int a = 0; a < kFactorAttempts; a++) {
-    rc = attempt();
-    if (rc != kNotPositiveDefinite) return rc;
-    if (a + 1 < kFactorAttempts)
-      fprintf(stderr, "liber_hip: %s: %s -- assembling and factoring again (attempt %d of %d)\n", what, er_last_error(), a + 2, kFactorAttempts);
+// Recursive blocked Cholesky, lower triangle of a column-major n x n matrix in place:  A = [A11 . ; A21 A22] -> factor A11 (recursively,
+// down to k_potrf_block on 64 x 64 diagonal blocks), L21 = A21 L11^-T (rocblas_dtrsm), A22 -= L21 L21^T (rocblas_dsyrk), factor A22.  The
+// halving keeps the level-3 updates large (compute-bound on the FP64 matrix cores) at every size from the 2 211 unknowns of the test scenes to
+// the 109 350 of 50 fragments.  *h->d_info = 0, or the 1-based index of the first non-positive pivot (the rest of the matrix is then
+// meaningless).  Replaces rocsolver_dpotrf (round 3): under multi-process load that routine reported non-positive pivots near the end of
+// matrices that ARE positive definite (3-6 of 120-160 concurrent runs in round 2, the same assembled matrix factored fine on the host), and
+// round 2 could only retry around it.
+static int potrf_rec(er_fopt_t h, double* A, long n, long lda, long j_base) {
+  if (n <= kPotrfNb) {
+    hipLaunchKernelGGL(k_potrf_block, dim3(1), dim3(256), 0, h->stream, A, lda, (int)n, (int)j_base, h->d_info);
+    return 0;
   }
-  return 1;
+  const double one = 1.0, minus = -1.0;
+  const long n1 = ((n / 2 + kPotrfNb - 1) / kPotrfNb) * kPotrfNb, n2 = n - n1;
+  if (potrf_rec(h, A, n1, lda, j_base)) return 1;
+  if (h->roc.dtrsm(h->roc.handle, kSideRight, kFillLower, kOpT, kDiagNonUnit, (int)n2, (int)n1, &one, A, (int)lda, A + n1, (int)lda) != 0)
+    return er::fail("rocblas_dtrsm failed (Cholesky, columns %ld..%ld)", j_base, j_base + n1);
+  double* A22 = A + (size_t)n1 * lda + n1;
+  if (h->roc.dsyrk(h->roc.handle, kFillLower, kOpN, (int)n2, (int)n1, &minus, A + n1, (int)lda, &one, A22, (int)lda) != 0)
+    return er::fail("rocblas_dsyrk failed (Cholesky, columns %ld..%ld)", j_base, j_base + n1);
+  return potrf_rec(h, A22, n2, lda, j_base + n1);
 }
-extern "C" {
+
+static int potrf_lower(er_fopt_t h, double* A, long n, long lda) {
+  ER_HIP_TRY(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+  if (potrf_rec(h, A, n, lda, 0)) return 1;
+  ER_HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 static int factor_common(er_fopt_t h, double* A, long n) {
-  if (rocsolver_load(h->roc, h->stream)) return 1;
+  if (rocblas_load(h->roc, h->stream)) return 1;
   if (!h->d_info) ER_HIP_TRY(hipMalloc((void**)&h->d_info, sizeof(int)));
   if (h->d_rhs) {
     (void)hipFree(h->d_rhs);
@@ -857,7 +902,7 @@ static int factor_common(er_fopt_t h, double* A, long n) {
     ER_HIP_TRY(hipMemcpyAsync(diag_copy.data(), A, (size_t)n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     ER_HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  if (h->roc.dpotrf(h->roc.handle, kFillLower, (int)n, A, (int)n, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed");
+  if (potrf_lower(h, A, n, n)) return 1;
   int info = 0;
   ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -877,12 +922,12 @@ static int factor_common(er_fopt_t h, double* A, long n) {
         M[(size_t)j * n + c] = v / d;
       }
     }
-    er::fail("rocsolver_dpotrf info = %d; host Cholesky of the SAME assembled matrix: %s (pivot %ld)", info,
+    er::fail("Cholesky pivot %d is not positive; host Cholesky of the SAME assembled matrix: %s (pivot %ld)", info,
              bad ? "ALSO not positive definite -> the matrix is wrong" : "positive definite -> the factorisation is wrong", bad);
     return kNotPositiveDefinite;
   }
   if (info != 0) {
-    er::fail("the assembled system is not positive definite (rocsolver_dpotrf info = %d)", info);
+    er::fail("the assembled system is not positive definite (Cholesky pivot %d)", info);
     return kNotPositiveDefinite;
   }
   h->d_sys = A;
@@ -895,7 +940,7 @@ static int factor_common(er_fopt_t h, double* A, long n) {
 static int factor_slac_once(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score);
 
 int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score) {
-  return factor_with_retry("er_fopt_factor_slac", [&] { return factor_slac_once(h, pose_rot_t, default_weight, dataJb_host, score); });
+  return factor_slac_once(h, pose_rot_t, default_weight, dataJb_host, score) ? 1 : 0;
 }
 
 static int factor_slac_once(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score) {
@@ -962,7 +1007,7 @@ static int block_symbolic(er_fopt_t h) {
 }
 
 static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
-  if (rocsolver_load(h->roc, h->stream)) return 1;
+  if (rocblas_load(h->roc, h->stream)) return 1;
   const int nb = h->num;
   const int B = h->nper;
   const long bsz = (long)B * B;
@@ -1003,12 +1048,12 @@ static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
   const double one = 1.0, minus = -1.0;
   auto blk = [&](int i, int j) { return h->d_big + h->blk_off[(size_t)i * nb + j]; };
   for (int k = 0; k < nb; k++) {
-    if (h->roc.dpotrf(h->roc.handle, kFillLower, B, blk(k, k), B, h->d_info) != 0) return er::fail("rocsolver_dpotrf failed (block %d)", k);
+    if (potrf_lower(h, blk(k, k), B, B)) return 1;
     int info = 0;
     ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     ER_HIP_TRY(hipStreamSynchronize(h->stream));
     if (info != 0) {
-      er::fail("the assembled system is not positive definite (fragment block %d, rocsolver_dpotrf info = %d)", k, info);
+      er::fail("the assembled system is not positive definite (fragment block %d, Cholesky pivot %d)", k, info);
       return kNotPositiveDefinite;
     }
     const std::vector<int>& rows = h->blk_rows[(size_t)k];
@@ -1056,7 +1101,7 @@ static int solve_blocked(er_fopt_t h) {                              // d_rhs <-
 static int factor_nonrigid_once(er_fopt_t h, double weight);
 
 int er_fopt_factor_nonrigid(er_fopt_t h, double weight) {
-  return factor_with_retry("er_fopt_factor_nonrigid", [&] { return factor_nonrigid_once(h, weight); });
+  return factor_nonrigid_once(h, weight) ? 1 : 0;
 }
 
 static int factor_nonrigid_once(er_fopt_t h, double weight) {
@@ -1132,8 +1177,9 @@ int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* 
   }
   if (h->blocked) {
     if (solve_blocked(h)) return 1;
-  } else if (h->roc.dpotrs(h->roc.handle, kFillLower, (int)n, 1, h->d_sys, (int)n, h->d_rhs, (int)n) != 0) {
-    return er::fail("rocsolver_dpotrs failed");
+  } else if (h->roc.dtrsv(h->roc.handle, kFillLower, kOpN, kDiagNonUnit, (int)n, h->d_sys, (int)n, h->d_rhs, 1) != 0 ||       // L y = b
+             h->roc.dtrsv(h->roc.handle, kFillLower, kOpT, kDiagNonUnit, (int)n, h->d_sys, (int)n, h->d_rhs, 1) != 0) {     // L^T x = y
+    return er::fail("rocblas_dtrsv failed");
   }
   ER_HIP_TRY(hipMemcpyAsync(x_host, h->d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));

@@ -35,4 +35,4 @@ rhs = np.random.default_rng(0).normal(size=M)
 x = g.Solve(rhs); t2 = time.perf_counter()
 g.FactorNonrigid(1.0); t3 = time.perf_counter()
 print("%d fragments, %d pairs, %d correspondences, %d groups: system %d x %d (%.1f GB dense)" % (num, len(pairs), sum(p[2].shape[0] for p in pairs), ng, M, M, M * M * 8 / 1e9))
-print("assemble + scatter + Cholesky: first %.2f s (loads rocSOLVER), again %.2f s; one solve %.3f s; |x| %.3g" % (t1 - t0, t3 - t2, t2 - t1, np.abs(x).max()))
+print("assemble + scatter + Cholesky: first %.2f s (loads rocBLAS), again %.2f s; one solve %.3f s; |x| %.3g" % (t1 - t0, t3 - t2, t2 - t1, np.abs(x).max()))

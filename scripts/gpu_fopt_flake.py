@@ -28,6 +28,8 @@ def one(i):
     if r.returncode != 0:
         print("run %d FAILED: %s" % (i, r.stderr.strip()[-200:]), flush=True)
         return None
+    if "not positive" in r.stderr or "again" in r.stderr:
+        print("run %d NOTE on stderr: %s" % (i, r.stderr.strip()[-200:]), flush=True)
     return np.loadtxt(out)
 
 
