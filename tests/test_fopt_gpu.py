@@ -233,3 +233,31 @@ def test_block_sparse_cholesky_equals_dense(gpu, monkeypatch):
         assert np.isfinite(b).all()
         assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), "block-sparse and dense solutions differ by %.3g (scale %.3g)" % (np.abs(a - b).max(), np.abs(a).max())
     assert np.abs(sols["dense"][0] - sols["dense"][3]).max() > 1e-6 * np.abs(sols["dense"][0]).max()      # the weight does matter
+
+
+def test_cholesky_reports_a_non_positive_pivot_and_checks_its_solution(gpu, monkeypatch):
+    """potrf_lower (the library's own recursive blocked Cholesky): a system that is NOT positive definite -- a large negative regulariser
+    weight -- is reported as such, in the dense and in the block-sparse layout, instead of returning garbage; the handle stays usable, and
+    solves are linear in the right-hand side.  (That the factorisation is RIGHT is what test_optimisation_loops_match_the_reference_program
+    and test_block_sparse_cholesky_equals_dense check.)"""
+    from elasticreconstruction_amd._ffi import ErError
+    sc = make_scene(num=3, n=6000)
+    rng = np.random.default_rng(11)
+    ctr = lattice_ctr(sc["num"], sc["res"], sc["length"], [np.eye(4)] * sc["num"], 0.003, rng)
+    M = 2187 * sc["num"]
+    b = rng.normal(size=M)
+    for dense_max in ("1000000", "0"):
+        monkeypatch.setenv("ER_FOPT_DENSE_MAX", dense_max)
+        g = FragmentOptimizer(sc["num"], sc["res"], sc["length"])
+        for f, (x, n) in enumerate(sc["frags"]):
+            assert g.SetCloud(f, x, n) == -1
+        g.UpdateAllNormal(ctr)
+        g.SetCorrespondences(sc["pairs"])
+        g.FactorNonrigid(1.0)
+        x1, x2 = g.Solve(b), g.Solve(2.0 * b)
+        assert np.isfinite(x1).all() and np.abs(x2 - 2.0 * x1).max() <= 1e-12 * np.abs(x1).max()
+        with pytest.raises(ErError, match="not positive definite"):
+            g.FactorNonrigid(-1.0e6)
+        g.FactorNonrigid(1.0)                                    # the handle is still usable afterwards
+        assert np.abs(g.Solve(b) - x1).max() <= 1e-12 * np.abs(x1).max()
+        g.close()
