@@ -829,7 +829,8 @@ def main():
                                           "peak = 1024 SIMDs x clock_ghz / 4 cycles per wave64 instruction" % pj.get("run", "a committed rocprofv3 --pmc run")}
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "valu", "contract_bound": "hbm", "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS,
+            out["roofline"] = {"bound": "hbm", "contract_bound": "hbm", "limiter": "latency + VALU issue, and the longest work items (DESIGN.md 4, 'Path A, round 3')",
+                               "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
                                "measured_copy_peak": HBM_COPY_GBS, "traffic": traffic,
                                "traffic_source": ("static: %s, committed as profiles/pmc_latest.json (ONE run of this kernel, 50-frame launch: "
@@ -842,8 +843,8 @@ def main():
                                "voxel_updates_per_pass": sum_w, "unit_visits": prof["unit_visits"],
                                "note": ("rank 0 kernel; voxel updates = job total / ranks; " if world > 1 else "") +
                                        "frac prices the ALGORITHMIC bytes of SURVEY.md 8d (16 B per reference voxel update) against the HBM "
-                                       "peak, as the contract asks; the batched kernel moves about half of them (traffic, hbm_physical_frac) and is "
-                                       "bound by VALU issue (valu_issue.frac), hence bound = valu",
+                                       "peak, as the contract asks; the batched kernel moves about half of them (traffic, hbm_physical_frac); what it "
+                                       "waits for is latency and the longest items of a launch (limiter), valu_issue.frac is its share of the VALU issue peak",
                                "whole_job_frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS, "valu_issue": valu}
             if alone and alone["launches"] > 0 and alone["integrate_ms"] > 0:
                 ms_alone = alone["integrate_ms"] / alone["launches"]
@@ -855,7 +856,7 @@ def main():
                             "k_integrate alone on the chip.  'frac' above is the contract figure over the TIMED region, where the "
                             "kernel shares the SIMDs with the pre-pass kernels of the next two batches (three-stream pipeline)"}
         else:
-            out["roofline"] = {"bound": "valu", "contract_bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline"] = {"bound": "hbm", "contract_bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "avg_launch_ms": ms_launch, "launches": launches}
         if streamed is not None:
             out["streamed"] = streamed
