@@ -26,7 +26,7 @@ SYMBOLS = [
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_ransac_fitness_batch", "er_ransac_inliers",
     "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
     "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_group_count", "er_fopt_group_info", "er_fopt_update_normals", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
-    "er_fopt_assemble_nonrigid", "er_fopt_factor_slac", "er_fopt_factor_nonrigid", "er_fopt_solve",
+    "er_fopt_assemble_nonrigid", "er_fopt_factor_slac", "er_fopt_factor_nonrigid", "er_fopt_solve", "er_fopt_debug_shift_diagonal",
 ]
 
 
@@ -89,6 +89,9 @@ def lib():
     L.er_tsdf_sum_weight.argtypes = [vp, dp]
     L.er_tsdf_extract_world.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_long)]
     L.er_tsdf_extract_surface.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_long)]
+    L.er_tsdf_extract_mesh.argtypes = [vp, vp, C.c_long, C.POINTER(C.c_long)]
+    L.er_mc_table.argtypes = [vp]
+    L.er_request_hw_queues.argtypes = [C.c_int]
     L.er_tsdf_export_weighted.argtypes = [vp, vp, C.c_int, vp]
     L.er_tsdf_import_weighted.argtypes = [vp, vp, C.c_int, vp]
     L.er_comm_unique_id.argtypes = [vp]
@@ -133,6 +136,7 @@ def lib():
         L.er_fopt_factor_slac.argtypes = [vp, vp, C.c_double, vp, vp]
         L.er_fopt_factor_nonrigid.argtypes = [vp, C.c_double]
         L.er_fopt_solve.argtypes = [vp, vp, C.c_int, vp]
+        L.er_fopt_debug_shift_diagonal.argtypes = [vp, C.c_long, C.c_double]
     _lib = L
     return L
 

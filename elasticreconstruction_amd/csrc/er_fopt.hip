@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kBlock, ER_FOPT_MINBLOCKS) void k_fopt_gram(const C
 }
 
 // ---- the linear systems, kept and solved on the device -----------------------------------------------------------
-// Row-major UPPER triangle throughout (= column-major lower triangle for rocSOLVER).
+// Row-major UPPER triangle throughout (= column-major lower triangle for the Cholesky and rocBLAS).
 // AddHessian2( {v, w}, {1, -1} ) for every (vertex, neighbour) ordered pair of the lattice (OptApp.cpp:765-800, 811-836):
 // +scale on both diagonals, -scale on the coupling, per xyz component.
 // The non-rigid system either as ONE dense matrix (base, ld) or as the block-sparse lower triangle of fragment blocks
@@ -498,6 +498,8 @@ struct er_fopt_s {
   long sys_n = 0;
   int* d_info = nullptr;
   int* d_ginfo = nullptr;
+  long shift_index = -1;         // er_fopt_debug_shift_diagonal: added to one diagonal entry of every system before it is factored
+  double shift_value = 0.0;
   bool factored = false;
   long n_corr = 0;
   int *d_first = nullptr, *d_second = nullptr;
@@ -892,10 +894,14 @@ static int factor_common(er_fopt_t h, double* A, long n) {
     (void)hipFree(h->d_rhs);
     h->d_rhs = nullptr;
   }
-  if (n > 2147483647L) return er::fail("system too large for rocSOLVER (%ld unknowns)", n);
+  if (n > 2147483647L) return er::fail("system too large for the 32-bit rocBLAS interface (%ld unknowns)", n);
   ER_HIP_TRY(hipMalloc((void**)&h->d_rhs, (size_t)n * sizeof(double)));
-  // ER_FOPT_DIAG=1 (debugging aid): keep a host copy of the assembled matrix and, if rocSOLVER reports a non-positive pivot,
+  // ER_FOPT_DIAG=1 (debugging aid): keep a host copy of the assembled matrix and, if potrf_lower reports a non-positive pivot,
   // factor that copy on the host -- tells a wrong matrix (assembly) from a wrong factorisation.
+  if (h->shift_index >= 0 && h->shift_index < n) {
+    hipLaunchKernelGGL(k_fopt_add_diag, dim3(1), dim3(64), 0, h->stream, A, n, h->shift_index, 1, h->shift_value);
+    ER_HIP_TRY(hipGetLastError());
+  }
   std::vector<double> diag_copy;
   if (getenv("ER_FOPT_DIAG")) {
     diag_copy.resize((size_t)n * n);
@@ -922,7 +928,7 @@ static int factor_common(er_fopt_t h, double* A, long n) {
         M[(size_t)j * n + c] = v / d;
       }
     }
-    er::fail("Cholesky pivot %d is not positive; host Cholesky of the SAME assembled matrix: %s (pivot %ld)", info,
+    er::fail("the assembled system is not positive definite (Cholesky pivot %d); host Cholesky of the SAME assembled matrix: %s (pivot %ld)", info,
              bad ? "ALSO not positive definite -> the matrix is wrong" : "positive definite -> the factorisation is wrong", bad);
     return kNotPositiveDefinite;
   }
@@ -974,7 +980,7 @@ static int factor_slac_once(er_fopt_t h, const double* pose_rot_t, double defaul
 // matrix is kept as the lower triangle of FRAGMENT blocks (nper x nper = 2187 x 2187 at resolution 8, column-major): block
 // (i, j) exists iff fragments i and j share a correspondence list or it fills in during the elimination (symbolic pass on
 // the host over the fragment graph, natural order); the numeric factorisation is right-looking over those dense blocks --
-// rocSOLVER potrf on the diagonal block, rocBLAS trsm down the column, syrk / gemm into the trailing blocks -- and a solve is
+// potrf_lower (below) on the diagonal block, rocBLAS trsm down the column, syrk / gemm into the trailing blocks -- and a solve is
 // a block forward / backward substitution (trsv + gemv).  A 100-fragment scene whose pairs link neighbours needs a few
 // hundred 38 MB blocks; even the complete graph of 100 fragments (5050 blocks, 193 GB) fits the 288 GB of one MI355X, where
 // the dense square of the same system (383 GB) does not.
@@ -1037,6 +1043,8 @@ static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
   for (int l = 0; l < h->num; l++)                                            // baseAA, OptApp.cpp:765-810
     hipLaunchKernelGGL(k_fopt_add_laplacian_v, dim3((unsigned)((nv * 6 + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, V, (long)l * h->nper, h->res, 1.0);
   hipLaunchKernelGGL(k_fopt_add_diag_v, dim3(1), dim3(64), 0, h->stream, V, 0L, 3, 1.0);
+  if (h->shift_index >= 0 && h->shift_index < (long)nb * B)
+    hipLaunchKernelGGL(k_fopt_add_diag_v, dim3(1), dim3(64), 0, h->stream, V, h->shift_index, 1, h->shift_value);
   ER_HIP_TRY(hipGetLastError());
   // ---- numeric factorisation, right-looking over the blocks ----
   if (!h->d_info) ER_HIP_TRY(hipMalloc((void**)&h->d_info, sizeof(int)));
@@ -1053,7 +1061,7 @@ static int factor_nonrigid_blocked(er_fopt_t h, size_t nv, size_t nd) {
     ER_HIP_TRY(hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     ER_HIP_TRY(hipStreamSynchronize(h->stream));
     if (info != 0) {
-      er::fail("the assembled system is not positive definite (fragment block %d, Cholesky pivot %d)", k, info);
+      er::fail("the assembled system is not positive definite (Cholesky pivot %ld = fragment block %d, local pivot %d)", (long)k * B + info, k, info);
       return kNotPositiveDefinite;
     }
     const std::vector<int>& rows = h->blk_rows[(size_t)k];
@@ -1162,6 +1170,13 @@ static int factor_nonrigid_once(er_fopt_t h, double weight) {
   hipLaunchKernelGGL(k_fopt_add_diag, dim3(1), dim3(64), 0, h->stream, h->d_big, (long)M, 0L, 3, 1.0);
   ER_HIP_TRY(hipGetLastError());
   return factor_common(h, h->d_big, (long)M);
+}
+
+int er_fopt_debug_shift_diagonal(er_fopt_t h, long index, double value) {
+  if (!h) return er::fail("er_fopt_debug_shift_diagonal: NULL handle");
+  h->shift_index = index;
+  h->shift_value = value;
+  return 0;
 }
 
 int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* x_host) {

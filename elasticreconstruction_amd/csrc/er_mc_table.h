@@ -46,10 +46,8 @@ inline int mc_edge_between(int a, int b) {                        // the edge jo
   return -1;
 }
 
-inline const McTable& mc_table() {
-  static McTable T;
-  static bool built = false;
-  if (built) return T;
+inline McTable mc_table_build() {
+  McTable T;
   // the six faces as corner cycles (adjacent corners consecutive)
   int face[6][4];
   int nf = 0;
@@ -126,7 +124,13 @@ inline const McTable& mc_table() {
     }
     T.ntri[cs] = (unsigned char)(out / 3);
   }
-  built = true;
+  return T;
+}
+
+// Built once, by the initialiser of a function-local static (thread-safe since C++11: two host threads entering
+// er_tsdf_extract_mesh / er_mc_table at the same time cannot both run the build -- ADVICE round 3).
+inline const McTable& mc_table() {
+  static const McTable T = mc_table_build();
   return T;
 }
 

@@ -5,7 +5,9 @@
 //
 // Steps (every rank of the communicator executes them in the same order; root < 0 = the merged volume on every rank):
 //   1. local: the keys of the units this rank touched.  A LOCAL failure here (unit pool or hash table overflowed, allocation
-//      failed) must not make the rank leave -- the others would wait in the next collective for ever -- so it becomes a status;
+//      failed) -- or one the caller found BEFORE the protocol started and hands in as `pre_status` (a bad argument, a volume
+//      on another device than its communicator) -- must not make the rank leave: the others would wait in the next
+//      collective for ever.  So it becomes a status;
 //   2. all-reduce(MAX) of { key count, status }: every rank learns the padded key count and whether ANY rank failed; if one
 //      did, all of them return an error together, after that collective;
 //   3. fixed-size all-gather of the keys padded with -1 to that count -> sorted union (identical on every rank);
@@ -44,10 +46,10 @@ struct MergeVolume {
 enum { MERGE_OK = 0, MERGE_LOCAL_FAILURE = 1, MERGE_PEER_FAILURE = 2, MERGE_TRANSPORT_FAILURE = 3 };
 
 // Returns MERGE_OK, or -- on EVERY rank, after the same collective -- which kind of failure stopped the merge.
-inline int merge_protocol(MergeTransport& t, MergeVolume& v, int root, int* union_units) {
+inline int merge_protocol(MergeTransport& t, MergeVolume& v, int root, int* union_units, int pre_status = 0) {
   if (union_units) *union_units = 0;
   std::vector<int> keys;
-  const int st1 = v.touched_keys(keys) ? 1 : 0;
+  const int st1 = (pre_status || v.touched_keys(keys)) ? 1 : 0;
   if (st1) keys.clear();
   int agree[2] = {(int)keys.size(), st1};
   if (t.allreduce_max(agree, 2)) return MERGE_TRANSPORT_FAILURE;

@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace {
@@ -173,6 +174,15 @@ struct DeviceVolume : er::MergeVolume {
 
 }  // namespace
 
+// The int scratch every small collective of the merge stages through, allocated when the communicator is made: 64 Ki ints hold the
+// padded keys of a full 512-unit region from 100+ ranks, so er_tsdf_allreduce itself never allocates before its first collective.
+static int comm_scratch(er_comm_t c) {
+  ER_HIP_TRY(hipSetDevice(c->device));
+  ER_HIP_TRY(hipMalloc((void**)&c->ikeys, (size_t)65536 * sizeof(int)));
+  c->ikeys_cap = 65536;
+  return 0;
+}
+
 static_assert(ER_COMM_ID_BYTES == sizeof(ncclUniqueId), "ER_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
 
 extern "C" {
@@ -205,6 +215,11 @@ int er_comm_create(const unsigned char id[ER_COMM_ID_BYTES], int rank, int world
     delete c;
     return er::fail("er_comm_create: ncclCommInitRank failed: %s", R->GetErrorString(r));
   }
+  if (comm_scratch(c)) {
+    (void)R->CommDestroy(c->comm);
+    delete c;
+    return 1;
+  }
   *out = c;
   return 0;
 }
@@ -224,6 +239,8 @@ int er_comm_create_local(int n, const int* devices, er_comm_t* out) {
     c->device = devices[i];
     out[i] = c;
   }
+  for (int i = 0; i < n; i++)
+    if (comm_scratch(out[i])) return 1;                          // (the caller destroys the communicators it was given)
   return 0;
 }
 
@@ -243,24 +260,32 @@ int er_comm_world(er_comm_t c) { return c ? c->world : -1; }
 
 // The frame-split merge (see the file header): er_merge_protocol.h's steps over RCCL and the device-resident volume.  Every
 // rank of the communicator calls it once, each from its own host thread / process; root < 0 leaves the merged volume on
-// every rank, otherwise only on `root`.  A rank-local failure (unit pool / hash table overflow, allocation) is carried through
-// the first collective as a status, so ALL ranks return nonzero together instead of the healthy ones waiting for ever.
+// every rank, otherwise only on `root`.  A rank-local failure -- a bad `root`, a volume that lives on another device than the
+// communicator, a unit pool / hash table overflow, a failed allocation of the plane buffer -- is carried through the next collective
+// as a status, so ALL ranks return nonzero together instead of the healthy ones waiting for ever (the small device scratch the
+// status travels in is allocated by er_comm_create*, not here).  What stays fatal for the whole communicator: a NULL handle, RCCL
+// missing, and a HIP / RCCL error inside a collective itself (MERGE_TRANSPORT_FAILURE) -- after those the peers' state is unknown.
 int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   if (!h || !c) return er::fail("er_tsdf_allreduce: NULL argument");
-  if (root >= c->world) return er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
-  if (er::tsdf_device(h) != c->device) return er::fail("er_tsdf_allreduce: the volume lives on device %d, the communicator on %d", er::tsdf_device(h), c->device);
   Rccl* R = rccl();
   if (!R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded (%s)", rccl_reason());
-  ER_HIP_TRY(hipSetDevice(c->device));
-  RcclTransport t(R, c, er::tsdf_stream(h));
+  int pre = 0;
+  if (root >= c->world) pre = er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
+  else if (er::tsdf_device(h) != c->device)
+    pre = er::fail("er_tsdf_allreduce: the volume lives on device %d, the communicator on %d", er::tsdf_device(h), c->device);
+  const hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess && !pre) pre = er::fail("er_tsdf_allreduce: hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
+  std::string why = pre ? er_last_error() : "";                 // (the protocol's later steps may overwrite the thread's message)
+  RcclTransport t(R, c, pre && er::tsdf_device(h) != c->device ? nullptr : er::tsdf_stream(h));
   DeviceVolume v(h, c);
-  const int r = er::merge_protocol(t, v, root, union_units);
+  const int r = er::merge_protocol(t, v, root, union_units, pre ? 1 : 0);
   if (r == er::MERGE_OK) {
     ER_HIP_TRY(hipStreamSynchronize(er::tsdf_stream(h)));
     return 0;
   }
   if (r == er::MERGE_PEER_FAILURE)
     return er::fail("er_tsdf_allreduce: another rank of the communicator failed before the merge (its own er_last_error() says why); nothing was merged");
+  if (pre) return er::fail("%s", why.c_str());
   return 1;                                                     // local / transport failure: the message is already recorded
 }
 

@@ -11,7 +11,7 @@
 //                                             twin of TSDFVolume::data_ (TSDFVolume.h:27)
 //   lambda    float[rows*cols]                ScaleDepth's per-pixel ray-length factor (camera constant)
 //   scaled    float[64][rows*cols]            scaled depth of every frame of the batch in flight
-//   zbuf      uint32[64][rows*cols]           Reproject's z-buffer (atomicMin; 0xFFFFFFFF = empty)
+//   zbuf      uint32[64][rows*cols]           Reproject's z-buffer (atomicMin; 0xFFFFFFFF = empty); lastzero / zfix: its replay state
 //
 // Launch sequence for a batch of <= 64 frames (er_tsdf_integrate_frames); three batches are in flight (run_batch):
 //  pre-pass stream (batch b on stream b mod 2):
@@ -24,8 +24,7 @@
 //  main stream:
 //   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
-//                  frame-by-frame loop with 1/batch of its HBM traffic; hands out the pool slot of a unit
-//                  on its first ever visit
+//                  frame-by-frame loop with 1/batch of its HBM traffic
 // All kernels are HBM/latency/VALU work on scattered voxels and pixels: no MFMA.
 #include "er_common.h"
 #include "er_tsdf_math.h"
@@ -48,7 +47,8 @@ constexpr uint32_t kZEmpty = 0xFFFFFFFFu;
 
 // counters[] slots
 enum { C_NUNITS = 0, C_NBATCH = 1 /* and 6, 7: one per pipeline slot */, C_POOL_OVERFLOW = 2, C_TABLE_FULL = 3, C_OUT_OF_RANGE = 4,
-       C_ZERO_WRITE = 5 /* and 8: one per pre-pass stream */, C_NBATCH1 = 6, C_NBATCH2 = 7, C_ZERO_WRITE1 = 8, C_COUNT = 12 };
+       C_NBATCH1 = 6, C_NBATCH2 = 7, C_ZERO_WRITE = 8 /* 8, 9: frames 0-31 / 32-63 of the batch; 10, 11 for the second pre-pass stream */,
+       C_ZERO_WRITE1 = 10, C_COUNT = 12 };
 constexpr int kDepth = 3;                // batches in flight: voxel pass of n, pre-passes of n+1 and n+2 (depth 2 with one pre-pass
 constexpr int kAux = 2;                  // stream = the round-1 pipeline: profiles/r02n_ab_pipeline_depth_hw_queues.txt); pre-pass streams:
                                          // batch b runs on stream b mod kAux
@@ -92,8 +92,10 @@ __global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* _
 // Reproject, IntegrateApp.cpp:247-268: every source pixel is warped through its fragment's control
 // grid and scattered into the frame's z-buffer.  The reference's sequential "write if empty or
 // closer" is an order-independent min for dd != 0; a write of dd == 0 RESETS the cell (0 means
-// empty), which is order dependent, so such writes only record their source index and raise a flag;
-// k_reproject_fix then replays the affected cells exactly (practically never taken).
+// empty), which is order dependent.  Such a write (a warped depth below 0.5 mm: practically never) records its source index
+// in lastzero (max) and raises the FRAME's bit in the stream's flag word; k_reproject_fix then scatters the flagged frames a
+// second time into a side buffer, zfix, under the replay rule -- only writes that come after the cell's last zero write
+// count -- and the consumer of the z-buffer (k_prepare / k_zbuf_to_depth) takes cells with lastzero > 0 from zfix.
 struct ReprojArgs {
   const uint16_t* depth;
   int n_frames, cols, rows;
@@ -108,7 +110,8 @@ struct ReprojArgs {
   int floats_per_grid;
   uint32_t* zbuf;
   uint32_t* lastzero;
-  int* zero_flag;                        // raised by a write of dd == 0 (one flag per pre-pass stream)
+  uint32_t* zfix;                        // the replay's z-buffer (all-empty outside a replay; re-armed by the consumer)
+  int* zero_flag;                        // int[2], bit f: frame f of the batch saw a write of dd == 0 (one pair per pre-pass stream)
 };
 
 // The write half of one source pixel p of frame f that landed on `cell` with depth dd (IntegrateApp.cpp:260-263).
@@ -119,11 +122,11 @@ __device__ __forceinline__ void scatter_px(const ReprojArgs& A, int f, int p, in
       atomicMin(&A.zbuf[o], (uint32_t)dd);
     } else {
       atomicMax(&A.lastzero[o], (uint32_t)p + 1u);
-      atomicOr(A.zero_flag, 1);
+      atomicOr(&A.zero_flag[f >> 5], 1 << (f & 31));
     }
   } else {
     const uint32_t lz = A.lastzero[o];
-    if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&A.zbuf[o], (uint32_t)dd);
+    if (dd != 0 && lz > 0 && (uint32_t)p + 1u > lz) atomicMin(&A.zfix[o], (uint32_t)dd);
   }
 }
 
@@ -151,37 +154,44 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   reproject_scatter_px(A, f, u, v, 0);
 }
 
-// The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch that
-// returns at once unless a zero write was flagged -- it practically never is (a warped depth below 0.5 mm) -- and
-// otherwise lets a single workgroup run the three passes in order: cells that saw a zero write forget everything;
-// every source pixel is scattered again under the replay rule (only writes that come after the cell's last zero
-// write count); lastzero and the flag are re-armed.  Slow (one workgroup) by design: keeping it to one launch saves
-// three idle launches per batch on the pre-pass stream.  Round 3: a single wave with a capped register budget (the replay may
-// spill, it never runs in practice) -- as a 256-thread workgroup with 83 VGPRs the launch waited 46 us on average (max 237 us,
-// profiles/r03a_kernel_stats.csv) for FOUR free wave slots of that size on one CU next to the persistent k_integrate workgroups
-// and the other stream's pre-pass, on the serial pre-pass chain of every batch.
+// The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch of kFixBlocks
+// single-wave workgroups that return at once unless a frame of the batch is flagged -- practically never -- and otherwise share the
+// pixels of the flagged frames: every source pixel is warped again and scattered into zfix under the replay rule.  One phase, no
+// ordering between workgroups; the consumer merges (take_z below) and re-arms lastzero / zfix, k_plan (or the single-frame entry
+// point) clears the flag words.  History: round 1 ran three passes (forget, re-scatter, re-arm) as three launches, then as one
+// 256-thread workgroup; round 3 as ONE wave with a capped register budget, because a 256-thread workgroup with 83 VGPRs waited 46 us
+// on average (max 237 us, profiles/r03a_kernel_stats.csv) for four free wave slots on one CU next to the persistent k_integrate
+// workgroups and the other stream's pre-pass -- but a flagged batch then cost that one wave n_frames * cols * rows serial replays
+// (ADVICE round 3).  Single waves still find room at once, and now 256 of them share the flagged frames only.
 constexpr int kFixThreads = 64;
+constexpr int kFixBlocks = 256;
 __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_num_vgpr(48))) void k_reproject_fix(ReprojArgs A) {
-  if (*A.zero_flag == 0) return;
-  const long total = (long)A.n_frames * A.cols * A.rows;
-  for (long t = threadIdx.x; t < total; t += blockDim.x)
-    if (A.lastzero[t] > 0) A.zbuf[t] = kZEmpty;
-  __threadfence();
-  __syncthreads();
-  for (int f = 0; f < A.n_frames; f++)
-    for (int p = threadIdx.x; p < A.cols * A.rows; p += blockDim.x) reproject_scatter_px(A, f, p % A.cols, p / A.cols, 1);
-  __threadfence();
-  __syncthreads();
-  for (long t = threadIdx.x; t < total; t += blockDim.x) A.lastzero[t] = 0;
-  __syncthreads();
-  if (threadIdx.x == 0) *A.zero_flag = 0;
+  const int fl0 = A.zero_flag[0], fl1 = A.zero_flag[1];
+  if ((fl0 | fl1) == 0) return;
+  const int pixels = A.cols * A.rows;
+  for (int f = 0; f < A.n_frames; f++) {
+    if ((((f < 32 ? fl0 : fl1) >> (f & 31)) & 1) == 0) continue;
+    for (int p = blockIdx.x * kFixThreads + threadIdx.x; p < pixels; p += gridDim.x * kFixThreads) reproject_scatter_px(A, f, p % A.cols, p / A.cols, 1);
+  }
 }
 
-__global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total) {
+// The consumer's half of the replay: the value of z-buffer cell o of a FLAGGED frame (z = what the plain scatter-min left there);
+// cells that saw a zero write take the replay's value and re-arm both side buffers.
+__device__ __forceinline__ uint32_t take_z(uint32_t z, size_t o, uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix) {
+  if (lastzero[o] == 0) return z;
+  const uint32_t r = zfix[o];
+  zfix[o] = kZEmpty;
+  lastzero[o] = 0;
+  return r;
+}
+
+__global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total, uint32_t* __restrict__ lastzero,
+                                uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= total) return;
   uint32_t z = zbuf[t];
   zbuf[t] = kZEmpty;                                                    // leave the z-buffer re-armed
+  if (zero_flag[0] & 1) z = take_z(z, (size_t)t, lastzero, zfix);       // (single frame: bit 0)
   depth[t] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
 }
 
@@ -202,7 +212,7 @@ constexpr int kTileKeys = 96;
 
 // Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
 // returned 0) appends the unit to the batch list.  The pool slot of a unit that is new to the volume is handed out
-// by k_integrate itself (unit_slot below): the pre-passes of two batches run concurrently, the voxel passes run in order.
+// by k_plan (unit_slot_acquire below), on the same pre-pass stream.
 //
 // Unit-shard mode (the bit-exact multi-GPU alternative): with shard.y > 1 GPUs every GPU runs the pre-pass of
 // ALL frames but only owns -- allocates, integrates, reports -- the units with unit_owner(key) == shard.x.  Units are
@@ -233,12 +243,14 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard) {
+    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard,
+    uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
   __shared__ float s_wmax[kPrepThreads / 64], s_wlo[kPrepThreads / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
+  const bool replayed = zbuf && ((zero_flag[f >> 5] >> (f & 31)) & 1);  // this frame saw a zero write (uniform; practically never)
   const int tx = threadIdx.x & (kTile - 1), ty = threadIdx.x >> 5;      // ty in [0, 8)
   const int x = blockIdx.x * kTile + tx;
   if (threadIdx.x == 0) s_n = 0;
@@ -256,8 +268,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       const int p = y * cols + x;
       const size_t o = (size_t)f * pixels + p;
       if (zbuf) {
-        const uint32_t z = zbuf[o];
+        uint32_t z = zbuf[o];
         zbuf[o] = kZEmpty;                                              // re-arm the z-buffer for the next batch
+        if (replayed) z = take_z(z, o, lastzero, zfix);
         d[q] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
       } else {
         d[q] = depth[o];
@@ -377,7 +390,8 @@ __device__ int unit_slot_acquire(int e, int key, int* __restrict__ ht_slot, int*
 __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, const int* __restrict__ nbatch,
                                               const unsigned long long* __restrict__ ht_mask, const int* __restrict__ ht_key,
                                               int* __restrict__ ht_slot, int* __restrict__ unit_key, int max_units,
-                                              int* __restrict__ counters, PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan) {
+                                              int* __restrict__ counters, PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
+                                              int* __restrict__ zero_flag) {
   __shared__ int hist[65];
   __shared__ int start[66];
   const int n = *nbatch;                            // <= hash capacity = size of plan_rec
@@ -393,6 +407,7 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
     }
     plan->n_units = n;
     plan->next = 0;
+    if (zero_flag) zero_flag[0] = zero_flag[1] = 0;     // Reproject's replay flags of this batch: consumed by the k_prepare in front of this launch
   }
   __syncthreads();
   for (int t = threadIdx.x; t < n; t += blockDim.x) {
@@ -951,7 +966,7 @@ struct er_tsdf_s {
   bool ctr_rd_set[2] = {false, false};
   int ctr_parity = 0, ctr_cur = 0;
   uint16_t* depth_stage[kDepth] = {};              // host frames of the batch in flight, by pipeline slot
-  uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
+  uint32_t *zbuf[kAux] = {}, *lastzero[kAux] = {}, *zfix[kAux] = {};  // Reproject's z-buffer and replay state, one per pre-pass stream
   double *T12 = nullptr, *seg12 = nullptr, *madj12 = nullptr, *dsum = nullptr;
   int *grid_index = nullptr, *key_scratch = nullptr, *slot_scratch = nullptr;
   PlanRec* plan_rec[kDepth] = {};
@@ -1142,7 +1157,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     const int verts = (warp->resolution + 1) * (warp->resolution + 1) * (warp->resolution + 1);
     const float grid_ul = warp->length / (float)warp->resolution;       // ControlGrid.cpp:19
     const ReprojArgs RA{depth_dev, n, h->cols, h->rows, h->cam, h->cami, dev_seg, dev_madj, dev_gi, h->ctr, warp->resolution, grid_ul,
-                        verts * 3, h->zbuf[a], h->lastzero[a], h->counters + kZeroFlagSlot[a]};
+                        verts * 3, h->zbuf[a], h->lastzero[a], h->zfix[a], h->counters + kZeroFlagSlot[a]};
     if (launch_reproject(h, RA, n, X)) return 1;
     zsrc = h->zbuf[a];
   }
@@ -1150,9 +1165,10 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
-                     h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world));
+                     h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world), h->lastzero[a], h->zfix[a],
+                     h->counters + kZeroFlagSlot[a]);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->ht_key, h->ht_slot, h->unit_key, h->max_units,
-                     h->counters, h->plan_rec[p], h->plan[p]);
+                     h->counters, h->plan_rec[p], h->plan[p], warp ? h->counters + kZeroFlagSlot[a] : (int*)nullptr);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipEventRecord(h->pre_done[p], X));
 
@@ -1260,6 +1276,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->depth_stage[q], B * px * sizeof(uint16_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->zbuf[q], B * px * sizeof(uint32_t));
   for (int q = 0; q < kAux; q++) ER_ALLOC(h->lastzero[q], B * px * sizeof(uint32_t));
+  for (int q = 0; q < kAux; q++) ER_ALLOC(h->zfix[q], B * px * sizeof(uint32_t));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->dstage[q], sizeof(Staging));   // device twin of the pinned staging block: ONE copy per batch
   for (int q = 0; q < kDepth; q++) h->frames[q] = reinterpret_cast<er::FrameXform*>(reinterpret_cast<char*>(h->dstage[q]) + offsetof(Staging, fx));
   ER_ALLOC(h->T12, B * 12 * sizeof(double));
@@ -1283,7 +1300,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
          hipMemsetAsync(h->scaled[q], 0, B * (px + kScaledPad) * sizeof(float), s) == hipSuccess;   // (the pads stay zero)
   for (int q = 0; q < kAux; q++)
     ok = ok && hipMemsetAsync(h->lastzero[q], 0, B * px * sizeof(uint32_t), s) == hipSuccess &&
-         hipMemsetAsync(h->zbuf[q], 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
+         hipMemsetAsync(h->zbuf[q], 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess &&
+         hipMemsetAsync(h->zfix[q], 0xFF, B * px * sizeof(uint32_t), s) == hipSuccess;
   if (ok) {
     hipLaunchKernelGGL(k_lambda, dim3((h->pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, h->lambda, cols, rows, h->cam);
     ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
@@ -1316,6 +1334,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
   for (int q = 0; q < kAux; q++) {
     ptrs.push_back(h->zbuf[q]);
     ptrs.push_back(h->lastzero[q]);
+    ptrs.push_back(h->zfix[q]);
   }
   for (int q = 0; q < kDepth; q++) {
     if (h->pre_done[q]) (void)hipEventDestroy(h->pre_done[q]);
@@ -1425,7 +1444,7 @@ static int launch_reproject(er_tsdf_t h, const ReprojArgs& RA, int n, hipStream_
   // (staging the lattice in LDS for this kernel was measured: slower, profiles/r02d_ab_lds_lattice.txt; a float32 tier with a
   //  per-pixel proof in front of the exact chain, four designs: slower, profiles/r02b / r02c / r02z_ab_tiered_reproject_*.txt)
   hipLaunchKernelGGL(k_reproject_scatter, dim3((h->cols + 63) / 64, (h->rows + 3) / 4, n), dim3(kBlock), 0, X, RA);
-  hipLaunchKernelGGL(k_reproject_fix, dim3(1), dim3(kFixThreads), 0, X, RA);   // ONE WAVE: it has to find room next to three busy kernels
+  hipLaunchKernelGGL(k_reproject_fix, dim3(kFixBlocks), dim3(kFixThreads), 0, X, RA);   // single waves: they have to find room next to three busy kernels
   ER_HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1450,11 +1469,12 @@ int er_tsdf_reproject(er_tsdf_t h, uint16_t* depth_inout_host, const float* ctr_
   const float grid_ul = length / (float)resolution;
   const long total = (long)px;
   const ReprojArgs RA{h->depth_stage[0], 1, h->cols, h->rows, h->cam, h->cami, h->seg12, h->madj12, h->grid_index, h->ctr, resolution, grid_ul,
-                      verts * 3, h->zbuf[0], h->lastzero[0], h->counters + kZeroFlagSlot[0]};
+                      verts * 3, h->zbuf[0], h->lastzero[0], h->zfix[0], h->counters + kZeroFlagSlot[0]};
   if (launch_reproject(h, RA, 1, h->stream)) return 1;
   hipLaunchKernelGGL(k_zbuf_to_depth, dim3((int)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0, h->stream, h->zbuf[0],
-                     h->depth_stage[0], total);
+                     h->depth_stage[0], total, h->lastzero[0], h->zfix[0], h->counters + kZeroFlagSlot[0]);
   ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipMemsetAsync(h->counters + kZeroFlagSlot[0], 0, 2 * sizeof(int), h->stream));
   ER_HIP_TRY(hipMemcpyAsync(depth_inout_host, h->depth_stage[0], px * sizeof(uint16_t), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;

@@ -5,9 +5,9 @@
 // three modes -- runs in liber_hip.so (er_fopt_*, csrc/er_fopt.hip).  The host keeps what the reference keeps on the host:
 // the lattice regularizer, gauge terms, the pose / lattice updates and the linear solve.  The reference solves with CHOLMOD
 // (sparse supernodal LL^T); here the SLAC and non-rigid systems are assembled, factored and solved in HBM by a dense Cholesky
-// (er_fopt_factor_* / er_fopt_solve, rocSOLVER), the small rigid system (6 num unknowns) by a dense Cholesky on the host.  The non-rigid mode's system has num * 2187 unknowns: up to
+// (er_fopt_factor_* / er_fopt_solve: the library's own blocked Cholesky over rocBLAS), the small rigid system (6 num unknowns) by a dense Cholesky on the host.  The non-rigid mode's system has num * 2187 unknowns: up to
 // --dense_limit unknowns (default 30000) it is one dense matrix in HBM, beyond that the library keeps and factors it as the
-// block-sparse lower triangle of fragment blocks (rocSOLVER potrf / rocBLAS trsm, syrk, gemm per 2187 x 2187 block; fill-in
+// block-sparse lower triangle of fragment blocks (own potrf / rocBLAS trsm, syrk, gemm per 2187 x 2187 block; fill-in
 // from a symbolic pass over the fragment graph) -- a 100-fragment scene needs a few hundred 38 MB blocks when its pairs link
 // neighbours, 193 GB for the complete graph, both inside one MI355X.  A failed allocation is reported with a clear message.
 #include <omp.h>
@@ -497,7 +497,7 @@ class COptApp {                                     // OptApp.h:39-124
         for (int r = 0; r < 3; r++)
           for (int c = 0; c < 3; c++) rot[(size_t)l * 9 + r * 3 + c] = pose_[(size_t)l][(size_t)c * 4 + r];     // pose_rot_t_ = R^T
       double score = 0;
-      // thisJJ = Upper( baseJJ * default_weight ) + gauge + data term: assembled AND factored in HBM (dense Cholesky, rocSOLVER)
+      // thisJJ = Upper( baseJJ * default_weight ) + gauge + data term: assembled AND factored in HBM (the library's own Cholesky)
       if (er_fopt_factor_slac(fo_, rot.data(), default_weight, Jb.data(), &score)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       printf("Data error score is : %.2f\n", score);
       // regularizer right-hand side, OptApp.cpp:570-631
@@ -563,7 +563,7 @@ class COptApp {                                     // OptApp.h:39-124
     for (int itr = 0; itr < max_iteration_; itr++) {
       for (int l = 0; l < num_; l++)
         if (er_fopt_update_normals(fo_, l, &ctr[(size_t)l * nper_])) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
-      // thisAA = baseAA + data blocks: scattered into a dense matrix and factored in HBM (dense Cholesky, rocSOLVER)
+      // thisAA = baseAA + data blocks: scattered into a dense matrix and factored in HBM (the library's own Cholesky)
       if (er_fopt_factor_nonrigid(fo_, weight_)) { fprintf(stderr, "FragmentOptimizer: %s\n", er_last_error()); return false; }
       if (sample_num_ > 0) SaveCtr(oldctr, "itr" + std::to_string(itr) + ".ctr");           // :213-218 (oldctr: the lattice before the last inner solve)
       for (int m = 0; m < max_inner_iteration_; m++) {

@@ -221,7 +221,7 @@ class FragmentOptimizer:
         np.add.at(out, inv, vals)
         return uk // M, uk % M, out
 
-    # ---- systems kept and solved on the device (dense Cholesky in HBM, rocSOLVER) ---------------------------------
+    # ---- systems kept and solved on the device (own blocked Cholesky in HBM over rocBLAS level-3 calls) -----------
     def FactorSLAC(self, pose_rot_t, default_weight):
         """thisJJ of one OptimizeSLAC iteration assembled and factored on the device.  Returns (dataJb, data score)."""
         N = 6 * self.num_ + self.nper_
@@ -232,6 +232,10 @@ class FragmentOptimizer:
 
     def FactorNonrigid(self, weight):
         _ffi.check(self._lib.er_fopt_factor_nonrigid(self._h, float(weight)), "er_fopt_factor_nonrigid")
+
+    def DebugShiftDiagonal(self, index, value):
+        """Test hook (er_fopt_debug_shift_diagonal): add `value` to diagonal entry `index` of every system factored from now on; index < 0 = off."""
+        _ffi.check(self._lib.er_fopt_debug_shift_diagonal(self._h, int(index), float(value)), "er_fopt_debug_shift_diagonal")
 
     def Solve(self, rhs, add_data_jb=False):
         b = np.ascontiguousarray(rhs, np.float64).reshape(-1)

@@ -293,3 +293,27 @@ def warp_arrays(sc, lo=0, hi=None):
     madj = np.stack([reproject_matrix(sc["traj"][f], sc["traj"][0], sc["seg"][0]) for f in range(lo, hi)])
     return dict(ctr=sc["grids"], resolution=sc["resolution"], length=np.float32(sc["length"]), grid_index=gi,
                 seg=sc["seg"][lo:hi].copy(), madj=madj)
+
+
+# ---- pair lists over a fragment_set (configs[2] shape) ----------------------------------------------------------------
+def pair_list(frs, n_pairs, rot, trans, seed0):
+    """Pair k = fragment a = k mod F with its 1st / 2nd / 3rd neighbour b, guess = ground truth o perturbation(seed0 + k)."""
+    n_frag = len(frs)
+    out = []
+    for k in range(n_pairs):
+        a = k % n_frag
+        b = (a + 1 + (k // n_frag) % 3) % n_frag
+        out.append((a, b, np.linalg.inv(frs[a][2]) @ frs[b][2] @ perturbation(seed0 + k, rot, trans)))
+    return out
+
+
+def hard_pair_list(frs, n_pairs):
+    """The HARD list of bench.py's icp.hard_set and of tests/test_icp_gpu.py: guesses up to 6 deg / 6 cm off the ground truth -- three
+    times the configs[2] perturbation -- so that PCL's 20-iteration budget, the transform criterion and the iteration limit are all
+    reached (BuildCorrespondence/CorresApp.cpp:295-306)."""
+    return pair_list(frs, n_pairs, 6.0, 0.06, 1700)
+
+
+def config2_pair_list(frs, n_pairs):
+    """configs[2]'s list: guesses <= 2 deg / 2 cm off the ground truth."""
+    return pair_list(frs, n_pairs, 2.0, 0.02, 700)

@@ -300,8 +300,10 @@ int er_fopt_assemble_slac(er_fopt_t h, const double* pose_rot_t, double* JJ, dou
  * blocks that share lattice vertices when it builds the sparse matrix for the solver. */
 int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* offdiag);
 
-/* The systems can stay where they are assembled and be solved there: dense Cholesky in HBM (rocSOLVER potrf / potrs, loaded
- * on first use) instead of the reference's sparse CHOLMOD factorisation on the host.  288 GB hold the non-rigid mode's dense
+/* The systems can stay where they are assembled and be solved there: Cholesky in HBM (the library's own recursive blocked
+ * factorisation over rocBLAS level-3 calls, rocBLAS loaded on first use; dense, or block-sparse over fragments beyond ER_FOPT_DENSE_MAX
+ * unknowns) instead of the reference's sparse CHOLMOD factorisation on the host.  A system that is not positive definite is an error
+ * whose text names the 1-based index of the first non-positive pivot (CHOLMOD's status, OptApp.cpp:209-211, 389-393).  288 GB hold the non-rigid mode's dense
  * system up to ~180 k unknowns (82 fragments at resolution 8).
  *   er_fopt_factor_slac      thisJJ of one OptimizeSLAC iteration: data term + default_weight * (lattice Laplacian + anchor) +
  *                            the gauge "+1"s (OptApp.cpp:449-560, 811-846), factored.  dataJb_host (nullable, 6 num + nper) and
@@ -311,6 +313,9 @@ int er_fopt_assemble_nonrigid(er_fopt_t h, double weight, double* diag, double* 
 int er_fopt_factor_slac(er_fopt_t h, const double* pose_rot_t, double default_weight, double* dataJb_host, double* score);
 int er_fopt_factor_nonrigid(er_fopt_t h, double weight);
 int er_fopt_solve(er_fopt_t h, const double* rhs_host, int add_data_jb, double* x_host);
+/* Test hook for the failure path of the factorisation: every system factored from now on gets `value` added to diagonal entry
+ * `index` (0-based) after assembly and before the Cholesky; index < 0 switches it off.  Not used by any host program. */
+int er_fopt_debug_shift_diagonal(er_fopt_t h, long index, double value);
 
 #ifdef __cplusplus
 }

@@ -1,24 +1,47 @@
 #!/bin/bash
-# One-call validation sized for a short GPU budget: -m gpu suite (4 xdist workers), smoke, default bench, one interleaved
-# A/B pass over the library variants in elasticreconstruction_amd/_ab, kernel-trace stats, one PMC pass (VALU instructions).
-# Later steps are skipped when the clock runs out.   usage: bash scripts/gpu_final.sh <tag> [seconds]
-R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; TAG="${1:-r01u}"; LIMIT="${2:-360}"; mkdir -p gpurun_out
+# GPU side of scripts/final_gate.sh (also usable alone for mid-round validation): the driver's gate in the driver's order --
+#   1. python -m pytest tests -x -q -m gpu   (serial, -x: exactly what the driver runs; tests/conftest.py orders path A, path B, host
+#      programs first and the widening rows last)
+#   2. smoke()
+#   3. the default bench line
+# then, while the clock allows (GATE_ONLY=1 skips them): kernel-trace stats, one PMC pass (FETCH_SIZE / WRITE_SIZE / SQ_*).
+# Every log starts with the HEAD scripts/final_gate.sh stamped into .gate_head ("unstamped" when run outside the gate).
+#   usage: bash scripts/gpu_final.sh <tag> [seconds]
+R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; TAG="${1:-r04}"; LIMIT="${2:-600}"; mkdir -p gpurun_out
+HEAD_ID="$(cat .gate_head 2>/dev/null || echo unstamped)"
 SECONDS=0
-timeout 280 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -n 4 > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit $? after ${SECONDS}s" >> gpurun_out/pytest_gpu.log; tail -12 gpurun_out/pytest_gpu.log
-timeout 60 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?" >> gpurun_out/smoke.log; tail -2 gpurun_out/smoke.log
+LOG=gpurun_out/pytest_gpu_$TAG.log
+echo "# HEAD $HEAD_ID  tag $TAG  $(date -u +%FT%TZ)" > $LOG
+timeout $((LIMIT > 700 ? 560 : LIMIT * 4 / 5)) python -m pytest tests -x -q -m gpu --tb=short -p no:cacheprovider >> $LOG 2>&1
+PRC=$?; echo "pytest exit $PRC after ${SECONDS}s" >> $LOG; tail -6 $LOG
+echo "# HEAD $HEAD_ID" > gpurun_out/smoke_$TAG.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/smoke_$TAG.log 2>&1; SRC=$?; echo "smoke exit $SRC" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log
 echo "== t=${SECONDS}s bench"
-BT=$((LIMIT - SECONDS - 5)); [ $BT -gt 200 ] && BT=200; [ $BT -lt 20 ] && BT=20
-timeout $BT python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; tail -1 gpurun_out/bench_default_$TAG.json | cut -c1-700
-echo "== t=${SECONDS}s A/B"
-if [ $SECONDS -lt $((LIMIT - 110)) ]; then bash scripts/ab_libs.sh ${AB_REPS:-1} ${AB_LIST:-main r01s} > gpurun_out/ab_$TAG.txt 2>&1; cat gpurun_out/ab_$TAG.txt; fi
-echo "== t=${SECONDS}s stats"
-if [ $SECONDS -lt $((LIMIT - 60)) ]; then bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -12; fi
-echo "== t=${SECONDS}s pmc"
-if [ $SECONDS -lt $((LIMIT - 30)) ]; then
-  OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
-  timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d /tmp/pmc_${TAG}_1 -o p1 -- python $R/bench.py --steps 6 --warmup 1 --cpu-sample 0 --icp-pairs 0 > $OUT/run_1.log 2>&1
-  for f in $(find /tmp/pmc_${TAG}_1 -name "*counter_collection.csv"); do cp "$f" $OUT/pass1_counter_collection.csv; done
-  cd $R; python scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1; grep -A8 "^k_integrate" $OUT/summary.txt
+BT=$((LIMIT - SECONDS - 5)); [ $BT -gt 300 ] && BT=300; [ $BT -lt 20 ] && BT=20
+timeout $BT python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; BRC=$?
+python - "$TAG" "$HEAD_ID" <<'PY'
+import json, sys
+tag, head = sys.argv[1], sys.argv[2]
+p = "gpurun_out/bench_default_%s.json" % tag
+try:
+    line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    d["gate_head"] = head
+    open(p, "w").write(json.dumps(d) + "\n")
+    r, i = d.get("roofline", {}), d.get("icp", {})
+    print("bench: %.1f frames/s, frac %.3f, whole_job_frac %.3f, icp %.0f pairs/s, hard %.0f, parity %s / %s / %s" % (
+        d["value"], r.get("frac") or 0, r.get("whole_job_frac") or 0, i.get("pairs_per_s") or 0, (i.get("hard_set") or {}).get("pairs_per_s") or 0,
+        (d.get("parity_checked") or {}).get("bit_exact"), (i.get("parity_checked_reference") or {}).get("ok"),
+        ((i.get("hard_set") or {}).get("parity_checked_reference") or {}).get("ok")))
+except Exception as ex:
+    print("bench: no JSON line (%s)" % ex)
+PY
+echo "== gate: pytest $PRC smoke $SRC bench $BRC at t=${SECONDS}s (HEAD $HEAD_ID)"
+if [ "${GATE_ONLY:-0}" != "1" ]; then
+  echo "== t=${SECONDS}s stats"
+  if [ $SECONDS -lt $((LIMIT - 90)) ]; then bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 --other-configs 0 --min-seconds 0.1 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -12; fi
+  echo "== t=${SECONDS}s pmc"
+  if [ $SECONDS -lt $((LIMIT - 60)) ]; then bash scripts/gpu_pmc.sh $TAG > gpurun_out/pmc_$TAG.log 2>&1; tail -15 gpurun_out/pmc_$TAG.log; fi
 fi
 echo "== done t=${SECONDS}s"
+[ $PRC -eq 0 ] && [ $SRC -eq 0 ] && [ $BRC -eq 0 ]

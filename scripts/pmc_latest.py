@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
 """profiles/pmc_latest.json from ONE scripts/pmc_summary.py summary (the file bench.py reads the static counter figures from).
-usage: python scripts/pmc_latest.py profiles/<tag>_pmc_summary.txt <tag> "<what the kernel was>" > profiles/pmc_latest.json"""
+usage: python scripts/pmc_latest.py profiles/<tag>_pmc_summary.txt <tag> "<what the kernel was>" [profiles/<tag>_kernel_stats.csv] > profiles/pmc_latest.json
+Run it on the tree the profiled run used: the sha16 of the kernel sources is stamped into the file, and bench.py marks the static
+figures 'stale' when the sources have changed since."""
+import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def parse(path):
@@ -32,11 +38,22 @@ def main():
     fetch, write = ki["FETCH_SIZE"], ki["WRITE_SIZE"]                  # KiB per launch
     raw = (fetch + write) * 1024.0
     m = lambda k: s.get(k, {}).get("SQ_INSTS_VALU", 0.0) / 1e6
-    print(json.dumps({
+    import bench
+    extra = {"kernel_source_sha16": bench.kernel_source_sha16(),
+             "valu_wave_instructions_per_batch": {k: s[k]["SQ_INSTS_VALU"] for k in ("k_integrate", "k_reproject_scatter", "k_prepare")
+                                                  if "SQ_INSTS_VALU" in s.get(k, {})}}
+    if len(sys.argv) > 4:                                              # rocprofv3 --kernel-trace --stats of the same tree: AverageNs of k_integrate
+        for row in csv.DictReader(open(sys.argv[4])):
+            if row.get("Name", "").startswith("k_integrate") or "k_integrate" in row.get("Name", ""):
+                extra["rocprof_kernel_trace_avg_us"] = float(row["AverageNs"]) / 1e3
+                extra["rocprof_kernel_trace_calls"] = int(row["Calls"])
+                extra["rocprof_kernel_trace_file"] = sys.argv[4]
+                break
+    print(json.dumps({**extra, **{
         "source": "%s: rocprofv3 --kernel-trace --pmc ... in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), bench.py --steps 20 --warmup 1 "
                   "--no-alone --no-streamed: mean over the %d launches of 50 frames of a whole 3000-frame pass + warm-up; %s.  ALL figures below "
                   "come from this one run (scripts/pmc_latest.py)." % (path, ki["n"], what),
-        "run": "the round-3 rocprofv3 --pmc run %s" % tag,
+        "run": "the rocprofv3 --pmc run %s" % tag,
         "kernel": "k_integrate",
         "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write, "raw_bytes_per_launch": raw,
         "correction": "FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md (rocprofv3 tallies 128-B read requests at 64 B; calibrated "
@@ -50,7 +67,7 @@ def main():
                 % (m("k_integrate"), m("k_reproject_scatter"), m("k_prepare")),
         "measured_clock_ghz": ki.get("CLOCK_GHZ"),
         "measured_clock_source": "the same run: GRBM_GUI_ACTIVE (summed over 8 XCDs) / 8 / per-dispatch duration of k_integrate under the counters",
-    }, indent=1))
+    }}, indent=1))
 
 
 if __name__ == "__main__":

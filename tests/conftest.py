@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
 
 
+# SURVEY.md section 8 order of the GPU suite: the parity tests of the hot path -- 8(a) path A, 8(a) path B, the drop-in programs --
+# run FIRST, the widening rows 8(f) last, so that `pytest -m gpu -x` can never lose the hot path's evidence to a failure in a
+# widening row (round 3: tests/test_fopt_gpu.py sorted first, one wrong test in it hid 36 parity tests from the driver's run).
+GPU_ORDER = ("test_tsdf_gpu", "test_icp_gpu", "test_host_programs_gpu", "test_distributed_gpu")
+WIDENING = ("test_ransac_", "test_zero_crossing_", "test_marching_cubes_", "test_fragment_optimizer_program_")    # 8(f) rows inside 8(a) files
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if item.get_closest_marker("gpu") is None:
+            return -1                                             # CPU tests keep their place in front
+        if mod not in GPU_ORDER or item.name.startswith(WIDENING):
+            return len(GPU_ORDER) + (mod == "test_fopt_gpu")      # widening rows last, the FragmentOptimizer file at the very end
+        return GPU_ORDER.index(mod)
+    items.sort(key=rank)                                          # stable: the order inside a file is unchanged
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the C-ABI library and the oracle checkers exist (both build without a GPU)."""

@@ -88,3 +88,10 @@ def corres_golden():
     import json
     with open(os.path.join(HERE, "golden", "corres_golden.json")) as f:
         return json.load(f)
+
+
+# ---- the HARD pair list: guesses up to 6 deg / 6 cm off the ground truth -- three times the configs[2]
+# perturbation -- so that PCL's 20-iteration budget, the transform criterion and the iteration limit are all reached
+# (BuildCorrespondence/CorresApp.cpp:295-306).  bench.py times this very list (icp.hard_set) and runs the same checker.
+from elasticreconstruction_amd.synth import hard_pair_list, pair_list  # noqa: E402,F401
+from oracle.refcheck import check_pairs_against_reference, select_hard  # noqa: E402,F401

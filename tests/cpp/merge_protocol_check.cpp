@@ -126,7 +126,7 @@ struct HostVolume : er::MergeVolume {
 unsigned rng_state = 12345u;
 float frand() { rng_state = rng_state * 1664525u + 1013904223u; return (float)((rng_state >> 8) & 0xffff) / 65536.0f; }
 
-struct Case { int world, root; std::vector<int> nkeys; int fail_keys_rank, fail_export_rank; };
+struct Case { int world, root; std::vector<int> nkeys; int fail_keys_rank, fail_export_rank; int pre_status_rank = -1; };
 
 int run_case(const Case& c, int id) {
   const int W = c.world;
@@ -158,13 +158,13 @@ int run_case(const Case& c, int id) {
   for (int r = 0; r < W; r++)
     th.emplace_back([&, r] {
       ThreadTransport t(sh, r);
-      rc[(size_t)r] = er::merge_protocol(t, vols[(size_t)r], c.root, &nu[(size_t)r]);
+      rc[(size_t)r] = er::merge_protocol(t, vols[(size_t)r], c.root, &nu[(size_t)r], r == c.pre_status_rank ? 1 : 0);
     });
   for (auto& t : th) t.join();
-  const bool expect_fail = c.fail_keys_rank >= 0 || c.fail_export_rank >= 0;
+  const bool expect_fail = c.fail_keys_rank >= 0 || c.fail_export_rank >= 0 || c.pre_status_rank >= 0;
   for (int r = 0; r < W; r++) {
     if (expect_fail) {
-      const bool me = r == c.fail_keys_rank || r == c.fail_export_rank;
+      const bool me = r == c.fail_keys_rank || r == c.fail_export_rank || r == c.pre_status_rank;
       const int want = me ? er::MERGE_LOCAL_FAILURE : er::MERGE_PEER_FAILURE;
       // with only an export failure armed the union may be empty (nothing touched): then nobody fails -- not a case we build
       if (rc[(size_t)r] != want) { fprintf(stderr, "case %d rank %d: rc %d, want %d\n", id, r, rc[(size_t)r], want); return 1; }
@@ -198,6 +198,7 @@ int main() {
       {3, 0, {0, 0, 0}, -1, -1},         {2, 0, {23, 23}, -1, -1},                                      // nobody touched anything; identical sets
       {2, 0, {6, 6}, 1, -1},             {3, -1, {6, 2, 9}, 0, -1},       {3, 1, {6, 2, 9}, -1, 2},    // key query / export failure on one rank
       {2, -1, {0, 4}, -1, 0},
+      {2, 0, {5, 5}, -1, -1, 0},         {3, -1, {4, 0, 7}, -1, -1, 2},                                 // a failure found before the protocol (bad argument on one rank)
   };
   int id = 0;
   for (const Case& c : cases)

@@ -232,3 +232,25 @@ def test_ransac_fitness_and_information_equal_the_reference_header():
     ref = RefRansac(x1, n1, x0, n0, 0.05, inlier_fraction=0.999, inlier_number=100)
     assert ref.align_redux(gt.astype(np.float32))[0] is True
     ref.close()
+
+
+def test_hard_pairs_6deg_6cm_restatement_equals_the_reference(tmp_path):
+    """The checker of tests/test_icp_gpu.py::test_hard_pairs_at_config2_size_equal_the_reference_ccorresapp run here with the
+    restatement in the HIP path's place (30 k-point fragments, reg_dist 0.05): guesses 6 deg / 6 cm off, so the iteration limit,
+    the transform criterion and the pairs that walk away from the ground truth are all in the sample -- pre-check counts, iteration
+    counts, converged flags and correspondence files exact, transforms within 1e-5 of CCorresApp's."""
+    from corres_helpers import check_pairs_against_reference, hard_pair_list, select_hard
+    frs = synth.fragment_set(6, 30000, seed=11)
+    pairs = hard_pair_list(frs, 12)
+    oc = [IcpOracle(x, n, 0.05) for x, n, _ in frs]
+    cnts, fins, iters, conv, lists, infos, gt_err = [], [], [], [], [], [], []
+    for a, b, T in pairs:
+        cnts.append(oc[b].count_inliers(oc[a], T, 0.05))
+        F, it, cv, _ = oc[b].align(oc[a], T.astype(np.float32), max_dist=0.05)
+        l, info = oc[b].find_correspondence(oc[a], F.astype(np.float64), 0.025, want_info=True)
+        fins.append(F); iters.append(it); conv.append(cv); lists.append(l); infos.append(info)
+        gt_err.append(float(np.abs(F.astype(np.float64) - ground_truth(frs, a, b)).max()))
+    sel = select_hard(iters, gt_err, want=6)
+    out = check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, lists, infos, str(tmp_path), reg_dist=0.05)
+    assert out["pairs"] >= 6 and max(out["iterations"]) >= 8, out
+    print(out, "ground-truth errors:", [round(gt_err[k], 4) for k in sel])

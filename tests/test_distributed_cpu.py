@@ -182,3 +182,76 @@ def test_c_merge_protocol_world_1_2_3_on_threads(tmp_path):
     if tsan.returncode == 0:
         r = subprocess.run([exe + "_tsan"], capture_output=True, text=True, timeout=180)
         assert r.returncode == 0 and "WARNING: ThreadSanitizer" not in r.stderr, r.stdout + r.stderr
+
+
+def json_line(stdout):
+    import json
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 must print exactly ONE JSON line, got %d:\n%s" % (len(lines), stdout[-2000:])
+    return json.loads(lines[0])
+
+
+def _bench_dry_run(nproc, extra, timeout=420):
+    """`python -m torch.distributed.run ... bench.py --gpus N ... --dry-run` exactly as the driver launches the real thing (README /
+    the task contract), on CPU: returns the parsed JSON line of rank 0."""
+    import json
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--dry-run"] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="1", ER_ORACLE_QUIET="1")
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json_line(r.stdout)
+
+
+def test_bench_dry_run_four_ranks_through_the_drivers_command_line():
+    """nothing with world > 1 had ever run through bench.py's own control flow.  This launches the driver's
+    exact command line with 4 ranks and --dry-run (gloo, host-array volume, the merge protocol of parallel.merge_volumes behind
+    the stand-in communicator) and checks the JSON contract: one line from rank 0, whole-job value, weak scaling, the merge's
+    union (one unit shared by all ranks + one private unit per rank and launch), rccl_ranks, the sharded ICP figure, and that the
+    summed unit weights of the merged volume are those of every rank's frames (unit weights add exactly)."""
+    out = _bench_dry_run(4, ["--steps", "2", "--warmup", "1", "--frames-per-step", "50", "--icp-pairs", "5", "--min-seconds", "0.05"])
+    assert out["dry_run"] is True and out["n_gpus"] == 4 and out["steps"] == 2 and out["warmup"] == 1
+    assert out["metric"].startswith("depth frames/sec") and out["unit"] == "frames/s" and out["higher_is_better"] is True
+    assert out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert out["value"] > 0 and abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 4 * 100) < 1e-6 * 400      # value = ALL ranks' frames / time
+    cfg = out["config"]
+    assert cfg["rccl_ranks"] == 4 and cfg["merge_impl"].startswith("abi") and cfg["frames_per_gpu"] == 100
+    assert cfg["merge_union_units"] == 1 + 4                          # the shared unit + one private unit per rank (100 frames: (frames // 64) % 8 = 0, 0)
+    assert "frame-block shard x4" in cfg["parallelism"]
+    assert out["roofline"]["kernel"] == "k_integrate" and out["roofline"]["launches_timed"] > 0
+    # after the reduce rank 0 holds every rank's updates: sum(weight) / world = one rank's share = 2 units x 100 frames x 64^3 voxels
+    assert out["roofline"]["voxel_updates_per_pass"] == 2 * 100 * 64 ** 3
+    assert out["icp"]["pairs"] == 20 and "4 GPUs x 5 pairs" in out["icp"]["sharding"]
+    assert "cpu_baseline" not in out and "other_configs" not in out
+
+
+def test_bench_dry_run_config4_and_config5_two_ranks():
+    """configs[3] (strong scaling: the JOB's 10 000 frames are split over the ranks; K is derived from the world size) and configs[4]
+    (the all-pairs figure reduced over the ranks, then 5000 frames) through the same launcher with 2 ranks."""
+    out = _bench_dry_run(2, ["--config", "4", "--min-seconds", "0.01", "--max-passes", "2"])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["config"]["frames_per_gpu"] == 5000 and out["steps"] == 25
+    assert out["config"]["frames_per_step"] == 200
+    assert out["config"]["rccl_ranks"] == 2 and out["config"]["merge_union_units"] == 1 + 2 * 8 and out["config"]["baseline_config"] == 4
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 * out["steps"] - 10000) < 1e-6 * 10000
+    out = _bench_dry_run(2, ["--config", "5", "--min-seconds", "0.01", "--max-passes", "2"])
+    assert out["scaling"] == "strong" and out["config"]["frames_per_gpu"] == 2500 and out["config"]["baseline_config"] == 5
+    assert out["icp"]["pairs_total"] == 4950 and out["icp"]["pairs_per_s"] > 0
+
+
+def test_bench_step_plan_covers_the_jobs_frames_at_1_2_4_8_ranks():
+    """bench.plan_steps: configs[3]'s 10 000 frames are met exactly at 1 / 2 / 4 / 8 ranks, configs[4]'s 5000 exactly up to 4 ranks and
+    rounded UP to whole fragments at 8 (650 per rank); the headline's 20 steps cover configs[1]'s 3000 frames."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for world in (1, 2, 4, 8):
+        K, S = bench.plan_steps(4, 20, 0, 50, world)
+        assert K * S * world == 10000 and S % 50 == 0, (world, K, S)
+        K, S = bench.plan_steps(5, 20, 0, 50, world)
+        assert K * S == {1: 5000, 2: 2500, 4: 1250, 8: 650}[world] and S % 50 == 0
+        assert bench.plan_steps(2, 20, 0, 50, world) == (20, 150)
+    assert bench.plan_steps(2, 5, 0, 50, 1) == (5, 600) and bench.plan_steps(2, 7, 100, 50, 1) == (7, 100)

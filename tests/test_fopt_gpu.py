@@ -235,19 +235,34 @@ def test_block_sparse_cholesky_equals_dense(gpu, monkeypatch):
     assert np.abs(sols["dense"][0] - sols["dense"][3]).max() > 1e-6 * np.abs(sols["dense"][0]).max()      # the weight does matter
 
 
-def test_cholesky_reports_a_non_positive_pivot_and_checks_its_solution(gpu, monkeypatch):
-    """potrf_lower (the library's own recursive blocked Cholesky): a system that is NOT positive definite -- a large negative regulariser
-    weight -- is reported as such, in the dense and in the block-sparse layout, instead of returning garbage; the handle stays usable, and
-    solves are linear in the right-hand side.  (That the factorisation is RIGHT is what test_optimisation_loops_match_the_reference_program
-    and test_block_sparse_cholesky_equals_dense check.)"""
+def _pivot(err):
+    """1-based index of the first non-positive pivot as the library reports it (+ the host Cholesky's, under ER_FOPT_DIAG)."""
+    import re
+    m = re.search(r"not positive definite \(Cholesky pivot (\d+)", str(err))
+    assert m, str(err)
+    h = re.search(r"host Cholesky of the SAME assembled matrix: (.*?) \(pivot (\d+)\)", str(err))
+    return int(m.group(1)), (int(h.group(2)), h.group(1)) if h else None
+
+
+def test_cholesky_failure_path_reports_the_first_non_positive_pivot(gpu, monkeypatch):
+    """The failure path of potrf_lower (the library's own recursive blocked Cholesky) -- what the reference gets from CHOLMOD's status
+    (FragmentOptimizer/OptApp.cpp:209-211, 389-393).  A positive definite system A becomes indefinite at a KNOWN place when a large
+    negative number is added to one diagonal entry g (er_fopt_debug_shift_diagonal): the leading g x g block is untouched, so pivots
+    1 .. g succeed and pivot g + 1 is the first non-positive one -- in the first 64 x 64 diagonal block, deep in the matrix (the j_base
+    arithmetic of potrf_rec across recursion levels), in the last fragment block (the block-sparse layout's global index), and for a NaN
+    entry.  Dense layout: the reported index must also equal the one a plain host Cholesky of the SAME assembled matrix finds
+    (ER_FOPT_DIAG).  Afterwards the handle refactors cleanly and reproduces its first solution.  (Round 3's version of this test used a
+    negative DATA weight: that weight multiplies the Jacobian rows, the Hessian sees its square, and the system stays positive
+    definite -- checked here as such.)"""
     from elasticreconstruction_amd._ffi import ErError
     sc = make_scene(num=3, n=6000)
     rng = np.random.default_rng(11)
     ctr = lattice_ctr(sc["num"], sc["res"], sc["length"], [np.eye(4)] * sc["num"], 0.003, rng)
     M = 2187 * sc["num"]
     b = rng.normal(size=M)
-    for dense_max in ("1000000", "0"):
+    for layout, dense_max in (("dense", "1000000"), ("blocked", "0")):
         monkeypatch.setenv("ER_FOPT_DENSE_MAX", dense_max)
+        monkeypatch.delenv("ER_FOPT_DIAG", raising=False)
         g = FragmentOptimizer(sc["num"], sc["res"], sc["length"])
         for f, (x, n) in enumerate(sc["frags"]):
             assert g.SetCloud(f, x, n) == -1
@@ -256,8 +271,56 @@ def test_cholesky_reports_a_non_positive_pivot_and_checks_its_solution(gpu, monk
         g.FactorNonrigid(1.0)
         x1, x2 = g.Solve(b), g.Solve(2.0 * b)
         assert np.isfinite(x1).all() and np.abs(x2 - 2.0 * x1).max() <= 1e-12 * np.abs(x1).max()
-        with pytest.raises(ErError, match="not positive definite"):
-            g.FactorNonrigid(-1.0e6)
+        g.FactorNonrigid(-1.0e6)                                 # weight^2 reaches the Hessian: still positive definite, no error
+        assert np.isfinite(g.Solve(b)).all()
+        for idx, value in ((5, -1.0e12), (63, -1.0e12), (64, -1.0e12), (1000, -1.0e12), (2187 + 1093, -1.0e12), (2 * 2187 + 700, -1.0e12),
+                           (M - 1, -1.0e12), (4500, float("nan"))):
+            g.DebugShiftDiagonal(idx, value)
+            with pytest.raises(ErError, match="not positive definite") as e:
+                g.FactorNonrigid(1.0)
+            assert _pivot(e.value)[0] == idx + 1, (layout, idx, str(e.value))
+            with pytest.raises(ErError, match="no factored system"):
+                g.Solve(b)                                       # a failed factorisation leaves nothing to solve with
+        if layout == "dense":                                    # ... and the host Cholesky of the same matrix agrees on the index
+            monkeypatch.setenv("ER_FOPT_DIAG", "1")
+            for idx in (70, 3000):
+                g.DebugShiftDiagonal(idx, -1.0e12)
+                with pytest.raises(ErError, match="not positive definite") as e:
+                    g.FactorNonrigid(1.0)
+                dev, host = _pivot(e.value)
+                assert dev == idx + 1 and host is not None and host[0] == dev and host[1].startswith("ALSO not positive definite"), str(e.value)
+            monkeypatch.delenv("ER_FOPT_DIAG")
+        g.DebugShiftDiagonal(-1, 0.0)
         g.FactorNonrigid(1.0)                                    # the handle is still usable afterwards
         assert np.abs(g.Solve(b) - x1).max() <= 1e-12 * np.abs(x1).max()
         g.close()
+
+
+def test_slac_with_a_negative_regulariser_is_reported_not_positive_definite(gpu, monkeypatch):
+    """er_fopt_factor_slac scales the lattice Laplacian and the anchor by default_weight (OptApp.cpp:452-464): a large negative value
+    makes thisJJ indefinite in its lattice part.  The library must say so, name the same first pivot as a host Cholesky of the same
+    matrix, and factor the well-posed system afterwards."""
+    from elasticreconstruction_amd._ffi import ErError
+    sc = make_scene(num=3, n=6000)
+    g = FragmentOptimizer(sc["num"], sc["res"], sc["length"])
+    for f, (x, n) in enumerate(sc["frags"]):
+        assert g.SetCloud(f, x, n) == -1
+        g.UpdatePose(f, sc["init"][f].astype(np.float32))
+    g.SetCorrespondences(sc["pairs"])
+    Rt = np.stack([P[:3, :3].T.reshape(9) for P in sc["init"]])
+    N = 6 * sc["num"] + g.nper_
+    Jb, _ = g.FactorSLAC(Rt, 1000.0)
+    x1 = g.Solve(Jb)
+    monkeypatch.setenv("ER_FOPT_DIAG", "1")
+    with pytest.raises(ErError, match="not positive definite") as e:
+        g.FactorSLAC(Rt, -1.0e6)
+    dev, host = _pivot(e.value)
+    assert 6 * sc["num"] < dev <= N and host is not None and host[0] == dev, str(e.value)     # the pose block (gauge + data) is fine
+    monkeypatch.delenv("ER_FOPT_DIAG")
+    with pytest.raises(ErError, match="not positive definite") as e:
+        g.FactorSLAC(Rt, -1.0e6)
+    assert _pivot(e.value) == (dev, None)
+    Jb2, _ = g.FactorSLAC(Rt, 1000.0)
+    assert np.array_equal(Jb, Jb2) or np.allclose(Jb, Jb2, rtol=1e-12, atol=1e-12 * np.abs(Jb).max())
+    assert np.abs(g.Solve(Jb2) - x1).max() <= 1e-9 * np.abs(x1).max()
+    g.close()

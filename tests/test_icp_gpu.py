@@ -310,3 +310,45 @@ def test_config2_size_50_pairs_over_25_distinct_fragments(gpu):
         assert np.abs(fins[k].astype(np.float64) - gt).max() < 2e-3, "pair %d: ground truth missed" % k
     assert int(np.sum(iters)) >= n_pairs and min(l.shape[0] for l in lists) > 50000
     print("configs[2]: 50 pairs, mean %.2f ICP iterations, max |T_gpu - T_oracle| = %.2g" % (float(np.mean(iters)), worst_T))
+
+
+def test_hard_pairs_at_config2_size_equal_the_reference_ccorresapp(gpu, tmp_path):
+    """the HARD list bench.py times (icp.hard_set) -- the configs[2] fragments (250 k points) with guesses up to
+    6 deg / 6 cm off the ground truth, so that the 20-iteration limit, the transform criterion and pairs that walk AWAY from the truth
+    are on the path (BuildCorrespondence/CorresApp.cpp:295-312) -- through the batch entry points, then >= 8 of its pairs (every pair
+    at the iteration limit, the one that ends farthest from the ground truth, the slowest converging one, then the first ones) against
+    the reference's own compiled CCorresApp (oracle/_ref/libref_corres.so; tests/corres_helpers.py::check_pairs_against_reference):
+    pre-check counts and the accept rule, iteration counts and converged flags EXACT, |dT| <= 1e-5 against both CCorresApp::Registration
+    and the reference-side ICP, corres_<i>_<j>.txt byte for byte from the HIP transforms, information matrices to 1e-9.  Where the
+    reference build did not travel, the same quantities are compared with the restatement (oracle/icp_oracle.cpp)."""
+    from corres_helpers import check_pairs_against_reference, hard_pair_list, select_hard
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch, icp_align_batch
+    from oracle.pyoracle import RefCorres
+    n_frag, n_pairs = 25, 50
+    frs = synth.fragment_set(n_frag, 250000, device="cuda:0")
+    gc = [Cloud(x, n, 0.03) for x, n, _ in frs]
+    pairs = hard_pair_list(frs, n_pairs)
+    srcs, tgts = [gc[b] for _, b, _ in pairs], [gc[a] for a, _, _ in pairs]
+    cnts = count_inliers_batch(srcs, tgts, [T for _, _, T in pairs], 0.03)
+    fins, iters, conv, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for _, _, T in pairs], 0.03, 20, 1e-6, 0)
+    lists, infos = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in fins], 0.015, 0.8660, True)
+    gt_err = [float(np.abs(F.astype(np.float64) - np.linalg.inv(frs[a][2]) @ frs[b][2]).max()) for F, (a, b, _) in zip(fins, pairs)]
+    sel = select_hard(iters, gt_err, want=8)
+    assert len(sel) >= 8 and max(int(i) for i in iters) >= 12, "the hard list is not hard: %s" % [int(i) for i in iters]
+    if RefCorres.available():
+        out = check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, lists, infos, str(tmp_path))
+        assert out["pairs"] >= 8
+    else:
+        oc = {q: IcpOracle(frs[q][0], frs[q][1], 0.03) for k in sel for q in pairs[k][:2]}
+        out = {"against": "oracle/icp_oracle.cpp (the reference build did not travel)", "selected": sel}
+        for k in sel:
+            a, b, T = pairs[k]
+            assert int(cnts[k]) == oc[b].count_inliers(oc[a], T, 0.03)
+            To, ito, co, _ = oc[b].align(oc[a], T.astype(np.float32), 0.03, 20, 1e-6, 0)
+            assert (int(iters[k]), bool(conv[k])) == (ito, co) and np.abs(fins[k] - To).max() <= TOL_T, "pair %d" % k
+            po, io = oc[b].find_correspondence(oc[a], fins[k].astype(np.float64), 0.015, 0.8660, want_info=True)
+            assert np.array_equal(lists[k], po) and np.allclose(infos[k], io, rtol=1e-9, atol=1e-6)
+    print("hard list: iterations %s, converged %d / %d, max ground-truth error %.3g (pair %d); checked: %s"
+          % ([int(i) for i in iters], int(np.sum(conv)), n_pairs, max(gt_err), int(np.argmax(gt_err)), out))
+    for c in gc:
+        c.close()

@@ -125,6 +125,47 @@ def test_reproject_zero_depth_reset_semantics(gpu):
     vol.close()
 
 
+def test_reproject_zero_depth_reset_inside_a_batch(gpu):
+    """The same order-dependent case inside er_tsdf_integrate_frames (the pipeline's own consumer of the z-buffer, k_prepare): a
+    40-frame batch in which frames 3, 20 and 37 (bit 5 of the SECOND flag word) go through a grid that collapses the points onto
+    the camera (zero writes, flagged, replayed by k_reproject_fix) and all the others through a mild grid.  Every frame's
+    re-projected depth decides which units it touches and what it integrates: the volume must equal the oracle's frame-by-frame
+    Reproject + Integrate bit for bit -- twice, so that the second batch meets re-armed replay buffers on both pre-pass streams."""
+    res, length = 2, 3.0
+    n1 = res + 1
+    k, j, i = np.meshgrid(np.arange(n1), np.arange(n1), np.arange(n1), indexing="ij")
+    verts = np.stack([i.ravel(), j.ravel(), k.ravel()], 1).astype(np.float64) * (length / res)
+    squash = verts.copy()
+    squash[:, 2] = -0.3 + 0.0001 + (verts[:, 2] / length) * 0.0013
+    squash[:, 0] = 1.5 + (verts[:, 0] - 1.5) * 0.0005
+    squash[:, 1] = 1.5 + (verts[:, 1] - 1.5) * 0.0005
+    mild = verts + np.random.RandomState(3).normal(0, 0.004, verts.shape)
+    grids = np.stack([mild, squash]).astype(np.float32)
+    n = 40
+    special = (3, 20, 37)
+    rng = np.random.RandomState(6)
+    depth = rng.randint(600, 2400, (n, 307200)).astype(np.uint16)
+    depth[rng.rand(n, 307200) < 0.05] = 0
+    seg = np.stack([synth.basepose(length)] * n)
+    madj = np.stack([np.linalg.inv(seg[0])] * n)
+    traj = synth.circle_trajectory(3000)[::70][:n]
+    warp = dict(ctr=grids, resolution=res, length=np.float32(length), grid_index=np.array([1 if f in special else 0 for f in range(n)], np.int32),
+                seg=seg, madj=madj)
+    vol, ora = TSDFVolume(max_units=512), OracleVolume()
+    zero_cells = 0
+    for rep in range(2):
+        vol.IntegrateFrames(depth, traj, warp)
+        for f in range(n):
+            d = ora.Reproject(depth[f], grids[warp["grid_index"][f]], res, length, seg[f], madj[f])
+            if f in special:
+                zero_cells += int((d == 1).sum())
+            ora.Integrate(d, traj[f])
+        helpers.assert_volumes_identical(vol, ora, "zero-write replay inside a batch, pass %d" % rep)
+    assert zero_cells > 0, "test input does not exercise the 0/1 mm boundary"
+    assert vol.sum_weight() == ora.sum_weight() and vol.sum_weight() > 1e6
+    vol.close()
+
+
 def test_edge_cases_empty_and_far_frames(gpu):
     """Empty depth frame (no unit touched), frame entirely beyond integration_trunc (units allocated but
     all-zero), custom camera file."""
