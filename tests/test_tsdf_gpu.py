@@ -144,14 +144,14 @@ def test_reproject_zero_depth_reset_inside_a_batch(gpu):
     n = 40
     special = (3, 20, 37)
     rng = np.random.RandomState(6)
-    depth = rng.randint(600, 2400, (n, 307200)).astype(np.uint16)
+    traj = synth.circle_trajectory(3000)[::70][:n]
+    depth = synth.to_numpy_u16(synth.render_depth(traj)).copy()        # the room as the cameras see it (a few dozen units per frame)
     depth[rng.rand(n, 307200) < 0.05] = 0
     seg = np.stack([synth.basepose(length)] * n)
     madj = np.stack([np.linalg.inv(seg[0])] * n)
-    traj = synth.circle_trajectory(3000)[::70][:n]
     warp = dict(ctr=grids, resolution=res, length=np.float32(length), grid_index=np.array([1 if f in special else 0 for f in range(n)], np.int32),
                 seg=seg, madj=madj)
-    vol, ora = TSDFVolume(max_units=512), OracleVolume()
+    vol, ora = TSDFVolume(max_units=2048), OracleVolume()
     zero_cells = 0
     for rep in range(2):
         vol.IntegrateFrames(depth, traj, warp)
