@@ -23,7 +23,7 @@ SYMBOLS = [
     "er_tsdf_allreduce", "er_frame_block",
     "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
-    "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_ransac_fitness_batch", "er_ransac_inliers",
+    "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_registration_batch", "er_ransac_fitness_batch", "er_ransac_inliers",
     "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
     "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_group_count", "er_fopt_group_info", "er_fopt_update_normals", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
     "er_fopt_assemble_nonrigid", "er_fopt_factor_slac", "er_fopt_factor_nonrigid", "er_fopt_solve", "er_fopt_debug_shift_diagonal",
@@ -116,6 +116,8 @@ def lib():
         L.er_icp_align_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp]
         L.er_find_correspondence_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
         L.er_icp_release_workspaces.argtypes = []
+        L.er_registration_batch.argtypes = [C.c_int, vp, vp, vp, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.er_ransac_fitness_batch.argtypes = [vp, vp, C.c_int, vp, C.c_float, vp, vp]
         L.er_ransac_inliers.argtypes = [vp, vp, vp, C.c_float, vp, C.c_int, ip, vp, vp, vp]
     if hasattr(L, "er_fopt_create"):

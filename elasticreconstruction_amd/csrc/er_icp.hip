@@ -35,6 +35,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -77,14 +79,49 @@ struct Mat12f { float m[12]; };
 constexpr int kUnroll = ER_ICP_UNROLL;
 constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // (FLT_MAX, -1)
 
+// ---- LDS staging of the candidates (round 4) ---------------------------------------------------------------------------
+// The 256 queries of a workgroup are consecutive points of the source's cell-sorted order: after the pair's transform they
+// still sit on a short piece of surface, and the 27-cell neighbourhoods of ALL of them together hold only ~450 target points
+// (<= 930 over the pair lists measured, scripts/icp_stage_sim.py) in <= 185 distinct (y, z) rows of the target grid -- about two
+// points per query, where the per-thread search pulls ~40 candidates per query through L2 in chains of dependent loads
+// (cell bounds -> candidates, own cell -> x neighbours -> row tasks).  So the workgroup first builds, in LDS, the set of
+// rows its queries can touch with the x extent each row is needed over (a small open-addressing table keyed by the row id,
+// extents by atomicMin / atomicMax), then loads exactly those ranges ONCE -- two rounds of independent, coalesced global loads for
+// the whole workgroup: the cell bounds of every row, then its points -- and the search phases below read cell bounds and
+// candidates from LDS.  The candidate SETS are those of the global search, so the result is the same exact nearest neighbour
+// with the same tie rule.  A workgroup whose rows / points / cells exceed the LDS budget (never on the measured lists) runs
+// the global search.
+#ifndef ER_NN_STAGE
+#define ER_NN_STAGE 1
+#endif
+constexpr int kStSlots = 512;           // table slots (rows are capped at 3/4 of them)
+constexpr int kStPts = 1024;            // staged target points (16 KB)
+constexpr int kStCells = 1024;          // staged cell bounds
+constexpr int kTaskCap = kBlock * 4;    // (query, row) tasks of phase 1 held in LDS; a task beyond that is scanned by the thread that found it
+
+struct NnStage {
+  float4 pts[kStPts];
+  int cs[kStCells];                     // LDS index of the first staged point of every staged cell (+ one terminal per row)
+  int key[kStSlots];                    // row id z * dim_y + y, or -1
+  int xlo[kStSlots];                    // lowest cell column needed of the row
+  int xhi[kStSlots];                    // highest; after the scan: LDS index of the row's first point
+  int csb[kStSlots];                    // index into cs[] of the row's cell xlo
+  int g0[kStSlots];                     // index of the row's first staged point in the cell-sorted target
+  int wtot[2][kBlock / 64];
+  int nrows, tot_pts, tot_cells, fail;
+};
+
 struct NnShared {
   unsigned long long best[kBlock];
   float q[3][kBlock];
   int ix[kBlock];                 // the query's own cell column (may be -1 or dim[0]: one cell outside the grid)
-  int task_row[kBlock * 8];
-  unsigned char task_q[kBlock * 8];
-  unsigned char task_lr[kBlock * 8];   // bit 0: the row's cell x-1 can still hold a closer point, bit 1: cell x+1
+  int task_row[kTaskCap];         // global search: first cell of the row in cell_start; staged: the row's table slot
+  unsigned char task_q[kTaskCap];
+  unsigned char task_lr[kTaskCap];   // bit 0: the row's cell x-1 can still hold a closer point, bit 1: cell x+1
   int ntask;
+#if ER_NN_STAGE
+  NnStage st;
+#endif
 };
 
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
@@ -110,66 +147,248 @@ __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, i
   return scan_range(g, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, key);
 }
 
+#if ER_NN_STAGE
+// The same scan over candidates held in LDS.
+__device__ __forceinline__ unsigned long long scan_range_s(const NnStage& st, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
+  for (int s = s0; s < s1; s += kUnroll) {
+    float4 p[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) p[u] = st.pts[min(s + u, s1 - 1)];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
+      const float d = ((dx * dx) + dy * dy) + dz * dz;
+      const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
+      key = k < key ? k : key;
+    }
+  }
+  return key;
+}
+__device__ __forceinline__ unsigned long long scan_row_s(const NnStage& st, int slot, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
+  const int b = st.csb[slot] - st.xlo[slot];
+  return scan_range_s(st, st.cs[b + xa], st.cs[b + xb + 1], qx, qy, qz, key);
+}
+__device__ __forceinline__ unsigned stage_hash(int row) { return ((unsigned)row * 2654435761u) >> 23; }   // 9 bits = kStSlots
+static_assert(kStSlots == 512, "stage_hash yields 9 bits");
+// Slot of a row that IS in the table.
+__device__ __forceinline__ int stage_slot(const NnStage& st, int row) {
+  unsigned s = stage_hash(row);
+  for (int probe = 0; probe < kStSlots && st.key[s] != row; probe++) s = (s + 1) & (kStSlots - 1);   // (bounded: a missing row must not hang the GPU)
+  return (int)s;
+}
+__device__ __forceinline__ void stage_insert(NnStage& st, int row, int xa, int xb) {
+  unsigned s = stage_hash(row);
+  for (int probe = 0; probe < kStSlots; probe++, s = (s + 1) & (kStSlots - 1)) {
+    int k = st.key[s];
+    if (k == -1) {
+      k = atomicCAS(&st.key[s], -1, row);
+      if (k == -1) {
+        atomicAdd(&st.nrows, 1);
+        k = row;
+      }
+    }
+    if (k == row) {                                            // (extents only ever widen: a stale read costs one redundant atomic at most)
+      if (st.xlo[s] > xa) atomicMin(&st.xlo[s], xa);
+      if (st.xhi[s] < xb) atomicMax(&st.xhi[s], xb);
+      return;
+    }
+  }
+  st.fail = 1;
+}
+// Last slot whose base (a non-decreasing array over the slots; empty rows repeat the next row's base) is <= f: the row element f belongs to.
+__device__ __forceinline__ int stage_owner(const int* __restrict__ base, int f) {
+  int lo = 0, hi = kStSlots - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (base[mid] <= f) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// Builds the workgroup's candidate set in LDS (see above).  Every thread calls it; `valid` = the thread's query lies within one
+// cell of the grid.  Returns false (uniformly) when the set does not fit: the caller then searches in global memory.
+__device__ __forceinline__ bool nn_stage(NnStage& st, const Grid& g, bool valid, int ix, int iy, int iz) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int s = tid; s < kStSlots; s += kBlock) {
+    st.key[s] = -1;
+    st.xlo[s] = INT_MAX;
+    st.xhi[s] = INT_MIN;
+  }
+  if (tid == 0) {
+    st.nrows = 0;
+    st.fail = 0;
+  }
+  __syncthreads();
+  {
+    // consecutive queries share their cell about six at a time: only the first of a run inserts
+    const int pix = __shfl_up(ix, 1), piy = __shfl_up(iy, 1), piz = __shfl_up(iz, 1), pv = __shfl_up(valid ? 1 : 0, 1);
+    const bool lead = valid && (lane == 0 || !pv || pix != ix || piy != iy || piz != iz);
+    const int xa = max(ix - 1, 0), xb = min(ix + 1, g.dim[0] - 1);
+    if (lead && xa <= xb) {
+      for (int dz = -1; dz <= 1; dz++)
+        for (int dy = -1; dy <= 1; dy++) {
+          const int y = iy + dy, z = iz + dz;
+          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) stage_insert(st, z * g.dim[1] + y, xa, xb);
+        }
+    }
+  }
+  __syncthreads();
+  if (st.fail || st.nrows > (kStSlots * 3) / 4) return false;
+  // cell bounds of every row (one round of independent loads), sizes, exclusive scan over the slots (two per thread)
+  int np0 = 0, np1 = 0, nc0 = 0, nc1 = 0, c00 = 0, c01 = 0;
+  {
+    const int s0 = 2 * tid, s1 = 2 * tid + 1;
+    const int r0 = st.key[s0], l0 = st.xlo[s0], h0 = st.xhi[s0], r1 = st.key[s1], l1 = st.xlo[s1], h1 = st.xhi[s1];
+    const bool u0 = r0 >= 0 && l0 <= h0, u1 = r1 >= 0 && l1 <= h1;
+    int e0 = 0, e1 = 0;
+    if (u0) {
+      c00 = g.cell_start[r0 * g.dim[0] + l0];
+      e0 = g.cell_start[r0 * g.dim[0] + h0 + 1];
+    }
+    if (u1) {
+      c01 = g.cell_start[r1 * g.dim[0] + l1];
+      e1 = g.cell_start[r1 * g.dim[0] + h1 + 1];
+    }
+    if (u0) {
+      np0 = e0 - c00;
+      nc0 = h0 - l0 + 2;
+    }
+    if (u1) {
+      np1 = e1 - c01;
+      nc1 = h1 - l1 + 2;
+    }
+  }
+  int sp = np0 + np1, sc = nc0 + nc1;                         // inclusive wave scans of the pair sums
+  for (int off = 1; off < 64; off <<= 1) {
+    const int a = __shfl_up(sp, off), b = __shfl_up(sc, off);
+    if (lane >= off) {
+      sp += a;
+      sc += b;
+    }
+  }
+  if (lane == 63) {
+    st.wtot[0][wave] = sp;
+    st.wtot[1][wave] = sc;
+  }
+  __syncthreads();
+  int bp = 0, bc = 0;
+  for (int w = 0; w < wave; w++) {
+    bp += st.wtot[0][w];
+    bc += st.wtot[1][w];
+  }
+  if (tid == kBlock - 1) {
+    st.tot_pts = bp + sp;
+    st.tot_cells = bc + sc;
+  }
+  bp += sp - (np0 + np1);
+  bc += sc - (nc0 + nc1);
+  st.xhi[2 * tid] = bp;                                        // from here on: LDS index of the row's first point
+  st.csb[2 * tid] = bc;
+  st.g0[2 * tid] = c00;
+  st.xhi[2 * tid + 1] = bp + np0;
+  st.csb[2 * tid + 1] = bc + nc0;
+  st.g0[2 * tid + 1] = c01;
+  __syncthreads();
+  const int tp = st.tot_pts, tc = st.tot_cells;
+  if (tp > kStPts || tc > kStCells) return false;
+  // second round of independent loads: the cell bounds (as LDS point indices) and the points themselves
+  for (int f = tid; f < tc; f += kBlock) {
+    const int s = stage_owner(st.csb, f);
+    const int v = g.cell_start[st.key[s] * g.dim[0] + st.xlo[s] + (f - st.csb[s])];
+    st.cs[f] = v - st.g0[s] + st.xhi[s];
+  }
+  for (int f = tid; f < tp; f += kBlock) {                       // (tp <= 1024: at most four independent 16-byte loads per thread)
+    const int s = stage_owner(st.xhi, f);
+    st.pts[f] = g.pts[st.g0[s] + (f - st.xhi[s])];
+  }
+  __syncthreads();
+  return true;
+}
+#endif
+
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
 // Returns the index (or -1) and the squared distance of the nearest target point.
 // Round 3: the HOME row is no longer scanned as one range of three cells -- the query's own cell first, then the left / right
 // cell only if its face is closer than the best so far -- and the neighbour rows carry the same two flags, so a typical query
 // looks at about half the candidates (a cell is skipped only when every point in it is provably farther than the best: its
 // nearest face already is, with the same 1e-4 relative margin as the row test; ties cannot hide there).
+// Round 4: the candidates come from LDS when the workgroup's candidate set fits (nn_stage above).
 __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
                                         float& best_d) {
   const int tid = threadIdx.x;
   __syncthreads();                                            // the previous call's readers are done with `sh`
   if (tid == 0) sh.ntask = 0;
+  // the query's cell (float32 expressions shared with the grid build)
+  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
+  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
+  const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
+  const int ix = inside ? (int)cx : 0, iy = inside ? (int)cy : 0, iz = inside ? (int)cz : 0;
+  const int nx = g.dim[0];
+  const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
+  const bool valid = inside && (has_l | has_o | has_r);
+#if ER_NN_STAGE
+  const bool staged = nn_stage(sh.st, g, valid, ix, iy, iz);  // (synchronises; uniform)
+#else
+  const bool staged = false;
   __syncthreads();
+#endif
+  // a row as the scans address it: its table slot (staged) or its first cell in cell_start
+  auto rowref = [&](int y, int z) -> int {
+#if ER_NN_STAGE
+    if (staged) return stage_slot(sh.st, z * g.dim[1] + y);
+#endif
+    return (z * g.dim[1] + y) * nx;
+  };
+  auto scan = [&](int ref, int xa, int xb, float x, float y, float z, unsigned long long key) -> unsigned long long {
+#if ER_NN_STAGE
+    if (staged) return scan_row_s(sh.st, ref, xa, xb, x, y, z, key);
+#endif
+    return scan_row(g, ref, xa, xb, x, y, z, key);
+  };
   unsigned long long key = kNoHit;
-  if (active) {
-    const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
-    const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
-    const bool inside = cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
-    if (inside) {
-      const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-      const int nx = g.dim[0];
-      // distance from q to the lower / upper face of its own cell along x, y and z (metres)
-      const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
-                  zhi = g.cell - zlo;
-      const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
-      if (has_l | has_o | has_r) {
-        float bound = limit2 * 1.0001f + 1e-12f;
-        if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
-          const int row = (iz * g.dim[1] + iy) * nx;
-          if (has_o) {
-            key = scan_row(g, row, ix, ix, qx, qy, qz, key);
-            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
-          }
-          if (has_l && xlo * xlo <= bound) {
-            key = scan_row(g, row, ix - 1, ix - 1, qx, qy, qz, key);
-            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
-          }
-          if (has_r && xhi * xhi <= bound) {
-            key = scan_row(g, row, ix + 1, ix + 1, qx, qy, qz, key);
-            bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
-          }
-        }
-        sh.q[0][tid] = qx;
-        sh.q[1][tid] = qy;
-        sh.q[2][tid] = qz;
-        sh.ix[tid] = ix;
+  if (valid) {
+    // distance from q to the lower / upper face of its own cell along x, y and z (metres)
+    const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
+                zhi = g.cell - zlo;
+    float bound = limit2 * 1.0001f + 1e-12f;
+    if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
+      const int row = rowref(iy, iz);
+      if (has_o) {
+        key = scan(row, ix, ix, qx, qy, qz, key);
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
+      }
+      if (has_l && xlo * xlo <= bound) {
+        key = scan(row, ix - 1, ix - 1, qx, qy, qz, key);
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+      }
+      if (has_r && xhi * xhi <= bound) {
+        key = scan(row, ix + 1, ix + 1, qx, qy, qz, key);
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+      }
+    }
+    sh.q[0][tid] = qx;
+    sh.q[1][tid] = qy;
+    sh.q[2][tid] = qz;
+    sh.ix[tid] = ix;
 #pragma unroll
-        for (int pass = 0; pass < 9; pass++) {
-          if (pass == 4) continue;
-          const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-          const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
-          const int y = iy + dy, z = iz + dz;
-          const float e2 = ey * ey + ez * ez;
-          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
-            const int lr = ((has_l && xlo * xlo + e2 <= bound) ? 1 : 0) | ((has_r && xhi * xhi + e2 <= bound) ? 2 : 0);
-            if (has_o || lr) {
-              const int t = atomicAdd(&sh.ntask, 1);
-              sh.task_row[t] = (z * g.dim[1] + y) * nx;
-              sh.task_q[t] = (unsigned char)tid;
-              sh.task_lr[t] = (unsigned char)lr;
-            }
+    for (int pass = 0; pass < 9; pass++) {
+      if (pass == 4) continue;
+      const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+      const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
+      const int y = iy + dy, z = iz + dz;
+      const float e2 = ey * ey + ez * ez;
+      if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
+        const int lr = ((has_l && xlo * xlo + e2 <= bound) ? 1 : 0) | ((has_r && xhi * xhi + e2 <= bound) ? 2 : 0);
+        if (has_o || lr) {
+          const int ref = rowref(y, z);
+          const int t = atomicAdd(&sh.ntask, 1);
+          if (t < kTaskCap) {
+            sh.task_row[t] = ref;
+            sh.task_q[t] = (unsigned char)tid;
+            sh.task_lr[t] = (unsigned char)lr;
+          } else {                                            // the task list is full (never on the measured lists): scan it here
+            const int xa = max((lr & 1) ? ix - 1 : ix, 0), xb = min((lr & 2) ? ix + 1 : ix, nx - 1);
+            if (xa <= xb) key = scan(ref, xa, xb, qx, qy, qz, key);
           }
         }
       }
@@ -177,12 +396,12 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   }
   sh.best[tid] = key;
   __syncthreads();
-  const int nt = sh.ntask;
+  const int nt = min(sh.ntask, kTaskCap);
   for (int t = tid; t < nt; t += kBlock) {
-    const int q = sh.task_q[t], lr = sh.task_lr[t], ix = sh.ix[q];
-    const int xa = max((lr & 1) ? ix - 1 : ix, 0), xb = min((lr & 2) ? ix + 1 : ix, g.dim[0] - 1);
+    const int q = sh.task_q[t], lr = sh.task_lr[t], qix = sh.ix[q];
+    const int xa = max((lr & 1) ? qix - 1 : qix, 0), xb = min((lr & 2) ? qix + 1 : qix, nx - 1);
     if (xa > xb) continue;
-    const unsigned long long k = scan_row(g, sh.task_row[t], xa, xb, sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+    const unsigned long long k = scan(sh.task_row[t], xa, xb, sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
     if (k != kNoHit) atomicMin(&sh.best[q], k);
   }
   __syncthreads();
@@ -1696,6 +1915,89 @@ int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], d
   if (!T || !n_pairs || (capacity > 0 && !pairs_host)) return er::fail("er_find_correspondence: NULL argument");
   int* const bufs[1] = {pairs_host};
   return er_find_correspondence_batch(1, &src, &tgt, T, dist, normal_cos, bufs, &capacity, n_pairs, info36);
+}
+
+// CCorresApp::Registration followed by CCorresApp::FindCorrespondence for a whole pair list in ONE call (CorresApp.cpp:212-319, then
+// :112-210): per pair the pre-check count, the accept rule of :270 ("cnt >= reg_num_ || ( r1 > reg_ratio_ && r2 > reg_ratio_ )"), for
+// the accepted pairs icp.align from the float32 cast of the guess (:295-312) and -- from the float64 cast of its result, as :312 stores
+// it -- the correspondence list with the `Reduced too much` rule of :164-173 left to the caller (n_pairs and counts are both returned).
+// The pairs are independent, so the list is cut into a few contiguous shares and every share runs the three stages on a host thread
+// and a group workspace of its own: the host round trips of one share (accept rule, the states of an ICP chunk, list sizes) and its
+// list copies over PCIe overlap the kernels of the others -- what the reference's "#pragma omp parallel for" does for its CPU loops.
+// Results are those of the three *_batch calls in sequence (same kernels, same per-pair arithmetic).
+int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
+                          int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
+                          int* accepted, float* T_final, int* iterations, int* converged, int* const* pairs_host, const int* capacity,
+                          int* n_pairs, double* info36) {
+  int device;
+  if (n > 0 && (!T_guess || !counts || !accepted || !T_final || !pairs_host || !capacity || !n_pairs)) return er::fail("er_registration_batch: NULL argument");
+  if (batch_prologue(n, src, tgt, reg_dist, "er_registration_batch", &device)) return 1;
+  if (batch_prologue(n, src, tgt, corr_dist, "er_registration_batch", &device)) return 1;
+  if (n == 0) return 0;
+  const char* e = getenv("ER_ICP_SHARES");
+  int shares = e ? atoi(e) : 3;
+  shares = std::max(1, std::min(shares, std::min(8, (n + 7) / 8)));          // at least ~8 pairs per share: every launch still fills the chip
+  std::vector<int> rc((size_t)shares, 0);
+  std::vector<std::string> why((size_t)shares);
+  auto work = [&](int w) {
+    const int lo = (int)((long)n * w / shares), hi = (int)((long)n * (w + 1) / shares), m = hi - lo;
+    if (m <= 0) return;
+    auto failed = [&]() { rc[(size_t)w] = 1; why[(size_t)w] = er_last_error(); };   // (the message lives in this thread's buffer)
+    if (hipSetDevice(device) != hipSuccess) { er::fail("er_registration_batch: hipSetDevice(%d) failed", device); failed(); return; }
+    if (er_icp_count_inliers_batch(m, src + lo, tgt + lo, T_guess + (size_t)lo * 16, reg_dist, counts + lo)) { failed(); return; }
+    std::vector<int> idx;
+    for (int i = lo; i < hi; i++) {
+      const double r1 = (double)counts[i] / (double)tgt[i]->n, r2 = (double)counts[i] / (double)src[i]->n;   // :268-269 (0 / 0 = NaN: rejected)
+      accepted[i] = (counts[i] >= reg_num || (r1 > reg_ratio && r2 > reg_ratio)) ? 1 : 0;
+      n_pairs[i] = 0;
+      if (iterations) iterations[i] = 0;
+      if (converged) converged[i] = 0;
+      for (int q = 0; q < 16; q++) T_final[(size_t)i * 16 + q] = (float)T_guess[(size_t)i * 16 + q];      // a rejected pair keeps its transform (:277-283)
+      if (info36) memset(info36 + (size_t)i * 36, 0, 36 * sizeof(double));
+      if (accepted[i]) idx.push_back(i);
+    }
+    const int a = (int)idx.size();
+    if (a == 0) return;
+    std::vector<er_cloud_t> s2((size_t)a), t2((size_t)a);
+    std::vector<float> g2((size_t)a * 16), f2((size_t)a * 16);
+    std::vector<double> T2((size_t)a * 16), I2(info36 ? (size_t)a * 36 : 0);
+    std::vector<int> it2((size_t)a), cv2((size_t)a), cap2((size_t)a), np2((size_t)a);
+    std::vector<int*> buf2((size_t)a);
+    for (int k = 0; k < a; k++) {
+      const int i = idx[(size_t)k];
+      s2[(size_t)k] = src[i];
+      t2[(size_t)k] = tgt[i];
+      memcpy(&g2[(size_t)k * 16], &T_final[(size_t)i * 16], 16 * sizeof(float));                            // transformation_.cast<float>()
+      cap2[(size_t)k] = capacity[i];
+      buf2[(size_t)k] = pairs_host[i];
+    }
+    if (er_icp_align_batch(a, s2.data(), t2.data(), g2.data(), reg_dist, max_iter, transformation_epsilon, stop_rule, f2.data(), it2.data(), cv2.data(), nullptr)) {
+      failed();
+      return;
+    }
+    for (size_t q = 0; q < (size_t)a * 16; q++) T2[q] = (double)f2[q];                                        // getFinalTransformation().cast<double>()
+    const int frc = er_find_correspondence_batch(a, s2.data(), t2.data(), T2.data(), corr_dist, normal_cos, buf2.data(), cap2.data(), np2.data(),
+                                                 info36 ? I2.data() : nullptr);
+    for (int k = 0; k < a; k++) {
+      const int i = idx[(size_t)k];
+      memcpy(&T_final[(size_t)i * 16], &f2[(size_t)k * 16], 16 * sizeof(float));
+      if (iterations) iterations[i] = it2[(size_t)k];
+      if (converged) converged[i] = cv2[(size_t)k];
+      n_pairs[i] = np2[(size_t)k];
+      if (info36) memcpy(info36 + (size_t)i * 36, &I2[(size_t)k * 36], 36 * sizeof(double));
+    }
+    if (frc) failed();
+  };
+  if (shares == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int w = 0; w < shares; w++) th.emplace_back(work, w);
+    for (std::thread& t : th) t.join();
+  }
+  for (int w = 0; w < shares; w++)
+    if (rc[(size_t)w]) return er::fail("%s", why[(size_t)w].c_str());
+  return 0;
 }
 
 }  // extern "C"

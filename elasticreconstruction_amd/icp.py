@@ -165,6 +165,37 @@ def find_correspondence_batch(srcs, tgts, Ts, dist, normal_cos=0.8660, want_info
     return [(l.copy() if copy else l) for l in lists], (info.reshape(n, 6, 6) if want_info else None)
 
 
+def registration_batch(srcs, tgts, Ts, reg_dist=0.03, reg_num=40000, reg_ratio=0.25, max_iter=20, eps=1e-6, stop_rule=0, corr_dist=0.015,
+                       normal_cos=0.8660, want_info=False, copy=True):
+    """er_registration_batch: CCorresApp::Registration + FindCorrespondence over a pair list in one call (CorresApp.cpp:212-319, 112-210).
+    Returns dict(counts, accepted, T (float32 [n,4,4]), iterations, converged, lists ([int32 [m_i,2]], empty for rejected pairs), info or None).
+    copy=False: the lists are views into the process-wide page-locked arena, valid until the next *_batch call that returns lists."""
+    global _arena
+    n = len(srcs)
+    if n == 0:
+        return dict(counts=np.zeros(0, np.int32), accepted=np.zeros(0, bool), T=np.zeros((0, 4, 4), np.float32), iterations=np.zeros(0, np.int32),
+                    converged=np.zeros(0, bool), lists=[], info=np.zeros((0, 6, 6)) if want_info else None)
+    if _arena is None:
+        _arena = _ffi.PinnedArena()
+    Tm = np.ascontiguousarray(Ts, np.float64).reshape(n, 16)
+    cap = np.array([s.n for s in srcs], np.int32)
+    ints = ((np.maximum(cap, 1).astype(np.int64) * 2 + 1023) // 1024) * 1024
+    offs = np.concatenate([[0], np.cumsum(ints)[:-1]])
+    _arena.reset(int(ints.sum()) * 4 + 8192)
+    big = _arena.take((int(ints.sum()),), np.int32)
+    ptrs = (C.c_void_p * n)(*(big.ctypes.data + 4 * offs).tolist())
+    counts, acc, its, cv, m = (np.zeros(n, np.int32) for _ in range(5))
+    F = np.zeros((n, 16), np.float32)
+    info = np.zeros((n, 36), np.float64) if want_info else None
+    _ffi.check(srcs[0]._lib.er_registration_batch(n, _handles(srcs), _handles(tgts), _ffi.ptr(Tm), float(reg_dist), int(reg_num), float(reg_ratio),
+                                                  int(max_iter), float(eps), int(stop_rule), float(corr_dist), float(normal_cos), _ffi.ptr(counts),
+                                                  _ffi.ptr(acc), _ffi.ptr(F), _ffi.ptr(its), _ffi.ptr(cv), ptrs, _ffi.ptr(cap), _ffi.ptr(m),
+                                                  _ffi.ptr(info) if want_info else None), "er_registration_batch")
+    lists = [big[o:o + 2 * k].reshape(k, 2) for o, k in zip(offs.tolist(), m.tolist())]
+    return dict(counts=counts, accepted=acc.astype(bool), T=F.reshape(n, 4, 4), iterations=its, converged=cv.astype(bool),
+                lists=[(l.copy() if copy else l) for l in lists], info=info.reshape(n, 6, 6) if want_info else None)
+
+
 class CorresApp:
     """CCorresApp (CorresApp.h:12-82).  Defaults from the constructor, CorresApp.cpp:8-24."""
 

@@ -254,6 +254,21 @@ int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float co
 /* Frees the pooled ICP workspaces (streams, scratch, pinned blocks).  Optional; call when no ICP call is running. */
 int er_icp_release_workspaces(void);
 
+/* CCorresApp::Registration (CorresApp.cpp:212-319) followed by CCorresApp::FindCorrespondence (:112-210) for a whole pair list in ONE call:
+ *   counts[i]    the pre-check count of :257-264 (NN of T_guess * source within reg_dist);
+ *   accepted[i]  the accept rule of :270 -- counts >= reg_num, or both ratios counts / |target| and counts / |source| above reg_ratio;
+ *   T_final      16 floats per pair: icp.align from the float32 cast of the guess (:295-312) for an accepted pair, the cast of the guess itself
+ *                for a rejected one (its transformation_ is left alone, :277-283); iterations / converged (nullable) as er_icp_align_batch;
+ *   pairs_host, capacity, n_pairs, info36 (nullable): FindCorrespondence of the accepted pairs at the float64 cast of T_final (:312), as
+ *                er_find_correspondence_batch returns them; n_pairs = 0 for a rejected pair.  The `Reduced too much` rule of :164-173
+ *                (n_pairs / counts < 0.5) is the caller's: both numbers are returned.
+ * The list is cut into ER_ICP_SHARES (default 3) contiguous shares that run their three stages on a host thread and workspace each, so one
+ * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls. */
+int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
+                          int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
+                          int* accepted, float* T_final, int* iterations, int* converged, int* const* pairs_host, const int* capacity,
+                          int* n_pairs, double* info36);
+
 /* ------------------------------------------ next consumer: FragmentOptimizer ---- */
 typedef struct er_fopt_s* er_fopt_t;
 

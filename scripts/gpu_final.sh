@@ -12,7 +12,7 @@ HEAD_ID="$(cat .gate_head 2>/dev/null || echo unstamped)"
 SECONDS=0
 LOG=gpurun_out/pytest_gpu_$TAG.log
 echo "# HEAD $HEAD_ID  tag $TAG  $(date -u +%FT%TZ)" > $LOG
-timeout $((LIMIT > 700 ? 560 : LIMIT * 4 / 5)) python -m pytest tests ${GATE_X:--x} -q -m gpu --tb=short -p no:cacheprovider >> $LOG 2>&1
+timeout $((LIMIT > 700 ? 560 : LIMIT * 4 / 5)) python -m pytest tests ${GATE_X--x} -q -m gpu --tb=short -p no:cacheprovider >> $LOG 2>&1
 PRC=$?; echo "pytest exit $PRC after ${SECONDS}s" >> $LOG; tail -6 $LOG
 echo "# HEAD $HEAD_ID" > gpurun_out/smoke_$TAG.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/smoke_$TAG.log 2>&1; SRC=$?; echo "smoke exit $SRC" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log

@@ -28,4 +28,17 @@ for r in range(reps + 2):
     if r >= 2:
         ph.append((t1 - t0, t2 - t1, t3 - t2))
 ph = np.array(ph) * 1e3
+if os.environ.get("ER_PROBE_FUSED", "1") == "1":
+    from elasticreconstruction_amd.icp import registration_batch
+    for shares in os.environ.get("ER_PROBE_SHARES", "1 2 3 4").split():
+        os.environ["ER_ICP_SHARES"] = shares
+        tt = []
+        for r in range(reps + 2):
+            t0 = time.perf_counter()
+            out = registration_batch(srcs, tgts, Ts, 0.03, 40000, 0.25, 20, 1e-6, 0, 0.015, 0.8660, want_info=True, copy=False)
+            tt.append(time.perf_counter() - t0)
+        tt = np.array(tt[2:]) * 1e3
+        same = all(np.array_equal(out["T"][k], fins[k]) for k in range(n_pairs)) and [len(l) for l in out["lists"]] == [len(l) for l in lists]
+        print("fused er_registration_batch, %s share(s): median %.2f ms (min %.2f max %.2f) -> %.0f pairs/s; accepted %d / %d; equals the three calls bit for bit: %s"
+              % (shares, np.median(tt), tt.min(), tt.max(), n_pairs / np.median(tt) * 1e3, int(out["accepted"].sum()), n_pairs, same))
 print("phases ms median", np.median(ph, 0), "min", ph.min(0), "max", ph.max(0), "total median %.2f -> %.0f pairs/s" % (np.median(ph.sum(1)), n_pairs / np.median(ph.sum(1)) * 1e3))

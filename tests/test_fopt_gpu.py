@@ -253,7 +253,8 @@ def test_cholesky_failure_path_reports_the_first_non_positive_pivot(gpu, monkeyp
     entry.  Dense layout: the reported index must also equal the one a plain host Cholesky of the SAME assembled matrix finds
     (ER_FOPT_DIAG).  Afterwards the handle refactors cleanly and reproduces its first solution.  (Round 3's version of this test used a
     negative DATA weight: that weight multiplies the Jacobian rows, the Hessian sees its square, and the system stays positive
-    definite -- checked here as such.)"""
+    definite -- checked here as such with a weight of -3; at -1e6 the data term outweighs the regulariser by 1e12 and the
+    factorisation fails for a different reason, float64 cancellation, in the block-sparse layout: pivot 6549 of 6561.)"""
     from elasticreconstruction_amd._ffi import ErError
     sc = make_scene(num=3, n=6000)
     rng = np.random.default_rng(11)
@@ -271,8 +272,11 @@ def test_cholesky_failure_path_reports_the_first_non_positive_pivot(gpu, monkeyp
         g.FactorNonrigid(1.0)
         x1, x2 = g.Solve(b), g.Solve(2.0 * b)
         assert np.isfinite(x1).all() and np.abs(x2 - 2.0 * x1).max() <= 1e-12 * np.abs(x1).max()
-        g.FactorNonrigid(-1.0e6)                                 # weight^2 reaches the Hessian: still positive definite, no error
-        assert np.isfinite(g.Solve(b)).all()
+        g.FactorNonrigid(3.0)
+        x3 = g.Solve(b)
+        g.FactorNonrigid(-3.0)                                   # the weight multiplies the Jacobian ROWS: the Hessian sees its square, the
+        xm = g.Solve(b)                                          # system is the one of +3 -- positive definite, same solution, no error
+        assert np.isfinite(xm).all() and np.abs(xm - x3).max() <= 1e-9 * np.abs(x3).max() and np.abs(x3 - x1).max() > 1e-6 * np.abs(x1).max()
         for idx, value in ((5, -1.0e12), (63, -1.0e12), (64, -1.0e12), (1000, -1.0e12), (2187 + 1093, -1.0e12), (2 * 2187 + 700, -1.0e12),
                            (M - 1, -1.0e12), (4500, float("nan"))):
             g.DebugShiftDiagonal(idx, value)

@@ -352,3 +352,48 @@ def test_hard_pairs_at_config2_size_equal_the_reference_ccorresapp(gpu, tmp_path
           % ([int(i) for i in iters], int(np.sum(conv)), n_pairs, max(gt_err), int(np.argmax(gt_err)), out))
     for c in gc:
         c.close()
+
+
+def test_registration_batch_equals_the_three_stage_calls(gpu, monkeypatch):
+    """er_registration_batch (Registration + FindCorrespondence of a pair list in one call, the shares on host threads of their own) against
+    the three *_batch calls in sequence with the accept rule of CorresApp.cpp:270 applied in between: pre-check counts, accept flags,
+    iteration counts, converged flags and correspondence lists EXACT, transforms within 1e-6 (a share is a smaller group: k_icp_iter may
+    take fewer points per thread, which reorders its float64 sums), information matrices to 1e-9 -- with one, two and three shares, a
+    hopeless pair (rejected by the pre-check: no ICP, no list, its transform stays the guess), an empty source and shared clouds."""
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch, icp_align_batch, registration_batch
+    data = [make_pair(n=60000 + 9000 * i, rot=1.0 + 0.3 * i, trans=0.01, seed=40 + i) for i in range(3)]
+    cl = [(Cloud(x0, n0, 0.03), Cloud(x1, n1, 0.03), P) for (x0, n0), (x1, n1), P in data]
+    empty = Cloud(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.03)
+    srcs, tgts, Ts = [], [], []
+    for k in range(19):
+        tgt, src, P = cl[k % 3]
+        srcs.append(src); tgts.append(tgt)
+        Ts.append(P @ synth.perturbation(80 + k, 0.8 + 0.2 * (k % 5), 0.006) if k not in (4, 13) else synth.perturbation(3 + k, 40, 1.0))
+    srcs.append(empty); tgts.append(cl[0][0]); Ts.append(np.eye(4))
+    n = len(srcs)
+    reg_num, reg_ratio = 20000, 0.25
+    cnts = count_inliers_batch(srcs, tgts, Ts, 0.03)
+    ns, nt = np.array([max(len(s), 1) for s in srcs], float), np.array([len(t) for t in tgts], float)
+    acc = (cnts >= reg_num) | ((cnts / nt > reg_ratio) & (cnts / ns > reg_ratio))
+    acc &= np.array([len(s) > 0 for s in srcs])
+    ai = np.nonzero(acc)[0]
+    assert not acc[4] and not acc[13] and not acc[-1] and acc.sum() == n - 3
+    F, its, cv, _ = icp_align_batch([srcs[k] for k in ai], [tgts[k] for k in ai], [Ts[k].astype(np.float32) for k in ai], 0.03, 20, 1e-6, 0)
+    lists, infos = find_correspondence_batch([srcs[k] for k in ai], [tgts[k] for k in ai], [f.astype(np.float64) for f in F], 0.015, 0.8660, True)
+    for shares in ("1", "2", "3"):
+        monkeypatch.setenv("ER_ICP_SHARES", shares)
+        r = registration_batch(srcs, tgts, Ts, 0.03, reg_num, reg_ratio, 20, 1e-6, 0, 0.015, 0.8660, want_info=True)
+        assert np.array_equal(r["counts"], cnts) and np.array_equal(r["accepted"], acc), shares
+        for q, k in enumerate(ai):
+            assert (int(r["iterations"][k]), bool(r["converged"][k])) == (int(its[q]), bool(cv[q])), (shares, k)
+            assert np.abs(r["T"][k] - F[q]).max() <= 1e-6, (shares, k, np.abs(r["T"][k] - F[q]).max())
+            # the list is taken at the call's OWN final transform: identical whenever that transform is (it is, bit for bit, in practice)
+            if np.array_equal(r["T"][k], F[q]):
+                assert np.array_equal(r["lists"][k], lists[q]), (shares, k)
+                assert np.allclose(r["info"][k], infos[q], rtol=1e-9, atol=1e-6)
+            else:
+                assert abs(len(r["lists"][k]) - len(lists[q])) <= max(3, len(lists[q]) // 1000)
+        for k in np.nonzero(~acc)[0]:
+            assert r["iterations"][k] == 0 and not r["converged"][k] and len(r["lists"][k]) == 0 and not r["info"][k].any()
+            assert np.array_equal(r["T"][k], Ts[k].astype(np.float32))
+    assert sum(len(l) for l in lists) > 100000
