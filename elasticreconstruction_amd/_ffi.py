@@ -21,7 +21,7 @@ SYMBOLS = [
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_destroy", "er_comm_rank", "er_comm_world",
     "er_tsdf_allreduce", "er_frame_block",
-    "er_cloud_create", "er_cloud_destroy", "er_cloud_size",
+    "er_cloud_create", "er_cloud_create_batch", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_registration_batch", "er_ransac_fitness_batch", "er_ransac_inliers",
     "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
@@ -107,6 +107,7 @@ def lib():
     L.er_tsdf_get_profile.argtypes = [vp, dp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
     if hasattr(L, "er_cloud_create"):
         L.er_cloud_create.argtypes = [vp, vp, C.c_int, C.c_float, C.c_int, C.POINTER(vp)]
+        L.er_cloud_create_batch.argtypes = [C.c_int, vp, vp, vp, C.c_float, C.c_int, vp]
         L.er_cloud_destroy.argtypes = [vp]
         L.er_cloud_size.argtypes = [vp]
         L.er_icp_count_inliers.argtypes = [vp, vp, vp, C.c_double, ip]

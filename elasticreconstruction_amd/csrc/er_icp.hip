@@ -91,8 +91,19 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 // candidates from LDS.  The candidate SETS are those of the global search, so the result is the same exact nearest neighbour
 // with the same tie rule.  A workgroup whose rows / points / cells exceed the LDS budget (never on the measured lists) runs
 // the global search.
+// MEASURED (round 4, profiles/r04c_*): parity green, but 45 % SLOWER than the global search -- k_count_inliers 1301 us instead of 691 us
+// per 50-pair launch.  The counters say why: the search is not waiting for its dependent loads, it is short of VALU issue slots
+// (SQ_ACTIVE_INST_VALU: 0.70 of the chip's issue cycles in the shipped kernel); staging adds 30 % instructions (table inserts, two
+// binary searches per staged element), its 43 KB of LDS leave 3 workgroups per CU instead of 8, and the table sees 0.9 bank-conflict
+// cycles per LDS instruction.  Kept behind -DER_NN_STAGE=1 as the record of the experiment; the shipped search is the cell-task one below.
 #ifndef ER_NN_STAGE
-#define ER_NN_STAGE 1
+#define ER_NN_STAGE 0
+#endif
+#ifndef ER_NN_CELLTASKS
+#define ER_NN_CELLTASKS 0
+#endif
+#ifndef ER_NN_CT_UNROLL
+#define ER_NN_CT_UNROLL 0
 #endif
 constexpr int kStSlots = 512;           // table slots (rows are capped at 3/4 of them)
 constexpr int kStPts = 1024;            // staged target points (16 KB)
@@ -329,7 +340,8 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
 #if ER_NN_STAGE
   const bool staged = nn_stage(sh.st, g, valid, ix, iy, iz);  // (synchronises; uniform)
 #else
-  const bool staged = false;
+  constexpr bool staged = false;
+  (void)staged;
   __syncthreads();
 #endif
   // a row as the scans address it: its table slot (staged) or its first cell in cell_start
@@ -410,6 +422,147 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
 }
 
+#if ER_NN_CELLTASKS
+// ---- a second experiment of round 4 (NOT shipped): one task per NON-EMPTY CELL, binned by trip count -----------------------------------
+// MEASURED (profiles/r04d_*): parity green, 19 % slower than the row search (6.49 ms against 5.45 ms per 50-pair list).  The model below
+// counted candidate evaluations only; on the hardware the instruction count per wave did not fall at all (8 575 against 8 467 VALU
+// instructions in k_count_inliers: the four cell bounds per surviving row, the per-cell tests and the three list counters cost what the
+// shorter scans save), the three counters collide in LDS (3.2 bank-conflict cycles per LDS instruction) and the waves wait for instruction
+// issue 0.20 of their cycles instead of 0.06.  Kept behind -DER_NN_CELLTASKS=1 as the record; the row search (nn_block) ships.
+// The counters of the round-3 search (profiles/r04b_icp_pmc_before.txt) show a kernel that is short of VALU issue slots, not of
+// memory: 0.70 of the issue cycles busy, and a SIMT cost model of its two phases (scripts/icp_simt_sim.py) shows where they go -- a
+// wave executes ~90-110 candidate evaluations per lane where ~20 are useful: the left / right cell of the home row is scanned by the
+// whole wave when ONE lane needs it, and a (query, row) task covers one to three cells with anything from 0 to 30 candidates, so a
+// wave of tasks runs as long as its longest.  Here a thread scans only its query's OWN cell; every other cell of the neighbourhood
+// that is non-empty and whose box is within the best distance so far becomes a task of its own (the cell bounds arrive four at a time:
+// cells x-1, x, x+1 of a row are consecutive in cell_start), and the tasks go to three lists by trip count (<= 4, <= 8, more
+// candidates), which the workgroup then works off list by list: the lanes of a wave run the same number of trips.  The model
+// predicts ~30-38 evaluations per lane (a third).  Candidate SETS and tie rule are those of the row search: a cell is skipped only if
+// its box is provably farther than a point already found, with the same 1e-4 relative margin.
+constexpr int kCapA = 1024, kCapB = 768, kCapC = 512;           // tasks held in LDS per list; one beyond that is scanned by the thread that found it
+constexpr int kOffB = kCapA, kOffC = kCapA + kCapB, kTaskTotal = kCapA + kCapB + kCapC;
+struct NnSharedC {
+  unsigned long long best[kBlock];
+  float q[3][kBlock];
+  int t_start[kTaskTotal];           // the task's cell: index of its first point in the cell-sorted target
+  unsigned short t_cq[kTaskTotal];   // candidates << 8 | query (cells of more than 255 points are scanned by the thread that found them)
+  int nt[3];
+};
+
+// Cell bounds of cells x-1, x, x+1 of the row that starts at `row` in cell_start: b[0..3] = cell_start[row + x - 1 .. row + x + 2], indices
+// clamped into the array (a clamped value is only ever used for a cell that does not exist, i.e. never).
+__device__ __forceinline__ void row_bounds(const Grid& g, int row, int x, int ncell, int b[4]) {
+  const int i0 = row + x - 1;
+#pragma unroll
+  for (int j = 0; j < 4; j++) b[j] = g.cell_start[min(max(i0 + j, 0), ncell)];
+}
+
+__device__ __forceinline__ int nn_block_cells(NnSharedC& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2, float& best_d) {
+  const int tid = threadIdx.x;
+  __syncthreads();                                            // the previous call's readers are done with `sh`
+  if (tid < 3) sh.nt[tid] = 0;
+  __syncthreads();
+  unsigned long long key = kNoHit;
+  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
+  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
+  const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
+  if (inside) {
+    const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
+    const int nx = g.dim[0], ncell = g.dim[0] * g.dim[1] * g.dim[2];
+    const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
+                zhi = g.cell - zlo;
+    const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
+    if (has_l | has_o | has_r) {
+      sh.q[0][tid] = qx;
+      sh.q[1][tid] = qy;
+      sh.q[2][tid] = qz;
+      const bool home = iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2];
+      int hb[4] = {0, 0, 0, 0};
+      if (home) row_bounds(g, (iz * g.dim[1] + iy) * nx, ix, ncell, hb);
+      if (home && has_o) key = scan_range(g, hb[1], hb[2], qx, qy, qz, key);
+      // every other cell must beat the own cell's best (or the search radius)
+      const float bound = fminf(limit2, __uint_as_float((unsigned)(key >> 32))) * 1.0001f + 1e-12f;
+      auto push = [&](int start, int cnt) {
+        if (cnt <= 255) {
+          const int bin = cnt <= 4 ? 0 : (cnt <= 8 ? 1 : 2);
+          const int cap = bin == 0 ? kCapA : (bin == 1 ? kCapB : kCapC), off = bin == 0 ? 0 : (bin == 1 ? kOffB : kOffC);
+          const int t = atomicAdd(&sh.nt[bin], 1);
+          if (t < cap) {
+            sh.t_start[off + t] = start;
+            sh.t_cq[off + t] = (unsigned short)((cnt << 8) | tid);
+            return;
+          }
+        }
+        key = scan_range(g, start, start + cnt, qx, qy, qz, key);          // list full / oversized cell (never on the measured lists): scan it here
+      };
+      const float ex_l = xlo * xlo, ex_r = xhi * xhi;
+      if (home) {
+        if (has_l && hb[1] > hb[0] && ex_l <= bound) push(hb[0], hb[1] - hb[0]);
+        if (has_r && hb[3] > hb[2] && ex_r <= bound) push(hb[2], hb[3] - hb[2]);
+      }
+#if ER_NN_CT_UNROLL
+#pragma unroll
+#else
+#pragma unroll 1                                             // (unrolled, the eight rows' bounds are all fetched up front: 112 VGPRs instead of 73)
+#endif
+      for (int pass = 0; pass < 9; pass++) {
+        if (pass == 4) continue;
+        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+        const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
+        const int y = iy + dy, z = iz + dz;
+        const float e2 = ey * ey + ez * ez;
+        if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
+          int b[4];
+          row_bounds(g, (z * g.dim[1] + y) * nx, ix, ncell, b);
+          if (has_o && b[2] > b[1]) push(b[1], b[2] - b[1]);
+          if (has_l && b[1] > b[0] && ex_l + e2 <= bound) push(b[0], b[1] - b[0]);
+          if (has_r && b[3] > b[2] && ex_r + e2 <= bound) push(b[2], b[3] - b[2]);
+        }
+      }
+    }
+  }
+  sh.best[tid] = key;
+  __syncthreads();
+  // the lists, shortest tasks first: every task of the first list is ONE trip of four candidates, of the second two trips
+  {
+    const int n = min(sh.nt[0], kCapA);
+    for (int t = tid; t < n; t += kBlock) {
+      const int s0 = sh.t_start[t], cq = sh.t_cq[t], q = cq & 255;
+      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+      atomicMin(&sh.best[q], k);
+    }
+  }
+  {
+    const int n = min(sh.nt[1], kCapB);
+    for (int t = tid; t < n; t += kBlock) {
+      const int s0 = sh.t_start[kOffB + t], cq = sh.t_cq[kOffB + t], q = cq & 255;
+      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+      atomicMin(&sh.best[q], k);
+    }
+  }
+  {
+    const int n = min(sh.nt[2], kCapC);
+    for (int t = tid; t < n; t += kBlock) {
+      const int s0 = sh.t_start[kOffC + t], cq = sh.t_cq[kOffC + t], q = cq & 255;
+      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+      atomicMin(&sh.best[q], k);
+    }
+  }
+  __syncthreads();
+  key = sh.best[tid];
+  best_d = __uint_as_float((unsigned)(key >> 32));
+  return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
+}
+#endif
+
+#if ER_NN_CELLTASKS
+using NnSh = NnSharedC;
+#define nn_search nn_block_cells
+#else
+using NnSh = NnShared;
+#define nn_search nn_block
+#endif
+
 // Block reduction of NV float64 values per thread: wave shuffle (64 lanes) -> LDS -> lane 0 atomics.
 template <int NV>
 __device__ __forceinline__ void block_reduce_atomic(double (&v)[NV], double* __restrict__ out) {
@@ -445,7 +598,7 @@ __device__ __forceinline__ void xform_d(const Mat12d& T, float x, float y, float
 __global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restrict__ src_sorted, int n, const float* __restrict__ hyp,
                                                            int hyp0, Grid g, float radius, float max_range,
                                                            int* __restrict__ count, double* __restrict__ sum) {
-  __shared__ NnShared sh;
+  __shared__ NnSh sh;
   const int h = hyp0 + blockIdx.y;
   float M[12];
 #pragma unroll
@@ -461,7 +614,7 @@ __global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restr
       qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
       qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
     }
-    const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_search(sh, g, k < n, qx, qy, qz, radius * radius, d);
     if (k < n && i >= 0 && d < max_range) {
       local++;
       dsum += (double)d;
@@ -514,7 +667,7 @@ struct PairDev {
   int* block_offset;             // [nb]
   int* pairs;                    // [2 n]   compacted (target index, source index) list
   double* partial;               // [nbi][32] per-workgroup sums of one ICP iteration
-  int n, nb, nbi, pts;           // source points, ceil(n / 256), ceil(n / (256 pts)); pts = slices of 256 points per workgroup of k_icp_iter
+  int n, nb, nbi, pts;           // source points, ceil(n / 256); nbi, pts: unused since round 4 (the points per thread of k_icp_iter are a launch argument)
 };
 
 // ---- the ICP loop's state lives on the device ------------------------------------------------------------------------
@@ -702,7 +855,7 @@ constexpr int kIcpPtsMax = 8;              // source points per thread of k_icp_
 // Registration pre-check, CorresApp.cpp:257-264, for a group of pairs: counts[pair] = #{k : d2 < reg_dist^2}.  blockIdx.x
 // strides over the pair's points; ONE atomic per workgroup.
 __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restrict__ P, float radius, double maxd2, int* __restrict__ counts) {
-  __shared__ NnShared sh;
+  __shared__ NnSh sh;
   const PairDev& p = P[blockIdx.y];
   const int n = p.n;
   if ((int)blockIdx.x * kBlock >= n) return;                 // (wave-uniform: whole workgroups beyond a short pair's points)
@@ -714,7 +867,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
       const float4 s = p.src_sorted[k];
       xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
     }
-    const int i = nn_block(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
@@ -738,12 +891,12 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
 // `partial`; k_icp_final adds the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from
 // run to run (they still differ from a sequential CPU sum in the last bits).
 __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__ P, const int* __restrict__ active, const IcpDev* __restrict__ S,
-                                                     float radius, double maxd2) {
-  __shared__ NnShared sh;
+                                                     float radius, double maxd2, int pts) {
+  __shared__ NnSh sh;
   const int slot = active[blockIdx.y];
   const PairDev& p = P[slot];
   const IcpDev& st = S[slot];
-  if (st.done || (int)blockIdx.x >= p.nbi) return;           // the loop has ended / a shorter pair: wave-uniform exits
+  if (st.done || (int)blockIdx.x >= (p.nb + pts - 1) / pts) return;   // the loop has ended / a shorter pair: wave-uniform exits
   const int n = p.n;
   const bool first = st.iter == 0;
   const int apply = first ? st.init_apply : st.apply;        // wave-uniform (scalar loads)
@@ -758,7 +911,6 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
   __shared__ double part[kBlock / 64][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane < 32) part[wave][lane] = 0.0;                     // (each wave only ever touches its own row: no barrier needed until the end)
-  const int pts = p.pts;
   for (int c = 0; c < pts; c++) {
     const int k = (blockIdx.x * pts + c) * kBlock + threadIdx.x;
     if ((blockIdx.x * pts + c) * kBlock >= n) break;         // wave-uniform
@@ -783,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
       }
     }
     float d;
-    const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
+    const int i = nn_search(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
     double w[32];
 #pragma unroll
     for (int t = 0; t < 32; t++) w[t] = 0.0;
@@ -833,12 +985,13 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
 // (8 strided slices per value, then the slices in order) and decides -- 6x6 solve, increment, stop rule: the loop never leaves
 // the device.  A separate launch on purpose: finishing inside k_icp_iter ("last workgroup done" ticket + __threadfence) costs
 // an L2 write-back per workgroup on this multi-XCD part (measured in round 1: 100-600 us per launch instead of ~25).
-__global__ __launch_bounds__(kBlock) void k_icp_final(const PairDev* __restrict__ P, const int* __restrict__ active, IcpDev* __restrict__ S, IcpParams prm) {
+__global__ __launch_bounds__(kBlock) void k_icp_final(const PairDev* __restrict__ P, const int* __restrict__ active, IcpDev* __restrict__ S, IcpParams prm,
+                                                      int pts) {
   const int slot = active[blockIdx.x];
   IcpDev* st = S + slot;
   if (st->done) return;
   const double* __restrict__ partial = P[slot].partial;
-  const int nparts = P[slot].nbi;
+  const int nparts = (P[slot].nb + pts - 1) / pts;
   const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;   // 32 x 8
   double q = 0.0;
   if (val < 29) {
@@ -862,7 +1015,7 @@ __global__ __launch_bounds__(kBlock) void k_icp_final(const PairDev* __restrict_
 // getFitnessScore-style diagnostic (logging only, CorresApp.cpp:307): per pair the sum and the number of the squared NN
 // distances of final * source inside the search radius -> fit[2 pair], fit[2 pair + 1].
 __global__ __launch_bounds__(kBlock) void k_fitness(const PairDev* __restrict__ P, const IcpDev* __restrict__ S, float radius, double* __restrict__ fit) {
-  __shared__ NnShared sh;
+  __shared__ NnSh sh;
   const PairDev& p = P[blockIdx.y];
   const int n = p.n;
   if ((int)blockIdx.x * kBlock >= n) return;
@@ -877,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const PairDev* __restrict__ 
       qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
       qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
     }
-    const int i = nn_block(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius) {
       v[0] += (double)d;
       v[1] += 1.0;
@@ -889,7 +1042,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const PairDev* __restrict__ 
 
 // FindCorrespondence, CorresApp.cpp:144-161: match[original index] = NN index passing the distance and normal tests, else -1.
 __global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict__ P, float radius, double dist2, double normal_cos) {
-  __shared__ NnShared sh;
+  __shared__ NnSh sh;
   const PairDev& p = P[blockIdx.y];
   const int n = p.n;
   if ((int)blockIdx.x >= p.nb) return;
@@ -901,7 +1054,7 @@ __global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict_
     k = __float_as_int(s.w);                                   // original (file-order) index of this source point
     xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
   }
-  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
+  const int i = nn_search(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
   if (q >= n) return;
   int m = -1;
   if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {         // :154
@@ -920,7 +1073,7 @@ __global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict_
 // The accepted RANSAC hypothesis once more, this time keeping the lists (RansacCurvature.h:661-704: `inliers`, `inliers_target`):
 // match[original source index] = NN index if d < threshold^2, else -1; acc[20] += d over the inliers.  (One pair: P[0].)
 __global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restrict__ P, Mat12f M, float radius, float max_range, double* __restrict__ acc) {
-  __shared__ NnShared sh;
+  __shared__ NnSh sh;
   const PairDev& p = P[0];
   const int n = p.n;
   const int q = blockIdx.x * kBlock + threadIdx.x;
@@ -933,7 +1086,7 @@ __global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restri
     qy = ((M.m[4] * s.x + M.m[5] * s.y) + M.m[6] * s.z) + M.m[7];
     qz = ((M.m[8] * s.x + M.m[9] * s.y) + M.m[10] * s.z) + M.m[11];
   }
-  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
+  const int i = nn_search(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
   const bool hit = q < n && i >= 0 && d < max_range;
   if (q < n) p.match[k] = hit ? i : -1;
   double v[1] = {hit ? (double)d : 0.0};
@@ -1139,8 +1292,10 @@ struct GridScratch {
   int device = -1;
   unsigned *key[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
   void* cub = nullptr;
-  int* bounds = nullptr;
-  size_t n_cap = 0, cub_cap = 0;
+  int *bounds = nullptr, *h_bounds = nullptr;                   // 8 ints per cloud of a batch: device and its page-locked mirror (+ the initial pattern)
+  size_t n_cap = 0, cub_cap = 0, bounds_cap = 0;
+  hipStream_t up = nullptr, cs = nullptr;                       // uploads / grid kernels of er_cloud_create_batch
+  std::vector<hipEvent_t> ev;                                   // one per cloud of a batch (upload done) + one per chunk (bounds back)
 };
 GridScratch& grid_scratch(int device) {
   static GridScratch* tab = new GridScratch[64];             // intentionally leaked (see WsPool)
@@ -1234,6 +1389,15 @@ void group_destroy(Group* g) {
 }
 
 int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
+#ifndef ER_ICP_FIXED_PTS
+#define ER_ICP_FIXED_PTS 0
+#endif
+// Slices of 256 points per workgroup of k_icp_iter when `blocks` slices are to be searched in one launch (the 29 cross-lane sums are paid
+// once per workgroup, so more slices per workgroup are cheaper as long as the launch still fills the chip).
+int icp_pts(long blocks) {
+  if (ER_ICP_FIXED_PTS) return ER_ICP_FIXED_PTS;
+  return blocks >= 8 * 1024 ? kIcpPtsMax : (blocks >= 4 * 1024 ? 4 : (blocks >= 1024 ? 2 : 1));
+}
 int nparts_of(int n, int pts) { return (std::max(n, 1) + kBlock * pts - 1) / (kBlock * pts); }
 
 // Room for `pairs` descriptors and, when per-point scratch is needed, for `points` source points in `blocks` / `parts` blocks.
@@ -1360,10 +1524,8 @@ int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double r
 // the pre-check needs none).  T16: one row-major float64 4x4 per pair, or NULL.
 int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_cloud_t* tgt, const double* T16, bool scratch) {
   size_t points = 0, blocks = 0, parts = 0;
-  // points per thread of k_icp_iter: as many as leave ~4 workgroups per CU in flight (one pair of 250 k points alone: 2 -> 490 workgroups)
-  long all_blocks = 0;
-  for (int q = 0; q < m; q++) all_blocks += nblocks_of(src[i0 + q]->n);
-  const int pts = all_blocks >= 8 * 1024 ? kIcpPtsMax : (all_blocks >= 4 * 1024 ? 4 : (all_blocks >= 1024 ? 2 : 1));
+  // (the per-workgroup partial sums of k_icp_iter: room for one slice of 256 points per workgroup, the finest split icp_pts below can pick)
+  const int pts = 1;
   for (int q = 0; q < m; q++) {
     const int n = src[i0 + q]->n;
     points += (size_t)((n + 3) & ~3);                          // slices stay 16-byte aligned
@@ -1437,139 +1599,214 @@ constexpr int kIcpChunk = 3;
 
 extern "C" {
 
-int er_cloud_create(const float* xyz_host, const float* normal_host, int n, float grid_cell, int device, er_cloud_t* out) {
-  if (!out) return er::fail("er_cloud_create: out is NULL");
-  *out = nullptr;
-  if (n < 0 || (n > 0 && (!xyz_host || !normal_host))) return er::fail("er_cloud_create: bad arguments");
+// Clouds of a LIST of fragments (BuildCorrespondence's LoadData loop, CorresApp.cpp:82-110, builds them one after the other): the uploads
+// run back to back on a copy stream -- truly asynchronous when the caller's arrays are page-locked (er_host_alloc), which is what makes
+// the list PCIe-bound instead of host-bound -- while the grid kernels of the previous chunk of clouds run on a compute stream underneath.
+// Per chunk of kCloudChunk clouds: [upload + bounding box] -> ONE host wait for the boxes (the host sizes cell_start from them) ->
+// [cell ids, radix sort, prefix sum, gather, interleave]; the host waits twice per chunk instead of twice per cloud.
+constexpr int kCloudChunk = 8;
+int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const float* const* normal_host, const int* counts, float grid_cell, int device,
+                          er_cloud_t* out) {
+  if (n_clouds < 0 || (n_clouds > 0 && (!xyz_host || !normal_host || !counts || !out))) return er::fail("er_cloud_create: bad arguments");
+  for (int i = 0; i < n_clouds; i++) out[i] = nullptr;
+  for (int i = 0; i < n_clouds; i++)
+    if (counts[i] < 0 || (counts[i] > 0 && (!xyz_host[i] || !normal_host[i]))) return er::fail("er_cloud_create: bad arguments (cloud %d)", i);
   if (!(grid_cell > 0.f)) return er::fail("er_cloud_create: grid_cell must be positive");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return er::fail("er_cloud_create: no HIP device available (liber_hip has no CPU fallback)");
   if (device < 0 || device >= ndev) return er::fail("er_cloud_create: device %d out of range [0,%d)", device, ndev);
+  if (n_clouds == 0) return 0;
   ER_HIP_TRY(hipSetDevice(device));
-  er_cloud_t c = new er_cloud_s();
-  c->device = device;
-  c->n = n;
-  c->radius_cap = grid_cell;
-  const size_t nn = (size_t)std::max(n, 1);
-#define ER_CALLOC(ptr, bytes)                                                                 \
-  do {                                                                                        \
-    hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                       \
-    if (e_ != hipSuccess) {                                                                   \
-      er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", (size_t)(bytes), hipGetErrorString(e_)); \
-      er_cloud_destroy(c);                                                                    \
-      return 1;                                                                               \
-    }                                                                                         \
-  } while (0)
+  GridScratch& gs = grid_scratch(device);
+  std::lock_guard<std::mutex> lock(gs.mu);
+  auto undo = [&]() {
+    if (gs.up) (void)hipStreamSynchronize(gs.up);
+    if (gs.cs) (void)hipStreamSynchronize(gs.cs);
+    for (int i = 0; i < n_clouds; i++) {
+      if (out[i]) er_cloud_destroy(out[i]);
+      out[i] = nullptr;
+    }
+  };
 #define ER_CTRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) {                                                                   \
       er::fail("er_cloud_create: %s failed: %s", #expr, hipGetErrorString(e_));               \
-      er_cloud_destroy(c);                                                                    \
+      undo();                                                                                 \
       return 1;                                                                               \
     }                                                                                         \
   } while (0)
-  // one allocation for the per-point arrays: [xyz 3n | normals 3n | sorted n float4 | xn 2n float4]
-  const size_t off_sorted = (nn * 6 + 7) / 8 * 8;                 // float4 needs 16-byte alignment (32 for the xn records)
-  ER_CALLOC(c->xyz, (off_sorted + nn * 4 + nn * 8) * sizeof(float));
-  c->nrm = c->xyz + nn * 3;
-  c->sorted = reinterpret_cast<float4*>(c->xyz + off_sorted);
-  c->xn = c->sorted + nn;
-  if (n > 0) {
-    ER_CTRY(hipMemcpyAsync(c->xyz, xyz_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
-    ER_CTRY(hipMemcpyAsync(c->nrm, normal_host, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  if (!gs.up) ER_CTRY(hipStreamCreateWithFlags(&gs.up, hipStreamNonBlocking));
+  if (!gs.cs) ER_CTRY(hipStreamCreateWithFlags(&gs.cs, hipStreamNonBlocking));
+  const int n_chunks = (n_clouds + kCloudChunk - 1) / kCloudChunk;
+  while ((int)gs.ev.size() < n_clouds + n_chunks) {
+    hipEvent_t e = nullptr;
+    ER_CTRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    gs.ev.push_back(e);
   }
-  // ---- uniform grid on the DEVICE (once per fragment; every pair that uses it as target reuses it) ----
-  float cell = grid_cell * 1.001f;               // strictly larger than any admissible radius
-  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-  int dim[3] = {1, 1, 1};
-  GridScratch& gs = grid_scratch(device);
-  std::lock_guard<std::mutex> lock(gs.mu);
-  if (!gs.bounds) ER_CTRY(hipMalloc((void**)&gs.bounds, 8 * sizeof(int)));
-  if (n > 0) {
-    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
-    int got[8];
-    ER_CTRY(hipMemcpyAsync(gs.bounds, init, sizeof init, hipMemcpyHostToDevice, nullptr));
-    hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, nullptr, c->xyz, n, gs.bounds);
-    ER_CTRY(hipMemcpyAsync(got, gs.bounds, sizeof got, hipMemcpyDeviceToHost, nullptr));
-    ER_CTRY(hipStreamSynchronize(nullptr));
-    if (got[6]) {
-      er_cloud_destroy(c);
-      return er::fail("er_cloud_create: non-finite coordinates");
-    }
-    for (int a = 0; a < 3; a++) {
-      lo[a] = ordered_float(got[a]);
-      hi[a] = ordered_float(got[3 + a]);
-    }
+  if (gs.bounds_cap < (size_t)n_clouds) {
+    ER_CTRY(hipStreamSynchronize(gs.cs));
+    if (gs.bounds) (void)hipFree(gs.bounds);
+    if (gs.h_bounds) (void)hipHostFree(gs.h_bounds);
+    gs.bounds = gs.h_bounds = nullptr;
+    gs.bounds_cap = 0;
+    const size_t cap = (size_t)n_clouds + 16;
+    ER_CTRY(hipMalloc((void**)&gs.bounds, cap * 8 * sizeof(int)));
+    ER_CTRY(hipHostMalloc((void**)&gs.h_bounds, cap * 16 * sizeof(int), hipHostMallocDefault));   // [cap][8] results, then [cap][8] initial pattern
+    gs.bounds_cap = cap;
   }
-  for (;;) {
-    long total = 1;
-    for (int a = 0; a < 3; a++) {
-      dim[a] = (int)std::floor((hi[a] - lo[a]) / cell) + 1;
-      total *= dim[a];
-    }
-    if (total <= (1L << 25)) break;
-    cell *= 2.f;
-  }
-  const int ncell = dim[0] * dim[1] * dim[2];
-  ER_CALLOC(c->cell_start, ((size_t)ncell + 1) * sizeof(int));
-  ER_CTRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), nullptr));
-  if (n > 0) {
-    if (gs.n_cap < (size_t)n) {
+  int n_max = 0;
+  for (int i = 0; i < n_clouds; i++) n_max = std::max(n_max, counts[i]);
+  if (n_max > 0) {
+    if (gs.n_cap < (size_t)n_max) {
+      ER_CTRY(hipStreamSynchronize(gs.cs));
       for (int q = 0; q < 2; q++) {
         if (gs.key[q]) (void)hipFree(gs.key[q]);
         if (gs.idx[q]) (void)hipFree(gs.idx[q]);
         gs.key[q] = gs.idx[q] = nullptr;
       }
       gs.n_cap = 0;
-      const size_t cap = (size_t)n + (size_t)n / 8;
+      const size_t cap = (size_t)n_max + (size_t)n_max / 8;
       for (int q = 0; q < 2; q++) {
         ER_CTRY(hipMalloc((void**)&gs.key[q], cap * sizeof(unsigned)));
         ER_CTRY(hipMalloc((void**)&gs.idx[q], cap * sizeof(unsigned)));
       }
       gs.n_cap = cap;
     }
-    GridDims G;
-    for (int a = 0; a < 3; a++) {
-      G.org[a] = lo[a];
-      G.dim[a] = dim[a];
-    }
-    G.cell = cell;
-    hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, n, G, gs.key[0], gs.idx[0], c->cell_start);
-    int bits = 1;
-    while ((1L << bits) < (long)ncell) bits++;
+    // temporary storage of the sort / scan for the largest cloud and the largest grid (2^25 cells, 25 key bits) this call can meet
     size_t need_sort = 0, need_scan = 0;
-    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, (hipStream_t) nullptr));
-    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, c->cell_start, c->cell_start, ncell + 1, (hipStream_t) nullptr));
+    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n_max, 0, 25, gs.cs));
+    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, (int*)nullptr, (int*)nullptr, (1 << 25) + 1, gs.cs));
     const size_t need = std::max(need_sort, need_scan);
     if (gs.cub_cap < need) {
+      ER_CTRY(hipStreamSynchronize(gs.cs));
       if (gs.cub) (void)hipFree(gs.cub);
       gs.cub = nullptr;
       gs.cub_cap = 0;
       ER_CTRY(hipMalloc(&gs.cub, need + need / 4));
       gs.cub_cap = need + need / 4;
     }
-    size_t tmp = gs.cub_cap;
-    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(gs.cub, tmp, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, (hipStream_t) nullptr));
-    tmp = gs.cub_cap;
-    ER_CTRY(hipcub::DeviceScan::InclusiveSum(gs.cub, tmp, c->cell_start, c->cell_start, ncell + 1, (hipStream_t) nullptr));
-    hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, gs.idx[1], n, c->sorted);
-    hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, nullptr, c->xyz, c->nrm, n, c->xn);
-    ER_CTRY(hipGetLastError());
   }
-  ER_CTRY(hipStreamSynchronize(nullptr));          // the caller's host arrays and the shared scratch are free again
-#undef ER_CALLOC
+  int* h_got = gs.h_bounds;
+  int* h_init = gs.h_bounds + gs.bounds_cap * 8;
+  for (int i = 0; i < n_clouds; i++) {
+    const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
+    memcpy(h_init + (size_t)i * 8, init, sizeof init);
+  }
+  ER_CTRY(hipMemcpyAsync(gs.bounds, h_init, (size_t)n_clouds * 8 * sizeof(int), hipMemcpyHostToDevice, gs.cs));
+  // ---- stage A of a chunk: allocation, upload (copy stream), bounding box (compute stream) ----
+  auto stage_a = [&](int ch) -> int {
+    const int i0 = ch * kCloudChunk, i1 = std::min(n_clouds, i0 + kCloudChunk);
+    for (int i = i0; i < i1; i++) {
+      const int n = counts[i];
+      er_cloud_t c = new er_cloud_s();
+      out[i] = c;
+      c->device = device;
+      c->n = n;
+      c->radius_cap = grid_cell;
+      const size_t nn = (size_t)std::max(n, 1);
+      // one allocation for the per-point arrays: [xyz 3n | normals 3n | sorted n float4 | xn 2n float4]
+      const size_t off_sorted = (nn * 6 + 7) / 8 * 8;               // float4 needs 16-byte alignment (32 for the xn records)
+      const size_t bytes = (off_sorted + nn * 4 + nn * 8) * sizeof(float);
+      hipError_t e = hipMalloc((void**)&c->xyz, bytes);
+      if (e != hipSuccess) return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      c->nrm = c->xyz + nn * 3;
+      c->sorted = reinterpret_cast<float4*>(c->xyz + off_sorted);
+      c->xn = c->sorted + nn;
+      if (n > 0) {
+        ER_HIP_TRY(hipMemcpyAsync(c->xyz, xyz_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
+        ER_HIP_TRY(hipMemcpyAsync(c->nrm, normal_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
+        ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)i], gs.up));
+        ER_HIP_TRY(hipStreamWaitEvent(gs.cs, gs.ev[(size_t)i], 0));
+        hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, gs.cs, c->xyz, n, gs.bounds + (size_t)i * 8);
+      }
+    }
+    ER_HIP_TRY(hipGetLastError());
+    ER_HIP_TRY(hipMemcpyAsync(h_got + (size_t)i0 * 8, gs.bounds + (size_t)i0 * 8, (size_t)(i1 - i0) * 8 * sizeof(int), hipMemcpyDeviceToHost, gs.cs));
+    ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(n_clouds + ch)], gs.cs));
+    return 0;
+  };
+  // ---- stage B: the grid of every cloud of the chunk (the boxes are back) ----
+  auto stage_b = [&](int ch) -> int {
+    const int i0 = ch * kCloudChunk, i1 = std::min(n_clouds, i0 + kCloudChunk);
+    ER_HIP_TRY(hipEventSynchronize(gs.ev[(size_t)(n_clouds + ch)]));
+    for (int i = i0; i < i1; i++) {
+      er_cloud_t c = out[i];
+      const int n = c->n;
+      const int* got = h_got + (size_t)i * 8;
+      float cell = grid_cell * 1.001f;                            // strictly larger than any admissible radius
+      float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+      int dim[3] = {1, 1, 1};
+      if (n > 0) {
+        if (got[6]) return er::fail("er_cloud_create: non-finite coordinates");
+        for (int a = 0; a < 3; a++) {
+          lo[a] = ordered_float(got[a]);
+          hi[a] = ordered_float(got[3 + a]);
+        }
+      }
+      for (;;) {
+        long total = 1;
+        for (int a = 0; a < 3; a++) {
+          dim[a] = (int)std::floor((hi[a] - lo[a]) / cell) + 1;
+          total *= dim[a];
+        }
+        if (total <= (1L << 25)) break;
+        cell *= 2.f;
+      }
+      const int ncell = dim[0] * dim[1] * dim[2];
+      hipError_t e = hipMalloc((void**)&c->cell_start, ((size_t)ncell + 1) * sizeof(int));
+      if (e != hipSuccess) return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", ((size_t)ncell + 1) * sizeof(int), hipGetErrorString(e));
+      ER_HIP_TRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), gs.cs));
+      if (n > 0) {
+        GridDims G;
+        for (int a = 0; a < 3; a++) {
+          G.org[a] = lo[a];
+          G.dim[a] = dim[a];
+        }
+        G.cell = cell;
+        hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, n, G, gs.key[0], gs.idx[0], c->cell_start);
+        int bits = 1;
+        while ((1L << bits) < (long)ncell) bits++;
+        size_t tmp = gs.cub_cap;
+        ER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(gs.cub, tmp, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, gs.cs));
+        tmp = gs.cub_cap;
+        ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub, tmp, c->cell_start, c->cell_start, ncell + 1, gs.cs));
+        hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, gs.idx[1], n, c->sorted);
+        hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, c->nrm, n, c->xn);
+        ER_HIP_TRY(hipGetLastError());
+      }
+      c->grid.pts = c->sorted;
+      c->grid.cell_start = c->cell_start;
+      c->grid.cell = cell;
+      for (int a = 0; a < 3; a++) {
+        c->grid.org[a] = lo[a];
+        c->grid.dim[a] = dim[a];
+      }
+    }
+    return 0;
+  };
+  int rc = stage_a(0);
+  for (int ch = 0; ch < n_chunks && rc == 0; ch++) {
+    if (ch + 1 < n_chunks) rc = stage_a(ch + 1);                   // the next chunk's uploads run under this chunk's grid kernels
+    if (rc == 0) rc = stage_b(ch);
+  }
+  if (rc == 0 && (hipStreamSynchronize(gs.up) != hipSuccess || hipStreamSynchronize(gs.cs) != hipSuccess))   // the caller's arrays and the shared scratch are free again
+    rc = er::fail("er_cloud_create: %s", hipGetErrorString(hipGetLastError()));
 #undef ER_CTRY
-  c->grid.pts = c->sorted;
-  c->grid.cell_start = c->cell_start;
-  c->grid.cell = cell;
-  for (int a = 0; a < 3; a++) {
-    c->grid.org[a] = lo[a];
-    c->grid.dim[a] = dim[a];
+  if (rc) {
+    const std::string why = er_last_error();
+    undo();
+    return er::fail("%s", why.c_str());
   }
-  *out = c;
   return 0;
+}
+
+int er_cloud_create(const float* xyz_host, const float* normal_host, int n, float grid_cell, int device, er_cloud_t* out) {
+  if (!out) return er::fail("er_cloud_create: out is NULL");
+  *out = nullptr;
+  if (n < 0 || (n > 0 && (!xyz_host || !normal_host))) return er::fail("er_cloud_create: bad arguments");
+  return er_cloud_create_batch(1, &xyz_host, &normal_host, &n, grid_cell, device, out);
 }
 
 int er_cloud_destroy(er_cloud_t c) {
@@ -1666,12 +1903,22 @@ int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, cons
     ER_HIP_TRY(hipMemcpyAsync(g->d_state, g->h_state, (size_t)m * sizeof(IcpDev), hipMemcpyHostToDevice, g->stream));
     while (n_active > 0) {
       ER_HIP_TRY(hipMemcpyAsync(g->d_active, g->h_active, (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, g->stream));
-      int mxp = 1;
-      for (int a = 0; a < n_active; a++) mxp = std::max(mxp, g->h_pairs[g->h_active[a]].nbi);
+      // points per thread of k_icp_iter for THIS chunk: as many slices of 256 points per workgroup as still leave ~4 workgroups per CU in
+      // flight -- 8 for a full list, 1 for the two or three stragglers of a hard list on their way to the iteration limit (round 4: the
+      // split used to be fixed when the group was described, so three pairs in their 20th iteration ran as 369 workgroups of eight
+      // sequential searches each on a chip that holds 2048)
+      long act_blocks = 0;
+      int mxb = 1;
+      for (int a = 0; a < n_active; a++) {
+        act_blocks += g->h_pairs[g->h_active[a]].nb;
+        mxb = std::max(mxb, g->h_pairs[g->h_active[a]].nb);
+      }
+      const int pts = icp_pts(act_blocks);
+      const int mxp = (mxb + pts - 1) / pts;
       for (int c = 0; c < kIcpChunk; c++) {
         hipLaunchKernelGGL(k_icp_iter, dim3(mxp, n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, (float)max_dist,
-                           max_dist * max_dist);
-        hipLaunchKernelGGL(k_icp_final, dim3(n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, prm);
+                           max_dist * max_dist, pts);
+        hipLaunchKernelGGL(k_icp_final, dim3(n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, prm, pts);
       }
       ER_HIP_TRY(hipGetLastError());
       ER_HIP_TRY(hipMemcpyAsync(g->h_state, g->d_state, (size_t)m * sizeof(IcpDev), hipMemcpyDeviceToHost, g->stream));

@@ -47,6 +47,27 @@ class Cloud:
     def __len__(self):
         return self.n
 
+    @classmethod
+    def create_batch(cls, arrays, grid_cell=0.03, device=0):
+        """er_cloud_create_batch: [Cloud] for a list of (xyz, normals) in one call.  Arrays that live in page-locked memory
+        (_ffi.PinnedArena) are uploaded asynchronously -- the list is then PCIe-bound."""
+        lib = _ffi.lib()
+        xs = [np.ascontiguousarray(x, dtype=np.float32).reshape(-1, 3) for x, _ in arrays]
+        ns = [np.ascontiguousarray(n, dtype=np.float32).reshape(-1, 3) for _, n in arrays]
+        assert all(x.shape == n.shape for x, n in zip(xs, ns))
+        m = len(xs)
+        px = (C.c_void_p * m)(*[x.ctypes.data for x in xs])
+        pn = (C.c_void_p * m)(*[n.ctypes.data for n in ns])
+        cnt = np.array([x.shape[0] for x in xs], np.int32)
+        hs = (C.c_void_p * m)()
+        _ffi.check(lib.er_cloud_create_batch(m, px, pn, _ffi.ptr(cnt), C.c_float(grid_cell), int(device), hs), "er_cloud_create_batch")
+        out = []
+        for k in range(m):
+            c = cls.__new__(cls)
+            c._lib, c.n, c.grid_cell, c._h = lib, int(cnt[k]), float(grid_cell), C.c_void_p(hs[k])
+            out.append(c)
+        return out
+
 
 def count_inliers(src, tgt, T, max_dist):
     """Registration pre-check (CorresApp.cpp:249-264)."""

@@ -41,4 +41,42 @@ if os.environ.get("ER_PROBE_FUSED", "1") == "1":
         same = all(np.array_equal(out["T"][k], fins[k]) for k in range(n_pairs)) and [len(l) for l in out["lists"]] == [len(l) for l in lists]
         print("fused er_registration_batch, %s share(s): median %.2f ms (min %.2f max %.2f) -> %.0f pairs/s; accepted %d / %d; equals the three calls bit for bit: %s"
               % (shares, np.median(tt), tt.min(), tt.max(), n_pairs / np.median(tt) * 1e3, int(out["accepted"].sum()), n_pairs, same))
+if os.environ.get("ER_PROBE_HARD", "1") == "1":
+    hard = synth.hard_pair_list([(None, None, F) for _, F in clouds], n_pairs)
+    hT = [T for _, _, T in hard]
+    tt = []
+    for r in range(6):
+        t0 = time.perf_counter()
+        count_inliers_batch(srcs, tgts, hT, 0.03)
+        hf, hit, _, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for T in hT], 0.03, 20, 1e-6, 0)
+        find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in hf], 0.015, 0.8660, True, copy=False)
+        tt.append(time.perf_counter() - t0)
+    tt = np.array(tt[2:]) * 1e3
+    print("hard list (6 deg / 6 cm): median %.2f ms -> %.0f pairs/s; iterations mean %.2f max %d, at the limit %d"
+          % (np.median(tt), n_pairs / np.median(tt) * 1e3, np.mean(hit), int(np.max(hit)), int(np.sum(np.asarray(hit) >= 20))))
+if os.environ.get("ER_PROBE_CLOUDS", "1") == "1":
+    from elasticreconstruction_amd import _ffi
+    arena = _ffi.PinnedArena()
+    arena.reset(sum(x.nbytes + n.nbytes for x, n, _ in frs) + 16384 * len(frs))
+    pinned = []
+    for x, n, _ in frs:
+        px, pn = arena.take(x.shape, np.float32), arena.take(n.shape, np.float32)
+        px[...] = x
+        pn[...] = n
+        pinned.append((px, pn))
+    pageable = [(x, n) for x, n, _ in frs]
+    for name, arrs in (("pageable", pageable), ("page-locked", pinned)):
+        t1, tb = [], []
+        for r in range(4):
+            t0 = time.perf_counter()
+            cs = [Cloud(x, n, 0.03, 0) for x, n in arrs]
+            t1.append(time.perf_counter() - t0)
+            [c.close() for c in cs]
+            t0 = time.perf_counter()
+            cs = Cloud.create_batch(arrs, 0.03, 0)
+            tb.append(time.perf_counter() - t0)
+            [c.close() for c in cs]
+        print("cloud build, %d fragments of %d points, %s input: one by one %.2f ms, er_cloud_create_batch %.2f ms (%.0f us per fragment, %.1f GB/s of input)"
+              % (len(frs), len(frs[0][0]), name, np.median(t1[1:]) * 1e3, np.median(tb[1:]) * 1e3, np.median(tb[1:]) * 1e6 / len(frs),
+                 sum(x.nbytes + n.nbytes for x, n in arrs) / np.median(tb[1:]) / 1e9))
 print("phases ms median", np.median(ph, 0), "min", ph.min(0), "max", ph.max(0), "total median %.2f -> %.0f pairs/s" % (np.median(ph.sum(1)), n_pairs / np.median(ph.sum(1)) * 1e3))

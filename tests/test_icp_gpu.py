@@ -397,3 +397,46 @@ def test_registration_batch_equals_the_three_stage_calls(gpu, monkeypatch):
             assert r["iterations"][k] == 0 and not r["converged"][k] and len(r["lists"][k]) == 0 and not r["info"][k].any()
             assert np.array_equal(r["T"][k], Ts[k].astype(np.float32))
     assert sum(len(l) for l in lists) > 100000
+
+
+def test_cloud_create_batch_equals_single_creates(gpu):
+    """er_cloud_create_batch (uploads on a copy stream, grids of the previous chunk underneath, two host waits per chunk of 8) builds the
+    SAME clouds as er_cloud_create one by one: 11 fragments of different sizes (two chunks), one of them empty, the input arrays once in
+    pageable and once in page-locked memory; every pair search through them gives the single-create results exactly.  A non-finite
+    coordinate anywhere in the list fails the whole call and leaves no cloud behind."""
+    from elasticreconstruction_amd import _ffi
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch
+    frs = synth.fragment_set(5, 60000, seed=9)
+    arrays = [(x[:60000 - 4000 * k], n[:60000 - 4000 * k]) for k, (x, n, _) in enumerate(frs)] + [(frs[0][0][:777], frs[0][1][:777])]
+    arrays += [(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))] + [(frs[k][0][5:30005], frs[k][1][5:30005]) for k in range(4)]
+    assert len(arrays) == 11
+    single = [Cloud(x, n, 0.03) for x, n in arrays]
+    arena = _ffi.PinnedArena()
+    arena.reset(sum(x.nbytes + n.nbytes for x, n in arrays) + 8192 * 2 * len(arrays))
+    pinned = []
+    for x, n in arrays:
+        px, pn = arena.take(x.shape, np.float32), arena.take(n.shape, np.float32)
+        px[...] = x
+        pn[...] = n
+        pinned.append((px, pn))
+    T01 = np.linalg.inv(frs[0][2]) @ frs[1][2] @ synth.perturbation(5, 1.0, 0.01)
+    for src_arrays in (arrays, pinned):
+        batch = Cloud.create_batch(src_arrays, 0.03)
+        assert [len(c) for c in batch] == [len(c) for c in single]
+        pairs = [(1, 0, T01), (8, 7, np.linalg.inv(frs[0][2]) @ frs[1][2]), (5, 0, np.eye(4)), (6, 0, np.eye(4)), (0, 6, np.eye(4)), (2, 2, np.eye(4))]
+        for clouds in (batch,):
+            cb = count_inliers_batch([clouds[s] for s, _, _ in pairs], [clouds[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.03)
+            cs = count_inliers_batch([single[s] for s, _, _ in pairs], [single[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.03)
+            assert np.array_equal(cb, cs) and cb[0] > 10000 and cb[3] == 0 and cb[4] == 0 and cb[5] == len(single[2])
+            lb, ib = find_correspondence_batch([clouds[s] for s, _, _ in pairs], [clouds[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.015, 0.8660, True)
+            ls, is_ = find_correspondence_batch([single[s] for s, _, _ in pairs], [single[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.015, 0.8660, True)
+            assert all(np.array_equal(a, b) for a, b in zip(lb, ls)) and np.array_equal(ib, is_)
+        for c in batch:
+            c.close()
+    bad = [(x.copy(), n) for x, n in arrays]
+    bad[9][0][123, 1] = np.inf
+    with pytest.raises(_ffi.ErError, match="non-finite"):
+        Cloud.create_batch(bad, 0.03)
+    arena.close()
+    for c in single:
+        c.close()
