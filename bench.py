@@ -167,6 +167,26 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
         clouds.append((Cloud(x, n, 0.03, device), F))
         build_ms.append((time.perf_counter() - t0) * 1e3)
         hosts.append((x, n))
+    # the same fragments through er_cloud_create_batch from PAGE-LOCKED arrays (what a host that reads its PCD files into er_host_alloc memory
+    # gets): uploads back to back on a copy stream, grids underneath -- the list is PCIe-bound (24 bytes per point)
+    from elasticreconstruction_amd import _ffi
+    arena = _ffi.PinnedArena()
+    arena.reset(sum(x.nbytes + n.nbytes for x, n in hosts) + 16384 * len(hosts))
+    pinned = []
+    for x, n in hosts:
+        px, pn = arena.take(x.shape, np.float32), arena.take(n.shape, np.float32)
+        px[...] = x
+        pn[...] = n
+        pinned.append((px, pn))
+    batch_s = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        tmp = Cloud.create_batch(pinned, 0.03, device)
+        batch_s.append(time.perf_counter() - t0)
+        for c in tmp:
+            c.close()
+    arena.close()
+    batch_build_s = float(np.median(batch_s[1:]))
     frs_host = [(x, n, F) for (x, n), (_, F) in zip(hosts, clouds)]
     pairs = synth.config2_pair_list(frs_host, n_pairs)
 
@@ -229,6 +249,16 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     its, ncor = int(np.sum(iters)), int(np.sum(ncs))
     ncpu = min(n_pairs, 8)                                   # pairs that go to the CPU legs (>= 5; 8 = one per thread of the reference's num_threads( 8 ))
     head_lists = [np.array(l) for l in lists[:ncpu]]         # (views into the page-locked arena: copy before it is reused)
+    # the fused entry point (Registration + FindCorrespondence in one call, three shares of the list on host threads of their own)
+    from elasticreconstruction_amd.icp import registration_batch
+    f_srcs, f_tgts, f_T = [clouds[b][0] for _, b, _ in pairs], [clouds[a][0] for a, _, _ in pairs], [T for _, _, T in pairs]
+    fdt, fused = [], None
+    for _ in range(9):
+        t0 = time.perf_counter()
+        fused = registration_batch(f_srcs, f_tgts, f_T, 0.03, 40000, 0.25, 20, 1e-6, 0, 0.015, 0.8660, want_info=True, copy=False)
+        fdt.append(time.perf_counter() - t0)
+    fused_same = bool(all(np.array_equal(fused["T"][k], fins[k]) for k in range(n_pairs)) and [len(l) for l in fused["lists"]] == [int(c) for c in ncs])
+    fdt = fdt[2:]
     npts = sum(len(c[0]) for c in clouds) / float(len(clouds))
     # B_B = P [ (I+2) 12 + I_c 24 ] + C 24 per pair (P as the upper bound of the in-range points); NN traversal excluded
     bb = float(sum(len(clouds[b][0]) * ((int(i) + 2) * 12 + int(i) * 24) + int(c) * 24 for (_, b, _), i, c in zip(pairs, iters, ncs)))
@@ -240,13 +270,22 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
                         "frac": bb / dt / 1e9 / HBM_PEAK_GBS},
            "cloud_build_ms": {"per_fragment_median": float(np.median(build_ms)), "per_fragment_max": float(np.max(build_ms)),
                               "what": "er_cloud_create: upload + uniform-grid build of one fragment, once per fragment (the reference "
-                                      "rebuilds a kd-tree per pair and per function, CorresApp.cpp:129,238)"},
-           "pairs_per_s_incl_cloud_build": n_pairs / (dt + build_total),
+                                      "rebuilds a kd-tree per pair and per function, CorresApp.cpp:129,238)",
+                              "batch_all_fragments_ms": 1e3 * batch_build_s, "batch_per_fragment_ms": 1e3 * batch_build_s / len(clouds),
+                              "batch_input_GB_per_s": sum(x.nbytes + n.nbytes for x, n in hosts) / batch_build_s / 1e9,
+                              "batch_what": "er_cloud_create_batch over all %d fragments from page-locked host arrays: uploads on a copy stream, grid kernels "
+                                            "underneath, two host waits per chunk of 8 (PCIe-bound: 24 bytes per point)" % len(clouds)},
+           "pairs_per_s_incl_cloud_build": n_pairs / (dt + batch_build_s),
+           "pairs_per_s_incl_cloud_build_one_by_one": n_pairs / (dt + build_total),
            "mean_correspondences": ncor / n_pairs, "nn_queries_per_s": npts * (its + 2 * n_pairs) / dt,
            "flow": "er_icp_count_inliers_batch + er_icp_align_batch, then er_find_correspondence_batch over the pair list",
            "phase_ms": {"pre_check": phase[0], "icp": phase[1], "find_correspondence": phase[2]},
            "timing": "median of 7 passes over the pair list; min %.2f ms, max %.2f ms per pass" % (min(dts) * 1e3, max(dts) * 1e3),
            "pass_ms": [round(1e3 * t, 3) for t in dts],
+           "fused_entry": {"pairs_per_s": n_pairs / float(np.median(fdt)), "pass_ms": [round(1e3 * t, 3) for t in fdt], "accepted": int(fused["accepted"].sum()),
+                           "equals_the_three_calls": fused_same,
+                           "what": "er_registration_batch: pre-check, accept rule, ICP and FindCorrespondence of the whole list in ONE call, the list cut into "
+                                   "3 shares that run on host threads / workspaces of their own (ER_ICP_SHARES)"},
            "single_call_pairs_per_s": nseq / dt1,
            "single_call_8_host_threads_pairs_per_s": n_pairs / dt8}
     res["_pass_s"] = dt

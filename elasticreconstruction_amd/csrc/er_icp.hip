@@ -1290,11 +1290,13 @@ __global__ __launch_bounds__(kBlock) void k_interleave(const float* __restrict__
 struct GridScratch {
   std::mutex mu;
   int device = -1;
-  unsigned *key[2] = {nullptr, nullptr}, *idx[2] = {nullptr, nullptr};
-  void* cub = nullptr;
+  unsigned *key[4] = {nullptr, nullptr, nullptr, nullptr}, *idx[4] = {nullptr, nullptr, nullptr, nullptr};   // two sets: [2 lane], [2 lane + 1]
+  void* cub[2] = {nullptr, nullptr};
   int *bounds = nullptr, *h_bounds = nullptr;                   // 8 ints per cloud of a batch: device and its page-locked mirror (+ the initial pattern)
   size_t n_cap = 0, cub_cap = 0, bounds_cap = 0;
-  hipStream_t up = nullptr, cs = nullptr;                       // uploads / grid kernels of er_cloud_create_batch
+  hipStream_t up = nullptr, cs2[2] = {nullptr, nullptr};        // uploads / grid kernels (two lanes: the ~12 small launches of one cloud's grid are
+                                                                // launch-bound, so consecutive clouds build side by side) of er_cloud_create_batch
+  hipEvent_t lane_ev = nullptr;
   std::vector<hipEvent_t> ev;                                   // one per cloud of a batch (upload done) + one per chunk (bounds back)
 };
 GridScratch& grid_scratch(int device) {
@@ -1622,7 +1624,8 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   std::lock_guard<std::mutex> lock(gs.mu);
   auto undo = [&]() {
     if (gs.up) (void)hipStreamSynchronize(gs.up);
-    if (gs.cs) (void)hipStreamSynchronize(gs.cs);
+    for (int q = 0; q < 2; q++)
+      if (gs.cs2[q]) (void)hipStreamSynchronize(gs.cs2[q]);
     for (int i = 0; i < n_clouds; i++) {
       if (out[i]) er_cloud_destroy(out[i]);
       out[i] = nullptr;
@@ -1638,7 +1641,13 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     }                                                                                         \
   } while (0)
   if (!gs.up) ER_CTRY(hipStreamCreateWithFlags(&gs.up, hipStreamNonBlocking));
-  if (!gs.cs) ER_CTRY(hipStreamCreateWithFlags(&gs.cs, hipStreamNonBlocking));
+  for (int q = 0; q < 2; q++)
+    if (!gs.cs2[q]) ER_CTRY(hipStreamCreateWithFlags(&gs.cs2[q], hipStreamNonBlocking));
+  if (!gs.lane_ev) ER_CTRY(hipEventCreateWithFlags(&gs.lane_ev, hipEventDisableTiming));
+  auto sync_lanes = [&]() -> hipError_t {
+    hipError_t e0 = hipStreamSynchronize(gs.cs2[0]), e1 = hipStreamSynchronize(gs.cs2[1]);
+    return e0 != hipSuccess ? e0 : e1;
+  };
   const int n_chunks = (n_clouds + kCloudChunk - 1) / kCloudChunk;
   while ((int)gs.ev.size() < n_clouds + n_chunks) {
     hipEvent_t e = nullptr;
@@ -1646,7 +1655,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     gs.ev.push_back(e);
   }
   if (gs.bounds_cap < (size_t)n_clouds) {
-    ER_CTRY(hipStreamSynchronize(gs.cs));
+    ER_CTRY(sync_lanes());
     if (gs.bounds) (void)hipFree(gs.bounds);
     if (gs.h_bounds) (void)hipHostFree(gs.h_bounds);
     gs.bounds = gs.h_bounds = nullptr;
@@ -1660,15 +1669,15 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   for (int i = 0; i < n_clouds; i++) n_max = std::max(n_max, counts[i]);
   if (n_max > 0) {
     if (gs.n_cap < (size_t)n_max) {
-      ER_CTRY(hipStreamSynchronize(gs.cs));
-      for (int q = 0; q < 2; q++) {
+      ER_CTRY(sync_lanes());
+      for (int q = 0; q < 4; q++) {
         if (gs.key[q]) (void)hipFree(gs.key[q]);
         if (gs.idx[q]) (void)hipFree(gs.idx[q]);
         gs.key[q] = gs.idx[q] = nullptr;
       }
       gs.n_cap = 0;
       const size_t cap = (size_t)n_max + (size_t)n_max / 8;
-      for (int q = 0; q < 2; q++) {
+      for (int q = 0; q < 4; q++) {
         ER_CTRY(hipMalloc((void**)&gs.key[q], cap * sizeof(unsigned)));
         ER_CTRY(hipMalloc((void**)&gs.idx[q], cap * sizeof(unsigned)));
       }
@@ -1676,15 +1685,17 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     }
     // temporary storage of the sort / scan for the largest cloud and the largest grid (2^25 cells, 25 key bits) this call can meet
     size_t need_sort = 0, need_scan = 0;
-    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n_max, 0, 25, gs.cs));
-    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, (int*)nullptr, (int*)nullptr, (1 << 25) + 1, gs.cs));
+    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n_max, 0, 25, gs.cs2[0]));
+    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, (int*)nullptr, (int*)nullptr, (1 << 25) + 1, gs.cs2[0]));
     const size_t need = std::max(need_sort, need_scan);
     if (gs.cub_cap < need) {
-      ER_CTRY(hipStreamSynchronize(gs.cs));
-      if (gs.cub) (void)hipFree(gs.cub);
-      gs.cub = nullptr;
+      ER_CTRY(sync_lanes());
+      for (int q = 0; q < 2; q++) {
+        if (gs.cub[q]) (void)hipFree(gs.cub[q]);
+        gs.cub[q] = nullptr;
+      }
       gs.cub_cap = 0;
-      ER_CTRY(hipMalloc(&gs.cub, need + need / 4));
+      for (int q = 0; q < 2; q++) ER_CTRY(hipMalloc(&gs.cub[q], need + need / 4));
       gs.cub_cap = need + need / 4;
     }
   }
@@ -1694,7 +1705,9 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     const int init[8] = {INT_MAX, INT_MAX, INT_MAX, INT_MIN, INT_MIN, INT_MIN, 0, 0};
     memcpy(h_init + (size_t)i * 8, init, sizeof init);
   }
-  ER_CTRY(hipMemcpyAsync(gs.bounds, h_init, (size_t)n_clouds * 8 * sizeof(int), hipMemcpyHostToDevice, gs.cs));
+  ER_CTRY(hipMemcpyAsync(gs.bounds, h_init, (size_t)n_clouds * 8 * sizeof(int), hipMemcpyHostToDevice, gs.cs2[0]));
+  ER_CTRY(hipEventRecord(gs.lane_ev, gs.cs2[0]));
+  ER_CTRY(hipStreamWaitEvent(gs.cs2[1], gs.lane_ev, 0));
   // ---- stage A of a chunk: allocation, upload (copy stream), bounding box (compute stream) ----
   auto stage_a = [&](int ch) -> int {
     const int i0 = ch * kCloudChunk, i1 = std::min(n_clouds, i0 + kCloudChunk);
@@ -1718,13 +1731,16 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
         ER_HIP_TRY(hipMemcpyAsync(c->xyz, xyz_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
         ER_HIP_TRY(hipMemcpyAsync(c->nrm, normal_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
         ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)i], gs.up));
-        ER_HIP_TRY(hipStreamWaitEvent(gs.cs, gs.ev[(size_t)i], 0));
-        hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, gs.cs, c->xyz, n, gs.bounds + (size_t)i * 8);
+        hipStream_t L = gs.cs2[i & 1];
+        ER_HIP_TRY(hipStreamWaitEvent(L, gs.ev[(size_t)i], 0));
+        hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, L, c->xyz, n, gs.bounds + (size_t)i * 8);
       }
     }
     ER_HIP_TRY(hipGetLastError());
-    ER_HIP_TRY(hipMemcpyAsync(h_got + (size_t)i0 * 8, gs.bounds + (size_t)i0 * 8, (size_t)(i1 - i0) * 8 * sizeof(int), hipMemcpyDeviceToHost, gs.cs));
-    ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(n_clouds + ch)], gs.cs));
+    ER_HIP_TRY(hipEventRecord(gs.lane_ev, gs.cs2[1]));            // lane 0 collects the boxes of both lanes
+    ER_HIP_TRY(hipStreamWaitEvent(gs.cs2[0], gs.lane_ev, 0));
+    ER_HIP_TRY(hipMemcpyAsync(h_got + (size_t)i0 * 8, gs.bounds + (size_t)i0 * 8, (size_t)(i1 - i0) * 8 * sizeof(int), hipMemcpyDeviceToHost, gs.cs2[0]));
+    ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(n_clouds + ch)], gs.cs2[0]));
     return 0;
   };
   // ---- stage B: the grid of every cloud of the chunk (the boxes are back) ----
@@ -1757,7 +1773,10 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
       const int ncell = dim[0] * dim[1] * dim[2];
       hipError_t e = hipMalloc((void**)&c->cell_start, ((size_t)ncell + 1) * sizeof(int));
       if (e != hipSuccess) return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", ((size_t)ncell + 1) * sizeof(int), hipGetErrorString(e));
-      ER_HIP_TRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), gs.cs));
+      const int q = i & 1;
+      hipStream_t L = gs.cs2[q];
+      unsigned *k0 = gs.key[2 * q], *k1 = gs.key[2 * q + 1], *x0 = gs.idx[2 * q], *x1 = gs.idx[2 * q + 1];
+      ER_HIP_TRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), L));
       if (n > 0) {
         GridDims G;
         for (int a = 0; a < 3; a++) {
@@ -1765,15 +1784,15 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
           G.dim[a] = dim[a];
         }
         G.cell = cell;
-        hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, n, G, gs.key[0], gs.idx[0], c->cell_start);
+        hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, n, G, k0, x0, c->cell_start);
         int bits = 1;
         while ((1L << bits) < (long)ncell) bits++;
         size_t tmp = gs.cub_cap;
-        ER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(gs.cub, tmp, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n, 0, bits, gs.cs));
+        ER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(gs.cub[q], tmp, k0, k1, x0, x1, n, 0, bits, L));
         tmp = gs.cub_cap;
-        ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub, tmp, c->cell_start, c->cell_start, ncell + 1, gs.cs));
-        hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, gs.idx[1], n, c->sorted);
-        hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, gs.cs, c->xyz, c->nrm, n, c->xn);
+        ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub[q], tmp, c->cell_start, c->cell_start, ncell + 1, L));
+        hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, x1, n, c->sorted);
+        hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, c->nrm, n, c->xn);
         ER_HIP_TRY(hipGetLastError());
       }
       c->grid.pts = c->sorted;
@@ -1791,7 +1810,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     if (ch + 1 < n_chunks) rc = stage_a(ch + 1);                   // the next chunk's uploads run under this chunk's grid kernels
     if (rc == 0) rc = stage_b(ch);
   }
-  if (rc == 0 && (hipStreamSynchronize(gs.up) != hipSuccess || hipStreamSynchronize(gs.cs) != hipSuccess))   // the caller's arrays and the shared scratch are free again
+  if (rc == 0 && (hipStreamSynchronize(gs.up) != hipSuccess || sync_lanes() != hipSuccess))   // the caller's arrays and the shared scratch are free again
     rc = er::fail("er_cloud_create: %s", hipGetErrorString(hipGetLastError()));
 #undef ER_CTRY
   if (rc) {

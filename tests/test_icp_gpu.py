@@ -430,7 +430,7 @@ def test_cloud_create_batch_equals_single_creates(gpu):
             assert np.array_equal(cb, cs) and cb[0] > 10000 and cb[3] == 0 and cb[4] == 0 and cb[5] == len(single[2])
             lb, ib = find_correspondence_batch([clouds[s] for s, _, _ in pairs], [clouds[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.015, 0.8660, True)
             ls, is_ = find_correspondence_batch([single[s] for s, _, _ in pairs], [single[t] for _, t, _ in pairs], [T for _, _, T in pairs], 0.015, 0.8660, True)
-            assert all(np.array_equal(a, b) for a, b in zip(lb, ls)) and np.array_equal(ib, is_)
+            assert all(np.array_equal(a, b) for a, b in zip(lb, ls)) and np.allclose(ib, is_, rtol=1e-9, atol=1e-6)      # (float64 atomics: order-dependent last bits)
         for c in batch:
             c.close()
     bad = [(x.copy(), n) for x, n in arrays]
