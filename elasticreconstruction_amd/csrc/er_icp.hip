@@ -44,6 +44,26 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kAcc = 32;   // 21 ATA + 6 ATb + sum d^2 + count (+ padding)
 
+// The pair descriptors (PairDev) carry their pointers through MEMORY, so the compiler cannot know that they point into global memory and
+// emits FLAT loads for them: 64-bit address arithmetic in the VALU for every access, and a load that counts on BOTH wait counters
+// (a wave that waits for an LDS result then also waits for its outstanding candidate loads).  The hot accesses go through these
+// explicitly global pointer types instead (round 4): global_load with a scalar base and a 32-bit offset, vmcnt only.
+#ifndef ER_ICP_GLOBAL_PTR
+#define ER_ICP_GLOBAL_PTR 1
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+#if ER_ICP_GLOBAL_PTR
+#define ER_GLOBAL __attribute__((address_space(1)))
+#else
+#define ER_GLOBAL
+#endif
+typedef const ER_GLOBAL f4v* gp_f4;
+typedef const ER_GLOBAL float* gp_f;
+typedef const ER_GLOBAL int* gp_i;
+typedef ER_GLOBAL float* gp_fw;
+typedef ER_GLOBAL int* gp_iw;
+#define ER_GP(type, ptr) ((type)(ptr))
+
 struct Grid {
   const float4* pts;
   const int* cell_start;
@@ -137,10 +157,14 @@ struct NnShared {
 
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
 __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
-  for (int s = s0; s < s1; s += kUnroll) {
-    float4 p[kUnroll];
+  // candidates are addressed by UNSIGNED 32-bit byte offsets from the (wave-uniform) base: a scalar-base global load and one 32-bit
+  // add per candidate instead of a sign extension and a 64-bit multiply-add each
+  const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
+  const unsigned last = (unsigned)(s1 - 1) * 16u;
+  for (unsigned o = (unsigned)s0 * 16u; o <= last && s0 < s1; o += 16u * kUnroll) {
+    f4v p[kUnroll];
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) p[u] = g.pts[min(s + u, s1 - 1)];
+    for (int u = 0; u < kUnroll; u++) p[u] = *(const ER_GLOBAL f4v*)(base + min(o + 16u * (unsigned)u, last));
 #pragma unroll
     for (int u = 0; u < kUnroll; u++) {
       const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
@@ -155,7 +179,9 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
 
 // Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
 __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
-  return scan_range(g, g.cell_start[row + xa], g.cell_start[row + xb + 1], qx, qy, qz, key);
+  const ER_GLOBAL char* cs = (const ER_GLOBAL char*)g.cell_start;
+  const unsigned o = (unsigned)(row + xa) * 4u;
+  return scan_range(g, *(const ER_GLOBAL int*)(cs + o), *(const ER_GLOBAL int*)(cs + o + (unsigned)(xb - xa + 1) * 4u), qx, qy, qz, key);
 }
 
 #if ER_NN_STAGE
@@ -920,7 +946,8 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
         const float4 s = p.src_sorted[k];
         sx = s.x, sy = s.y, sz = s.z;
       } else {
-        sx = X[3 * k], sy = X[3 * k + 1], sz = X[3 * k + 2];
+        const ER_GLOBAL float* Xg = (const ER_GLOBAL float*)((const ER_GLOBAL char*)X + (unsigned)k * 12u);
+        sx = Xg[0], sy = Xg[1], sz = Xg[2];
       }
       if (apply) {
         const float x = sx, y = sy, z = sz;
@@ -929,9 +956,10 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
         sz = ((dm[8] * x + dm[9] * y) + dm[10] * z) + dm[11];
       }
       if (apply || first) {
-        X[3 * k] = sx;
-        X[3 * k + 1] = sy;
-        X[3 * k + 2] = sz;
+        ER_GLOBAL float* Xw = (ER_GLOBAL float*)((ER_GLOBAL char*)X + (unsigned)k * 12u);
+        Xw[0] = sx;
+        Xw[1] = sy;
+        Xw[2] = sz;
       }
     }
     float d;
@@ -940,7 +968,8 @@ __global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__
 #pragma unroll
     for (int t = 0; t < 32; t++) w[t] = 0.0;
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && !((double)d > maxd2)) {
-      const float4 tp = p.tgt_xn[2 * (size_t)i], tn = p.tgt_xn[2 * (size_t)i + 1];
+      const ER_GLOBAL f4v* rec = (const ER_GLOBAL f4v*)((const ER_GLOBAL char*)p.tgt_xn + (unsigned)i * 32u);
+      const f4v tp = rec[0], tn = rec[1];
       const float dx = tp.x, dy = tp.y, dz = tp.z, nx = tn.x, ny = tn.y, nz = tn.z;
       w[27] = (double)d;
       w[28] = 1.0;
