@@ -249,7 +249,7 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     its, ncor = int(np.sum(iters)), int(np.sum(ncs))
     ncpu = min(n_pairs, 8)                                   # pairs that go to the CPU legs (>= 5; 8 = one per thread of the reference's num_threads( 8 ))
     head_lists = [np.array(l) for l in lists[:ncpu]]         # (views into the page-locked arena: copy before it is reused)
-    # the fused entry point (Registration + FindCorrespondence in one call, three shares of the list on host threads of their own)
+    # the fused entry point (Registration + FindCorrespondence in one call, the shares of the list on host threads of their own)
     from elasticreconstruction_amd.icp import registration_batch
     f_srcs, f_tgts, f_T = [clouds[b][0] for _, b, _ in pairs], [clouds[a][0] for a, _, _ in pairs], [T for _, _, T in pairs]
     fdt, fused = [], None
@@ -285,7 +285,7 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
            "fused_entry": {"pairs_per_s": n_pairs / float(np.median(fdt)), "pass_ms": [round(1e3 * t, 3) for t in fdt], "accepted": int(fused["accepted"].sum()),
                            "equals_the_three_calls": fused_same,
                            "what": "er_registration_batch: pre-check, accept rule, ICP and FindCorrespondence of the whole list in ONE call, the list cut into "
-                                   "3 shares that run on host threads / workspaces of their own (ER_ICP_SHARES)"},
+                                   "up to 6 shares of >= 8 pairs that run on host threads / workspaces of their own (ER_ICP_SHARES)"},
            "single_call_pairs_per_s": nseq / dt1,
            "single_call_8_host_threads_pairs_per_s": n_pairs / dt8}
     res["_pass_s"] = dt

@@ -268,7 +268,7 @@ int er_icp_release_workspaces(void);
  *   pairs_host, capacity, n_pairs, info36 (nullable): FindCorrespondence of the accepted pairs at the float64 cast of T_final (:312), as
  *                er_find_correspondence_batch returns them; n_pairs = 0 for a rejected pair.  The `Reduced too much` rule of :164-173
  *                (n_pairs / counts < 0.5) is the caller's: both numbers are returned.
- * The list is cut into ER_ICP_SHARES (default 3) contiguous shares that run their three stages on a host thread and workspace each, so one
+ * The list is cut into ER_ICP_SHARES (default 6, at least ~8 pairs each) contiguous shares that run their three stages on a host thread and workspace each, so one
  * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls. */
 int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
                           int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
