@@ -1949,7 +1949,10 @@ int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, cons
       }
     }
     ER_HIP_TRY(hipMemcpyAsync(g->d_state, g->h_state, (size_t)m * sizeof(IcpDev), hipMemcpyHostToDevice, g->stream));
+    int chunk_no = 0;
     while (n_active > 0) {
+      // the first chunk ends the job for most pairs (three iterations); the stragglers then run six iterations per host visit
+      const int chunk_len = chunk_no++ == 0 ? kIcpChunk : 2 * kIcpChunk;
       ER_HIP_TRY(hipMemcpyAsync(g->d_active, g->h_active, (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, g->stream));
       // points per thread of k_icp_iter for THIS chunk: as many slices of 256 points per workgroup as still leave ~4 workgroups per CU in
       // flight -- 8 for a full list, 1 for the two or three stragglers of a hard list on their way to the iteration limit (round 4: the
@@ -1963,7 +1966,7 @@ int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, cons
       }
       const int pts = icp_pts(act_blocks);
       const int mxp = (mxb + pts - 1) / pts;
-      for (int c = 0; c < kIcpChunk; c++) {
+      for (int c = 0; c < chunk_len; c++) {
         hipLaunchKernelGGL(k_icp_iter, dim3(mxp, n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, (float)max_dist,
                            max_dist * max_dist, pts);
         hipLaunchKernelGGL(k_icp_final, dim3(n_active), dim3(kBlock), 0, g->stream, g->d_pairs, g->d_active, g->d_state, prm, pts);
