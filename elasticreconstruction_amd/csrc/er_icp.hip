@@ -156,7 +156,9 @@ struct NnShared {
 };
 
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
-__device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
+// The reference scan: every candidate against the packed (distance bits, index) key -- exact by construction, 51 VALU instructions per trip
+// of four candidates, 20 of them the selection (four 64-bit compares, eight selects, eight moves that pair distance and index).
+__device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
   // candidates are addressed by UNSIGNED 32-bit byte offsets from the (wave-uniform) base: a scalar-base global load and one 32-bit
   // add per candidate instead of a sign extension and a 64-bit multiply-add each
   const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
@@ -175,6 +177,58 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
     }
   }
   return key;
+}
+
+#ifndef ER_NN_TOURNAMENT
+#define ER_NN_TOURNAMENT 1
+#endif
+// Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
+// Round 4: whole groups of four candidates go through a TOURNAMENT on the 32-bit distance bits (three v_min_u32, three compare +
+// select pairs for the index: no 64-bit keys, no index clamps, the three extra addresses are immediate offsets of the loads), the one to
+// three candidates left over through the exact 64-bit rule.  The tournament returns the FIRST candidate of the smallest distance in scan
+// order, which is the lexicographic (distance, index) minimum unless two candidates share that distance -- and every such tie makes
+// one of the tournament's equality tests true (within a group d0 = d1, d2 = d3 or min(d0, d1) = min(d2, d3); across groups the group's
+// minimum equals the running one), so a lane that saw ANY equality rescans its range with the exact rule (duplicated points do that;
+// otherwise equal float distances of different points are a once-in-millions event).  Same result as scan_range_exact, bit for bit.
+__device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
+#if ER_NN_TOURNAMENT
+  const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
+  const int n4 = (s1 - s0) >> 2;
+  unsigned rd = 0xffffffffu, ri = 0xffffffffu;                 // best distance bits / index of the groups of four
+  bool tie = false;
+  unsigned o = (unsigned)s0 * 16u;
+  for (int t = 0; t < n4; t++, o += 64u) {
+    const f4v p0 = *(const ER_GLOBAL f4v*)(base + o), p1 = *(const ER_GLOBAL f4v*)(base + o + 16u), p2 = *(const ER_GLOBAL f4v*)(base + o + 32u),
+              p3 = *(const ER_GLOBAL f4v*)(base + o + 48u);
+    float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
+    const unsigned d0 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
+    dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
+    const unsigned d1 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
+    dx = qx - p2.x, dy = qy - p2.y, dz = qz - p2.z;
+    const unsigned d2 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
+    dx = qx - p3.x, dy = qy - p3.y, dz = qz - p3.z;
+    const unsigned d3 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
+    const unsigned m01 = min(d0, d1), m23 = min(d2, d3), m = min(m01, m23);
+    const unsigned i01 = d1 < d0 ? __float_as_uint(p1.w) : __float_as_uint(p0.w), i23 = d3 < d2 ? __float_as_uint(p3.w) : __float_as_uint(p2.w);
+    const unsigned im = m23 < m01 ? i23 : i01;
+    tie = tie | (d0 == d1) | (d2 == d3) | (m01 == m23) | (m == rd);
+    ri = m < rd ? im : ri;
+    rd = min(rd, m);
+  }
+  unsigned long long k = ((unsigned long long)rd << 32) | ri;  // (0xffffffff / 0xffffffff when there was no group: above every real key)
+  for (int s = s0 + 4 * n4; s < s1; s++) {                     // the one to three candidates left over: exact rule
+    const f4v p = *(const ER_GLOBAL f4v*)(base + (unsigned)s * 16u);
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float d = ((dx * dx) + dy * dy) + dz * dz;
+    const unsigned long long c = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+    k = c < k ? c : k;
+  }
+  if (tie) k = scan_range_exact(g, s0, s1, qx, qy, qz, kNoHit);
+  // NaN / inf distances have bit patterns above FLT_MAX's: kNoHit (FLT_MAX, -1) beats them, as in the exact scan
+  return k < key ? k : key;
+#else
+  return scan_range_exact(g, s0, s1, qx, qy, qz, key);
+#endif
 }
 
 // Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
