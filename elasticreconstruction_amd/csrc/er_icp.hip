@@ -180,10 +180,13 @@ __device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, in
 }
 
 #ifndef ER_NN_TOURNAMENT
-#define ER_NN_TOURNAMENT 1
+#define ER_NN_TOURNAMENT 0
 #endif
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
-// Round 4: whole groups of four candidates go through a TOURNAMENT on the 32-bit distance bits (three v_min_u32, three compare +
+// A third experiment of round 4 (-DER_NN_TOURNAMENT=1, NOT shipped: parity green, 7 % slower -- 5.5 ms against 5.1 ms per list,
+// profiles/r04i_ab_tournament.txt; hipcc packs the distance arithmetic of a group into v_pk_* pairs and pays for it with 16 register moves
+// per group, and without the SLP vectoriser the 4 + 5 compares of the tournament cost what the four 64-bit compares did):
+// whole groups of four candidates go through a TOURNAMENT on the 32-bit distance bits (three v_min_u32, three compare +
 // select pairs for the index: no 64-bit keys, no index clamps, the three extra addresses are immediate offsets of the loads), the one to
 // three candidates left over through the exact 64-bit rule.  The tournament returns the FIRST candidate of the smallest distance in scan
 // order, which is the lexicographic (distance, index) minimum unless two candidates share that distance -- and every such tie makes
