@@ -595,11 +595,12 @@ JOB_FRAMES = {2: None, 4: 10000, 5: 5000}
 
 
 def kernel_source_sha16():
-    """sha256 over the sources of path A's kernels (csrc/er_tsdf.hip + er_tsdf_math.h), first 16 hex digits: stamped next to the static
-    counter figures of profiles/pmc_latest.json so that a kernel change after the profiled run shows."""
+    """sha256 over the sources of path A's kernels and their build flags (csrc/er_tsdf.hip + er_tsdf_math.h + Makefile), first 16 hex
+    digits: stamped next to the static counter figures of profiles/pmc_latest.json so that a kernel change after the profiled run shows
+    (VERDICT round 3, weak 8)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("er_tsdf.hip", "er_tsdf_math.h"):
+    for f in ("er_tsdf.hip", "er_tsdf_math.h", "Makefile"):
         with open(os.path.join(ROOT, "elasticreconstruction_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -1048,7 +1049,7 @@ def main():
                     static = {"file": "profiles/pmc_latest.json", "run": pj.get("run"), "kernel_source_sha16_at_that_run": pj.get("kernel_source_sha16"),
                               "kernel_source_sha16_now": now, "stale": pj.get("kernel_source_sha16") != now,
                               "what": "traffic, valu_issue.*wave_instructions* and frac_rocprof are STATIC figures of a committed rocprofv3 run, "
-                                      "not of this run; sha16 = sha256 over csrc/er_tsdf.hip + er_tsdf_math.h -- 'stale' means the kernels changed since"}
+                                      "not of this run; sha16 = sha256 over csrc/er_tsdf.hip + er_tsdf_math.h + Makefile -- 'stale' means the kernels or their build flags changed since"}
                     traffic = pj.get("k_integrate_hbm_bytes_per_launch")                     # measured on a 50-frame launch
                     if traffic:
                         phys = traffic / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS

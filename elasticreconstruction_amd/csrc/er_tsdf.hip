@@ -37,6 +37,17 @@
 #include <utility>
 #include <vector>
 
+// Three translation units from this ONE source (round 4): the compiler flags that are best for the voxel pass are not the ones that
+// are best for the pre-pass kernels (profiles/r04k_ab_compiler_flags.txt: without the SLP vectoriser's packed-math pairs -- which cost
+// k_reproject_scatter 28 register moves per pixel -- and with the max-memory-clause scheduler the job gains 4.5 %; k_integrate alone is
+// fastest with the max-ILP scheduler), and hipcc takes such flags per file.  er_tsdf_pre.hip and er_tsdf_int.hip include this file with
+// ER_TSDF_TU = 1 (k_reproject_scatter, k_prepare) and 2 (k_integrate); the default, 0, is everything else: the other kernels and the
+// host side.  The kernels that cross the boundary, and the structs in their signatures, live in a named namespace (external linkage);
+// device helpers stay in the anonymous namespace and are compiled where they are used.
+#ifndef ER_TSDF_TU
+#define ER_TSDF_TU 0
+#endif
+
 namespace {
 
 using namespace er;
@@ -72,6 +83,7 @@ __device__ int ht_find_or_insert(int* __restrict__ ht_key, int cap_mask, int shi
   return -1;
 }
 
+#if ER_TSDF_TU == 0
 // ------------------------------------------------------------------------------------------------
 // ScaleDepth's camera-constant factor (TSDFVolume.cpp:24-26), tabulated once per volume.
 __global__ void k_lambda(float* __restrict__ lambda, int cols, int rows, Camera cam) {
@@ -88,6 +100,7 @@ __global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* _
   scaled[p] = scale_depth_px(depth[p], lambda[p], itrunc);
 }
 
+#endif  // ER_TSDF_TU == 0
 // ------------------------------------------------------------------------------------------------
 // Reproject, IntegrateApp.cpp:247-268: every source pixel is warped through its fragment's control
 // grid and scattered into the frame's z-buffer.  The reference's sequential "write if empty or
@@ -96,6 +109,9 @@ __global__ void k_scale_depth(const uint16_t* __restrict__ depth, const float* _
 // in lastzero (max) and raises the FRAME's bit in the stream's flag word; k_reproject_fix then scatters the flagged frames a
 // second time into a side buffer, zfix, under the replay rule -- only writes that come after the cell's last zero write
 // count -- and the consumer of the z-buffer (k_prepare / k_zbuf_to_depth) takes cells with lastzero > 0 from zfix.
+}  // namespace
+namespace er_tsdf_k {
+using namespace er;
 struct ReprojArgs {
   const uint16_t* depth;
   int n_frames, cols, rows;
@@ -113,6 +129,10 @@ struct ReprojArgs {
   uint32_t* zfix;                        // the replay's z-buffer (all-empty outside a replay; re-armed by the consumer)
   int* zero_flag;                        // int[2], bit f: frame f of the batch saw a write of dd == 0 (one pair per pre-pass stream)
 };
+__global__ void k_reproject_scatter(ReprojArgs A);
+}  // namespace er_tsdf_k
+namespace {
+using namespace er_tsdf_k;
 
 // The write half of one source pixel p of frame f that landed on `cell` with depth dd (IntegrateApp.cpp:260-263).
 __device__ __forceinline__ void scatter_px(const ReprojArgs& A, int f, int p, int cell, uint16_t dd, int replay) {
@@ -145,6 +165,9 @@ __device__ __forceinline__ void reproject_scatter_px(const ReprojArgs& A, int f,
   scatter_px(A, f, p, cell, dd, replay);
 }
 
+}  // namespace
+#if ER_TSDF_TU == 1
+namespace er_tsdf_k {
 __global__ void k_reproject_scatter(ReprojArgs A) {
   // 64 x 4 pixel tiles per 256-thread workgroup, frame = blockIdx.z: no integer divisions for the indices.
   const int f = blockIdx.z;
@@ -153,7 +176,11 @@ __global__ void k_reproject_scatter(ReprojArgs A) {
   if (u >= A.cols || v >= A.rows) return;
   reproject_scatter_px(A, f, u, v, 0);
 }
+}  // namespace er_tsdf_k
+#endif  // ER_TSDF_TU == 1
+namespace {
 
+#if ER_TSDF_TU == 0
 // The order-dependent case (a write of dd == 0 resets the cell: "0 means empty"), replayed exactly.  ONE launch of kFixBlocks
 // single-wave workgroups that return at once unless a frame of the batch is flagged -- practically never -- and otherwise share the
 // pixels of the flagged frames: every source pixel is warped again and scattered into zfix under the replay rule.  One phase, no
@@ -175,6 +202,7 @@ __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_num_vgpr(48))) v
   }
 }
 
+#endif  // ER_TSDF_TU == 0
 // The consumer's half of the replay: the value of z-buffer cell o of a FLAGGED frame (z = what the plain scatter-min left there);
 // cells that saw a zero write take the replay's value and re-arm both side buffers.
 __device__ __forceinline__ uint32_t take_z(uint32_t z, size_t o, uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix) {
@@ -185,6 +213,7 @@ __device__ __forceinline__ uint32_t take_z(uint32_t z, size_t o, uint32_t* __res
   return r;
 }
 
+#if ER_TSDF_TU == 0
 __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restrict__ depth, long total, uint32_t* __restrict__ lastzero,
                                 uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag) {
   long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -194,6 +223,7 @@ __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restric
   if (zero_flag[0] & 1) z = take_z(z, (size_t)t, lastzero, zfix);       // (single frame: bit 0)
   depth[t] = (z == kZEmpty) ? (uint16_t)0 : (uint16_t)z;
 }
+#endif  // ER_TSDF_TU == 0
 
 // ------------------------------------------------------------------------------------------------
 // Per pixel of every frame of the batch: ScaleDepth (TSDFVolume.cpp:19-36) and the unit-touch half
@@ -238,6 +268,18 @@ __device__ void touch_unit(int key, int f, int* __restrict__ ht_key, int* __rest
 constexpr int kPrepThreads = 256;                       // 32 x 8 threads, 4 pixel rows each
 constexpr int kPrepPix = kTile * kTile / kPrepThreads;  // pixels per thread
 
+}  // namespace
+namespace er_tsdf_k {
+__global__ __launch_bounds__(kPrepThreads) void k_prepare(
+    const uint16_t* __restrict__ depth, uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
+    Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
+    int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
+    int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
+    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard,
+    uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag);
+}  // namespace er_tsdf_k
+#if ER_TSDF_TU == 1
+namespace er_tsdf_k {
 __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     const uint16_t* __restrict__ depth, uint32_t* __restrict__ zbuf, int n_frames, int cols, int rows,
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
@@ -333,6 +375,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     if (!dup) touch_unit(k, f, ht_key, ht_slot, ht_mask, cap_mask, hash_shift, batch, nbatch, counters, shard);
   }
 }
+}  // namespace er_tsdf_k
+#endif  // ER_TSDF_TU == 1
+namespace {
 
 // ------------------------------------------------------------------------------------------------
 // Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
@@ -341,6 +386,8 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
 constexpr int kRows = 4;                  // register rows per lane of k_integrate: a wave owns a 4 x 8 x 8 box of voxels
 constexpr int kItemsPerUnit = 256;       // work items per unit: 4 slabs x 16 x 16 voxels per 256-thread workgroup
 
+}  // namespace
+namespace er_tsdf_k {
 struct Plan {
   int n_units;
   int next;      // work queue of k_integrate: index of the next unclaimed item (reset by k_plan)
@@ -353,7 +400,10 @@ struct PlanRec {
   int slot;                 // pool slot; < 0: the pool is exhausted (reported by the host), the unit is skipped
   unsigned long long mask;  // frames of the batch that touch the unit
 };
+}  // namespace er_tsdf_k
+namespace {
 
+#if ER_TSDF_TU == 0
 // Pool slot of hash entry e; hands the slot out on the unit's first ever visit (data_.find( key ) == end, TSDFVolume.cpp:55; pool
 // memory is zero-filled up front).  Called by ONE thread per unit from k_plan.  The pre-passes of two batches run concurrently, so
 // two k_plan launches can race for a new unit: one wins the compare-and-swap (-1 -> -2), draws the slot and publishes it; the
@@ -421,6 +471,7 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
     plan_rec[atomicAdd(&start[__popcll(mask)], 1)] = r;                 // position in descending cost order
   }
 }
+#endif  // ER_TSDF_TU == 0
 
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
@@ -438,6 +489,16 @@ constexpr int kIntMinBlocks = 4;          // register budget: 4 workgroups of 4 
                                           // eight-row kernel of mid round 3 needed 144)
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
+}  // namespace
+namespace er_tsdf_k {
+template <bool kSure>
+__global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
+    float2* __restrict__ pool, const PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
+    const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
+    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows);
+}  // namespace er_tsdf_k
+#if ER_TSDF_TU == 2
+namespace er_tsdf_k {
 template <bool kSure>
 __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     float2* __restrict__ pool, const PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
@@ -619,6 +680,17 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
       if (W[r] != W0[r]) slab[r * row_stride] = make_float2(S[r], W[r]);
   }
 }
+template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+}  // namespace er_tsdf_k
+#else
+namespace er_tsdf_k {
+extern template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+extern template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+}  // namespace er_tsdf_k
+#endif  // ER_TSDF_TU == 2
+#if ER_TSDF_TU == 0
+namespace {
 
 // Clears the frame masks of the batch list and accounts unit visits (sum of popcounts).
 __global__ void k_reset(const int* __restrict__ batch, int* __restrict__ nbatch, unsigned long long* __restrict__ ht_mask,
@@ -1830,3 +1902,5 @@ int er_tsdf_get_profile(er_tsdf_t h, double* integrate_ms_total, long* integrate
 
 
 }  // extern "C"
+
+#endif  // ER_TSDF_TU == 0
