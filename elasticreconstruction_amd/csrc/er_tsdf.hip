@@ -1282,6 +1282,7 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   if (!out) return er::fail("er_tsdf_create: out is NULL");
   *out = nullptr;
   if (cols <= 0 || rows <= 0 || max_units <= 0) return er::fail("er_tsdf_create: bad dimensions");
+  if ((long)cols * rows >= (1L << 30)) return er::fail("er_tsdf_create: image of %d x %d pixels is too large", cols, rows);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return er::fail("er_tsdf_create: no HIP device available (liber_hip has no CPU fallback)");

@@ -299,7 +299,7 @@ ER_HD bool voxel_project(float g0, float g1, float g2, const FrameXform& f, cons
   // :78-80  round( float expr ) and the image-range test, see pixel_index.
   int px, py;
   const bool vx = pixel_index(qu + c.cx, (float)cols - 0.5f, px), vy = pixel_index(qv + c.cy, (float)rows - 0.5f, py);
-  pixel = (unsigned)(py * cols + px);
+  pixel = (unsigned)(py * cols + px);                                   // (a 24-bit multiply-add here was measured: 0.8 % slower, round 4)
   return (t2 > 0.0f) & vx & vy;                                          // :77,:80
 }
 
