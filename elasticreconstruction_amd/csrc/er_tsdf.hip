@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // the 64 workgroups of one XCD, so that its depth tiles stay in that L2) 0.415 ms against 0.263 ms for the global queue; claiming
 // one or two items ahead (to take the claim's latency off the critical path) 0.345 / 0.385 ms.  The global queue, claimed when the
 // workgroup is free, stays.
-constexpr int kIntMinBlocks = 4;          // register budget: 4 workgroups of 4 waves per CU guaranteed (94 VGPRs with four rows per lane; the
+#ifndef ER_INT_MIN_BLOCKS
+#define ER_INT_MIN_BLOCKS 4
+#endif
+constexpr int kIntMinBlocks = ER_INT_MIN_BLOCKS;          // register budget: 4 workgroups of 4 waves per CU guaranteed (94 VGPRs with four rows per lane; the
                                           // eight-row kernel of mid round 3 needed 144)
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
@@ -1191,7 +1194,10 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipStream_t X = h->aux_stream[a], S = h->stream;
   int* nbatch = h->counters + kNbatchSlot[p];
 
-  constexpr int kIntBlocksPerCu = 4;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
+#ifndef ER_INT_BLOCKS_PER_CU
+#define ER_INT_BLOCKS_PER_CU 4
+#endif
+  constexpr int kIntBlocksPerCu = ER_INT_BLOCKS_PER_CU;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
                                            // space next to them (round 2, four rows per lane: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s;
                                            // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; four rows with the plan records: 2 -> 153.3 k,
                                            // 3 -> 158.5 k, 4 -> 159.2 k, 5 -> 155.2 k; profiles/r02G_*, r03i_ab_rows8.txt, r03D_ab_rows4_again.txt)
