@@ -7,9 +7,10 @@ dur = collections.defaultdict(dict)          # kernel -> {(file, dispatch id): d
 for f in sorted(glob.glob(os.path.join(d, "pass*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
-        if "anonymous namespace)::k_" not in k:
+        tag = "(anonymous namespace)::" if "anonymous namespace)::k_" in k else ("er_tsdf_k::" if "er_tsdf_k::k_" in k else None)
+        if tag is None:
             continue
-        k = k.split("(anonymous namespace)::", 1)[1].split("(")[0]
+        k = k.split(tag, 1)[1].split("(")[0]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         if r.get("Start_Timestamp") and r.get("End_Timestamp"):
             dur[k][(f, r.get("Dispatch_Id"))] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
