@@ -407,8 +407,12 @@ __device__ __forceinline__ bool nn_stage(NnStage& st, const Grid& g, bool valid,
 // looks at about half the candidates (a cell is skipped only when every point in it is provably farther than the best: its
 // nearest face already is, with the same 1e-4 relative margin as the row test; ties cannot hide there).
 // Round 4: the candidates come from LDS when the workgroup's candidate set fits (nn_stage above).
+// hit2 >= 0 (the Registration pre-check only, round 4): the caller does not need the NEAREST point, only whether ANY target point lies closer
+// than sqrt(hit2) -- "count the points whose nearest neighbour is within reg_dist" is "count the points that have a neighbour within
+// reg_dist" -- so a query stops as soon as it holds a candidate below hit2 (its remaining cells and row tasks are dropped); the returned
+// distance is then that candidate's, not the minimum.  Queries without such a candidate run the full exact search as before.
 __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
-                                        float& best_d) {
+                                        float& best_d, float hit2 = -1.f) {
   const int tid = threadIdx.x;
   __syncthreads();                                            // the previous call's readers are done with `sh`
   if (tid == 0) sh.ntask = 0;
@@ -451,14 +455,17 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
       if (has_o) {
         key = scan(row, ix, ix, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
+        if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
       }
       if (has_l && xlo * xlo <= bound) {
         key = scan(row, ix - 1, ix - 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+        if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
       if (has_r && xhi * xhi <= bound) {
         key = scan(row, ix + 1, ix + 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+        if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
     }
     sh.q[0][tid] = qx;
@@ -638,12 +645,21 @@ __device__ __forceinline__ int nn_block_cells(NnSharedC& sh, const Grid& g, bool
 }
 #endif
 
+#ifndef ER_NN_ANY_HIT
+#define ER_NN_ANY_HIT 1
+#endif
 #if ER_NN_CELLTASKS
 using NnSh = NnSharedC;
 #define nn_search nn_block_cells
+#define ER_ANY_HIT_ARG
 #else
 using NnSh = NnShared;
 #define nn_search nn_block
+#if ER_NN_ANY_HIT
+#define ER_ANY_HIT_ARG , hit2
+#else
+#define ER_ANY_HIT_ARG
+#endif
 #endif
 
 // Block reduction of NV float64 values per thread: wave shuffle (64 lanes) -> LDS -> lane 0 atomics.
@@ -943,6 +959,11 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
   const int n = p.n;
   if ((int)blockIdx.x * kBlock >= n) return;                 // (wave-uniform: whole workgroups beyond a short pair's points)
   int local = 0;
+  // any-hit threshold: a float strictly below both limits of the count test (d <= radius^2 as doubles, d < maxd2), so "d < hit2" implies the test
+  const double lim = fmin((double)radius * (double)radius, maxd2);
+  float hit2 = (float)lim;
+  if ((double)hit2 >= lim) hit2 = __uint_as_float(__float_as_uint(hit2) - 1u);      // (lim > 0: the next float below)
+  (void)hit2;
   for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
     const int k = base + (int)threadIdx.x;
     float qx = 0.f, qy = 0.f, qz = 0.f, d;
@@ -950,7 +971,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
       const float4 s = p.src_sorted[k];
       xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
     }
-    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d ER_ANY_HIT_ARG);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
