@@ -238,6 +238,19 @@ __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restric
 // create, never written): a voxel whose projection misses the image gathers from it instead of taking a predicated load.
 constexpr int kScaledPad = 64;
 constexpr int kTile = 32;
+// Granularity of tile_lo_fine, the second-level per-tile MINIMUM of the scaled depth behind k_integrate's "full" verdict: 2^kLoShift pixels.
+// Round 4: 16-pixel tiles next to the 32-pixel tiles of tile_max / tile_lo (measured: 16 px 167.2 k frames/s, 8 px 165.5 k, none 165.5 k) -- a pixel without usable depth (the warp's scatter leaves holes) spoils the minimum of its
+// whole tile, and the CPU replay (tests/hostcheck, hc_set_lo_shift) counts 39 % of the kept (patch, frame) visits as full with 8-pixel tiles
+// against 27 % with 32 (34 % with 16; with 4 the verdict's cap of 64 tiles per patch hull cuts in: 22 %), zero violations either way.
+// The fine tiles are the SECOND level of the verdict (er_tsdf_math.h: patch_may_update_box): the 32-pixel minimum decides first, the fine
+// ones are read only when it fails for a patch that lies clearly in front of everything under it -- consulting them for every (patch,
+// frame) made the culling preamble as much slower as the frame loop got faster (profiles/r04q_ab_tile_lo.txt).
+#ifndef ER_TILE_LO_SHIFT
+#define ER_TILE_LO_SHIFT 4
+#endif
+constexpr int kLoShift = ER_TILE_LO_SHIFT;
+static_assert(kLoShift >= 3 && kLoShift <= 5, "tile_lo tiles of 8, 16 or 32 pixels");
+constexpr int kLoSub = kTile >> kLoShift;               // tile_lo tiles per side of a 32 x 32 k_prepare tile: 4, 2 or 1
 constexpr int kTileKeys = 96;
 
 // Marks frame f in the unit's mask; the first toucher of the unit IN THIS BATCH (unique: its atomicOr
@@ -275,7 +288,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard,
+    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, float* __restrict__ tile_lo_fine, int2 shard,
     uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag);
 }  // namespace er_tsdf_k
 #if ER_TSDF_TU == 1
@@ -285,11 +298,11 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     Camera cam, CameraInv cami, const float* __restrict__ lambda, const double* __restrict__ T12, float* __restrict__ scaled,
     int* __restrict__ ht_key, int* __restrict__ ht_slot, unsigned long long* __restrict__ ht_mask, int cap_mask,
     int hash_shift, int* __restrict__ batch, int* __restrict__ nbatch,
-    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, int2 shard,
+    int* __restrict__ counters, float* __restrict__ tile_max, float* __restrict__ tile_lo, float* __restrict__ tile_lo_fine, int2 shard,
     uint32_t* __restrict__ lastzero, uint32_t* __restrict__ zfix, const int* __restrict__ zero_flag) {
   __shared__ int s_keys[kTileKeys];
   __shared__ int s_n;
-  __shared__ float s_wmax[kPrepThreads / 64], s_wlo[kPrepThreads / 64];
+  __shared__ float s_wmax[kPrepThreads / 64], s_wlo[kLoSub][kLoSub][kPrepThreads / 64];
   const int pixels = cols * rows;
   const int f = blockIdx.z;
   const bool replayed = zbuf && ((zero_flag[f >> 5] >> (f & 31)) & 1);  // this frame saw a zero write (uniform; practically never)
@@ -320,7 +333,9 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       lam[q] = lambda[p];
     }
   }
-  float wmax = 0.0f, wlo = 3.0e38f;
+  float wmax = 0.0f, vlo[kPrepPix];
+#pragma unroll
+  for (int q = 0; q < kPrepPix; q++) vlo[q] = 3.0e38f;
 #pragma unroll
   for (int q = 0; q < kPrepPix; q++) {
     const int y = blockIdx.y * kTile + ty + q * (kTile / kPrepPix);
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       const float sc = scale_depth_px(d[q], lam[q], cam.integration_trunc);
       scaled[(size_t)f * (pixels + kScaledPad) + y * cols + x] = sc;
       wmax = fmaxf(wmax, sc);
-      wlo = fminf(wlo, sc > 0.001f ? sc : 0.0f);                        // over EVERY pixel of the tile: 0 as soon as one carries no usable depth
+      vlo[q] = sc > 0.001f ? sc : 0.0f;                                 // (min over EVERY pixel of its tile below: 0 as soon as one carries no usable depth
                                                                         // (a NaN depth -- degenerate camera -- fails ":82 dp > 0.001" too: it counts as 0, fminf alone would skip it)
       if (d[q] > 0) {                                                   // TSDFVolume.cpp:47 (no range cut-off)
         key = touch_key(x, y, d[q], cam, cami, T12 + f * 12);
@@ -347,25 +362,40 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
       }
     }
   }
-  // max and min of the scaled depth over the tile (consumed by patch_may_update_box in k_integrate: culling / the full verdict)
-  for (int off = 32; off > 0; off >>= 1) {
-    wmax = fmaxf(wmax, __shfl_xor(wmax, off));
-    wlo = fminf(wlo, __shfl_xor(wlo, off));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_wmax[threadIdx.x >> 6] = wmax;
-    s_wlo[threadIdx.x >> 6] = wlo;
+  // max of the scaled depth over the 32 x 32 tile and min over its kLoSub x kLoSub sub-tiles of 2^kLoShift pixels (consumed by
+  // patch_may_update_box in k_integrate: culling / the full verdict).  A thread's pixel q lies in row 8 q + ty of the tile, column tx: the
+  // sub-tile row is (8 q + ty) >> kLoShift, the column tx >> kLoShift; a wave holds rows ty = 2 w, 2 w + 1 (lane = 32 (ty & 1) + tx).
+  for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off));
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = wmax;
+  {
+    constexpr int qper = kPrepPix / kLoSub;             // pixel rows q of a thread per sub-tile row: 1, 2 or 4
+#pragma unroll
+    for (int sr = 0; sr < kLoSub; sr++) {
+      float r = vlo[sr * qper];
+#pragma unroll
+      for (int e = 1; e < qper; e++) r = fminf(r, vlo[sr * qper + e]);
+#pragma unroll
+      for (int off = 1; off < (1 << kLoShift); off <<= 1) r = fminf(r, __shfl_xor(r, off));     // the columns of the sub-tile
+      r = fminf(r, __shfl_xor(r, 32));                                                        // the wave's two rows
+      if ((threadIdx.x & 32) == 0 && (tx & ((1 << kLoShift) - 1)) == 0) s_wlo[sr][tx >> kLoShift][threadIdx.x >> 6] = r;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     float m = 0.0f, lo = 3.0e38f;
-    for (int w = 0; w < kPrepThreads / 64; w++) {
-      m = fmaxf(m, s_wmax[w]);
-      lo = fminf(lo, s_wlo[w]);
-    }
+    for (int w = 0; w < kPrepThreads / 64; w++) m = fmaxf(m, s_wmax[w]);
+    for (int e = 0; e < kLoSub * kLoSub * (kPrepThreads / 64); e++) lo = fminf(lo, (&s_wlo[0][0][0])[e]);
     const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     tile_max[t] = m;
-    tile_lo[t] = lo;
+    tile_lo[t] = lo;                                      // the 32-pixel minimum: first level of the full verdict
+  }
+  if (kLoShift < 5 && (int)threadIdx.x < kLoSub * kLoSub) {
+    const int sr = threadIdx.x / kLoSub, sg = threadIdx.x % kLoSub;
+    float lo = 3.0e38f;
+    for (int w = 0; w < kPrepThreads / 64; w++) lo = fminf(lo, s_wlo[sr][sg][w]);
+    const int lx = blockIdx.x * kLoSub + sg, ly = blockIdx.y * kLoSub + sr;
+    const int lo_tx = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_ty = (rows + (1 << kLoShift) - 1) >> kLoShift;
+    if (lx < lo_tx && ly < lo_ty) tile_lo_fine[((size_t)f * lo_ty + ly) * lo_tx + lx] = lo;
   }
   const int n = min(s_n, kTileKeys);
   if ((int)threadIdx.x < n) {
@@ -498,7 +528,7 @@ template <bool kSure>
 __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     float2* __restrict__ pool, const PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows);
+    const float* __restrict__ tile_lo, const float* __restrict__ tile_lo_fine, int tiles_x, int tiles_y, Camera cam, int cols, int rows);
 }  // namespace er_tsdf_k
 #if ER_TSDF_TU == 2
 namespace er_tsdf_k {
@@ -506,10 +536,11 @@ template <bool kSure>
 __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     float2* __restrict__ pool, const PlanRec* __restrict__ plan_rec, Plan* __restrict__ plan,
     const FrameXform* __restrict__ frames, const float* __restrict__ scaled, const float* __restrict__ tile_max,
-    const float* __restrict__ tile_lo, int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
+    const float* __restrict__ tile_lo, const float* __restrict__ tile_lo_fine, int tiles_x, int tiles_y, Camera cam, int cols, int rows) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
+  const int lo_tiles_x = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_tiles = lo_tiles_x * ((rows + (1 << kLoShift) - 1) >> kLoShift);
   const int n_items = plan->n_units * kItemsPerUnit;
   // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
   // its own (one atomic per item and workgroup; the grid is 4 persistent workgroups per CU): longest-processing-time-
@@ -579,7 +610,8 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
         keep = patch_may_update_box(grid_coord(i, xs), grid_coord(i + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
                                     grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), frames[lane], cam, cols, rows,
                                     tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside,
-                                    tile_lo + (size_t)lane * tiles_x * tiles_y, &full);
+                                    tile_lo + (size_t)lane * tiles_x * tiles_y, &full, kLoShift, lo_tiles_x,
+                                    kLoShift < 5 ? tile_lo_fine + (size_t)lane * lo_tiles : (const float*)nullptr);
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
       m_full = __ballot(keep && full);
@@ -683,13 +715,13 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
       if (W[r] != W0[r]) slab[r * row_stride] = make_float2(S[r], W[r]);
   }
 }
-template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
-template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
 }  // namespace er_tsdf_k
 #else
 namespace er_tsdf_k {
-extern template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
-extern template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+extern template __global__ void k_integrate<true>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
+extern template __global__ void k_integrate<false>(float2* __restrict__, const PlanRec* __restrict__, Plan* __restrict__, const FrameXform* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, const float* __restrict__, int, int, Camera, int, int);
 }  // namespace er_tsdf_k
 #endif  // ER_TSDF_TU == 2
 #if ER_TSDF_TU == 0
@@ -1024,7 +1056,7 @@ struct er_tsdf_s {
   bool used[kDepth] = {};
   int* batch[kDepth] = {};
   unsigned long long* ht_mask[kDepth] = {};
-  float *scaled[kDepth] = {}, *tile_max[kDepth] = {}, *tile_lo[kDepth] = {};
+  float *scaled[kDepth] = {}, *tile_max[kDepth] = {}, *tile_lo[kDepth] = {}, *tile_lo_fine[kDepth] = {};
   er::FrameXform* frames[kDepth] = {};              // = &dstage[q]->fx
   void* dstage[kDepth] = {};                        // device twin of the pinned per-batch constants (struct Staging)
   hipEvent_t pre_done[kDepth] = {}, int_done[kDepth] = {};
@@ -1243,7 +1275,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   hipLaunchKernelGGL(k_prepare, dim3((h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile, n), dim3(kPrepThreads), 0, X,
                      depth_dev, zsrc, n, h->cols, h->rows, h->cam, h->cami, h->lambda, dev_t12, h->scaled[p], h->ht_key, h->ht_slot,
                      h->ht_mask[p], h->ht_cap - 1, h->ht_shift, h->batch[p], nbatch, h->counters,
-                     h->tile_max[p], h->tile_lo[p], make_int2(h->shard_rank, h->shard_world), h->lastzero[a], h->zfix[a],
+                     h->tile_max[p], h->tile_lo[p], h->tile_lo_fine[p], make_int2(h->shard_rank, h->shard_world), h->lastzero[a], h->zfix[a],
                      h->counters + kZeroFlagSlot[a]);
   hipLaunchKernelGGL(k_plan, dim3(1), dim3(256), 0, X, h->batch[p], nbatch, h->ht_mask[p], h->ht_key, h->ht_slot, h->unit_key, h->max_units,
                      h->counters, h->plan_rec[p], h->plan[p], warp ? h->counters + kZeroFlagSlot[a] : (int*)nullptr);
@@ -1260,7 +1292,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   }
   const bool sure = h->cam.integration_trunc < 64.0f;                   // voxel_classify's bound on the scaled depth (false for NaN)
   hipLaunchKernelGGL(sure ? k_integrate<true> : k_integrate<false>, dim3(wide_grid), dim3(kBlock), 0, S, h->pool, h->plan_rec[p], h->plan[p],
-                     h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], (h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile,
+                     h->frames[p], h->scaled[p], h->tile_max[p], h->tile_lo[p], h->tile_lo_fine[p], (h->cols + kTile - 1) / kTile, (h->rows + kTile - 1) / kTile,
                      h->cam, h->cols, h->rows);
   if (timed) {
     ER_HIP_TRY(hipEventRecord(e1, S));
@@ -1365,6 +1397,8 @@ int er_tsdf_create(int cols, int rows, const float cam6[6], int max_units, int d
   ER_ALLOC(h->dsum, sizeof(double));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_max[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->tile_lo[q], B * (size_t)((cols + kTile - 1) / kTile) * ((rows + kTile - 1) / kTile) * sizeof(float));
+  for (int q = 0; q < kDepth; q++)
+    ER_ALLOC(h->tile_lo_fine[q], B * (size_t)((cols + (1 << kLoShift) - 1) >> kLoShift) * ((rows + (1 << kLoShift) - 1) >> kLoShift) * sizeof(float));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan_rec[q], (size_t)cap * sizeof(PlanRec));
   for (int q = 0; q < kDepth; q++) ER_ALLOC(h->plan[q], sizeof(Plan));
 #undef ER_ALLOC
@@ -1407,7 +1441,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
                              h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->key_scratch,
                              h->slot_scratch};
   for (int q = 0; q < kDepth; q++)
-    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q],
+    for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q], (void*)h->tile_lo_fine[q],
                     (void*)h->plan_rec[q], (void*)h->plan[q]})
       ptrs.push_back(x);
   for (int q = 0; q < kAux; q++) {

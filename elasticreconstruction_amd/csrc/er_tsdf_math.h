@@ -439,7 +439,8 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 // NaNs fail a comparison and the verdict.  tests/hostcheck replays it against the full update for every voxel it covers.
 ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
                                 int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
-                                const float* __restrict__ tile_lo = nullptr, bool* full = nullptr, int lo_shift = 5, int lo_tiles_x = 0) {
+                                const float* __restrict__ tile_lo = nullptr, bool* full = nullptr, int lo_shift = 5, int lo_tiles_x = 0,
+                                const float* __restrict__ tile_lo_fine = nullptr) {
   *inside = false;
   if (full) *full = false;
   float lo_tile = 0.0f;                                   // min of the scaled depth over every pixel a voxel can sample (0: unknown)
@@ -488,21 +489,10 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
       for (int ty = y0; ty <= y1; ty++)
         for (int tx = x0; tx <= x1; tx++) {
           m = fmaxf(m, tile_max[ty * tiles_x + tx]);
-          if (tile_lo && lo_shift == 5) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
+          if (tile_lo) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
         }
       dmax_tile = m;
-      if (tile_lo && lo_shift == 5) lo_tile = lo;
-      if (tile_lo && lo_shift != 5) {
-        // (experiment, host replay only so far: tile_lo at a finer granularity of 2^lo_shift pixels, lo_tiles_x tiles per row -- the
-        //  warp's scatter holes then spoil fewer verdicts)
-        const int a0 = (int)fmaxf(umin - 1.5f, 0.0f) >> lo_shift, a1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> lo_shift;
-        const int b0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> lo_shift, b1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> lo_shift;
-        if ((a1 - a0 + 1) * (b1 - b0 + 1) <= 64) {
-          for (int ty = b0; ty <= b1; ty++)
-            for (int tx = a0; tx <= a1; tx++) lo = fminf(lo, tile_lo[ty * lo_tiles_x + tx]);
-          lo_tile = lo;
-        }
-      }
+      if (tile_lo) lo_tile = lo;
     }
   }
   if (!(dmax_tile > 0.001f)) return false;                // no pixel with usable depth under the patch
@@ -524,11 +514,26 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
     *inside = (tau >= 0x1p-20f) & (t2max + 2.0f * e2 <= 0x1p20f) & (e2 * 4096.0f <= tau) & (su <= 0.125f) & (sv <= 0.125f) &
               (umin >= 0.5f) & (umax <= (float)cols - 1.5f) & (vmin >= 0.5f) & (vmax <= (float)rows - 1.5f);
   }
-  if (full && *inside && lo_tile > 0.001f) {
+  if (full && *inside && tile_lo) {
     const float ex = fmaxf(fabsf(g0lo - f.tx), fabsf(g0hi - f.tx)), ey = fmaxf(fabsf(g1lo - f.ty), fabsf(g1hi - f.ty)),
                 ez = fmaxf(fabsf(g2lo - f.tz), fabsf(g2hi - f.tz));
     const float dfar = sqrtf((ex * ex + ey * ey) + ez * ez);
-    *full = lo_tile - dfar > ((float)kTsdfTrunc + 1e-4f) + 1e-6f * dfar;      // (NaN / inf: false)
+    const float need = ((float)kTsdfTrunc + 1e-4f) + 1e-6f * dfar;
+    // first the 32-pixel tiles that were read for the culling anyway ...
+    *full = (lo_tile > 0.001f) & (lo_tile - dfar > need);                     // (NaN / inf: false)
+    // ... and only if they fail -- typically because ONE pixel of a tile carries no depth (the warp's scatter leaves holes) -- and the
+    // patch lies clearly in front of everything under it (the tile MAXIMUM passes the distance test: a patch near or behind the surface
+    // can never be full), the minimum over the finer tiles of 2^lo_shift pixels under the hull (round 4; at most 64 of them)
+    if (!*full && tile_lo_fine && dmax_tile - dfar > need) {
+      const int a0 = (int)fmaxf(umin - 1.5f, 0.0f) >> lo_shift, a1 = (int)fminf(umax + 1.5f, (float)(cols - 1)) >> lo_shift;
+      const int b0 = (int)fmaxf(vmin - 1.5f, 0.0f) >> lo_shift, b1 = (int)fminf(vmax + 1.5f, (float)(rows - 1)) >> lo_shift;
+      if ((a1 - a0 + 1) * (b1 - b0 + 1) <= 64) {
+        float lo = 3.0e38f;
+        for (int ty = b0; ty <= b1; ty++)
+          for (int tx = a0; tx <= a1; tx++) lo = fminf(lo, tile_lo_fine[ty * lo_tiles_x + tx]);
+        *full = (lo > 0.001f) & (lo - dfar > need);
+      }
+    }
   }
   return true;
 }

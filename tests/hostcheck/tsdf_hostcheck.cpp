@@ -14,7 +14,7 @@
 using namespace er;
 
 struct HcUnit { std::vector<float> sdf, w; std::vector<int> frames; };
-static int g_lo_shift = 5;             // granularity of tile_lo in the replay (5 = the 32-pixel tiles k_prepare writes)
+static int g_lo_shift = 4;             // granularity of the second-level tile_lo in the replay (k_prepare: 16-pixel tiles; 5 = no second level)
 static int g_patch_shape = 1;          // 1 = the 4 x 8 x 8 box k_integrate gives a wave (default), 2 = the 8 x 8 x 8 cube of mid round 3, 0 = a 16 x 16 square of one slab
 struct HcVolume { Camera cam; CameraInv cami; int cols, rows; std::map<int, HcUnit> units; long culled = 0, kept = 0, inside = 0, inside_violations = 0, sure = 0, visited = 0, unsure_pf = 0, sure_violations = 0, full_pf = 0, full_violations = 0, exact_rows = 0, exact_rows_needing = 0; };
 
@@ -84,13 +84,16 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
   const int tiles_x = (v->cols + 31) / 32, tiles_y = (v->rows + 31) / 32;
   std::vector<std::vector<float>> tile_max(n, std::vector<float>((size_t)tiles_x * tiles_y, 0.f));
   const int lts = 1 << g_lo_shift, lo_tx = (v->cols + lts - 1) / lts, lo_ty = (v->rows + lts - 1) / lts;
-  std::vector<std::vector<float>> tile_lo(n, std::vector<float>((size_t)lo_tx * lo_ty, 3.0e38f));   // min over ALL pixels of the tile
+  std::vector<std::vector<float>> tile_lo(n, std::vector<float>((size_t)tiles_x * tiles_y, 3.0e38f));   // min over ALL pixels of the 32-pixel tile
+  std::vector<std::vector<float>> tile_lo_fine(n, std::vector<float>((size_t)lo_tx * lo_ty, 3.0e38f)); // ... and of the 2^g_lo_shift-pixel tile
   for (int f = 0; f < n; f++)
     for (int p = 0; p < px; p++) {
       const size_t t = (size_t)((p / v->cols) / 32) * tiles_x + (p % v->cols) / 32;
       tile_max[f][t] = std::max(tile_max[f][t], scaled[f][p]);
       const size_t tl = (size_t)((p / v->cols) >> g_lo_shift) * lo_tx + ((p % v->cols) >> g_lo_shift);
-      tile_lo[f][tl] = std::min(tile_lo[f][tl], scaled[f][p] > 0.001f ? scaled[f][p] : 0.0f);   // as k_prepare: NaN / unusable -> 0
+      const float usable = scaled[f][p] > 0.001f ? scaled[f][p] : 0.0f;                          // as k_prepare: NaN / unusable -> 0
+      tile_lo[f][t] = std::min(tile_lo[f][t], usable);
+      tile_lo_fine[f][tl] = std::min(tile_lo_fine[f][tl], usable);
     }
   long culled = 0, kept = 0;
   for (auto& kv : v->units) {
@@ -114,7 +117,7 @@ int hc_integrate_frames(void* h, int n, const uint16_t* depth, const double* T, 
           bool inside = false, full = false;
           if (patch_may_update_box(grid_coord(i0, xs), grid_coord(i0 + ni - 1, xs), grid_coord(j0, ys), grid_coord(j0 + nj - 1, ys), grid_coord(k0, zs),
                                    grid_coord(k0 + nk - 1, zs), fx[f], v->cam, v->cols, v->rows, tile_max[f].data(), tiles_x, tiles_y, &inside,
-                                   tile_lo[f].data(), &full, g_lo_shift, lo_tx)) {
+                                   tile_lo[f].data(), &full, g_lo_shift, lo_tx, g_lo_shift < 5 ? tile_lo_fine[f].data() : nullptr)) {
             frames.push_back(f);
             in.push_back(inside);
             ful.push_back(full);
