@@ -158,17 +158,18 @@ struct NnShared {
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
 // The reference scan: every candidate against the packed (distance bits, index) key -- exact by construction, 51 VALU instructions per trip
 // of four candidates, 20 of them the selection (four 64-bit compares, eight selects, eight moves that pair distance and index).
+template <int kU = kUnroll>
 __device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
   // candidates are addressed by UNSIGNED 32-bit byte offsets from the (wave-uniform) base: a scalar-base global load and one 32-bit
   // add per candidate instead of a sign extension and a 64-bit multiply-add each
   const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
   const unsigned last = (unsigned)(s1 - 1) * 16u;
-  for (unsigned o = (unsigned)s0 * 16u; o <= last && s0 < s1; o += 16u * kUnroll) {
-    f4v p[kUnroll];
+  for (unsigned o = (unsigned)s0 * 16u; o <= last && s0 < s1; o += 16u * kU) {
+    f4v p[kU];
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) p[u] = *(const ER_GLOBAL f4v*)(base + min(o + 16u * (unsigned)u, last));
+    for (int u = 0; u < kU; u++) p[u] = *(const ER_GLOBAL f4v*)(base + min(o + 16u * (unsigned)u, last));
 #pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
+    for (int u = 0; u < kU; u++) {
       const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
       const float d = ((dx * dx) + dy * dy) + dz * dz;
       // d >= 0, so its bit pattern orders like its value; NaN / inf patterns exceed FLT_MAX's and never win
@@ -193,6 +194,7 @@ __device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, in
 // one of the tournament's equality tests true (within a group d0 = d1, d2 = d3 or min(d0, d1) = min(d2, d3); across groups the group's
 // minimum equals the running one), so a lane that saw ANY equality rescans its range with the exact rule (duplicated points do that;
 // otherwise equal float distances of different points are a once-in-millions event).  Same result as scan_range_exact, bit for bit.
+template <int kU = kUnroll>
 __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
 #if ER_NN_TOURNAMENT
   const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
@@ -230,15 +232,16 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
   // NaN / inf distances have bit patterns above FLT_MAX's: kNoHit (FLT_MAX, -1) beats them, as in the exact scan
   return k < key ? k : key;
 #else
-  return scan_range_exact(g, s0, s1, qx, qy, qz, key);
+  return scan_range_exact<kU>(g, s0, s1, qx, qy, qz, key);
 #endif
 }
 
 // Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
+template <int kU = kUnroll>
 __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
   const ER_GLOBAL char* cs = (const ER_GLOBAL char*)g.cell_start;
   const unsigned o = (unsigned)(row + xa) * 4u;
-  return scan_range(g, *(const ER_GLOBAL int*)(cs + o), *(const ER_GLOBAL int*)(cs + o + (unsigned)(xb - xa + 1) * 4u), qx, qy, qz, key);
+  return scan_range<kU>(g, *(const ER_GLOBAL int*)(cs + o), *(const ER_GLOBAL int*)(cs + o + (unsigned)(xb - xa + 1) * 4u), qx, qy, qz, key);
 }
 
 #if ER_NN_STAGE
@@ -411,6 +414,9 @@ __device__ __forceinline__ bool nn_stage(NnStage& st, const Grid& g, bool valid,
 // than sqrt(hit2) -- "count the points whose nearest neighbour is within reg_dist" is "count the points that have a neighbour within
 // reg_dist" -- so a query stops as soon as it holds a candidate below hit2 (its remaining cells and row tasks are dropped); the returned
 // distance is then that candidate's, not the minimum.  Queries without such a candidate run the full exact search as before.
+// kU = candidates per trip of the scans: 4 for the kernels that need the nearest neighbour, 3 for the any-hit pre-check (measured, round 4:
+// pre-check 0.58 -> 0.51 ms per list with 3, the ICP iterations 2.56 -> 2.63 ms: profiles/r04t_ab_scan_unroll.txt).
+template <int kU = kUnroll>
 __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
                                         float& best_d, float hit2 = -1.f) {
   const int tid = threadIdx.x;
@@ -442,7 +448,7 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
 #if ER_NN_STAGE
     if (staged) return scan_row_s(sh.st, ref, xa, xb, x, y, z, key);
 #endif
-    return scan_row(g, ref, xa, xb, x, y, z, key);
+    return scan_row<kU>(g, ref, xa, xb, x, y, z, key);
   };
   unsigned long long key = kNoHit;
   if (valid) {
@@ -660,6 +666,11 @@ using NnSh = NnShared;
 #else
 #define ER_ANY_HIT_ARG
 #endif
+#endif
+#if !ER_NN_CELLTASKS && !defined(ER_PRECHECK_UNROLL_OFF)
+#define ER_PRECHECK_UNROLL <3>
+#else
+#define ER_PRECHECK_UNROLL
 #endif
 
 // Block reduction of NV float64 values per thread: wave shuffle (64 lanes) -> LDS -> lane 0 atomics.
@@ -971,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
       const float4 s = p.src_sorted[k];
       xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
     }
-    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d ER_ANY_HIT_ARG);
+    const int i = nn_search ER_PRECHECK_UNROLL(sh, p.g, k < n, qx, qy, qz, radius * radius, d ER_ANY_HIT_ARG);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
