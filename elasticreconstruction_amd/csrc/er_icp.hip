@@ -84,7 +84,7 @@ struct Mat12f { float m[12]; };
 //   phase 0  every thread scans the HOME row of its query (the three cells x-1..x+1 of its own (y,z) row, one
 //            contiguous range) and learns a first best distance; the eight neighbouring rows that can still hold
 //            a closer point (distance from q to the row's cell slab <= best so far) are appended to an LDS task
-//            list as (query, row) pairs;
+//            list as (query, row) pairs -- since round 4 as (query, candidate range) pairs, empty ranges dropped;
 //   phase 1  the threads of the workgroup share the task list -- one row scan per thread and trip -- and fold the
 //            results into the query's packed (distance bits, index) key with a 64-bit LDS atomicMin, which IS the
 //            lexicographic (distance, index) minimum.
@@ -128,7 +128,10 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 constexpr int kStSlots = 512;           // table slots (rows are capped at 3/4 of them)
 constexpr int kStPts = 1024;            // staged target points (16 KB)
 constexpr int kStCells = 1024;          // staged cell bounds
-constexpr int kTaskCap = kBlock * 4;    // (query, row) tasks of phase 1 held in LDS; a task beyond that is scanned by the thread that found it
+#ifndef ER_NN_TASKCAP
+#define ER_NN_TASKCAP (kBlock * 4)
+#endif
+constexpr int kTaskCap = ER_NN_TASKCAP;   // (query, row) tasks of phase 1 held in LDS; a task beyond that is scanned by the thread that found it
 
 struct NnStage {
   float4 pts[kStPts];
@@ -142,13 +145,33 @@ struct NnStage {
   int nrows, tot_pts, tot_cells, fail;
 };
 
+// Round 4, last step (-DER_NN_COMPACT=1, ships): the thread that finds a surviving neighbour row also fetches the row's two cell bounds -- all
+// eight rows at once, sixteen independent loads behind ONE wait -- and appends only the NON-EMPTY ranges as (first candidate, count, query)
+// tasks.  Why: 55-63 % of the queries of a Registration pair at its initial guess have no target point within reg_dist at all; their bound
+// never shrinks, all eight rows survive, and most of those rows are empty -- 6.1 row tasks per query of which 1.6-2.2 hold candidates (0.7 of
+// 1.7 once the pair is aligned).  An empty task costs nothing by itself, but it takes the lane a real task could have had: a wave of 64 tasks
+// runs as long as its longest.  The candidate SETS are unchanged: same result, bit for bit.
+// MEASURED (profiles/r04v_ab_compact_tasks.txt): 5.05 -> 4.80 ms per 50-pair list (pre-check 0.51 -> 0.44, ICP 2.59 -> 2.37, correspondences
+// unchanged), i.e. +5 %, where the SIMT model (scripts/icp_simt_sim.py) promised half the candidate slots.  The counters of both builds
+// (profiles/r04w_icp_pmc_compact.txt) say why: VALU instructions per wave fell by 8 % / 3.5 % / -5 % only (k_count_inliers / k_icp_iter /
+// k_find_corr) -- of the ~870 VALU instructions a wave spends per slice of 64 queries in the pre-check, ~500 are the FIXED part (transform,
+// cell, the bounds of the home row, the eight row tests and pushes: counted in the ISA), which no scan order touches.  A two-bin list (tasks
+// of at most two trips apart from the longer ones) measured within the noise of this one (4.74-4.79 ms) and was not kept.
+#ifndef ER_NN_COMPACT
+#define ER_NN_COMPACT 1
+#endif
 struct NnShared {
   unsigned long long best[kBlock];
   float q[3][kBlock];
+#if ER_NN_COMPACT && !ER_NN_STAGE
+  int task_s0[kTaskCap];          // first candidate of the task's range in the cell-sorted target
+  int task_nq[kTaskCap];          // candidates << 8 | query
+#else
   int ix[kBlock];                 // the query's own cell column (may be -1 or dim[0]: one cell outside the grid)
   int task_row[kTaskCap];         // global search: first cell of the row in cell_start; staged: the row's table slot
   unsigned char task_q[kTaskCap];
   unsigned char task_lr[kTaskCap];   // bit 0: the row's cell x-1 can still hold a closer point, bit 1: cell x+1
+#endif
   int ntask;
 #if ER_NN_STAGE
   NnStage st;
@@ -477,6 +500,41 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     sh.q[0][tid] = qx;
     sh.q[1][tid] = qy;
     sh.q[2][tid] = qz;
+#if ER_NN_COMPACT && !ER_NN_STAGE
+    // the two cell bounds of every surviving row (a row that did not survive reads cell_start[0] twice: an empty range)
+    const ER_GLOBAL int* csb = (const ER_GLOBAL int*)g.cell_start;
+    int row_home = (iz * g.dim[1] + iy) * nx;                 // the eight rows are wave-uniform steps away from it: one integer multiply per
+    asm volatile("" : "+v"(row_home));                        // query, not one per row (opaque, or the compiler folds the steps back into y and z)
+    int r_s0[8], r_s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int pass = j < 4 ? j : j + 1;
+      const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+      const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
+      const int y = iy + dy, z = iz + dz;
+      const float e2 = ey * ey + ez * ez;
+      const bool wl = has_l && xlo * xlo + e2 <= bound, wr = has_r && xhi * xhi + e2 <= bound;
+      const int xa = max(wl ? ix - 1 : ix, 0), xb = min(wr ? ix + 1 : ix, nx - 1);
+      const bool live = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound && (has_o || wl || wr) && xa <= xb;
+      const int row = row_home + (dz * g.dim[1] + dy) * nx;
+      const unsigned i0 = live ? (unsigned)(row + xa) : 0u, i1 = live ? (unsigned)(row + xb) : 0u;
+      r_s0[j] = csb[i0];
+      r_s1[j] = csb[i1 + (live ? 1u : 0u)];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int n = r_s1[j] - r_s0[j];
+      if (n > 0) {
+        const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
+        if (t < kTaskCap) {
+          sh.task_s0[t] = r_s0[j];
+          sh.task_nq[t] = (n << 8) | tid;
+        } else {                                              // the task list is full (or the range does not fit the packing): scan it here
+          key = scan_range<kU>(g, r_s0[j], r_s1[j], qx, qy, qz, key);
+        }
+      }
+    }
+#else
     sh.ix[tid] = ix;
 #pragma unroll
     for (int pass = 0; pass < 9; pass++) {
@@ -501,10 +559,18 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
         }
       }
     }
+#endif
   }
   sh.best[tid] = key;
   __syncthreads();
   const int nt = min(sh.ntask, kTaskCap);
+#if ER_NN_COMPACT && !ER_NN_STAGE
+  for (int t = tid; t < nt; t += kBlock) {
+    const int s0 = sh.task_s0[t], nq = sh.task_nq[t], q = nq & 255;
+    const unsigned long long k = scan_range<kU>(g, s0, s0 + (nq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
+    atomicMin(&sh.best[q], k);
+  }
+#else
   for (int t = tid; t < nt; t += kBlock) {
     const int q = sh.task_q[t], lr = sh.task_lr[t], qix = sh.ix[q];
     const int xa = max((lr & 1) ? qix - 1 : qix, 0), xb = min((lr & 2) ? qix + 1 : qix, nx - 1);
@@ -512,6 +578,7 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     const unsigned long long k = scan(sh.task_row[t], xa, xb, sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
     if (k != kNoHit) atomicMin(&sh.best[q], k);
   }
+#endif
   __syncthreads();
   key = sh.best[tid];
   best_d = __uint_as_float((unsigned)(key >> 32));
@@ -1005,7 +1072,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
 // and adds their rows up privately; then thread rows -> wave shuffle tree -> LDS -> ONE partial vector per workgroup in
 // `partial`; k_icp_final adds the partial vectors in a fixed order.  No float64 atomics: the sums are bit-reproducible from
 // run to run (they still differ from a sequential CPU sum in the last bits).
-__global__ __launch_bounds__(kBlock) void k_icp_iter(const PairDev* __restrict__ P, const int* __restrict__ active, const IcpDev* __restrict__ S,
+__global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restrict__ P, const int* __restrict__ active, const IcpDev* __restrict__ S,
                                                      float radius, double maxd2, int pts) {
   __shared__ NnSh sh;
   const int slot = active[blockIdx.y];
