@@ -99,55 +99,26 @@ struct Mat12f { float m[12]; };
 constexpr int kUnroll = ER_ICP_UNROLL;
 constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // (FLT_MAX, -1)
 
-// ---- LDS staging of the candidates (round 4) ---------------------------------------------------------------------------
-// The 256 queries of a workgroup are consecutive points of the source's cell-sorted order: after the pair's transform they
-// still sit on a short piece of surface, and the 27-cell neighbourhoods of ALL of them together hold only ~450 target points
-// (<= 930 over the pair lists measured, scripts/icp_stage_sim.py) in <= 185 distinct (y, z) rows of the target grid -- about two
-// points per query, where the per-thread search pulls ~40 candidates per query through L2 in chains of dependent loads
-// (cell bounds -> candidates, own cell -> x neighbours -> row tasks).  So the workgroup first builds, in LDS, the set of
-// rows its queries can touch with the x extent each row is needed over (a small open-addressing table keyed by the row id,
-// extents by atomicMin / atomicMax), then loads exactly those ranges ONCE -- two rounds of independent, coalesced global loads for
-// the whole workgroup: the cell bounds of every row, then its points -- and the search phases below read cell bounds and
-// candidates from LDS.  The candidate SETS are those of the global search, so the result is the same exact nearest neighbour
-// with the same tie rule.  A workgroup whose rows / points / cells exceed the LDS budget (never on the measured lists) runs
-// the global search.
-// MEASURED (round 4, profiles/r04c_*): parity green, but 45 % SLOWER than the global search -- k_count_inliers 1301 us instead of 691 us
-// per 50-pair launch.  The counters say why: the search is not waiting for its dependent loads, it is short of VALU issue slots
-// (SQ_ACTIVE_INST_VALU: 0.70 of the chip's issue cycles in the shipped kernel); staging adds 30 % instructions (table inserts, two
-// binary searches per staged element), its 43 KB of LDS leave 3 workgroups per CU instead of 8, and the table sees 0.9 bank-conflict
-// cycles per LDS instruction.  Kept behind -DER_NN_STAGE=1 as the record of the experiment; the shipped search is the cell-task one below.
-#ifndef ER_NN_STAGE
-#define ER_NN_STAGE 0
-#endif
-#ifndef ER_NN_CELLTASKS
-#define ER_NN_CELLTASKS 0
-#endif
-#ifndef ER_NN_CT_UNROLL
-#define ER_NN_CT_UNROLL 0
-#endif
-constexpr int kStSlots = 512;           // table slots (rows are capped at 3/4 of them)
-constexpr int kStPts = 1024;            // staged target points (16 KB)
-constexpr int kStCells = 1024;          // staged cell bounds
+// ---- what round 4 tried on this search and did not keep (parity green every time; all of them behind their macros in commit 09fbe87) ------
+//   LDS staging (commit 5632ff7, -DER_NN_STAGE): the 256 cell-sorted queries of a workgroup need only ~450 distinct target points, so the workgroup
+//     built the set of rows it can touch in an LDS hash table, loaded those ranges once and searched from LDS.  45 % SLOWER (k_count_inliers 1301
+//     against 691 us per 50-pair launch, profiles/r04c_*): the search is short of VALU issue slots, not waiting for its loads; staging adds 30 %
+//     instructions, its 43 KB of LDS leave 3 workgroups per CU instead of 8, the table sees 0.9 bank-conflict cycles per LDS instruction.
+//   One task per non-empty CELL, binned by trip count (commit 86e1e31, -DER_NN_CELLTASKS): 19 % slower (6.49 against 5.45 ms per list,
+//     profiles/r04d_*): four cell bounds per surviving row, per-cell tests and three list counters cost what the shorter scans saved.
+//   A tournament on the 32-bit distance bits for groups of four candidates (commit 25fd209, -DER_NN_TOURNAMENT): 7 % slower
+//     (profiles/r04i_ab_tournament.txt): the packed distance arithmetic pays 16 register moves per group.
+//   Two / eight candidates per trip instead of four: 10 % / 7 % slower (profiles/r04t_ab_scan_unroll.txt); three only pays in the any-hit pre-check.
+//   A two-bin task list on top of the compacted one: within the noise (profiles/r04v_ab_compact_tasks.txt).
+// What the counters say binds it (profiles/r04w_icp_pmc_compact.txt): VALU issue, and within it the straight-line part every query runs.
 #ifndef ER_NN_TASKCAP
 #define ER_NN_TASKCAP (kBlock * 4)
 #endif
 constexpr int kTaskCap = ER_NN_TASKCAP;   // (query, row) tasks of phase 1 held in LDS; a task beyond that is scanned by the thread that found it
 
-struct NnStage {
-  float4 pts[kStPts];
-  int cs[kStCells];                     // LDS index of the first staged point of every staged cell (+ one terminal per row)
-  int key[kStSlots];                    // row id z * dim_y + y, or -1
-  int xlo[kStSlots];                    // lowest cell column needed of the row
-  int xhi[kStSlots];                    // highest; after the scan: LDS index of the row's first point
-  int csb[kStSlots];                    // index into cs[] of the row's cell xlo
-  int g0[kStSlots];                     // index of the row's first staged point in the cell-sorted target
-  int wtot[2][kBlock / 64];
-  int nrows, tot_pts, tot_cells, fail;
-};
-
-// Round 4, last step (-DER_NN_COMPACT=1, ships): the thread that finds a surviving neighbour row also fetches the row's two cell bounds -- all
-// eight rows at once, sixteen independent loads behind ONE wait -- and appends only the NON-EMPTY ranges as (first candidate, count, query)
-// tasks.  Why: 55-63 % of the queries of a Registration pair at its initial guess have no target point within reg_dist at all; their bound
+// Round 4, last step (the round-3 (query, row) list it replaces: -DER_NN_COMPACT=0 in commit 09fbe87): the thread that finds a surviving
+// neighbour row also fetches the row's two cell bounds -- all eight rows at once, sixteen independent loads behind ONE wait -- and appends only
+// the NON-EMPTY ranges as (first candidate, count, query) tasks.  Why: 55-63 % of the queries of a Registration pair at its initial guess have no target point within reg_dist at all; their bound
 // never shrinks, all eight rows survive, and most of those rows are empty -- 6.1 row tasks per query of which 1.6-2.2 hold candidates (0.7 of
 // 1.7 once the pair is aligned).  An empty task costs nothing by itself, but it takes the lane a real task could have had: a wave of 64 tasks
 // runs as long as its longest.  The candidate SETS are unchanged: same result, bit for bit.
@@ -157,32 +128,19 @@ struct NnStage {
 // k_find_corr) -- of the ~870 VALU instructions a wave spends per slice of 64 queries in the pre-check, ~500 are the FIXED part (transform,
 // cell, the bounds of the home row, the eight row tests and pushes: counted in the ISA), which no scan order touches.  A two-bin list (tasks
 // of at most two trips apart from the longer ones) measured within the noise of this one (4.74-4.79 ms) and was not kept.
-#ifndef ER_NN_COMPACT
-#define ER_NN_COMPACT 1
-#endif
 struct NnShared {
   unsigned long long best[kBlock];
   float q[3][kBlock];
-#if ER_NN_COMPACT && !ER_NN_STAGE
   int task_s0[kTaskCap];          // first candidate of the task's range in the cell-sorted target
   int task_nq[kTaskCap];          // candidates << 8 | query
-#else
-  int ix[kBlock];                 // the query's own cell column (may be -1 or dim[0]: one cell outside the grid)
-  int task_row[kTaskCap];         // global search: first cell of the row in cell_start; staged: the row's table slot
-  unsigned char task_q[kTaskCap];
-  unsigned char task_lr[kTaskCap];   // bit 0: the row's cell x-1 can still hold a closer point, bit 1: cell x+1
-#endif
   int ntask;
-#if ER_NN_STAGE
-  NnStage st;
-#endif
 };
 
 // Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
 // The reference scan: every candidate against the packed (distance bits, index) key -- exact by construction, 51 VALU instructions per trip
 // of four candidates, 20 of them the selection (four 64-bit compares, eight selects, eight moves that pair distance and index).
 template <int kU = kUnroll>
-__device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
+__device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
   // candidates are addressed by UNSIGNED 32-bit byte offsets from the (wave-uniform) base: a scalar-base global load and one 32-bit
   // add per candidate instead of a sign extension and a 64-bit multiply-add each
   const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
@@ -203,62 +161,6 @@ __device__ __forceinline__ unsigned long long scan_range_exact(const Grid& g, in
   return key;
 }
 
-#ifndef ER_NN_TOURNAMENT
-#define ER_NN_TOURNAMENT 0
-#endif
-// Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
-// A third experiment of round 4 (-DER_NN_TOURNAMENT=1, NOT shipped: parity green, 7 % slower -- 5.5 ms against 5.1 ms per list,
-// profiles/r04i_ab_tournament.txt; hipcc packs the distance arithmetic of a group into v_pk_* pairs and pays for it with 16 register moves
-// per group, and without the SLP vectoriser the 4 + 5 compares of the tournament cost what the four 64-bit compares did):
-// whole groups of four candidates go through a TOURNAMENT on the 32-bit distance bits (three v_min_u32, three compare +
-// select pairs for the index: no 64-bit keys, no index clamps, the three extra addresses are immediate offsets of the loads), the one to
-// three candidates left over through the exact 64-bit rule.  The tournament returns the FIRST candidate of the smallest distance in scan
-// order, which is the lexicographic (distance, index) minimum unless two candidates share that distance -- and every such tie makes
-// one of the tournament's equality tests true (within a group d0 = d1, d2 = d3 or min(d0, d1) = min(d2, d3); across groups the group's
-// minimum equals the running one), so a lane that saw ANY equality rescans its range with the exact rule (duplicated points do that;
-// otherwise equal float distances of different points are a once-in-millions event).  Same result as scan_range_exact, bit for bit.
-template <int kU = kUnroll>
-__device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
-#if ER_NN_TOURNAMENT
-  const ER_GLOBAL char* base = (const ER_GLOBAL char*)g.pts;
-  const int n4 = (s1 - s0) >> 2;
-  unsigned rd = 0xffffffffu, ri = 0xffffffffu;                 // best distance bits / index of the groups of four
-  bool tie = false;
-  unsigned o = (unsigned)s0 * 16u;
-  for (int t = 0; t < n4; t++, o += 64u) {
-    const f4v p0 = *(const ER_GLOBAL f4v*)(base + o), p1 = *(const ER_GLOBAL f4v*)(base + o + 16u), p2 = *(const ER_GLOBAL f4v*)(base + o + 32u),
-              p3 = *(const ER_GLOBAL f4v*)(base + o + 48u);
-    float dx = qx - p0.x, dy = qy - p0.y, dz = qz - p0.z;
-    const unsigned d0 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
-    dx = qx - p1.x, dy = qy - p1.y, dz = qz - p1.z;
-    const unsigned d1 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
-    dx = qx - p2.x, dy = qy - p2.y, dz = qz - p2.z;
-    const unsigned d2 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
-    dx = qx - p3.x, dy = qy - p3.y, dz = qz - p3.z;
-    const unsigned d3 = __float_as_uint(((dx * dx) + dy * dy) + dz * dz);
-    const unsigned m01 = min(d0, d1), m23 = min(d2, d3), m = min(m01, m23);
-    const unsigned i01 = d1 < d0 ? __float_as_uint(p1.w) : __float_as_uint(p0.w), i23 = d3 < d2 ? __float_as_uint(p3.w) : __float_as_uint(p2.w);
-    const unsigned im = m23 < m01 ? i23 : i01;
-    tie = tie | (d0 == d1) | (d2 == d3) | (m01 == m23) | (m == rd);
-    ri = m < rd ? im : ri;
-    rd = min(rd, m);
-  }
-  unsigned long long k = ((unsigned long long)rd << 32) | ri;  // (0xffffffff / 0xffffffff when there was no group: above every real key)
-  for (int s = s0 + 4 * n4; s < s1; s++) {                     // the one to three candidates left over: exact rule
-    const f4v p = *(const ER_GLOBAL f4v*)(base + (unsigned)s * 16u);
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    const float d = ((dx * dx) + dy * dy) + dz * dz;
-    const unsigned long long c = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-    k = c < k ? c : k;
-  }
-  if (tie) k = scan_range_exact(g, s0, s1, qx, qy, qz, kNoHit);
-  // NaN / inf distances have bit patterns above FLT_MAX's: kNoHit (FLT_MAX, -1) beats them, as in the exact scan
-  return k < key ? k : key;
-#else
-  return scan_range_exact<kU>(g, s0, s1, qx, qy, qz, key);
-#endif
-}
-
 // Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
 template <int kU = kUnroll>
 __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
@@ -267,172 +169,12 @@ __device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, i
   return scan_range<kU>(g, *(const ER_GLOBAL int*)(cs + o), *(const ER_GLOBAL int*)(cs + o + (unsigned)(xb - xa + 1) * 4u), qx, qy, qz, key);
 }
 
-#if ER_NN_STAGE
-// The same scan over candidates held in LDS.
-__device__ __forceinline__ unsigned long long scan_range_s(const NnStage& st, int s0, int s1, float qx, float qy, float qz, unsigned long long key) {
-  for (int s = s0; s < s1; s += kUnroll) {
-    float4 p[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) p[u] = st.pts[min(s + u, s1 - 1)];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      const float dx = qx - p[u].x, dy = qy - p[u].y, dz = qz - p[u].z;
-      const float d = ((dx * dx) + dy * dy) + dz * dz;
-      const unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p[u].w);
-      key = k < key ? k : key;
-    }
-  }
-  return key;
-}
-__device__ __forceinline__ unsigned long long scan_row_s(const NnStage& st, int slot, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
-  const int b = st.csb[slot] - st.xlo[slot];
-  return scan_range_s(st, st.cs[b + xa], st.cs[b + xb + 1], qx, qy, qz, key);
-}
-__device__ __forceinline__ unsigned stage_hash(int row) { return ((unsigned)row * 2654435761u) >> 23; }   // 9 bits = kStSlots
-static_assert(kStSlots == 512, "stage_hash yields 9 bits");
-// Slot of a row that IS in the table.
-__device__ __forceinline__ int stage_slot(const NnStage& st, int row) {
-  unsigned s = stage_hash(row);
-  for (int probe = 0; probe < kStSlots && st.key[s] != row; probe++) s = (s + 1) & (kStSlots - 1);   // (bounded: a missing row must not hang the GPU)
-  return (int)s;
-}
-__device__ __forceinline__ void stage_insert(NnStage& st, int row, int xa, int xb) {
-  unsigned s = stage_hash(row);
-  for (int probe = 0; probe < kStSlots; probe++, s = (s + 1) & (kStSlots - 1)) {
-    int k = st.key[s];
-    if (k == -1) {
-      k = atomicCAS(&st.key[s], -1, row);
-      if (k == -1) {
-        atomicAdd(&st.nrows, 1);
-        k = row;
-      }
-    }
-    if (k == row) {                                            // (extents only ever widen: a stale read costs one redundant atomic at most)
-      if (st.xlo[s] > xa) atomicMin(&st.xlo[s], xa);
-      if (st.xhi[s] < xb) atomicMax(&st.xhi[s], xb);
-      return;
-    }
-  }
-  st.fail = 1;
-}
-// Last slot whose base (a non-decreasing array over the slots; empty rows repeat the next row's base) is <= f: the row element f belongs to.
-__device__ __forceinline__ int stage_owner(const int* __restrict__ base, int f) {
-  int lo = 0, hi = kStSlots - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (base[mid] <= f) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
-
-// Builds the workgroup's candidate set in LDS (see above).  Every thread calls it; `valid` = the thread's query lies within one
-// cell of the grid.  Returns false (uniformly) when the set does not fit: the caller then searches in global memory.
-__device__ __forceinline__ bool nn_stage(NnStage& st, const Grid& g, bool valid, int ix, int iy, int iz) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int s = tid; s < kStSlots; s += kBlock) {
-    st.key[s] = -1;
-    st.xlo[s] = INT_MAX;
-    st.xhi[s] = INT_MIN;
-  }
-  if (tid == 0) {
-    st.nrows = 0;
-    st.fail = 0;
-  }
-  __syncthreads();
-  {
-    // consecutive queries share their cell about six at a time: only the first of a run inserts
-    const int pix = __shfl_up(ix, 1), piy = __shfl_up(iy, 1), piz = __shfl_up(iz, 1), pv = __shfl_up(valid ? 1 : 0, 1);
-    const bool lead = valid && (lane == 0 || !pv || pix != ix || piy != iy || piz != iz);
-    const int xa = max(ix - 1, 0), xb = min(ix + 1, g.dim[0] - 1);
-    if (lead && xa <= xb) {
-      for (int dz = -1; dz <= 1; dz++)
-        for (int dy = -1; dy <= 1; dy++) {
-          const int y = iy + dy, z = iz + dz;
-          if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2]) stage_insert(st, z * g.dim[1] + y, xa, xb);
-        }
-    }
-  }
-  __syncthreads();
-  if (st.fail || st.nrows > (kStSlots * 3) / 4) return false;
-  // cell bounds of every row (one round of independent loads), sizes, exclusive scan over the slots (two per thread)
-  int np0 = 0, np1 = 0, nc0 = 0, nc1 = 0, c00 = 0, c01 = 0;
-  {
-    const int s0 = 2 * tid, s1 = 2 * tid + 1;
-    const int r0 = st.key[s0], l0 = st.xlo[s0], h0 = st.xhi[s0], r1 = st.key[s1], l1 = st.xlo[s1], h1 = st.xhi[s1];
-    const bool u0 = r0 >= 0 && l0 <= h0, u1 = r1 >= 0 && l1 <= h1;
-    int e0 = 0, e1 = 0;
-    if (u0) {
-      c00 = g.cell_start[r0 * g.dim[0] + l0];
-      e0 = g.cell_start[r0 * g.dim[0] + h0 + 1];
-    }
-    if (u1) {
-      c01 = g.cell_start[r1 * g.dim[0] + l1];
-      e1 = g.cell_start[r1 * g.dim[0] + h1 + 1];
-    }
-    if (u0) {
-      np0 = e0 - c00;
-      nc0 = h0 - l0 + 2;
-    }
-    if (u1) {
-      np1 = e1 - c01;
-      nc1 = h1 - l1 + 2;
-    }
-  }
-  int sp = np0 + np1, sc = nc0 + nc1;                         // inclusive wave scans of the pair sums
-  for (int off = 1; off < 64; off <<= 1) {
-    const int a = __shfl_up(sp, off), b = __shfl_up(sc, off);
-    if (lane >= off) {
-      sp += a;
-      sc += b;
-    }
-  }
-  if (lane == 63) {
-    st.wtot[0][wave] = sp;
-    st.wtot[1][wave] = sc;
-  }
-  __syncthreads();
-  int bp = 0, bc = 0;
-  for (int w = 0; w < wave; w++) {
-    bp += st.wtot[0][w];
-    bc += st.wtot[1][w];
-  }
-  if (tid == kBlock - 1) {
-    st.tot_pts = bp + sp;
-    st.tot_cells = bc + sc;
-  }
-  bp += sp - (np0 + np1);
-  bc += sc - (nc0 + nc1);
-  st.xhi[2 * tid] = bp;                                        // from here on: LDS index of the row's first point
-  st.csb[2 * tid] = bc;
-  st.g0[2 * tid] = c00;
-  st.xhi[2 * tid + 1] = bp + np0;
-  st.csb[2 * tid + 1] = bc + nc0;
-  st.g0[2 * tid + 1] = c01;
-  __syncthreads();
-  const int tp = st.tot_pts, tc = st.tot_cells;
-  if (tp > kStPts || tc > kStCells) return false;
-  // second round of independent loads: the cell bounds (as LDS point indices) and the points themselves
-  for (int f = tid; f < tc; f += kBlock) {
-    const int s = stage_owner(st.csb, f);
-    const int v = g.cell_start[st.key[s] * g.dim[0] + st.xlo[s] + (f - st.csb[s])];
-    st.cs[f] = v - st.g0[s] + st.xhi[s];
-  }
-  for (int f = tid; f < tp; f += kBlock) {                       // (tp <= 1024: at most four independent 16-byte loads per thread)
-    const int s = stage_owner(st.xhi, f);
-    st.pts[f] = g.pts[st.g0[s] + (f - st.xhi[s])];
-  }
-  __syncthreads();
-  return true;
-}
-#endif
-
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
 // Returns the index (or -1) and the squared distance of the nearest target point.
 // Round 3: the HOME row is no longer scanned as one range of three cells -- the query's own cell first, then the left / right
 // cell only if its face is closer than the best so far -- and the neighbour rows carry the same two flags, so a typical query
 // looks at about half the candidates (a cell is skipped only when every point in it is provably farther than the best: its
 // nearest face already is, with the same 1e-4 relative margin as the row test; ties cannot hide there).
-// Round 4: the candidates come from LDS when the workgroup's candidate set fits (nn_stage above).
 // hit2 >= 0 (the Registration pre-check only, round 4): the caller does not need the NEAREST point, only whether ANY target point lies closer
 // than sqrt(hit2) -- "count the points whose nearest neighbour is within reg_dist" is "count the points that have a neighbour within
 // reg_dist" -- so a query stops as soon as it holds a candidate below hit2 (its remaining cells and row tasks are dropped); the returned
@@ -453,26 +195,7 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   const int nx = g.dim[0];
   const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
   const bool valid = inside && (has_l | has_o | has_r);
-#if ER_NN_STAGE
-  const bool staged = nn_stage(sh.st, g, valid, ix, iy, iz);  // (synchronises; uniform)
-#else
-  constexpr bool staged = false;
-  (void)staged;
-  __syncthreads();
-#endif
-  // a row as the scans address it: its table slot (staged) or its first cell in cell_start
-  auto rowref = [&](int y, int z) -> int {
-#if ER_NN_STAGE
-    if (staged) return stage_slot(sh.st, z * g.dim[1] + y);
-#endif
-    return (z * g.dim[1] + y) * nx;
-  };
-  auto scan = [&](int ref, int xa, int xb, float x, float y, float z, unsigned long long key) -> unsigned long long {
-#if ER_NN_STAGE
-    if (staged) return scan_row_s(sh.st, ref, xa, xb, x, y, z, key);
-#endif
-    return scan_row<kU>(g, ref, xa, xb, x, y, z, key);
-  };
+  __syncthreads();                                            // (sh.ntask is zero)
   unsigned long long key = kNoHit;
   if (valid) {
     // distance from q to the lower / upper face of its own cell along x, y and z (metres)
@@ -480,19 +203,19 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
                 zhi = g.cell - zlo;
     float bound = limit2 * 1.0001f + 1e-12f;
     if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
-      const int row = rowref(iy, iz);
+      const int row = (iz * g.dim[1] + iy) * nx;
       if (has_o) {
-        key = scan(row, ix, ix, qx, qy, qz, key);
+        key = scan_row<kU>(g, row, ix, ix, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
       }
       if (has_l && xlo * xlo <= bound) {
-        key = scan(row, ix - 1, ix - 1, qx, qy, qz, key);
+        key = scan_row<kU>(g, row, ix - 1, ix - 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
       if (has_r && xhi * xhi <= bound) {
-        key = scan(row, ix + 1, ix + 1, qx, qy, qz, key);
+        key = scan_row<kU>(g, row, ix + 1, ix + 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
@@ -500,7 +223,6 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     sh.q[0][tid] = qx;
     sh.q[1][tid] = qy;
     sh.q[2][tid] = qz;
-#if ER_NN_COMPACT && !ER_NN_STAGE
     // the two cell bounds of every surviving row (a row that did not survive reads cell_start[0] twice: an empty range)
     const ER_GLOBAL int* csb = (const ER_GLOBAL int*)g.cell_start;
     int row_home = (iz * g.dim[1] + iy) * nx;                 // the eight rows are wave-uniform steps away from it: one integer multiply per
@@ -534,211 +256,23 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
         }
       }
     }
-#else
-    sh.ix[tid] = ix;
-#pragma unroll
-    for (int pass = 0; pass < 9; pass++) {
-      if (pass == 4) continue;
-      const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-      const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
-      const int y = iy + dy, z = iz + dz;
-      const float e2 = ey * ey + ez * ez;
-      if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
-        const int lr = ((has_l && xlo * xlo + e2 <= bound) ? 1 : 0) | ((has_r && xhi * xhi + e2 <= bound) ? 2 : 0);
-        if (has_o || lr) {
-          const int ref = rowref(y, z);
-          const int t = atomicAdd(&sh.ntask, 1);
-          if (t < kTaskCap) {
-            sh.task_row[t] = ref;
-            sh.task_q[t] = (unsigned char)tid;
-            sh.task_lr[t] = (unsigned char)lr;
-          } else {                                            // the task list is full (never on the measured lists): scan it here
-            const int xa = max((lr & 1) ? ix - 1 : ix, 0), xb = min((lr & 2) ? ix + 1 : ix, nx - 1);
-            if (xa <= xb) key = scan(ref, xa, xb, qx, qy, qz, key);
-          }
-        }
-      }
-    }
-#endif
   }
   sh.best[tid] = key;
   __syncthreads();
   const int nt = min(sh.ntask, kTaskCap);
-#if ER_NN_COMPACT && !ER_NN_STAGE
   for (int t = tid; t < nt; t += kBlock) {
     const int s0 = sh.task_s0[t], nq = sh.task_nq[t], q = nq & 255;
     const unsigned long long k = scan_range<kU>(g, s0, s0 + (nq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
     atomicMin(&sh.best[q], k);
   }
-#else
-  for (int t = tid; t < nt; t += kBlock) {
-    const int q = sh.task_q[t], lr = sh.task_lr[t], qix = sh.ix[q];
-    const int xa = max((lr & 1) ? qix - 1 : qix, 0), xb = min((lr & 2) ? qix + 1 : qix, nx - 1);
-    if (xa > xb) continue;
-    const unsigned long long k = scan(sh.task_row[t], xa, xb, sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
-    if (k != kNoHit) atomicMin(&sh.best[q], k);
-  }
-#endif
   __syncthreads();
   key = sh.best[tid];
   best_d = __uint_as_float((unsigned)(key >> 32));
   return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
 }
 
-#if ER_NN_CELLTASKS
-// ---- a second experiment of round 4 (NOT shipped): one task per NON-EMPTY CELL, binned by trip count -----------------------------------
-// MEASURED (profiles/r04d_*): parity green, 19 % slower than the row search (6.49 ms against 5.45 ms per 50-pair list).  The model below
-// counted candidate evaluations only; on the hardware the instruction count per wave did not fall at all (8 575 against 8 467 VALU
-// instructions in k_count_inliers: the four cell bounds per surviving row, the per-cell tests and the three list counters cost what the
-// shorter scans save), the three counters collide in LDS (3.2 bank-conflict cycles per LDS instruction) and the waves wait for instruction
-// issue 0.20 of their cycles instead of 0.06.  Kept behind -DER_NN_CELLTASKS=1 as the record; the row search (nn_block) ships.
-// The counters of the round-3 search (profiles/r04b_icp_pmc_before.txt) show a kernel that is short of VALU issue slots, not of
-// memory: 0.70 of the issue cycles busy, and a SIMT cost model of its two phases (scripts/icp_simt_sim.py) shows where they go -- a
-// wave executes ~90-110 candidate evaluations per lane where ~20 are useful: the left / right cell of the home row is scanned by the
-// whole wave when ONE lane needs it, and a (query, row) task covers one to three cells with anything from 0 to 30 candidates, so a
-// wave of tasks runs as long as its longest.  Here a thread scans only its query's OWN cell; every other cell of the neighbourhood
-// that is non-empty and whose box is within the best distance so far becomes a task of its own (the cell bounds arrive four at a time:
-// cells x-1, x, x+1 of a row are consecutive in cell_start), and the tasks go to three lists by trip count (<= 4, <= 8, more
-// candidates), which the workgroup then works off list by list: the lanes of a wave run the same number of trips.  The model
-// predicts ~30-38 evaluations per lane (a third).  Candidate SETS and tie rule are those of the row search: a cell is skipped only if
-// its box is provably farther than a point already found, with the same 1e-4 relative margin.
-constexpr int kCapA = 1024, kCapB = 768, kCapC = 512;           // tasks held in LDS per list; one beyond that is scanned by the thread that found it
-constexpr int kOffB = kCapA, kOffC = kCapA + kCapB, kTaskTotal = kCapA + kCapB + kCapC;
-struct NnSharedC {
-  unsigned long long best[kBlock];
-  float q[3][kBlock];
-  int t_start[kTaskTotal];           // the task's cell: index of its first point in the cell-sorted target
-  unsigned short t_cq[kTaskTotal];   // candidates << 8 | query (cells of more than 255 points are scanned by the thread that found them)
-  int nt[3];
-};
-
-// Cell bounds of cells x-1, x, x+1 of the row that starts at `row` in cell_start: b[0..3] = cell_start[row + x - 1 .. row + x + 2], indices
-// clamped into the array (a clamped value is only ever used for a cell that does not exist, i.e. never).
-__device__ __forceinline__ void row_bounds(const Grid& g, int row, int x, int ncell, int b[4]) {
-  const int i0 = row + x - 1;
-#pragma unroll
-  for (int j = 0; j < 4; j++) b[j] = g.cell_start[min(max(i0 + j, 0), ncell)];
-}
-
-__device__ __forceinline__ int nn_block_cells(NnSharedC& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2, float& best_d) {
-  const int tid = threadIdx.x;
-  __syncthreads();                                            // the previous call's readers are done with `sh`
-  if (tid < 3) sh.nt[tid] = 0;
-  __syncthreads();
-  unsigned long long key = kNoHit;
-  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
-  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
-  const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
-  if (inside) {
-    const int ix = (int)cx, iy = (int)cy, iz = (int)cz;
-    const int nx = g.dim[0], ncell = g.dim[0] * g.dim[1] * g.dim[2];
-    const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
-                zhi = g.cell - zlo;
-    const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
-    if (has_l | has_o | has_r) {
-      sh.q[0][tid] = qx;
-      sh.q[1][tid] = qy;
-      sh.q[2][tid] = qz;
-      const bool home = iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2];
-      int hb[4] = {0, 0, 0, 0};
-      if (home) row_bounds(g, (iz * g.dim[1] + iy) * nx, ix, ncell, hb);
-      if (home && has_o) key = scan_range(g, hb[1], hb[2], qx, qy, qz, key);
-      // every other cell must beat the own cell's best (or the search radius)
-      const float bound = fminf(limit2, __uint_as_float((unsigned)(key >> 32))) * 1.0001f + 1e-12f;
-      auto push = [&](int start, int cnt) {
-        if (cnt <= 255) {
-          const int bin = cnt <= 4 ? 0 : (cnt <= 8 ? 1 : 2);
-          const int cap = bin == 0 ? kCapA : (bin == 1 ? kCapB : kCapC), off = bin == 0 ? 0 : (bin == 1 ? kOffB : kOffC);
-          const int t = atomicAdd(&sh.nt[bin], 1);
-          if (t < cap) {
-            sh.t_start[off + t] = start;
-            sh.t_cq[off + t] = (unsigned short)((cnt << 8) | tid);
-            return;
-          }
-        }
-        key = scan_range(g, start, start + cnt, qx, qy, qz, key);          // list full / oversized cell (never on the measured lists): scan it here
-      };
-      const float ex_l = xlo * xlo, ex_r = xhi * xhi;
-      if (home) {
-        if (has_l && hb[1] > hb[0] && ex_l <= bound) push(hb[0], hb[1] - hb[0]);
-        if (has_r && hb[3] > hb[2] && ex_r <= bound) push(hb[2], hb[3] - hb[2]);
-      }
-#if ER_NN_CT_UNROLL
-#pragma unroll
-#else
-#pragma unroll 1                                             // (unrolled, the eight rows' bounds are all fetched up front: 112 VGPRs instead of 73)
-#endif
-      for (int pass = 0; pass < 9; pass++) {
-        if (pass == 4) continue;
-        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-        const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
-        const int y = iy + dy, z = iz + dz;
-        const float e2 = ey * ey + ez * ez;
-        if (y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound) {
-          int b[4];
-          row_bounds(g, (z * g.dim[1] + y) * nx, ix, ncell, b);
-          if (has_o && b[2] > b[1]) push(b[1], b[2] - b[1]);
-          if (has_l && b[1] > b[0] && ex_l + e2 <= bound) push(b[0], b[1] - b[0]);
-          if (has_r && b[3] > b[2] && ex_r + e2 <= bound) push(b[2], b[3] - b[2]);
-        }
-      }
-    }
-  }
-  sh.best[tid] = key;
-  __syncthreads();
-  // the lists, shortest tasks first: every task of the first list is ONE trip of four candidates, of the second two trips
-  {
-    const int n = min(sh.nt[0], kCapA);
-    for (int t = tid; t < n; t += kBlock) {
-      const int s0 = sh.t_start[t], cq = sh.t_cq[t], q = cq & 255;
-      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
-      atomicMin(&sh.best[q], k);
-    }
-  }
-  {
-    const int n = min(sh.nt[1], kCapB);
-    for (int t = tid; t < n; t += kBlock) {
-      const int s0 = sh.t_start[kOffB + t], cq = sh.t_cq[kOffB + t], q = cq & 255;
-      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
-      atomicMin(&sh.best[q], k);
-    }
-  }
-  {
-    const int n = min(sh.nt[2], kCapC);
-    for (int t = tid; t < n; t += kBlock) {
-      const int s0 = sh.t_start[kOffC + t], cq = sh.t_cq[kOffC + t], q = cq & 255;
-      const unsigned long long k = scan_range(g, s0, s0 + (cq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
-      atomicMin(&sh.best[q], k);
-    }
-  }
-  __syncthreads();
-  key = sh.best[tid];
-  best_d = __uint_as_float((unsigned)(key >> 32));
-  return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
-}
-#endif
-
-#ifndef ER_NN_ANY_HIT
-#define ER_NN_ANY_HIT 1
-#endif
-#if ER_NN_CELLTASKS
-using NnSh = NnSharedC;
-#define nn_search nn_block_cells
-#define ER_ANY_HIT_ARG
-#else
 using NnSh = NnShared;
-#define nn_search nn_block
-#if ER_NN_ANY_HIT
-#define ER_ANY_HIT_ARG , hit2
-#else
-#define ER_ANY_HIT_ARG
-#endif
-#endif
-#if !ER_NN_CELLTASKS && !defined(ER_PRECHECK_UNROLL_OFF)
-#define ER_PRECHECK_UNROLL <3>
-#else
-#define ER_PRECHECK_UNROLL
-#endif
+constexpr int kPrecheckUnroll = 3;   // candidates per trip of the any-hit pre-check (see nn_block)
 
 // Block reduction of NV float64 values per thread: wave shuffle (64 lanes) -> LDS -> lane 0 atomics.
 template <int NV>
@@ -791,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_ransac_fitness(const float4* __restr
       qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
       qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
     }
-    const int i = nn_search(sh, g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_block(sh, g, k < n, qx, qy, qz, radius * radius, d);
     if (k < n && i >= 0 && d < max_range) {
       local++;
       dsum += (double)d;
@@ -1041,7 +575,6 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
   const double lim = fmin((double)radius * (double)radius, maxd2);
   float hit2 = (float)lim;
   if ((double)hit2 >= lim) hit2 = __uint_as_float(__float_as_uint(hit2) - 1u);      // (lim > 0: the next float below)
-  (void)hit2;
   for (int base = blockIdx.x * kBlock; base < n; base += gridDim.x * kBlock) {
     const int k = base + (int)threadIdx.x;
     float qx = 0.f, qy = 0.f, qz = 0.f, d;
@@ -1049,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
       const float4 s = p.src_sorted[k];
       xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
     }
-    const int i = nn_search ER_PRECHECK_UNROLL(sh, p.g, k < n, qx, qy, qz, radius * radius, d ER_ANY_HIT_ARG);
+    const int i = nn_block<kPrecheckUnroll>(sh, p.g, k < n, qx, qy, qz, radius * radius, d, hit2);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < maxd2) local++;
   }
   for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off);
@@ -1119,7 +652,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restric
       }
     }
     float d;
-    const int i = nn_search(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
+    const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
     double w[32];
 #pragma unroll
     for (int t = 0; t < 32; t++) w[t] = 0.0;
@@ -1215,7 +748,7 @@ __global__ __launch_bounds__(kBlock) void k_fitness(const PairDev* __restrict__ 
       qy = ((M[4] * s.x + M[5] * s.y) + M[6] * s.z) + M[7];
       qz = ((M[8] * s.x + M[9] * s.y) + M[10] * s.z) + M[11];
     }
-    const int i = nn_search(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
+    const int i = nn_block(sh, p.g, k < n, qx, qy, qz, radius * radius, d);
     if (k < n && i >= 0 && (double)d <= (double)radius * (double)radius) {
       v[0] += (double)d;
       v[1] += 1.0;
@@ -1239,7 +772,7 @@ __global__ __launch_bounds__(kBlock) void k_find_corr(const PairDev* __restrict_
     k = __float_as_int(s.w);                                   // original (file-order) index of this source point
     xform_d(p.T, s.x, s.y, s.z, qx, qy, qz);
   }
-  const int i = nn_search(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
+  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
   if (q >= n) return;
   int m = -1;
   if (i >= 0 && (double)d <= (double)radius * (double)radius && (double)d < dist2) {         // :154
@@ -1271,7 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restri
     qy = ((M.m[4] * s.x + M.m[5] * s.y) + M.m[6] * s.z) + M.m[7];
     qz = ((M.m[8] * s.x + M.m[9] * s.y) + M.m[10] * s.z) + M.m[11];
   }
-  const int i = nn_search(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
+  const int i = nn_block(sh, p.g, q < n, qx, qy, qz, radius * radius, d);
   const bool hit = q < n && i >= 0 && d < max_range;
   if (q < n) p.match[k] = hit ? i : -1;
   double v[1] = {hit ? (double)d : 0.0};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How much of the target does ONE workgroup of the NN kernels need?  (design study for nn_stage in csrc/er_icp.hip, round 4; CPU only)
+"""How much of the target does ONE workgroup of the NN kernels need?  (design study for the LDS-staged search of round 4 -- nn_stage, measured slower and removed: commit 09fbe87 has it; CPU only)
 For pairs of the configs[2] fragment set: the 256 consecutive cell-sorted source points of every workgroup, transformed by the pair's
 guess, and the union of their 27-cell neighbourhoods in the target grid: distinct (y, z) rows, staged points, staged cell bounds.
 Result on the 250 k-point fragments: <= 185 rows, <= 930 points, <= 890 cell bounds per workgroup -- a dense (y, z) table over the
