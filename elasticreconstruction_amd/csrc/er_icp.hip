@@ -31,6 +31,7 @@
 #include <hipcub/hipcub.hpp>   // device radix sort / prefix sum of the grid build (library primitives; everything else is hand-written)
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -903,15 +904,21 @@ __global__ __launch_bounds__(kBlock) void k_compact(const PairDev* __restrict__ 
   }
 }
 
-// ---- uniform grid of a cloud, built on the device ---------------------------------------------------------------------
+// ---- uniform grids of a CHUNK of clouds, built on the device ---------------------------------------------------------------
 // (the reference builds a kd-tree per pair and per function, CorresApp.cpp:129,238; here once per fragment)
-//   k_grid_bounds   min / max of the coordinates (float bits mapped to ordered ints, block reduce, 6 atomics per block) + a
-//                   non-finite flag;
-//   k_grid_cells    cell id of every point (the same float32 expression nn_block evaluates for a query) + histogram;
-//   hipcub          stable radix sort of (cell id, original index) and the prefix sum of the histogram -> cell_start;
-//   k_grid_gather   sorted[s] = {x, y, z, original index}.
+// Up to kCloudChunk clouds go through ONE set of launches (round 4; before, every cloud had its own ~23 launches and a list of fragments was bound by
+// the host's launch rate, not by PCIe: profiles/r04y_cloud_build_timeline.txt):
+//   k_chunk_bounds  per cloud (blockIdx.y): min / max of the coordinates (float bits mapped to ordered ints, block reduce, 7 atomics per
+//                   workgroup) + a non-finite flag;
+//   k_chunk_cells   cell id of every point (the same float32 expression nn_block evaluates for a query) -> key = cloud << shift | cell, the
+//                   histogram of every cloud's cells in one concatenated array [ncell_0 + 1 | ncell_1 + 1 | ...], and the interleaved
+//                   {point, normal} records;
+//   hipcub          ONE stable radix sort of (key, position in the chunk) and ONE prefix sum over the concatenated histograms: element 0 of
+//                   cloud k's segment holds -n_(k-1), which cancels the running total at the segment's start, so every segment comes out as that
+//                   cloud's own cell_start (0 ... n_k);
+//   k_chunk_gather  sorted[s] = {x, y, z, original index within its cloud}; the clouds' sorted arrays are consecutive pieces of one array.
 // A stable sort keeps the points of a cell in file order, like a counting sort on the host would: the layout -- and with it the
-// order of every float64 reduction that walks the cloud -- is reproducible from run to run.
+// order of every float64 reduction that walks the cloud -- is reproducible from run to run, and the same for a cloud built alone or in a list.
 __device__ __forceinline__ int ordered_int(float f) {
   const int i = __float_as_int(f);
   return i >= 0 ? i : i ^ 0x7fffffff;
@@ -923,7 +930,28 @@ __host__ __device__ __forceinline__ float ordered_float(int i) {
   return f;
 }
 
-__global__ __launch_bounds__(kBlock) void k_grid_bounds(const float* __restrict__ xyz, int n, int* __restrict__ out7) {
+constexpr int kCloudChunk = 8;          // clouds per chunk (3 key bits above the cell id)
+struct GridDims {
+  float org[3];
+  float cell;
+  int dim[3];
+};
+struct ChunkDesc {                      // passed by value (kernel argument)
+  int m;                                // clouds in the chunk
+  int shift;                            // key = cloud << shift | cell
+  int n[kCloudChunk];
+  int pt_off[kCloudChunk + 1];          // prefix sum of n: a point's position in the chunk
+  long cs_off[kCloudChunk + 1];         // prefix sum of (cells + 1): where a cloud's cell_start begins in the chunk's array
+  const float* xyz[kCloudChunk];
+  const float* nrm[kCloudChunk];
+  float4* xn[kCloudChunk];
+  GridDims G[kCloudChunk];
+};
+
+__global__ __launch_bounds__(kBlock) void k_chunk_bounds(ChunkDesc D, int* __restrict__ out8) {
+  const int y = blockIdx.y, n = D.n[y];
+  const float* __restrict__ xyz = D.xyz[y];
+  int* out7 = out8 + 8 * y;
   int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {INT_MIN, INT_MIN, INT_MIN};
   int bad = 0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -954,7 +982,7 @@ __global__ __launch_bounds__(kBlock) void k_grid_bounds(const float* __restrict_
     part[wave][6] = bad;
   }
   __syncthreads();
-  if (threadIdx.x < 7) {                                      // 7 atomics per workgroup (one per wave serialised on 6 words: 245 us)
+  if (threadIdx.x < 7 && (int)blockIdx.x * kBlock < n) {       // 7 atomics per workgroup that saw points
     int v = part[0][threadIdx.x];
     for (int w = 1; w < kBlock / 64; w++)
       v = threadIdx.x < 3 ? min(v, part[w][threadIdx.x]) : (threadIdx.x < 6 ? max(v, part[w][threadIdx.x]) : (v | part[w][threadIdx.x]));
@@ -964,43 +992,42 @@ __global__ __launch_bounds__(kBlock) void k_grid_bounds(const float* __restrict_
   }
 }
 
-struct GridDims {
-  float org[3];
-  float cell;
-  int dim[3];
-};
-
-__global__ __launch_bounds__(kBlock) void k_grid_cells(const float* __restrict__ xyz, int n, GridDims G, unsigned* __restrict__ key,
-                                                       unsigned* __restrict__ idx, int* __restrict__ count) {
+// xn[2 i] = {x, y, z, 0}, xn[2 i + 1] = {nx, ny, nz, 0} in file order: the matched target point of k_icp_iter is one aligned
+// 32-byte record = one cache line instead of two 12-byte gathers from two arrays (those were ~30 % of an ICP iteration).
+__global__ __launch_bounds__(kBlock) void k_chunk_cells(ChunkDesc D, unsigned* __restrict__ key, unsigned* __restrict__ idx, int* __restrict__ count) {
+  const int y = blockIdx.y, n = D.n[y];
+  int* __restrict__ cnt = count + D.cs_off[y];
+  if (blockIdx.x == 0 && threadIdx.x == 0) cnt[0] = y > 0 ? -D.n[y - 1] : 0;   // (see the prefix sum above; nothing else touches element 0)
   const int i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  const float* __restrict__ xyz = D.xyz[y];
+  const float* __restrict__ nrm = D.nrm[y];
+  const GridDims G = D.G[y];
+  const float p[3] = {xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2]};
   int q[3];
 #pragma unroll
   for (int a = 0; a < 3; a++) {
-    q[a] = (int)floorf((xyz[3 * (size_t)i + a] - G.org[a]) / G.cell);
+    q[a] = (int)floorf((p[a] - G.org[a]) / G.cell);
     q[a] = min(max(q[a], 0), G.dim[a] - 1);
   }
   const int c = (q[2] * G.dim[1] + q[1]) * G.dim[0] + q[0];
-  key[i] = (unsigned)c;
-  idx[i] = (unsigned)i;
-  atomicAdd(&count[c + 1], 1);                               // integer histogram: the result does not depend on the order
-}
-
-__global__ __launch_bounds__(kBlock) void k_grid_gather(const float* __restrict__ xyz, const unsigned* __restrict__ idx, int n,
-                                                        float4* __restrict__ sorted) {
-  const int s = blockIdx.x * kBlock + threadIdx.x;
-  if (s >= n) return;
-  const unsigned i = idx[s];
-  sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float((int)i));
-}
-
-// xn[2 i] = {x, y, z, 0}, xn[2 i + 1] = {nx, ny, nz, 0} in file order: the matched target point of k_icp_iter is one aligned
-// 32-byte record = one cache line instead of two 12-byte gathers from two arrays (those were ~30 % of an ICP iteration).
-__global__ __launch_bounds__(kBlock) void k_interleave(const float* __restrict__ xyz, const float* __restrict__ nrm, int n, float4* __restrict__ xn) {
-  const int i = blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  xn[2 * (size_t)i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+  const unsigned g = (unsigned)(D.pt_off[y] + i);
+  key[g] = ((unsigned)y << D.shift) | (unsigned)c;
+  idx[g] = g;
+  atomicAdd(&cnt[c + 1], 1);                                 // integer histogram: the result does not depend on the order
+  float4* __restrict__ xn = D.xn[y];
+  xn[2 * (size_t)i] = make_float4(p[0], p[1], p[2], 0.f);
   xn[2 * (size_t)i + 1] = make_float4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], 0.f);
+}
+
+__global__ __launch_bounds__(kBlock) void k_chunk_gather(ChunkDesc D, const unsigned* __restrict__ key, const unsigned* __restrict__ idx, int total,
+                                                         float4* __restrict__ sorted) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= total) return;
+  const int y = (int)(key[s] >> D.shift);
+  const int i = (int)idx[s] - D.pt_off[y];
+  const float* __restrict__ xyz = D.xyz[y];
+  sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
 }
 
 // Grow-only scratch of the grid build, one per device, handed out under a mutex (er_cloud_create may be called from
@@ -1012,14 +1039,26 @@ struct GridScratch {
   void* cub[2] = {nullptr, nullptr};
   int *bounds = nullptr, *h_bounds = nullptr;                   // 8 ints per cloud of a batch: device and its page-locked mirror (+ the initial pattern)
   size_t n_cap = 0, cub_cap = 0, bounds_cap = 0;
-  hipStream_t up = nullptr, cs2[2] = {nullptr, nullptr};        // uploads / grid kernels (two lanes: the ~12 small launches of one cloud's grid are
-                                                                // launch-bound, so consecutive clouds build side by side) of er_cloud_create_batch
+  hipStream_t up[2] = {nullptr, nullptr};                       // uploads: coordinates on one, normals on the other (two DMA engines keep the link busy)
+  hipStream_t cs2[2] = {nullptr, nullptr};                      // grid kernels: consecutive chunks alternate between two lanes
   hipEvent_t lane_ev = nullptr;
-  std::vector<hipEvent_t> ev;                                   // one per cloud of a batch (upload done) + one per chunk (bounds back)
+  std::vector<hipEvent_t> ev;                                   // three per chunk of a batch: uploads done (two streams), bounds back
 };
 GridScratch& grid_scratch(int device) {
   static GridScratch* tab = new GridScratch[64];             // intentionally leaked (see WsPool)
   return tab[device & 63];
+}
+
+// One device allocation shared by the clouds of a chunk (freed with the last of them).
+struct CloudSlab {
+  void* p = nullptr;
+  std::atomic<int> refs{0};
+};
+void slab_release(CloudSlab* sl) {
+  if (sl && sl->refs.fetch_sub(1) == 1) {
+    if (sl->p) (void)hipFree(sl->p);
+    delete sl;
+  }
 }
 
 }  // namespace
@@ -1032,6 +1071,7 @@ struct er_cloud_s {
   int* cell_start = nullptr;
   Grid grid{};
   float radius_cap = 0.f;       // largest search radius the grid supports
+  CloudSlab *pts_slab = nullptr, *cell_slab = nullptr;   // the chunk's allocations these pointers live in
 };
 
 namespace {
@@ -1319,12 +1359,13 @@ constexpr int kIcpChunk = 3;
 
 extern "C" {
 
-// Clouds of a LIST of fragments (BuildCorrespondence's LoadData loop, CorresApp.cpp:82-110, builds them one after the other): the uploads
-// run back to back on a copy stream -- truly asynchronous when the caller's arrays are page-locked (er_host_alloc), which is what makes
-// the list PCIe-bound instead of host-bound -- while the grid kernels of the previous chunk of clouds run on a compute stream underneath.
-// Per chunk of kCloudChunk clouds: [upload + bounding box] -> ONE host wait for the boxes (the host sizes cell_start from them) ->
-// [cell ids, radix sort, prefix sum, gather, interleave]; the host waits twice per chunk instead of twice per cloud.
-constexpr int kCloudChunk = 8;
+// Clouds of a LIST of fragments (BuildCorrespondence's LoadData loop, CorresApp.cpp:82-110, builds them one after the other), in chunks of up to
+// kCloudChunk clouds that share two device allocations and ONE set of grid launches:
+//   stage A, for every chunk up front: the chunk's allocation, its uploads -- coordinates and normals on two copy streams, truly asynchronous
+//            when the caller's arrays are page-locked (er_host_alloc) -- and its bounding boxes on a compute lane as soon as the uploads are in;
+//   stage B, chunk by chunk: ONE host wait for the boxes (the host sizes the grids from them), then cell ids + histogram + interleave, one
+//            radix sort, one prefix sum, one gather for the whole chunk, while the later chunks are still uploading.
+// The list is PCIe-bound; before round 4's last step it was bound by the host's launch rate (23 launches per cloud).
 int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const float* const* normal_host, const int* counts, float grid_cell, int device,
                           er_cloud_t* out) {
   if (n_clouds < 0 || (n_clouds > 0 && (!xyz_host || !normal_host || !counts || !out))) return er::fail("er_cloud_create: bad arguments");
@@ -1340,10 +1381,17 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   ER_HIP_TRY(hipSetDevice(device));
   GridScratch& gs = grid_scratch(device);
   std::lock_guard<std::mutex> lock(gs.mu);
+  auto sync_all = [&]() -> hipError_t {
+    hipError_t e = hipSuccess;
+    for (hipStream_t st : {gs.up[0], gs.up[1], gs.cs2[0], gs.cs2[1]})
+      if (st) {
+        const hipError_t e1 = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = e1;
+      }
+    return e;
+  };
   auto undo = [&]() {
-    if (gs.up) (void)hipStreamSynchronize(gs.up);
-    for (int q = 0; q < 2; q++)
-      if (gs.cs2[q]) (void)hipStreamSynchronize(gs.cs2[q]);
+    (void)sync_all();
     for (int i = 0; i < n_clouds; i++) {
       if (out[i]) er_cloud_destroy(out[i]);
       out[i] = nullptr;
@@ -1358,22 +1406,41 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
       return 1;                                                                               \
     }                                                                                         \
   } while (0)
-  if (!gs.up) ER_CTRY(hipStreamCreateWithFlags(&gs.up, hipStreamNonBlocking));
-  for (int q = 0; q < 2; q++)
+  for (int q = 0; q < 2; q++) {
+    if (!gs.up[q]) ER_CTRY(hipStreamCreateWithFlags(&gs.up[q], hipStreamNonBlocking));
     if (!gs.cs2[q]) ER_CTRY(hipStreamCreateWithFlags(&gs.cs2[q], hipStreamNonBlocking));
+  }
   if (!gs.lane_ev) ER_CTRY(hipEventCreateWithFlags(&gs.lane_ev, hipEventDisableTiming));
-  auto sync_lanes = [&]() -> hipError_t {
-    hipError_t e0 = hipStreamSynchronize(gs.cs2[0]), e1 = hipStreamSynchronize(gs.cs2[1]);
-    return e0 != hipSuccess ? e0 : e1;
+  // ---- the chunks: consecutive clouds, at most kCloudChunk of them and kChunkPoints points (the first cloud of a chunk always fits) ----
+  constexpr long kChunkPoints = 16L << 20;
+  struct Chunk {
+    int i0 = 0, i1 = 0;
+    long total = 0;                     // points
+    CloudSlab *pts = nullptr, *cells = nullptr;
+    float4* sorted = nullptr;           // the chunk's sorted array (the clouds' pieces are consecutive)
+    ChunkDesc D{};
   };
-  const int n_chunks = (n_clouds + kCloudChunk - 1) / kCloudChunk;
-  while ((int)gs.ev.size() < n_clouds + n_chunks) {
+  std::vector<Chunk> chunks;
+  {
+    // a chunk takes half of what is left (at most kCloudChunk): the list ends in small chunks, and what remains to be done after the
+    // last upload -- the last chunk's grids -- is short (25 fragments: 8, 8, 5, 2, 1, 1)
+    for (int i = 0; i < n_clouds;) {
+      Chunk c;
+      c.i0 = i;
+      const int per = std::min(kCloudChunk, std::max(1, (n_clouds - i + 1) / 2));
+      while (i < n_clouds && i - c.i0 < per && (i == c.i0 || c.total + counts[i] <= kChunkPoints)) c.total += counts[i++];
+      c.i1 = i;
+      chunks.push_back(c);
+    }
+  }
+  const int n_chunks = (int)chunks.size();
+  while ((int)gs.ev.size() < 3 * n_chunks) {
     hipEvent_t e = nullptr;
     ER_CTRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     gs.ev.push_back(e);
   }
   if (gs.bounds_cap < (size_t)n_clouds) {
-    ER_CTRY(sync_lanes());
+    ER_CTRY(sync_all());
     if (gs.bounds) (void)hipFree(gs.bounds);
     if (gs.h_bounds) (void)hipHostFree(gs.h_bounds);
     gs.bounds = gs.h_bounds = nullptr;
@@ -1383,31 +1450,32 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     ER_CTRY(hipHostMalloc((void**)&gs.h_bounds, cap * 16 * sizeof(int), hipHostMallocDefault));   // [cap][8] results, then [cap][8] initial pattern
     gs.bounds_cap = cap;
   }
-  int n_max = 0;
-  for (int i = 0; i < n_clouds; i++) n_max = std::max(n_max, counts[i]);
-  if (n_max > 0) {
-    if (gs.n_cap < (size_t)n_max) {
-      ER_CTRY(sync_lanes());
+  long t_max = 0;
+  for (const Chunk& c : chunks) t_max = std::max(t_max, c.total);
+  if (t_max >= (1L << 31) - kBlock) return er::fail("er_cloud_create: a cloud of %ld points is beyond the 32-bit point index", t_max);
+  if (t_max > 0) {
+    if (gs.n_cap < (size_t)t_max) {
+      ER_CTRY(sync_all());
       for (int q = 0; q < 4; q++) {
         if (gs.key[q]) (void)hipFree(gs.key[q]);
         if (gs.idx[q]) (void)hipFree(gs.idx[q]);
         gs.key[q] = gs.idx[q] = nullptr;
       }
       gs.n_cap = 0;
-      const size_t cap = (size_t)n_max + (size_t)n_max / 8;
+      const size_t cap = (size_t)t_max + (size_t)t_max / 8;
       for (int q = 0; q < 4; q++) {
         ER_CTRY(hipMalloc((void**)&gs.key[q], cap * sizeof(unsigned)));
         ER_CTRY(hipMalloc((void**)&gs.idx[q], cap * sizeof(unsigned)));
       }
       gs.n_cap = cap;
     }
-    // temporary storage of the sort / scan for the largest cloud and the largest grid (2^25 cells, 25 key bits) this call can meet
+    // temporary storage of the sort / scan for the largest chunk and the largest grids (2^25 cells and 3 cloud bits: 28 key bits) this call can meet
     size_t need_sort = 0, need_scan = 0;
-    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], n_max, 0, 25, gs.cs2[0]));
-    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, (int*)nullptr, (int*)nullptr, (1 << 25) + 1, gs.cs2[0]));
+    ER_CTRY(hipcub::DeviceRadixSort::SortPairs(nullptr, need_sort, gs.key[0], gs.key[1], gs.idx[0], gs.idx[1], (int)t_max, 0, 28, gs.cs2[0]));
+    ER_CTRY(hipcub::DeviceScan::InclusiveSum(nullptr, need_scan, (int*)nullptr, (int*)nullptr, kCloudChunk * ((1 << 25) + 1), gs.cs2[0]));
     const size_t need = std::max(need_sort, need_scan);
     if (gs.cub_cap < need) {
-      ER_CTRY(sync_lanes());
+      ER_CTRY(sync_all());
       for (int q = 0; q < 2; q++) {
         if (gs.cub[q]) (void)hipFree(gs.cub[q]);
         gs.cub[q] = nullptr;
@@ -1426,49 +1494,79 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   ER_CTRY(hipMemcpyAsync(gs.bounds, h_init, (size_t)n_clouds * 8 * sizeof(int), hipMemcpyHostToDevice, gs.cs2[0]));
   ER_CTRY(hipEventRecord(gs.lane_ev, gs.cs2[0]));
   ER_CTRY(hipStreamWaitEvent(gs.cs2[1], gs.lane_ev, 0));
-  // ---- stage A of a chunk: allocation, upload (copy stream), bounding box (compute stream) ----
+  // ---- stage A of a chunk: allocation, uploads (two copy streams), bounding boxes (the chunk's compute lane) ----
   auto stage_a = [&](int ch) -> int {
-    const int i0 = ch * kCloudChunk, i1 = std::min(n_clouds, i0 + kCloudChunk);
-    for (int i = i0; i < i1; i++) {
-      const int n = counts[i];
+    Chunk& C = chunks[(size_t)ch];
+    const int m = C.i1 - C.i0;
+    const size_t N = (size_t)C.total;
+    // one allocation: [sorted N float4 | xn 2N float4 (32-byte aligned records) | per cloud: xyz 3n, normals 3n floats]
+    const size_t xn_base = (N + 1) & ~(size_t)1;
+    const size_t f_base = (xn_base + 2 * N) * 4;
+    const size_t bytes = std::max((f_base + 6 * N) * sizeof(float), (size_t)256);
+    C.pts = new CloudSlab();
+    hipError_t e = hipMalloc(&C.pts->p, bytes);
+    if (e != hipSuccess) {
+      delete C.pts;
+      C.pts = nullptr;
+      return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    C.pts->refs = m;
+    C.sorted = static_cast<float4*>(C.pts->p);
+    float* fbase = static_cast<float*>(C.pts->p) + f_base;
+    C.D.m = m;
+    long off = 0;
+    for (int k = 0; k < m; k++) {                                 // the cloud objects first: from here on undo() releases the allocation through them
+      const int i = C.i0 + k, n = counts[i];
       er_cloud_t c = new er_cloud_s();
       out[i] = c;
       c->device = device;
       c->n = n;
       c->radius_cap = grid_cell;
-      const size_t nn = (size_t)std::max(n, 1);
-      // one allocation for the per-point arrays: [xyz 3n | normals 3n | sorted n float4 | xn 2n float4]
-      const size_t off_sorted = (nn * 6 + 7) / 8 * 8;               // float4 needs 16-byte alignment (32 for the xn records)
-      const size_t bytes = (off_sorted + nn * 4 + nn * 8) * sizeof(float);
-      hipError_t e = hipMalloc((void**)&c->xyz, bytes);
-      if (e != hipSuccess) return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-      c->nrm = c->xyz + nn * 3;
-      c->sorted = reinterpret_cast<float4*>(c->xyz + off_sorted);
-      c->xn = c->sorted + nn;
+      c->pts_slab = C.pts;
+      c->sorted = C.sorted + off;
+      c->xn = C.sorted + xn_base + 2 * off;
+      c->xyz = fbase + 6 * off;
+      c->nrm = c->xyz + 3 * (size_t)n;
+      C.D.n[k] = n;
+      C.D.pt_off[k] = (int)off;
+      C.D.xyz[k] = c->xyz;
+      C.D.nrm[k] = c->nrm;
+      C.D.xn[k] = c->xn;
+      off += n;
+    }
+    C.D.pt_off[m] = (int)off;
+    for (int k = 0; k < m; k++) {
+      const int i = C.i0 + k, n = counts[i];
       if (n > 0) {
-        ER_HIP_TRY(hipMemcpyAsync(c->xyz, xyz_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
-        ER_HIP_TRY(hipMemcpyAsync(c->nrm, normal_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up));
-        ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)i], gs.up));
-        hipStream_t L = gs.cs2[i & 1];
-        ER_HIP_TRY(hipStreamWaitEvent(L, gs.ev[(size_t)i], 0));
-        hipLaunchKernelGGL(k_grid_bounds, dim3(std::min(nblocks_of(n), 128)), dim3(kBlock), 0, L, c->xyz, n, gs.bounds + (size_t)i * 8);
+        ER_HIP_TRY(hipMemcpyAsync(out[i]->xyz, xyz_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up[0]));
+        ER_HIP_TRY(hipMemcpyAsync(out[i]->nrm, normal_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up[1]));
       }
     }
+    hipStream_t L = gs.cs2[ch & 1];
+    for (int q = 0; q < 2; q++) {
+      ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(3 * ch + q)], gs.up[q]));
+      ER_HIP_TRY(hipStreamWaitEvent(L, gs.ev[(size_t)(3 * ch + q)], 0));
+    }
+    int n_big = 0;
+    for (int k = 0; k < m; k++) n_big = std::max(n_big, C.D.n[k]);
+    if (n_big > 0)
+      hipLaunchKernelGGL(k_chunk_bounds, dim3(std::min(nblocks_of(n_big), 128), m), dim3(kBlock), 0, L, C.D, gs.bounds + (size_t)C.i0 * 8);
     ER_HIP_TRY(hipGetLastError());
-    ER_HIP_TRY(hipEventRecord(gs.lane_ev, gs.cs2[1]));            // lane 0 collects the boxes of both lanes
-    ER_HIP_TRY(hipStreamWaitEvent(gs.cs2[0], gs.lane_ev, 0));
-    ER_HIP_TRY(hipMemcpyAsync(h_got + (size_t)i0 * 8, gs.bounds + (size_t)i0 * 8, (size_t)(i1 - i0) * 8 * sizeof(int), hipMemcpyDeviceToHost, gs.cs2[0]));
-    ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(n_clouds + ch)], gs.cs2[0]));
+    ER_HIP_TRY(hipMemcpyAsync(h_got + (size_t)C.i0 * 8, gs.bounds + (size_t)C.i0 * 8, (size_t)m * 8 * sizeof(int), hipMemcpyDeviceToHost, L));
+    ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(3 * ch + 2)], L));
     return 0;
   };
-  // ---- stage B: the grid of every cloud of the chunk (the boxes are back) ----
+  // ---- stage B: the grids of the chunk (its boxes are back) ----
   auto stage_b = [&](int ch) -> int {
-    const int i0 = ch * kCloudChunk, i1 = std::min(n_clouds, i0 + kCloudChunk);
-    ER_HIP_TRY(hipEventSynchronize(gs.ev[(size_t)(n_clouds + ch)]));
-    for (int i = i0; i < i1; i++) {
-      er_cloud_t c = out[i];
+    Chunk& C = chunks[(size_t)ch];
+    const int m = C.i1 - C.i0;
+    ER_HIP_TRY(hipEventSynchronize(gs.ev[(size_t)(3 * ch + 2)]));
+    long cs_total = 0;
+    int max_cells = 1;
+    for (int k = 0; k < m; k++) {
+      er_cloud_t c = out[C.i0 + k];
       const int n = c->n;
-      const int* got = h_got + (size_t)i * 8;
+      const int* got = h_got + (size_t)(C.i0 + k) * 8;
       float cell = grid_cell * 1.001f;                            // strictly larger than any admissible radius
       float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
       int dim[3] = {1, 1, 1};
@@ -1489,46 +1587,55 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
         cell *= 2.f;
       }
       const int ncell = dim[0] * dim[1] * dim[2];
-      hipError_t e = hipMalloc((void**)&c->cell_start, ((size_t)ncell + 1) * sizeof(int));
-      if (e != hipSuccess) return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", ((size_t)ncell + 1) * sizeof(int), hipGetErrorString(e));
-      const int q = i & 1;
-      hipStream_t L = gs.cs2[q];
-      unsigned *k0 = gs.key[2 * q], *k1 = gs.key[2 * q + 1], *x0 = gs.idx[2 * q], *x1 = gs.idx[2 * q + 1];
-      ER_HIP_TRY(hipMemsetAsync(c->cell_start, 0, ((size_t)ncell + 1) * sizeof(int), L));
-      if (n > 0) {
-        GridDims G;
-        for (int a = 0; a < 3; a++) {
-          G.org[a] = lo[a];
-          G.dim[a] = dim[a];
-        }
-        G.cell = cell;
-        hipLaunchKernelGGL(k_grid_cells, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, n, G, k0, x0, c->cell_start);
-        int bits = 1;
-        while ((1L << bits) < (long)ncell) bits++;
-        size_t tmp = gs.cub_cap;
-        ER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(gs.cub[q], tmp, k0, k1, x0, x1, n, 0, bits, L));
-        tmp = gs.cub_cap;
-        ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub[q], tmp, c->cell_start, c->cell_start, ncell + 1, L));
-        hipLaunchKernelGGL(k_grid_gather, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, x1, n, c->sorted);
-        hipLaunchKernelGGL(k_interleave, dim3(nblocks_of(n)), dim3(kBlock), 0, L, c->xyz, c->nrm, n, c->xn);
-        ER_HIP_TRY(hipGetLastError());
-      }
-      c->grid.pts = c->sorted;
-      c->grid.cell_start = c->cell_start;
+      max_cells = std::max(max_cells, ncell);
+      C.D.cs_off[k] = cs_total;
+      cs_total += (long)ncell + 1;
       c->grid.cell = cell;
       for (int a = 0; a < 3; a++) {
-        c->grid.org[a] = lo[a];
-        c->grid.dim[a] = dim[a];
+        c->grid.org[a] = C.D.G[k].org[a] = lo[a];
+        c->grid.dim[a] = C.D.G[k].dim[a] = dim[a];
       }
+      C.D.G[k].cell = cell;
     }
+    C.D.cs_off[m] = cs_total;
+    C.cells = new CloudSlab();
+    hipError_t e = hipMalloc(&C.cells->p, (size_t)cs_total * sizeof(int));
+    if (e != hipSuccess) {
+      delete C.cells;
+      C.cells = nullptr;
+      return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", (size_t)cs_total * sizeof(int), hipGetErrorString(e));
+    }
+    C.cells->refs = m;
+    int* cs = static_cast<int*>(C.cells->p);
+    for (int k = 0; k < m; k++) {
+      er_cloud_t c = out[C.i0 + k];
+      c->cell_slab = C.cells;
+      c->cell_start = cs + C.D.cs_off[k];
+      c->grid.pts = c->sorted;
+      c->grid.cell_start = c->cell_start;
+    }
+    int bits = 1;
+    while ((1L << bits) < (long)max_cells) bits++;
+    C.D.shift = bits;
+    const int q = ch & 1;
+    hipStream_t L = gs.cs2[q];
+    unsigned *k0 = gs.key[2 * q], *k1 = gs.key[2 * q + 1], *x0 = gs.idx[2 * q], *x1 = gs.idx[2 * q + 1];
+    ER_HIP_TRY(hipMemsetAsync(cs, 0, (size_t)cs_total * sizeof(int), L));
+    int n_big = 0;
+    for (int k = 0; k < m; k++) n_big = std::max(n_big, C.D.n[k]);
+    hipLaunchKernelGGL(k_chunk_cells, dim3(nblocks_of(n_big), m), dim3(kBlock), 0, L, C.D, k0, x0, cs);
+    size_t tmp = gs.cub_cap;
+    if (C.total > 0) ER_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(gs.cub[q], tmp, k0, k1, x0, x1, (int)C.total, 0, bits + 3, L));
+    tmp = gs.cub_cap;
+    ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub[q], tmp, cs, cs, (int)cs_total, L));
+    if (C.total > 0) hipLaunchKernelGGL(k_chunk_gather, dim3(nblocks_of((int)C.total)), dim3(kBlock), 0, L, C.D, k1, x1, (int)C.total, C.sorted);
+    ER_HIP_TRY(hipGetLastError());
     return 0;
   };
-  int rc = stage_a(0);
-  for (int ch = 0; ch < n_chunks && rc == 0; ch++) {
-    if (ch + 1 < n_chunks) rc = stage_a(ch + 1);                   // the next chunk's uploads run under this chunk's grid kernels
-    if (rc == 0) rc = stage_b(ch);
-  }
-  if (rc == 0 && (hipStreamSynchronize(gs.up) != hipSuccess || sync_lanes() != hipSuccess))   // the caller's arrays and the shared scratch are free again
+  int rc = 0;
+  for (int ch = 0; ch < n_chunks && rc == 0; ch++) rc = stage_a(ch);   // every upload is queued before the first host wait
+  for (int ch = 0; ch < n_chunks && rc == 0; ch++) rc = stage_b(ch);
+  if (rc == 0 && sync_all() != hipSuccess)                              // the caller's arrays and the shared scratch are free again
     rc = er::fail("er_cloud_create: %s", hipGetErrorString(hipGetLastError()));
 #undef ER_CTRY
   if (rc) {
@@ -1549,9 +1656,8 @@ int er_cloud_create(const float* xyz_host, const float* normal_host, int n, floa
 int er_cloud_destroy(er_cloud_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
-  void* ptrs[] = {c->xyz, c->cell_start};          // xyz heads the one allocation that also holds nrm and sorted
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  slab_release(c->pts_slab);                    // xyz, normals, sorted and xn live in the chunk's allocation, cell_start in its second one:
+  slab_release(c->cell_slab);                   // both go with the last cloud of the chunk
   delete c;
   return 0;
 }

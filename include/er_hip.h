@@ -200,9 +200,11 @@ typedef struct er_cloud_s* er_cloud_t;
 int er_cloud_create(const float* xyz_host, const float* normal_host, int n, float grid_cell, int device,
                     er_cloud_t* out);
 /* The clouds of a LIST of fragments in one call (LoadData's loop, CorresApp.cpp:82-110): xyz_host[i] / normal_host[i] hold counts[i] points.
- * Uploads run back to back on a copy stream while the grids of the previous clouds are built underneath, and the host waits twice per
- * chunk of 8 clouds instead of twice per cloud.  Page-locked input arrays (er_host_alloc) make the uploads asynchronous: the list is then
- * bound by PCIe (6 x 4 bytes per point), not by the host.  All or nothing: on failure no cloud is left behind.  out[i] as er_cloud_create. */
+ * All uploads are queued up front (coordinates and normals on two copy streams); chunks of up to 8 clouds share their device allocations
+ * and ONE set of grid launches, built while the later chunks are still uploading; the host waits once per chunk.  Page-locked input
+ * arrays (er_host_alloc) make the uploads asynchronous: the list is then bound by PCIe (6 x 4 bytes per point), not by the host.
+ * All or nothing: on failure no cloud is left behind.  out[i] as er_cloud_create; the clouds may be destroyed in any order (a chunk's
+ * allocations go with its last cloud). */
 int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const float* const* normal_host, const int* counts, float grid_cell,
                           int device, er_cloud_t* out);
 int er_cloud_destroy(er_cloud_t c);

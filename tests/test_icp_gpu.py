@@ -400,8 +400,8 @@ def test_registration_batch_equals_the_three_stage_calls(gpu, monkeypatch):
 
 
 def test_cloud_create_batch_equals_single_creates(gpu):
-    """er_cloud_create_batch (uploads on a copy stream, grids of the previous chunk underneath, two host waits per chunk of 8) builds the
-    SAME clouds as er_cloud_create one by one: 11 fragments of different sizes (two chunks), one of them empty, the input arrays once in
+    """er_cloud_create_batch (chunks of up to 8 clouds that share their allocations and ONE set of grid launches; all uploads queued up front) builds
+    the SAME clouds as er_cloud_create one by one: 11 fragments of different sizes (two chunks), one of them empty, the input arrays once in
     pageable and once in page-locked memory; every pair search through them gives the single-create results exactly.  A non-finite
     coordinate anywhere in the list fails the whole call and leaves no cloud behind."""
     from elasticreconstruction_amd import _ffi
@@ -433,6 +433,32 @@ def test_cloud_create_batch_equals_single_creates(gpu):
             assert all(np.array_equal(a, b) for a, b in zip(lb, ls)) and np.allclose(ib, is_, rtol=1e-9, atol=1e-6)      # (float64 atomics: order-dependent last bits)
         for c in batch:
             c.close()
+    # 19 small clouds = three chunks (the first and the third share a compute lane and its scratch), with an empty one, a single point and a
+    # cloud whose points all share one cell among them: the same searches through single creates
+    rng = np.random.default_rng(77)
+    small = []
+    for k in range(19):
+        m = [0, 1, 300][k] if k < 3 else int(rng.integers(50, 4000))
+        sel = rng.choice(len(frs[k % 5][0]), m, replace=False)
+        small.append((np.ascontiguousarray(frs[k % 5][0][sel]), np.ascontiguousarray(frs[k % 5][1][sel])))
+    small[2] = (np.ascontiguousarray(small[2][0] * np.float32(1e-3) + frs[0][0][0]), small[2][1])      # 300 points within a few millimetres
+    s_single = [Cloud(x, n, 0.03) for x, n in small]
+    s_batch = Cloud.create_batch(small, 0.03)
+    assert [len(c) for c in s_batch] == [len(x) for x, _ in small]
+    sp = [(k, (k + 5) % 19, np.eye(4)) for k in range(19)] + [(2, 2, np.eye(4)), (1, 1, np.eye(4)), (0, 4, np.eye(4)), (4, 0, np.eye(4))]
+    cb = count_inliers_batch([s_batch[s] for s, _, _ in sp], [s_batch[t] for _, t, _ in sp], [T for _, _, T in sp], 0.03)
+    cs = count_inliers_batch([s_single[s] for s, _, _ in sp], [s_single[t] for _, t, _ in sp], [T for _, _, T in sp], 0.03)
+    assert np.array_equal(cb, cs) and cb[19] == 300 and cb[20] == 1 and cb[21] == 0 and cb[22] == 0 and cb.sum() > 600
+    lb, _ = find_correspondence_batch([s_batch[s] for s, _, _ in sp], [s_batch[t] for _, t, _ in sp], [T for _, _, T in sp], 0.015, 0.0, False)
+    ls, _ = find_correspondence_batch([s_single[s] for s, _, _ in sp], [s_single[t] for _, t, _ in sp], [T for _, _, T in sp], 0.015, 0.0, False)
+    assert all(np.array_equal(a, b) for a, b in zip(lb, ls)) and len(lb[19]) == 300
+    for c in s_batch[::2]:                                        # clouds of a chunk share their allocations: any order of closing is fine
+        c.close()
+    cb2 = count_inliers_batch([s_batch[1], s_batch[3]], [s_batch[1], s_batch[5]], [np.eye(4)] * 2, 0.03)
+    cs2 = count_inliers_batch([s_single[1], s_single[3]], [s_single[1], s_single[5]], [np.eye(4)] * 2, 0.03)
+    assert np.array_equal(cb2, cs2) and cb2[0] == 1
+    for c in s_batch[1::2] + s_single:
+        c.close()
     bad = [(x.copy(), n) for x, n in arrays]
     bad[9][0][123, 1] = np.inf
     with pytest.raises(_ffi.ErError, match="non-finite"):
