@@ -18,14 +18,16 @@ for x, n, _ in frs:
     px[...] = x
     pn[...] = n
     pinned.append((px, pn))
+resident = [Cloud(x, n, 0.03, 0) for x, n, _ in frs] if os.environ.get("ER_CBP_RESIDENT", "0") == "1" else []   # (the bench keeps 25 clouds resident)
+nap = 0.0 if os.environ.get("ER_CBP_NOSLEEP", "0") == "1" else 0.05
 tb = []
 for r in range(reps):
-    time.sleep(0.05)
+    time.sleep(nap)
     t0 = time.perf_counter()
     cs = Cloud.create_batch(pinned, 0.03, 0)
     tb.append(time.perf_counter() - t0)
-    time.sleep(0.05)
+    time.sleep(nap)
     [c.close() for c in cs]
 nbytes = sum(x.nbytes + n.nbytes for x, n in pinned)
-print("er_cloud_create_batch, %d fragments of %d points, page-locked input: %s ms -> median %.2f ms (%.0f us per fragment, %.1f GB/s of input)"
+print("resident %d, pause %.2f s:" % (len(resident), nap), "er_cloud_create_batch, %d fragments of %d points, page-locked input: %s ms -> median %.2f ms (%.0f us per fragment, %.1f GB/s of input)"
       % (n_frag, n_pts, " ".join("%.2f" % (t * 1e3) for t in tb), np.median(tb[1:]) * 1e3, np.median(tb[1:]) * 1e6 / n_frag, nbytes / np.median(tb[1:]) / 1e9))
