@@ -71,15 +71,33 @@ struct Grid {
   float org[3];
   float cell;
   int dim[3];
+  float slack;     // absolute part of nn_block's pruning margin (square metres), from the grid's extent: grid_slack()
 };
+
+// The pruning margin of nn_block.  A cell (or row of cells) is skipped when the squared distance f'^2 from the query to its nearest face, as the
+// kernel computes it, exceeds  B * (1 + 1e-4) + slack,  B = the best float32 squared distance so far (or the squared search radius).  For that to
+// be exact -- no point p of a skipped cell may have a float32 distance below B -- the margin has to cover what the float32 cell arithmetic can be
+// off by:  u = fl(fl(q - org) / cell) carries a relative error of 2 x 2^-24, i.e. up to 1.2e-7 x |q - org| metres in the face distance, and the
+// target points were assigned to their cells by the same expression, so the face itself is that fuzzy once more:  f' <= f + D  per axis with
+// D = 2.5e-7 x (largest extent + 2 cells) + 4e-9, and sqrt(3) D for the rows and corners that combine two or three axes.  With S^2 = B (1 + r) + A,
+// a skipped point has a true distance >= S - sqrt(3) D, its float32 squared distance is >= (S - sqrt(3) D)^2 (1 - 3e-7), and
+// 2 S sqrt(3) D <= (r / 4) S^2 + 12 D^2 / r  gives  (S - sqrt(3) D)^2 (1 - 3e-7) >= B  as soon as  A >= 1.2001e5 D^2  (r = 1e-4); the code takes 1.3e5.
+// Until round 4 the absolute part was a constant 1e-12, which covers D only for best distances below a micrometre or above several millimetres:
+// in between, a nearest neighbour sitting straight behind a face, with a competitor in an already scanned cell that is farther by less than
+// ~0.2 um, could be skipped (about once in 1e9 queries on fragment data; tests/test_icp_gpu.py builds such queries on purpose).
+inline float grid_slack(const int dim[3], float cell) {
+  const int big = std::max(dim[0], std::max(dim[1], dim[2]));
+  const double D = 2.5e-7 * (double)(big + 2) * (double)cell + 4e-9;
+  return (float)(1.3e5 * D * D);
+}
 
 struct Mat12d { double m[12]; };
 struct Mat12f { float m[12]; };
 
 // Exact 1-NN of q among target points inside the 27 neighbouring cells: float32 squared distance
 // ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.  limit2 = squared search radius:
-// callers discard anything farther, so rows of cells lying entirely beyond the radius are skipped (margin 1e-4
-// relative for the float32 cell assignment).
+// callers discard anything farther, so rows of cells lying entirely beyond the radius are skipped (margin: 1e-4
+// relative plus an absolute part sized from the grid's extent, see grid_slack).
 //
 // Block-cooperative, two phases (one query per thread, kBlock queries per workgroup):
 //   phase 0  every thread scans the HOME row of its query (the three cells x-1..x+1 of its own (y,z) row, one
@@ -202,22 +220,22 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     // distance from q to the lower / upper face of its own cell along x, y and z (metres)
     const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
                 zhi = g.cell - zlo;
-    float bound = limit2 * 1.0001f + 1e-12f;
+    float bound = limit2 * 1.0001f + g.slack;
     if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
       const int row = (iz * g.dim[1] + iy) * nx;
       if (has_o) {
         key = scan_row<kU>(g, row, ix, ix, qx, qy, qz, key);
-        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);   // the other cells must beat this one
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);   // the other cells must beat this one
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
       }
       if (has_l && xlo * xlo <= bound) {
         key = scan_row<kU>(g, row, ix - 1, ix - 1, qx, qy, qz, key);
-        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
       if (has_r && xhi * xhi <= bound) {
         key = scan_row<kU>(g, row, ix + 1, ix + 1, qx, qy, qz, key);
-        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + 1e-12f);
+        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
     }
@@ -1596,6 +1614,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
         c->grid.dim[a] = C.D.G[k].dim[a] = dim[a];
       }
       C.D.G[k].cell = cell;
+      c->grid.slack = grid_slack(dim, cell);
     }
     C.D.cs_off[m] = cs_total;
     C.cells = new CloudSlab();

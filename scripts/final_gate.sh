@@ -17,7 +17,7 @@ python -c "import __graft_entry__ as g; g.build()" > /tmp/final_gate_build.log 2
 if [ -n "$(git status --porcelain)" ]; then echo "final_gate: build() changed tracked files"; git status --short; exit 1; fi
 git rev-parse HEAD > .gate_head
 echo "final_gate: HEAD $(cat .gate_head)  tag $TAG"
-/usr/local/graft/bin/gpurun --timeout "$LIMIT" -- "GATE_ONLY=${GATE_ONLY:-0} bash scripts/gpu_final.sh $TAG $LIMIT"
+/usr/local/graft/bin/gpurun --timeout "$LIMIT" -- "GATE_ONLY=${GATE_ONLY:-0} GATE_TESTS=\"${GATE_TESTS:-tests}\" bash scripts/gpu_final.sh $TAG $LIMIT"
 rc=$?
 echo "final_gate: gpurun exit $rc; logs: gpurun_out/pytest_gpu_$TAG.log gpurun_out/smoke_$TAG.log gpurun_out/bench_default_$TAG.json"
 [ "$(git rev-parse HEAD)" = "$(cat .gate_head)" ] || echo "final_gate: WARNING: HEAD moved during the run"

@@ -6,13 +6,14 @@
 #   3. the default bench line
 # then, while the clock allows (GATE_ONLY=1 skips them): kernel-trace stats, one PMC pass (FETCH_SIZE / WRITE_SIZE / SQ_*).
 # Every log starts with the HEAD scripts/final_gate.sh stamped into .gate_head ("unstamped" when run outside the gate).
-#   GATE_X="" (mid-round runs): do not stop at the first failing test.   usage: bash scripts/gpu_final.sh <tag> [seconds]
+#   GATE_X="" (mid-round runs): do not stop at the first failing test.   GATE_TESTS="tests/a.py tests/b.py": a subset (a change confined to one path, when
+#   the round's GPU minutes no longer cover the whole suite; the log's first line then names the subset).   usage: bash scripts/gpu_final.sh <tag> [seconds]
 R="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$R"; TAG="${1:-r04}"; LIMIT="${2:-600}"; mkdir -p gpurun_out
 HEAD_ID="$(cat .gate_head 2>/dev/null || echo unstamped)"
 SECONDS=0
 LOG=gpurun_out/pytest_gpu_$TAG.log
-echo "# HEAD $HEAD_ID  tag $TAG  $(date -u +%FT%TZ)" > $LOG
-timeout $((LIMIT > 700 ? 560 : LIMIT * 4 / 5)) python -m pytest tests ${GATE_X--x} -q -m gpu --tb=short -p no:cacheprovider >> $LOG 2>&1
+echo "# HEAD $HEAD_ID  tag $TAG  $(date -u +%FT%TZ)  tests: ${GATE_TESTS:-tests (all)}" > $LOG
+timeout $((LIMIT > 700 ? 560 : LIMIT * 4 / 5)) python -m pytest ${GATE_TESTS:-tests} ${GATE_X--x} -q -m gpu --tb=short -p no:cacheprovider >> $LOG 2>&1
 PRC=$?; echo "pytest exit $PRC after ${SECONDS}s" >> $LOG; tail -6 $LOG
 echo "# HEAD $HEAD_ID" > gpurun_out/smoke_$TAG.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/smoke_$TAG.log 2>&1; SRC=$?; echo "smoke exit $SRC" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log

@@ -466,3 +466,20 @@ def test_cloud_create_batch_equals_single_creates(gpu):
     arena.close()
     for c in single:
         c.close()
+
+
+def test_nearest_neighbour_straight_behind_a_cell_face(gpu):
+    """The pruning margin of nn_block (grid_slack): 40 queries whose nearest neighbour lies just behind a cell face, straight along the axis,
+    with a competitor in the query's own cell that is farther by a fraction of a micrometre (tests/nn_margin_cases.py; tests/test_nn_margin.py
+    shows in float32 arithmetic that the margin of rounds 1-4 skipped the neighbour's cell for every one of them).  The HIP search names the
+    point behind the face, like the oracle's unpruned 27-cell scan."""
+    from nn_margin_cases import build
+    tgt, src, expect, _, _ = build()
+    nt = np.tile(np.array([[0, 0, 1]], np.float32), (len(tgt), 1))
+    ns = np.tile(np.array([[0, 0, 1]], np.float32), (len(src), 1))
+    ct, cs = Cloud(tgt, nt, 0.03), Cloud(src, ns, 0.03)
+    pg, _ = find_correspondence(cs, ct, np.eye(4), 0.015, 0.8660)
+    po, _ = IcpOracle(src, ns, 0.03).find_correspondence(IcpOracle(tgt, nt, 0.03), np.eye(4), 0.015, 0.8660)
+    assert pg.shape == (40, 2) and np.array_equal(pg, po), "%d of 40 rows differ from the oracle" % int((pg != po).any(1).sum())
+    assert np.array_equal(pg[:, 0], expect)
+    assert count_inliers(cs, ct, np.eye(4), 0.03) == 40
