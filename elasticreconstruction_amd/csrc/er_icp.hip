@@ -65,6 +65,12 @@ typedef ER_GLOBAL float* gp_fw;
 typedef ER_GLOBAL int* gp_iw;
 #define ER_GP(type, ptr) ((type)(ptr))
 
+// -DER_NN_ROWMASK=1 (prepared at the end of round 4, NOT measured yet -- DESIGN.md section 9): a 10-bit mask per target cell, built with the grid, says
+// which neighbour rows of a query that lives in this cell hold any point at all; nn_block then skips, for a whole wave, the tests, bound loads and
+// pushes of rows that are empty for every lane -- part of the ~500 straight-line instructions per slice that bind the search.  Same candidate sets.
+#ifndef ER_NN_ROWMASK
+#define ER_NN_ROWMASK 0
+#endif
 struct Grid {
   const float4* pts;
   const int* cell_start;
@@ -72,6 +78,9 @@ struct Grid {
   float cell;
   int dim[3];
   float slack;     // absolute part of nn_block's pruning margin (square metres), from the grid's extent: grid_slack()
+#if ER_NN_ROWMASK
+  const unsigned short* rowmask;   // per cell: which of the 8 neighbour rows (bits 0-7, cells x-1..x+1) and of the home row's side cells (8, 9) hold points
+#endif
 };
 
 // The pruning margin of nn_block.  A cell (or row of cells) is skipped when the squared distance f'^2 from the query to its nearest face, as the
@@ -214,6 +223,12 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   const int nx = g.dim[0];
   const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
   const bool valid = inside && (has_l | has_o | has_r);
+#if ER_NN_ROWMASK
+  // the home cell's mask (all ones for a query whose home cell is outside the grid): fetched now, needed after the own cell's scan
+  unsigned rmask = 0x3ffu;
+  if (valid && has_o && iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2])
+    rmask = ((const ER_GLOBAL unsigned short*)g.rowmask)[(unsigned)((iz * g.dim[1] + iy) * nx + ix)];
+#endif
   __syncthreads();                                            // (sh.ntask is zero)
   unsigned long long key = kNoHit;
   if (valid) {
@@ -228,12 +243,20 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);   // the other cells must beat this one
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
       }
+#if ER_NN_ROWMASK
+      if (has_l && xlo * xlo <= bound && (rmask & 0x100u)) {
+#else
       if (has_l && xlo * xlo <= bound) {
+#endif
         key = scan_row<kU>(g, row, ix - 1, ix - 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
+#if ER_NN_ROWMASK
+      if (has_r && xhi * xhi <= bound && (rmask & 0x200u)) {
+#else
       if (has_r && xhi * xhi <= bound) {
+#endif
         key = scan_row<kU>(g, row, ix + 1, ix + 1, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
@@ -251,12 +274,21 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     for (int j = 0; j < 8; j++) {
       const int pass = j < 4 ? j : j + 1;
       const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+#if ER_NN_ROWMASK
+      const bool holds = (rmask >> j) & 1u;
+      if (__ballot(holds) == 0ull) {                          // wave-uniform: no lane's row j holds a point
+        r_s0[j] = r_s1[j] = 0;
+        continue;
+      }
+#else
+      constexpr bool holds = true;
+#endif
       const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
       const int y = iy + dy, z = iz + dz;
       const float e2 = ey * ey + ez * ez;
       const bool wl = has_l && xlo * xlo + e2 <= bound, wr = has_r && xhi * xhi + e2 <= bound;
       const int xa = max(wl ? ix - 1 : ix, 0), xb = min(wr ? ix + 1 : ix, nx - 1);
-      const bool live = y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound && (has_o || wl || wr) && xa <= xb;
+      const bool live = holds && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound && (has_o || wl || wr) && xa <= xb;
       const int row = row_home + (dz * g.dim[1] + dy) * nx;
       const unsigned i0 = live ? (unsigned)(row + xa) : 0u, i1 = live ? (unsigned)(row + xb) : 0u;
       r_s0[j] = csb[i0];
@@ -1048,6 +1080,35 @@ __global__ __launch_bounds__(kBlock) void k_chunk_gather(ChunkDesc D, const unsi
   sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
 }
 
+#if ER_NN_ROWMASK
+// One thread per cell of every cloud of the chunk (blockIdx.y = cloud), after the prefix sum: bit j (0-7) = the cells x-1..x+1 of neighbour row j
+// (nn_block's order: dy fastest, the home row left out) hold a point; bit 8 / 9 = the home row's cell x-1 / x+1 does.
+__global__ __launch_bounds__(kBlock) void k_chunk_rowmask(ChunkDesc D, const int* __restrict__ cs_all, unsigned short* __restrict__ mask_all) {
+  const int yc = blockIdx.y;
+  const GridDims G = D.G[yc];
+  const int nx = G.dim[0], ny = G.dim[1], nz = G.dim[2];
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= nx * ny * nz) return;
+  const int* __restrict__ cs = cs_all + D.cs_off[yc];
+  const int x = c % nx, y = (c / nx) % ny, z = c / (nx * ny);
+  const int xa = max(x - 1, 0), xb = min(x + 1, nx - 1);
+  unsigned m = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const int pass = j < 4 ? j : j + 1;
+    const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+    const int yy = y + dy, zz = z + dz;
+    if (yy < 0 || yy >= ny || zz < 0 || zz >= nz) continue;
+    const int row = (zz * ny + yy) * nx;
+    if (cs[row + xb + 1] - cs[row + xa] > 0) m |= 1u << j;
+  }
+  const int rh = (z * ny + y) * nx;
+  if (x - 1 >= 0 && cs[rh + x] - cs[rh + x - 1] > 0) m |= 0x100u;
+  if (x + 1 < nx && cs[rh + x + 2] - cs[rh + x + 1] > 0) m |= 0x200u;
+  mask_all[D.cs_off[yc] + c] = (unsigned short)m;            // (indexed like cell_start: one spare entry per cloud)
+}
+#endif
+
 // Grow-only scratch of the grid build, one per device, handed out under a mutex (er_cloud_create may be called from
 // several host threads; builds on one device then take turns).
 struct GridScratch {
@@ -1618,11 +1679,16 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     }
     C.D.cs_off[m] = cs_total;
     C.cells = new CloudSlab();
-    hipError_t e = hipMalloc(&C.cells->p, (size_t)cs_total * sizeof(int));
+#if ER_NN_ROWMASK
+    const size_t cells_bytes = (size_t)cs_total * sizeof(int) + (size_t)cs_total * sizeof(unsigned short);   // [cell_start of the chunk | row masks]
+#else
+    const size_t cells_bytes = (size_t)cs_total * sizeof(int);
+#endif
+    hipError_t e = hipMalloc(&C.cells->p, cells_bytes);
     if (e != hipSuccess) {
       delete C.cells;
       C.cells = nullptr;
-      return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", (size_t)cs_total * sizeof(int), hipGetErrorString(e));
+      return er::fail("er_cloud_create: hipMalloc(%zu) failed: %s", cells_bytes, hipGetErrorString(e));
     }
     C.cells->refs = m;
     int* cs = static_cast<int*>(C.cells->p);
@@ -1632,6 +1698,9 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
       c->cell_start = cs + C.D.cs_off[k];
       c->grid.pts = c->sorted;
       c->grid.cell_start = c->cell_start;
+#if ER_NN_ROWMASK
+      c->grid.rowmask = reinterpret_cast<const unsigned short*>(cs + cs_total) + C.D.cs_off[k];
+#endif
     }
     int bits = 1;
     while ((1L << bits) < (long)max_cells) bits++;
@@ -1648,6 +1717,9 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     tmp = gs.cub_cap;
     ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub[q], tmp, cs, cs, (int)cs_total, L));
     if (C.total > 0) hipLaunchKernelGGL(k_chunk_gather, dim3(nblocks_of((int)C.total)), dim3(kBlock), 0, L, C.D, k1, x1, (int)C.total, C.sorted);
+#if ER_NN_ROWMASK
+    hipLaunchKernelGGL(k_chunk_rowmask, dim3(nblocks_of(max_cells), m), dim3(kBlock), 0, L, C.D, cs, reinterpret_cast<unsigned short*>(cs + cs_total));
+#endif
     ER_HIP_TRY(hipGetLastError());
     return 0;
   };
