@@ -71,6 +71,16 @@ typedef ER_GLOBAL int* gp_iw;
 #ifndef ER_NN_ROWMASK
 #define ER_NN_ROWMASK 0
 #endif
+// Two smaller steps on the same straight-line part, prepared with it (same status: compiled out, not measured; scripts/gpu_r5a.sh):
+//   -DER_NN_ONE_RESERVE=1  a wave reserves the list slots of all its rows' tasks with ONE LDS atomic (ballots + mbcnt per row) instead of one per row;
+//   -DER_NN_RCP_CELL=1     the query's cell coordinates by a multiplication with 1 / cell instead of three correctly rounded divisions; the pruning
+//                          margin pays for the extra rounding (grid_slack: D x 1.5).  The grid build keeps the division.
+#ifndef ER_NN_ONE_RESERVE
+#define ER_NN_ONE_RESERVE 0
+#endif
+#ifndef ER_NN_RCP_CELL
+#define ER_NN_RCP_CELL 0
+#endif
 struct Grid {
   const float4* pts;
   const int* cell_start;
@@ -96,7 +106,11 @@ struct Grid {
 // ~0.2 um, could be skipped (about once in 1e9 queries on fragment data; tests/test_icp_gpu.py builds such queries on purpose).
 inline float grid_slack(const int dim[3], float cell) {
   const int big = std::max(dim[0], std::max(dim[1], dim[2]));
+#if ER_NN_RCP_CELL
+  const double D = 3.75e-7 * (double)(big + 2) * (double)cell + 4e-9;   // (query side: subtraction, rounded reciprocal, product = 3 roundings instead of 2)
+#else
   const double D = 2.5e-7 * (double)(big + 2) * (double)cell + 4e-9;
+#endif
   return (float)(1.3e5 * D * D);
 }
 
@@ -216,7 +230,12 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   __syncthreads();                                            // the previous call's readers are done with `sh`
   if (tid == 0) sh.ntask = 0;
   // the query's cell (float32 expressions shared with the grid build)
+#if ER_NN_RCP_CELL
+  const float inv_cell = 1.0f / g.cell;                      // (wave-uniform operand; one division per call instead of three per query)
+  const float ux = (qx - g.org[0]) * inv_cell, uy = (qy - g.org[1]) * inv_cell, uz = (qz - g.org[2]) * inv_cell;
+#else
   const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
+#endif
   const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
   const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
   const int ix = inside ? (int)cx : 0, iy = inside ? (int)cy : 0, iz = inside ? (int)cz : 0;
@@ -294,6 +313,38 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
       r_s0[j] = csb[i0];
       r_s1[j] = csb[i1 + (live ? 1u : 0u)];
     }
+#if ER_NN_ONE_RESERVE
+    unsigned long long wants[8];
+    int total = 0;                                            // (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int n = r_s1[j] - r_s0[j];
+      wants[j] = __ballot(n > 0 && n < (1 << 23));
+      total += __popcll(wants[j]);
+    }
+    int slot = 0;                                             // (wave-uniform) the wave's first slot, then the first slot of row j's tasks
+    if (total) {
+      const int leader = __ffsll((long long)__ballot(1)) - 1;
+      int b = 0;
+      if ((int)__lane_id() == leader) b = atomicAdd(&sh.ntask, total);
+      slot = __builtin_amdgcn_readlane(b, leader);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int n = r_s1[j] - r_s0[j];
+      if (n > 0) {
+        const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wants[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wants[j], 0u));
+        const int t = n < (1 << 23) ? slot + before : kTaskCap;
+        if (t < kTaskCap) {
+          sh.task_s0[t] = r_s0[j];
+          sh.task_nq[t] = (n << 8) | tid;
+        } else {                                              // the task list is full (or the range does not fit the packing): scan it here
+          key = scan_range<kU>(g, r_s0[j], r_s1[j], qx, qy, qz, key);
+        }
+      }
+      slot += __popcll(wants[j]);
+    }
+#else
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int n = r_s1[j] - r_s0[j];
@@ -307,6 +358,7 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
         }
       }
     }
+#endif
   }
   sh.best[tid] = key;
   __syncthreads();
