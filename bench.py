@@ -149,6 +149,48 @@ def parity_check(vol, ref_units, n_frames, kind):
     return res
 
 
+def sampled_parity(sc, depth, n_sample, interval, max_units, device):
+    """configs[3] / configs[4] (strong-scaling jobs of 10 000 / 5000 frames): the CPU leg and the parity check on a SAMPLED stream --
+    runs of 10 consecutive frames spread from the first to the last fragment of the job, every frame with its true frame id (its own
+    lattice of the job's .ctr, its own trajectory entry) -- through the reference's own CIntegrateApp::Execute (oracle/_ref) and
+    through the host mirror on the GPU, both reading the same pose.log / seg.log / g.ctr.  The head of such a job says nothing about
+    its hard part (negative unit coordinates, > 512 hashed units appear as the path drifts outward).
+    Returns (cpu_baseline object, parity_checked object)."""
+    import numpy as np
+    import torch
+    from elasticreconstruction_amd import synth
+    from elasticreconstruction_amd.tsdf import IntegrateApp
+    from oracle import pyoracle, refcheck
+    if not pyoracle.have_ref():
+        return {"value": None, "kind": "reference", "note": "oracle/_ref not present on this host"}, None
+    run_len = min(10, interval)
+    ids = refcheck.sampled_frames(sc["n"], interval, max(2, n_sample // run_len), run_len)
+    host = synth.to_numpy_u16(depth.view(torch.int16)[torch.as_tensor(ids, device=depth.device)])
+    with tempfile.TemporaryDirectory() as fdir:
+        with _StdoutToStderr():
+            ref_units, dt, paths = refcheck.reference_volume_of_frames(sc, host, ids, fdir)
+        app = IntegrateApp(max_units=max_units, device=device)
+        app.pose_filename_, app.seg_filename_, app.ctr_filename_ = paths
+        app.ctr_num_, app.ctr_resolution_, app.ctr_length_, app.ctr_interval_ = sc["n"] // interval, sc["resolution"], sc["length"], interval
+        app.Init()
+        for k, f in enumerate(ids):
+            app.Execute(int(f) + 1, host[k])
+        app.Finish(save=False)
+    par = parity_check(app.volume_, ref_units, len(ids), "reference")
+    c = refcheck.unit_coordinates(sorted(ref_units))
+    par.update({"frames_sampled": "%d runs of %d consecutive frames, first fragment to last, true frame ids" % (len(ids) // run_len, run_len),
+                "job_frames": sc["n"], "lattices_in_ctr": sc["n"] // interval,
+                "unit_coordinate_min": [int(x) for x in c.min(0)], "unit_coordinate_max": [int(x) for x in c.max(0)],
+                "units_at_negative_coordinates": int((c < 0).any(axis=1).sum()),
+                "units_outside_the_512_cube_region": int(((c < 0) | (c > 7)).any(axis=1).sum())})
+    app.volume_.close()
+    cpu = {"value": len(ids) / dt, "unit": "frames/s", "cores": 8, "kind": "reference",
+           "sample": "%d frames sampled across the %d-frame job (runs of %d) through the reference's own CIntegrateApp::Execute "
+                     "(Reproject+ScaleDepth+Integrate), compiled unmodified, num_threads( 8 ) as hard-coded; %d host hardware threads present"
+                     % (len(ids), sc["n"], run_len, os.cpu_count() or 0)}
+    return cpu, par
+
+
 def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     """configs[2] shape: n_pairs fragment pairs over n_frag DISTINCT fragments of 250 k points each (seeded surfels of the
     synthetic room seen from n_frag places on the config-2 circle; pair k = fragment a with its 1st / 2nd neighbour, ground
@@ -173,11 +215,13 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     arena = _ffi.PinnedArena()
     arena.reset(sum(x.nbytes + n.nbytes for x, n in hosts) + 16384 * len(hosts))
     pinned = []
+    t0 = time.perf_counter()
     for x, n in hosts:
         px, pn = arena.take(x.shape, np.float32), arena.take(n.shape, np.float32)
         px[...] = x
         pn[...] = n
         pinned.append((px, pn))
+    staging_s = time.perf_counter() - t0                      # pageable -> page-locked staging of the whole fragment list (reported)
     batch_s = []
     for _ in range(6):
         t0 = time.perf_counter()
@@ -264,12 +308,24 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     npts = sum(len(c[0]) for c in clouds) / float(len(clouds))
     # B_B = P [ (I+2) 12 + I_c 24 ] + C 24 per pair (P as the upper bound of the in-range points); NN traversal excluded
     bb = float(sum(len(clouds[b][0]) * ((int(i) + 2) * 12 + int(i) * 24) + int(c) * 24 for (_, b, _), i, c in zip(pairs, iters, ncs)))
+    bb_pre = float(sum(len(clouds[b][0]) * 12 for _, b, _ in pairs))
+    bb_icp = float(sum(len(clouds[b][0]) * int(i) * 36 for (_, b, _), i in zip(pairs, iters)))
+    bb_fc = float(sum(len(clouds[b][0]) * 12 + int(c) * 24 for (_, b, _), c in zip(pairs, ncs)))
     build_total = float(np.sum(build_ms)) * 1e-3
     res = {"pairs_per_s": n_pairs / dt, "pairs": n_pairs, "distinct_fragments": len(clouds), "points_per_fragment": npts,
            "mean_icp_iterations": its / n_pairs,
            "roofline": {"bound": "hbm (lower bound: NN-structure traversal bytes are implementation-defined and excluded)",
                         "algorithmic_bytes_per_pair": bb / n_pairs, "achieved": bb / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": bb / dt / 1e9 / HBM_PEAK_GBS},
+                        "frac": bb / dt / 1e9 / HBM_PEAK_GBS,
+                        # SURVEY.md 8d's B_B split by the phase (= kernel family) that moves each term, each over ITS OWN wall time of the median pass
+                        "phases": {ph: {"kernels": kn, "algorithmic_bytes_per_list": b, "ms": ms, "achieved": b / (ms * 1e-3) / 1e9,
+                                        "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                                   for ph, kn, b, ms in (("pre_check", "k_count_inliers", bb_pre, phase[0]),
+                                                         ("icp", "k_icp_iter + k_icp_final", bb_icp, phase[1]),
+                                                         ("find_correspondence", "k_find_corr + k_count_blocks / k_scan_blocks / k_compact + the list copies to the host",
+                                                          bb_fc, phase[2]))},
+                        "phases_definition": "B_B = P [(I + 2) 12 + I 24] + C 24 per pair: the pre-check reads P x 12, the ICP loop P x I x (12 + 24), "
+                                             "FindCorrespondence P x 12 + C x 24; the three sum to algorithmic_bytes_per_pair x pairs"},
            "cloud_build_ms": {"per_fragment_median": float(np.median(build_ms)), "per_fragment_max": float(np.max(build_ms)),
                               "what": "er_cloud_create: upload + uniform-grid build of one fragment, once per fragment (the reference "
                                       "rebuilds a kd-tree per pair and per function, CorresApp.cpp:129,238)",
@@ -278,8 +334,16 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
                               "batch_what": "er_cloud_create_batch over all %d fragments from page-locked host arrays: all uploads queued up front on two copy streams, "
                                             "chunks of up to 8 clouds share one set of grid launches, one host wait per chunk (PCIe-bound: 24 bytes per point); "
                                             "median of 4 calls, each 50 ms after the previous batch was destroyed" % len(clouds)},
-           "pairs_per_s_incl_cloud_build": n_pairs / (dt + batch_build_s),
-           "pairs_per_s_incl_cloud_build_one_by_one": n_pairs / (dt + build_total),
+           # this key is back on its round 1-3 definition (clouds built ONE BY ONE from pageable arrays, er_cloud_create);
+           # round 4 had silently moved it to the batched build from page-locked arrays, which now has a key of its own
+           "pairs_per_s_incl_cloud_build": n_pairs / (dt + build_total),
+           "pairs_per_s_incl_cloud_build_batched": n_pairs / (dt + batch_build_s),
+           "pairs_per_s_incl_cloud_build_batched_and_staging": n_pairs / (dt + batch_build_s + staging_s),
+           "pairs_per_s_incl_cloud_build_basis": "pairs_per_s_incl_cloud_build = list time + the sum of 25 er_cloud_create calls from pageable arrays (rounds 1-3 and "
+                                                 "again now; BENCH_r04's value under this key was the batched figure); _batched = list time + ONE er_cloud_create_batch from "
+                                                 "page-locked arrays (median of the last 4 of 6 calls, 50 ms after the previous batch was freed); _batched_and_staging adds the "
+                                                 "pageable -> page-locked copy of the 25 fragments (%.2f ms), which a host that reads its PCD files straight into er_host_alloc "
+                                                 "memory does not pay" % (1e3 * staging_s),
            "mean_correspondences": ncor / n_pairs, "nn_queries_per_s": npts * (its + 2 * n_pairs) / dt,
            "flow": "er_icp_count_inliers_batch + er_icp_align_batch, then er_find_correspondence_batch over the pair list",
            "phase_ms": {"pre_check": phase[0], "icp": phase[1], "find_correspondence": phase[2]},
@@ -563,15 +627,17 @@ def other_configs(device):
     its error text here and never touches the headline line."""
     import subprocess
     import time
-    res = {"what": "python bench.py --config 4 | 5 --min-seconds 0.2 --cpu-sample 0, run after the headline measurement in child "
-                   "processes; one GPU: configs[3] forces the frame-split merge (er_tsdf_allreduce on a 1-rank communicator)"}
+    res = {"what": "python bench.py --config 4 | 5 --min-seconds 0.2 --cpu-sample 100, run after the headline measurement in child "
+                   "processes; one GPU: configs[3] forces the frame-split merge (er_tsdf_allreduce on a 1-rank communicator); "
+                   "parity_checked = 100 frames sampled across the job (first fragment to last, true frame ids and lattices) against "
+                   "the reference's own CIntegrateApp::Execute, bit for bit"}
     env = dict(os.environ, HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)), MASTER_PORT="29531")
     if "HIP_VISIBLE_DEVICES" not in os.environ:
         env["LOCAL_RANK"] = "0"
     for cfg in (4, 5):
         t0 = time.time()
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--min-seconds", "0.2", "--cpu-sample", "0",
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", str(cfg), "--min-seconds", "0.2", "--cpu-sample", "100",
                                 "--no-alone", "--no-streamed", "--other-configs", "0"], env=env, stdout=subprocess.PIPE,
                                stderr=subprocess.PIPE, timeout=240)
             line = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
@@ -583,7 +649,8 @@ def other_configs(device):
                  "workload": d["config"]["workload"], "frames": d["config"]["frames_per_gpu"],
                  "volume_units_touched": d["config"].get("volume_units_touched"),
                  "merge_union_units": d["config"].get("merge_union_units"), "merge_impl": d["config"].get("merge_impl"),
-                 "roofline_frac": (d.get("roofline") or {}).get("frac"), "wall_s": time.time() - t0}
+                 "roofline_frac": (d.get("roofline") or {}).get("frac"), "parity_checked": d.get("parity_checked"),
+                 "cpu_baseline": d.get("cpu_baseline"), "wall_s": time.time() - t0}
             i = d.get("icp")
             if i:
                 r["icp"] = {k: i[k] for k in ("pairs_per_s", "pairs_total", "pairs_this_rank", "accepted_this_rank", "rejected_by_pre_check",
@@ -1043,7 +1110,7 @@ def main():
             bytes_pass = 16.0 * sum_w + FRAME_BYTES_FIXED * n_frames + (2 * FRAME_BYTES_RAW * n_frames if warp_on else 0)
             per_launch = bytes_pass * n_pass / launches
             ach = per_launch / (ms_launch * 1e-3) / 1e9
-            traffic, valu, phys, static, frac_rocprof = None, None, None, None, None
+            traffic, valu, phys, static, frac_rocprof, pj = None, None, None, None, None, {}
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc) and abs(frames_per_launch - 50.0) < 1e-9:
                 try:
@@ -1081,18 +1148,48 @@ def main():
                             valu["job_frac"] = tot / batch_s / peak
                 except Exception:
                     traffic = None
+            # ---- the contract figure: ALL algorithmic bytes of the pass over the timed wall time of the pass -------------
+            job_ach = bytes_pass / dt / 1e9
+            # ---- per kernel: each kernel priced with ONLY the bytes it is responsible for ------------------------------------------------
+            n_launch_pass = launches / float(n_pass)                                  # launches of each kernel per pass
+            kb = {"k_integrate": 16.0 * sum_w / n_launch_pass,                        # 8 B read + 8 B write per reference voxel update
+                  "k_prepare": FRAME_BYTES_FIXED * frames_per_launch}                 # ScaleDepth: 2 B raw read + 4 B scaled write/read per pixel
+            if warp_on:
+                kb["k_reproject_scatter"] = 2.0 * FRAME_BYTES_RAW * frames_per_launch  # Reproject: 2 B read + 2 B scatter per pixel
+            by_kernel = dict(pj.get("rocprof_kernel_trace_avg_us_by_kernel") or {}) if static else {}
+            if static and pj.get("rocprof_kernel_trace_avg_us") and "k_integrate" not in by_kernel:
+                by_kernel = dict(by_kernel, k_integrate=float(pj["rocprof_kernel_trace_avg_us"]))
+            kernels = {}
+            for kname, nbytes in kb.items():
+                e = {"algorithmic_bytes_per_launch": nbytes}
+                if kname == "k_integrate":
+                    e.update({"avg_launch_ms": ms_launch, "achieved": nbytes / (ms_launch * 1e-3) / 1e9,
+                              "frac": nbytes / (ms_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_source": "HIP events on the launch stream, this run"})
+                if by_kernel.get(kname):
+                    e.update({"rocprof_avg_us": float(by_kernel[kname]),
+                              "frac_rocprof": nbytes / (float(by_kernel[kname]) * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                kernels[kname] = e
+            kint = kernels["k_integrate"]
             out["roofline"] = {"bound": "hbm", "contract_bound": "hbm", "limiter": "latency + VALU issue, and the longest work items (DESIGN.md 4, 'Path A, round 3')",
-                               "kernel": "k_integrate", "achieved": ach, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "frac_source": "HIP events on the launch stream, this run",
-                               "frac_rocprof": frac_rocprof,
-                               "frac_rocprof_source": ("static: the same algorithmic bytes over the k_integrate average of the last committed rocprofv3 --kernel-trace "
-                                                       "--stats run (%s us, %s); tracing perturbs the three-stream overlap, so it reads lower than frac"
-                                                       % (pj.get("rocprof_kernel_trace_avg_us"), pj.get("rocprof_kernel_trace_file"))) if frac_rocprof else None,
+                               "kernel": "k_integrate", "kernels_of_the_job": "k_integrate + k_prepare + k_reproject_scatter: the three kernels of a batch run concurrently on three streams",
+                               "achieved": job_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": job_ach / HBM_PEAK_GBS,
+                               "frac_definition": "SURVEY.md 8d's contract: (16 x sum(weight_) + 1 843 200 x F + 1 228 800 x F with the warp) / t_total / 8e12 -- "
+                                                  "every algorithmic byte of the pass over the timed wall time of the pass (value x bytes per frame); recompute: "
+                                                  "algorithmic_bytes_per_pass / (ms_per_step x steps x 1e-3) / 8e12.  Rounds 1-4 printed the k_integrate-only figure "
+                                                  "here WITH the pre-pass bytes in its numerator (0.84 in round 4); that figure is gone, kernel_frac replaces it",
+                               "algorithmic_bytes_per_pass": bytes_pass, "frames_per_pass": n_frames, "pass_ms": 1e3 * dt,
+                               "whole_job_frac": job_ach / HBM_PEAK_GBS,
+                               "kernel_frac": kint["frac"], "kernel_frac_rocprof": kint.get("frac_rocprof"),
+                               "kernel_frac_definition": "k_integrate alone with ONLY its own bytes, 16 x (voxel updates per launch), over its average launch duration: "
+                                                         "kernel_frac by HIP events inside the timed pipeline, kernel_frac_rocprof by the committed rocprofv3 "
+                                                         "--kernel-trace --stats average (static_figures; tracing perturbs the three-stream overlap, so it reads lower)",
+                               "kernels": kernels,
+                               "frac_rocprof": kint.get("frac_rocprof"),
                                "static_figures": static,
-                               "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
+                               "frac_of_measured_copy_peak": job_ach / HBM_COPY_GBS,
                                "measured_copy_peak": HBM_COPY_GBS, "traffic": traffic,
-                               "traffic_source": ("static: %s, committed as profiles/pmc_latest.json (ONE run of this kernel, 50-frame launch: "
-                                                  "2 x FETCH_SIZE + WRITE_SIZE, an upper bound), not this run" % pj.get("run", "a rocprofv3 --pmc run"))
+                               "traffic_source": ("static: %s, committed as profiles/pmc_latest.json (ONE run of k_integrate, 50-frame launch: "
+                                                  "2 x FETCH_SIZE + WRITE_SIZE, an upper bound), per launch, not this run" % pj.get("run", "a rocprofv3 --pmc run"))
                                if traffic else None,
                                "hbm_physical_frac": phys,
                                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": ms_launch, "launches": launches,
@@ -1103,22 +1200,27 @@ def main():
                                        "frac prices the ALGORITHMIC bytes of SURVEY.md 8d (16 B per reference voxel update) against the HBM "
                                        "peak, as the contract asks; the batched kernel moves about half of them (traffic, hbm_physical_frac); what it "
                                        "waits for is latency and the longest items of a launch (limiter), valu_issue.frac is its share of the VALU issue peak",
-                               "whole_job_frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS, "valu_issue": valu}
+                               "valu_issue": valu}
             if alone and alone["launches"] > 0 and alone["integrate_ms"] > 0:
                 ms_alone = alone["integrate_ms"] / alone["launches"]
-                per_alone = bytes_pass / alone["launches"]
+                per_alone = 16.0 * sum_w / alone["launches"]                     # the kernel's own bytes only (rounds 1-4: the job's)
                 out["roofline"]["kernel_alone"] = {
                     "avg_launch_ms": ms_alone, "launches": alone["launches"], "achieved": per_alone / (ms_alone * 1e-3) / 1e9,
                     "frac": per_alone / (ms_alone * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "what": "the same kernel and bytes in one extra untimed pass that synchronises after every 50-frame launch: "
-                            "k_integrate alone on the chip.  'frac' above is the contract figure over the TIMED region, where the "
-                            "kernel shares the SIMDs with the pre-pass kernels of the next two batches (three-stream pipeline)"}
+                            "k_integrate alone on the chip, priced with 16 x (voxel updates per launch) only.  kernel_frac above is the same "
+                            "figure inside the TIMED region, where the kernel shares the SIMDs with the pre-pass kernels of the next two "
+                            "batches (three-stream pipeline)"}
         else:
             out["roofline"] = {"bound": "hbm", "contract_bound": "hbm", "kernel": "k_integrate", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": None, "traffic": None, "avg_launch_ms": ms_launch, "launches": launches}
         if streamed is not None:
             out["streamed"] = streamed
-        if world == 1 and args.cpu_sample > 0 and warp_on and not dry:
+        if world == 1 and args.cpu_sample > 0 and warp_on and not dry and args.config != 2:
+            out["cpu_baseline"], par = sampled_parity(sc, depth, args.cpu_sample, I, max_units, local)
+            if par is not None:
+                out["parity_checked"] = par
+        elif world == 1 and args.cpu_sample > 0 and warp_on and not dry:
             ns = min(n_frames, max(I, (args.cpu_sample // I) * I))
             host = synth.to_numpy_u16(depth[:ns])
             with tempfile.TemporaryDirectory() as fdir:

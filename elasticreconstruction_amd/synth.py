@@ -258,7 +258,8 @@ def perturbation(seed, max_rot_deg=2.0, max_trans=0.02):
 
 # ----------------------------------------------------------------------------------------------
 def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, amplitude=0.005, revolutions=None,
-                  frame_offset=0, total_frames=None, radius_drift=0.0, device="cpu", seed=SEED, room=(ROOM_LO, ROOM_HI)):
+                  frame_offset=0, total_frames=None, radius_drift=0.0, device="cpu", seed=SEED, room=(ROOM_LO, ROOM_HI),
+                  render_frames=None):
     """Everything one Integrate run needs (BASELINE.json configs 1/2/4), all in memory:
       depth  uint16 [n, 480*640] torch tensor on `device`
       traj   float64 [n,4,4]  world_T_camera as the reference composes it: pose[i] * seg[i*interval+j]
@@ -266,7 +267,10 @@ def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, am
       grids  float32 [n/interval, (res+1)^3, 3] (None when warp is False)
     frame_offset/total_frames select a window of a longer trajectory (multi-GPU frame split).
     room = (lo, hi) of the box room; the default keeps every surface inside 8x8x8 volume units ("512^3"), a larger room
-    (config 4) makes the hashed unit grid grow past 512 units."""
+    (config 4) makes the hashed unit grid grow past 512 units.
+    render_frames = sorted 0-based frame indices: only those frames are ray cast (depth [len(render_frames), 480*640], in that
+    order; sc["rendered"] names them) while traj / pose / seg / grids still describe ALL n_frames -- a sampled stream of a long
+    path (the configs[3] / configs[4] parity checks integrate a few hundred frames of a 10 000-frame job)."""
     from .tsdf import mat4_mul
     total = total_frames if total_frames is not None else n_frames
     revs = revolutions if revolutions is not None else max(1.0, total / 3000.0)
@@ -280,9 +284,13 @@ def make_scenario(n_frames, interval=50, warp=True, resolution=8, length=3.0, am
         for j in range(interval):
             traj[i * interval + j] = mat4_mul(pose[i], seg[i * interval + j])
     grids = control_grids(pose, resolution, length, amplitude, seed) if warp else None
-    depth = render_depth(w, lo=room[0], hi=room[1], device=device)
+    if render_frames is None:
+        depth, rendered = render_depth(w, lo=room[0], hi=room[1], device=device), None
+    else:
+        rendered = np.asarray(render_frames, np.int64)
+        depth = render_depth(w[rendered], lo=room[0], hi=room[1], device=device)
     return dict(depth=depth, traj=traj, pose=pose, seg=seg, grids=grids, interval=interval, resolution=resolution,
-                length=length, n=n_frames)
+                length=length, n=n_frames, rendered=rendered)
 
 
 def warp_arrays(sc, lo=0, hi=None):

@@ -43,12 +43,16 @@ def main():
              "valu_wave_instructions_per_batch": {k: s[k]["SQ_INSTS_VALU"] for k in ("k_integrate", "k_reproject_scatter", "k_prepare")
                                                   if "SQ_INSTS_VALU" in s.get(k, {})}}
     if len(sys.argv) > 4:                                              # rocprofv3 --kernel-trace --stats of the same tree: AverageNs of k_integrate
+        by = {}
         for row in csv.DictReader(open(sys.argv[4])):
-            if row.get("Name", "").startswith("k_integrate") or "k_integrate" in row.get("Name", ""):
-                extra["rocprof_kernel_trace_avg_us"] = float(row["AverageNs"]) / 1e3
-                extra["rocprof_kernel_trace_calls"] = int(row["Calls"])
-                extra["rocprof_kernel_trace_file"] = sys.argv[4]
-                break
+            for kname in ("k_integrate", "k_prepare", "k_reproject_scatter"):
+                if kname + "(" in row.get("Name", "") or kname + "<" in row.get("Name", ""):
+                    by[kname] = float(row["AverageNs"]) / 1e3
+                    if kname == "k_integrate":
+                        extra["rocprof_kernel_trace_avg_us"] = by[kname]
+                        extra["rocprof_kernel_trace_calls"] = int(row["Calls"])
+                        extra["rocprof_kernel_trace_file"] = sys.argv[4]
+        extra["rocprof_kernel_trace_avg_us_by_kernel"] = by            # the three kernels of a batch, same run (bench.py: roofline.kernels)
     print(json.dumps({**extra, **{
         "source": "%s: rocprofv3 --kernel-trace --pmc ... in separate passes (FETCH_SIZE | WRITE_SIZE | SQ_*), bench.py --steps 20 --warmup 1 "
                   "--no-alone --no-streamed: mean over the %d launches of 50 frames of a whole 3000-frame pass + warm-up; %s.  ALL figures below "

@@ -224,6 +224,11 @@ def test_bench_dry_run_four_ranks_through_the_drivers_command_line():
     assert cfg["merge_union_units"] == 1 + 4                          # the shared unit + one private unit per rank (100 frames: (frames // 64) % 8 = 0, 0)
     assert "frame-block shard x4" in cfg["parallelism"]
     assert out["roofline"]["kernel"] == "k_integrate" and out["roofline"]["launches_timed"] > 0
+    # the contract figure can be recomputed from the line itself: every algorithmic byte of the pass over the timed wall time of the pass
+    rf = out["roofline"]
+    assert abs(rf["frac"] - rf["algorithmic_bytes_per_pass"] / (out["ms_per_step"] * out["steps"] * 1e-3) / 8e12) < 1e-9 * max(rf["frac"], 1.0)
+    assert rf["frac"] == rf["whole_job_frac"] and set(rf["kernels"]) == {"k_integrate", "k_prepare", "k_reproject_scatter"}
+    assert abs(rf["kernels"]["k_integrate"]["algorithmic_bytes_per_launch"] - 16.0 * rf["voxel_updates_per_pass"] / (rf["launches"] / out["timing"]["passes"])) < 1.0
     # after the reduce rank 0 holds every rank's updates: sum(weight) / world = one rank's share = 2 units x 100 frames x 64^3 voxels
     assert out["roofline"]["voxel_updates_per_pass"] == 2 * 100 * 64 ** 3
     assert out["icp"]["pairs"] == 20 and "4 GPUs x 5 pairs" in out["icp"]["sharding"]

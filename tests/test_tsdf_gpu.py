@@ -373,6 +373,86 @@ def test_full_config2_equals_the_reference_build(gpu):
     vol.close()
 
 
+class _DictVolume:
+    """{key: (sdf_, weight_)} behind the unit_keys / read_unit surface helpers.volume_digest and assert_volumes_identical use."""
+
+    def __init__(self, units):
+        self.u = units
+
+    def unit_keys(self):
+        return np.array(sorted(self.u), np.int32)
+
+    def read_unit(self, k):
+        s, w = self.u[int(k)]
+        return np.ascontiguousarray(s, np.float32), np.ascontiguousarray(w, np.float32)
+
+
+def _sampled_job_against_the_reference(tmp_path, tag, n_frames, n_runs, run_len, max_units, **scene):
+    """A sampled stream of a LONG Integrate job -- n_runs runs of run_len consecutive frames spread from the first to the last
+    fragment of an n_frames job, every frame with its TRUE frame id, i.e. its own lattice of the job's full .ctr and its own entry of
+    the full trajectory -- through the host mirror of CIntegrateApp (-> er_tsdf_integrate_frames with the warp) and through the
+    REFERENCE's own CIntegrateApp::Execute (oracle/_ref/libref_tsdf.so, Integrate/*.cpp compiled in place), both reading the same
+    pose.log / seg.log / g.ctr.  Unit key sets equal, every sdf_ / weight_ bit pattern equal; where the reference build is absent the
+    committed digest of tests/golden/configs34_golden.json (tests/golden/make_golden_configs34.py, same files + depth digests) stands in."""
+    import hashlib
+    import json
+    from oracle import pyoracle, refcheck
+    ids = refcheck.sampled_frames(n_frames, 50, n_runs, run_len)
+    sc = synth.make_scenario(n_frames, interval=50, warp=True, revolutions=n_frames / 3000.0, render_frames=ids, device="cuda:0", **scene)
+    depth = synth.to_numpy_u16(sc["depth"])
+    paths = refcheck.write_integrate_files(sc, str(tmp_path))
+    app = IntegrateApp(max_units=max_units)
+    app.pose_filename_, app.seg_filename_, app.ctr_filename_ = paths
+    app.ctr_num_, app.ctr_resolution_, app.ctr_length_, app.ctr_interval_ = n_frames // 50, sc["resolution"], sc["length"], 50
+    app.Init()
+    for k, f in enumerate(ids):
+        app.Execute(int(f) + 1, depth[k])
+    app.Finish(save=False)
+    assert not app.exit_ and app.frames_integrated == len(ids)
+    flags, skipped = app.volume_.status()
+    assert flags == 0 and skipped == 0, "overflow flags %d, %d pixels beyond +-96 m" % (flags, skipped)
+    checked = []
+    if pyoracle.have_ref():
+        ref_units, _, _ = refcheck.reference_volume_of_frames(sc, depth, ids, str(tmp_path))
+        n = helpers.assert_volumes_identical(app.volume_, _DictVolume(ref_units), tag + " vs the reference build")
+        checked.append("reference")
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "configs34_golden.json")))[tag]
+    assert g["frame_ids_sha256"] == hashlib.sha256(ids.tobytes()).hexdigest()
+    inputs = {os.path.basename(p): hashlib.sha256(open(p, "rb").read()).hexdigest() for p in paths}
+    inputs["depth"] = hashlib.sha256(depth.tobytes()).hexdigest()
+    if inputs == g["inputs"]:                         # same text files and images as the golden run saw: its digest must come out
+        d = helpers.volume_digest(app.volume_)
+        assert d["keys"] == g["volume"]["keys"] and d["sum_weight"] == g["volume"]["sum_weight"] and d["sha256"] == g["volume"]["sha256"], \
+            tag + ": volume differs from the golden digest of the reference build"
+        checked.append("golden")
+    assert checked, "neither oracle/_ref nor bit-reproducible golden inputs on this host: %s" % sorted(k for k in inputs if inputs[k] != g["inputs"][k])
+    keys = app.volume_.unit_keys()
+    app.volume_.close()
+    return keys, checked
+
+
+def test_config4_hashed_grid_stream_equals_the_reference_build(gpu, tmp_path):
+    """BASELINE.json configs[3]'s scene (bench.py --config 4: 10 000 frames on a drifting path through a 6 m room, 200 control
+    lattices): 400 frames sampled from the first to the last fragment.  This is the part of the reference the 512^3 scenes never
+    reach: unit index arithmetic at NEGATIVE world coordinates (the +256*64 offset, TSDFVolume.cpp:50-53), keys of hash_key
+    (TSDFVolume.h:62-64) outside the 8x8x8 region, a hashed grid that grows past 512 units, and warped pixels the fragment's lattice
+    rejects (ControlGrid.h:51-54: most of the room is outside the fragment's 3 m cube)."""
+    from oracle import refcheck
+    keys, checked = _sampled_job_against_the_reference(tmp_path, "config4", 10000, 40, 10, 4096, radius_drift=1.5, room=(-1.5, 4.5))
+    c = refcheck.unit_coordinates(keys)
+    assert len(keys) > 512, "the scene must grow the hashed grid past 512 units, got %d" % len(keys)
+    assert int((c < 0).any(axis=1).sum()) > 100 and c.min() <= -4 and c.max() >= 12, "negative / far unit coordinates were not reached"
+    print("config4 sampled stream: %d units, coordinates %s .. %s, checked against %s" % (len(keys), c.min(0), c.max(0), checked))
+
+
+def test_config5_100_lattice_stream_equals_the_reference_build(gpu, tmp_path):
+    """BASELINE.json configs[4]'s integrate half (bench.py --config 5: 5000 frames, 100 control lattices, 1.67 revolutions): 200
+    frames sampled from the first to the last fragment, each warped with ITS lattice of the 100 (IntegrateApp.cpp:241)."""
+    keys, checked = _sampled_job_against_the_reference(tmp_path, "config5", 5000, 20, 10, 1024)
+    assert 100 <= len(keys) <= 512
+    print("config5 sampled stream: %d units, checked against %s" % (len(keys), checked))
+
+
 @pytest.mark.gpu
 def test_exact_arithmetic_cores_exhaustive(gpu):
     """The voxel update replaces hipcc's IEEE '/' and sqrtf by their un-wrapped cores and the float64 pixel rounding
