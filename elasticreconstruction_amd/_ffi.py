@@ -18,9 +18,10 @@ SYMBOLS = [
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
     "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
     "er_tsdf_extract_world", "er_tsdf_extract_surface", "er_tsdf_extract_mesh", "er_mc_table", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
+    "er_tsdf_export_raw", "er_tsdf_import_raw",
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_destroy", "er_comm_rank", "er_comm_world",
-    "er_tsdf_allreduce", "er_frame_block",
+    "er_tsdf_allreduce", "er_comm_merge_stats", "er_frame_block",
     "er_cloud_create", "er_cloud_create_batch", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_registration_batch", "er_ransac_fitness_batch", "er_ransac_inliers",
@@ -94,6 +95,8 @@ def lib():
     L.er_request_hw_queues.argtypes = [C.c_int]
     L.er_tsdf_export_weighted.argtypes = [vp, vp, C.c_int, vp]
     L.er_tsdf_import_weighted.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_export_raw.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_import_raw.argtypes = [vp, vp, C.c_int, vp]
     L.er_comm_unique_id.argtypes = [vp]
     L.er_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.er_comm_create_local.argtypes = [C.c_int, vp, vp]
@@ -101,6 +104,7 @@ def lib():
     L.er_comm_rank.argtypes = [vp]
     L.er_comm_world.argtypes = [vp]
     L.er_tsdf_allreduce.argtypes = [vp, vp, C.c_int, ip]
+    L.er_comm_merge_stats.argtypes = [vp, vp]
     L.er_frame_block.restype = None
     L.er_frame_block.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.er_tsdf_set_profiling.argtypes = [vp, C.c_int]

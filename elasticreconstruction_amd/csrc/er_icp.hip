@@ -65,32 +65,30 @@ typedef ER_GLOBAL float* gp_fw;
 typedef ER_GLOBAL int* gp_iw;
 #define ER_GP(type, ptr) ((type)(ptr))
 
-// -DER_NN_ROWMASK=1 (prepared at the end of round 4, NOT measured yet -- DESIGN.md section 9): a 10-bit mask per target cell, built with the grid, says
-// which neighbour rows of a query that lives in this cell hold any point at all; nn_block then skips, for a whole wave, the tests, bound loads and
-// pushes of rows that are empty for every lane -- part of the ~500 straight-line instructions per slice that bind the search.  Same candidate sets.
-#ifndef ER_NN_ROWMASK
-#define ER_NN_ROWMASK 0
+// Three steps on the straight-line part of nn_block that round 4 prepared and round 5 measured (profiles/r05a_ab_nn_prepared_variants.txt; parity green for
+// all of them, none outside the 0.5 % run-to-run spread of the 50-pair list, so none is in the source any more -- commits 8857abb..2b7f283 have them):
+//   a 10-bit "which neighbour rows of this cell hold points" mask per target cell, wave-uniform skip of empty rows   -0.8 % (one more dependent load)
+//   one LDS atomic per wave for the tasks of all eight rows (ballots + mbcnt)                                         +-0
+//   the query's cell coordinates by a reciprocal instead of three divisions (pruning margin widened by one rounding)   +0.4 %
+// Round 5: the grid carries TWO RINGS OF EMPTY CELLS around the cloud's bounding box (cell (x, y, z) of the box is cell (x + 2, y + 2, z + 2) of the
+// array).  A query is searched only if its home cell lies within one cell of the box, so with two rings every cell of its 27-neighbourhood EXISTS:
+// the has-a-left / own / right-cell flags, the y / z range tests of the eight neighbour rows and the clamps of their x ranges (rounds 1-4) are gone, and
+// the four bounds L, O, R, E of a row's three cells x-1, x, x+1 are four CONSECUTIVE ints of cell_start -- one 16-byte load per row instead of two 4-byte
+// loads behind a clamped index each.  Same candidate sets (ring cells hold no point), same cell-sorted order of the points (padded cell ids order like the
+// plain ones).  Measured against the clamped search (profiles/r05b_ab_padded_grid.txt): ~100 VALU and ~130 SALU instructions fewer per slice in the image,
+// the ICP phase of the 50-pair list 2.33 -> 2.27 ms, the hard list 6.45 k -> 6.7 k pairs/s, every path-B parity test unchanged.
+#ifndef ER_NN_PAD_BATCH
+#define ER_NN_PAD_BATCH 4      // rows whose four bounds are in flight at a time (4 registers per row; 8 = all rows: +11 VGPRs, within the noise)
 #endif
-// Two smaller steps on the same straight-line part, prepared with it (same status: compiled out, not measured; scripts/gpu_r5a.sh):
-//   -DER_NN_ONE_RESERVE=1  a wave reserves the list slots of all its rows' tasks with ONE LDS atomic (ballots + mbcnt per row) instead of one per row;
-//   -DER_NN_RCP_CELL=1     the query's cell coordinates by a multiplication with 1 / cell instead of three correctly rounded divisions; the pruning
-//                          margin pays for the extra rounding (grid_slack: D x 1.5).  The grid build keeps the division.
-#ifndef ER_NN_ONE_RESERVE
-#define ER_NN_ONE_RESERVE 0
-#endif
-#ifndef ER_NN_RCP_CELL
-#define ER_NN_RCP_CELL 0
-#endif
+typedef int i4v __attribute__((ext_vector_type(4)));
 struct Grid {
   const float4* pts;
   const int* cell_start;
   float org[3];
   float cell;
-  int dim[3];
+  int dim[3];      // cells of the bounding box per axis (the array has dim + 4 per axis: two rings of empty cells)
   float slack;     // absolute part of nn_block's pruning margin (square metres), from the grid's extent: grid_slack()
-#if ER_NN_ROWMASK
-  const unsigned short* rowmask;   // per cell: which of the 8 neighbour rows (bits 0-7, cells x-1..x+1) and of the home row's side cells (8, 9) hold points
-#endif
+  int pnx, pny;    // dim[0] + 4, dim[1] + 4: strides of the padded array
 };
 
 // The pruning margin of nn_block.  A cell (or row of cells) is skipped when the squared distance f'^2 from the query to its nearest face, as the
@@ -106,11 +104,7 @@ struct Grid {
 // ~0.2 um, could be skipped (about once in 1e9 queries on fragment data; tests/test_icp_gpu.py builds such queries on purpose).
 inline float grid_slack(const int dim[3], float cell) {
   const int big = std::max(dim[0], std::max(dim[1], dim[2]));
-#if ER_NN_RCP_CELL
-  const double D = 3.75e-7 * (double)(big + 2) * (double)cell + 4e-9;   // (query side: subtraction, rounded reciprocal, product = 3 roundings instead of 2)
-#else
   const double D = 2.5e-7 * (double)(big + 2) * (double)cell + 4e-9;
-#endif
   return (float)(1.3e5 * D * D);
 }
 
@@ -203,14 +197,6 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
   return key;
 }
 
-// Cells xa..xb of one (y, z) row are ONE contiguous range of the cell-sorted target.
-template <int kU = kUnroll>
-__device__ __forceinline__ unsigned long long scan_row(const Grid& g, int row, int xa, int xb, float qx, float qy, float qz, unsigned long long key) {
-  const ER_GLOBAL char* cs = (const ER_GLOBAL char*)g.cell_start;
-  const unsigned o = (unsigned)(row + xa) * 4u;
-  return scan_range<kU>(g, *(const ER_GLOBAL int*)(cs + o), *(const ER_GLOBAL int*)(cs + o + (unsigned)(xb - xa + 1) * 4u), qx, qy, qz, key);
-}
-
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
 // Returns the index (or -1) and the squared distance of the nearest target point.
 // Round 3: the HOME row is no longer scanned as one range of three cells -- the query's own cell first, then the left / right
@@ -230,53 +216,33 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   __syncthreads();                                            // the previous call's readers are done with `sh`
   if (tid == 0) sh.ntask = 0;
   // the query's cell (float32 expressions shared with the grid build)
-#if ER_NN_RCP_CELL
-  const float inv_cell = 1.0f / g.cell;                      // (wave-uniform operand; one division per call instead of three per query)
-  const float ux = (qx - g.org[0]) * inv_cell, uy = (qy - g.org[1]) * inv_cell, uz = (qz - g.org[2]) * inv_cell;
-#else
   const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
-#endif
   const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
   const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
   const int ix = inside ? (int)cx : 0, iy = inside ? (int)cy : 0, iz = inside ? (int)cz : 0;
-  const int nx = g.dim[0];
-  const bool has_l = ix - 1 >= 0 && ix - 1 < nx, has_o = ix >= 0 && ix < nx, has_r = ix + 1 >= 0 && ix + 1 < nx;
-  const bool valid = inside && (has_l | has_o | has_r);
-#if ER_NN_ROWMASK
-  // the home cell's mask (all ones for a query whose home cell is outside the grid): fetched now, needed after the own cell's scan
-  unsigned rmask = 0x3ffu;
-  if (valid && has_o && iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2])
-    rmask = ((const ER_GLOBAL unsigned short*)g.rowmask)[(unsigned)((iz * g.dim[1] + iy) * nx + ix)];
-#endif
   __syncthreads();                                            // (sh.ntask is zero)
   unsigned long long key = kNoHit;
-  if (valid) {
-    // distance from q to the lower / upper face of its own cell along x, y and z (metres)
+  if (inside) {
+    // distance from q to the lower / upper face of its own cell along x, y and z (metres), squared
     const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
                 zhi = g.cell - zlo;
+    const float xl2 = xlo * xlo, xr2 = xhi * xhi;
     float bound = limit2 * 1.0001f + g.slack;
-    if (iy >= 0 && iy < g.dim[1] && iz >= 0 && iz < g.dim[2]) {
-      const int row = (iz * g.dim[1] + iy) * nx;
-      if (has_o) {
-        key = scan_row<kU>(g, row, ix, ix, qx, qy, qz, key);
-        bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);   // the other cells must beat this one
-        if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
-      }
-#if ER_NN_ROWMASK
-      if (has_l && xlo * xlo <= bound && (rmask & 0x100u)) {
-#else
-      if (has_l && xlo * xlo <= bound) {
-#endif
-        key = scan_row<kU>(g, row, ix - 1, ix - 1, qx, qy, qz, key);
+    const ER_GLOBAL char* csb = (const ER_GLOBAL char*)g.cell_start;
+    const int pnx = g.pnx, pny = g.pny;
+    int home = ((iz + 2) * pny + (iy + 2)) * pnx + (ix + 1);   // the cell LEFT of the query's own cell: where the four bounds of a row's three cells begin
+    {
+      const i4v h = *(const ER_GLOBAL i4v*)(csb + (unsigned)home * 4u);   // L, O, R, E of the home row
+      key = scan_range<kU>(g, h.y, h.z, qx, qy, qz, key);                  // the query's own cell first
+      bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);   // the other cells must beat this one
+      if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;                   // (any-hit mode: done)
+      if (xl2 <= bound) {
+        key = scan_range<kU>(g, h.x, h.y, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
-#if ER_NN_ROWMASK
-      if (has_r && xhi * xhi <= bound && (rmask & 0x200u)) {
-#else
-      if (has_r && xhi * xhi <= bound) {
-#endif
-        key = scan_row<kU>(g, row, ix + 1, ix + 1, qx, qy, qz, key);
+      if (xr2 <= bound) {
+        key = scan_range<kU>(g, h.z, h.w, qx, qy, qz, key);
         bound = fminf(bound, __uint_as_float((unsigned)(key >> 32)) * 1.0001f + g.slack);
         if (__uint_as_float((unsigned)(key >> 32)) < hit2) bound = -1.f;
       }
@@ -284,81 +250,46 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
     sh.q[0][tid] = qx;
     sh.q[1][tid] = qy;
     sh.q[2][tid] = qz;
-    // the two cell bounds of every surviving row (a row that did not survive reads cell_start[0] twice: an empty range)
-    const ER_GLOBAL int* csb = (const ER_GLOBAL int*)g.cell_start;
-    int row_home = (iz * g.dim[1] + iy) * nx;                 // the eight rows are wave-uniform steps away from it: one integer multiply per
-    asm volatile("" : "+v"(row_home));                        // query, not one per row (opaque, or the compiler folds the steps back into y and z)
-    int r_s0[8], r_s1[8];
+    // the eight neighbour rows: wave-uniform steps away from the home row, every one of them inside the array -- all eight 16-byte loads are issued
+    // up front behind one wait (a row that does not survive the test below is loaded anyway: no address select)
+    asm volatile("" : "+v"(home));                            // (opaque, or the compiler folds the steps back into y and z)
+    const float yl2 = ylo * ylo, yh2 = yhi * yhi, zl2 = zlo * zlo, zh2 = zhi * zhi;
+    int r_s0[8], r_n[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int pass = j < 4 ? j : j + 1;
-      const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-#if ER_NN_ROWMASK
-      const bool holds = (rmask >> j) & 1u;
-      if (__ballot(holds) == 0ull) {                          // wave-uniform: no lane's row j holds a point
-        r_s0[j] = r_s1[j] = 0;
-        continue;
+    for (int j0 = 0; j0 < 8; j0 += ER_NN_PAD_BATCH) {           // (ER_NN_PAD_BATCH rows' bounds in flight at a time: 4 registers per row)
+      i4v rb[ER_NN_PAD_BATCH];
+#pragma unroll
+      for (int jj = 0; jj < ER_NN_PAD_BATCH; jj++) {
+        const int j = j0 + jj, pass = j < 4 ? j : j + 1;
+        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+        rb[jj] = *(const ER_GLOBAL i4v*)(csb + (unsigned)(home + (dz * pny + dy) * pnx) * 4u);
       }
-#else
-      constexpr bool holds = true;
-#endif
-      const float ey = dy < 0 ? ylo : (dy > 0 ? yhi : 0.f), ez = dz < 0 ? zlo : (dz > 0 ? zhi : 0.f);
-      const int y = iy + dy, z = iz + dz;
-      const float e2 = ey * ey + ez * ez;
-      const bool wl = has_l && xlo * xlo + e2 <= bound, wr = has_r && xhi * xhi + e2 <= bound;
-      const int xa = max(wl ? ix - 1 : ix, 0), xb = min(wr ? ix + 1 : ix, nx - 1);
-      const bool live = holds && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && e2 <= bound && (has_o || wl || wr) && xa <= xb;
-      const int row = row_home + (dz * g.dim[1] + dy) * nx;
-      const unsigned i0 = live ? (unsigned)(row + xa) : 0u, i1 = live ? (unsigned)(row + xb) : 0u;
-      r_s0[j] = csb[i0];
-      r_s1[j] = csb[i1 + (live ? 1u : 0u)];
-    }
-#if ER_NN_ONE_RESERVE
-    unsigned long long wants[8];
-    int total = 0;                                            // (wave-uniform)
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int n = r_s1[j] - r_s0[j];
-      wants[j] = __ballot(n > 0 && n < (1 << 23));
-      total += __popcll(wants[j]);
-    }
-    int slot = 0;                                             // (wave-uniform) the wave's first slot, then the first slot of row j's tasks
-    if (total) {
-      const int leader = __ffsll((long long)__ballot(1)) - 1;
-      int b = 0;
-      if ((int)__lane_id() == leader) b = atomicAdd(&sh.ntask, total);
-      slot = __builtin_amdgcn_readlane(b, leader);
+      for (int jj = 0; jj < ER_NN_PAD_BATCH; jj++) {
+        const int j = j0 + jj, pass = j < 4 ? j : j + 1;
+        const int dy = pass % 3 - 1, dz = pass / 3 - 1;
+        const float e2 = (dy < 0 ? yl2 : (dy > 0 ? yh2 : 0.f)) + (dz < 0 ? zl2 : (dz > 0 ? zh2 : 0.f));
+        const bool wl = xl2 + e2 <= bound, wr = xr2 + e2 <= bound;
+        const int s0 = wl ? rb[jj].x : rb[jj].y, s1 = wr ? rb[jj].w : rb[jj].z;
+        r_s0[j] = s0;
+        r_n[j] = e2 <= bound ? s1 - s0 : 0;
+        asm volatile("" : "+v"(r_s0[j]), "+v"(r_n[j]));         // materialised HERE: the four bounds die now (left alone, the compiler sinks the selects
+      }                                                        // to each row's push and keeps all 32 bound registers alive across the fallback scans)
+      __builtin_amdgcn_sched_barrier(0);                       // (... and the scheduler hoists all eight loads above the first batch's selects)
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const int n = r_s1[j] - r_s0[j];
-      if (n > 0) {
-        const int before = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(wants[j] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wants[j], 0u));
-        const int t = n < (1 << 23) ? slot + before : kTaskCap;
-        if (t < kTaskCap) {
-          sh.task_s0[t] = r_s0[j];
-          sh.task_nq[t] = (n << 8) | tid;
-        } else {                                              // the task list is full (or the range does not fit the packing): scan it here
-          key = scan_range<kU>(g, r_s0[j], r_s1[j], qx, qy, qz, key);
-        }
-      }
-      slot += __popcll(wants[j]);
-    }
-#else
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int n = r_s1[j] - r_s0[j];
+      const int n = r_n[j];
       if (n > 0) {
         const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
         if (t < kTaskCap) {
           sh.task_s0[t] = r_s0[j];
           sh.task_nq[t] = (n << 8) | tid;
         } else {                                              // the task list is full (or the range does not fit the packing): scan it here
-          key = scan_range<kU>(g, r_s0[j], r_s1[j], qx, qy, qz, key);
+          key = scan_range<kU>(g, r_s0[j], r_s0[j] + n, qx, qy, qz, key);
         }
       }
     }
-#endif
   }
   sh.best[tid] = key;
   __syncthreads();
@@ -726,6 +657,11 @@ __global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restric
   // l >> 1 -- and the wave adds it to ITS row of the LDS accumulator.  The row values are live only between the NN search and the
   // butterfly, so the kernel keeps the register footprint of the plain NN kernels (occupancy is what the latency-bound search
   // needs: with thread-private float64 sums carried across the slices the kernel held 126 VGPRs = 4 waves per SIMD).
+  // The order in which a pair's 29 sums are added depends on `pts` (one partial vector per workgroup of pts slices), which the host re-picks per chunk
+  // from the pairs still running: a pair's transform can differ in its last bits between two lists it is part of.  Round 5 tried one
+  // partial vector per SLICE, flushed behind the next slice's barriers (order independent of pts): parity green, but the kernel then needs one more
+  // 64-bit value across the row arithmetic than its 80 registers hold (12 bytes of scratch) and the ICP phase of the 50-pair list went from 2.26 to
+  // 2.36 ms (profiles/r05c_ab_slice_partials.txt) -- not kept; include/er_hip.h states the dependence.
   __shared__ double part[kBlock / 64][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane < 32) part[wave][lane] = 0.0;                     // (each wave only ever touches its own row: no barrier needed until the end)
@@ -920,47 +856,66 @@ __global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restri
 // :723-731 with which = 1):  info[0..2] = sum 2sx,2sy,2sz; [3..5] = sum (4sz^2+4sy^2),(4sz^2+4sx^2),(4sy^2+4sx^2);
 // [6..8] = sum -4sysx, -4szsx, -4szsy; [9] = count   (the distinct terms of sum A^T A, A = [I | 2*skew-like(s)]); info is
 // kAcc doubles per pair (source terms at 0, target terms at 10).
-__global__ __launch_bounds__(kBlock) void k_count_blocks(const PairDev* __restrict__ P, double* __restrict__ info, int want_source, int want_target) {
+// Round 5: a workgroup takes kCountSlices consecutive blocks, keeps the twenty sums thread-private across them and leaves ONE partial vector per
+// workgroup in the pair's `partial` scratch (free here: the ICP loop that owns it has ended); k_scan_blocks adds the partial vectors in a fixed order.
+// Rounds 1-4 reduced every block of 256 points by itself and added its ten sums to the pair's accumulator with float64 atomics: 977 workgroups x 10
+// atomics per pair on 10 addresses -- the kernel took 86 us per 8-pair launch, 0.60 ms per 50-pair list, more than the pre-check's NN search
+// (profiles/r05b_icp_three_call_kernel_stats.txt), and its result depended on the order the atomics arrived in.
+constexpr int kCountSlices = 8;
+__global__ __launch_bounds__(kBlock) void k_count_blocks(const PairDev* __restrict__ P, int want_source, int want_target) {
   const PairDev& p = P[blockIdx.y];
-  const int n = p.n;
-  if ((int)blockIdx.x >= p.nb) return;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  const int m = k < n ? p.match[k] : -1;
-  const bool hit = m >= 0;
-  const unsigned long long b = __ballot(hit);
-  __shared__ int wcnt[kBlock / 64];
-  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = __popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 0; w < kBlock / 64; w++) s += wcnt[w];
-    p.block_count[blockIdx.x] = s;
-  }
-  for (int which = 0; which < 2; which++) {
-    if (!(which ? want_target : want_source)) continue;        // uniform
-    double v[10];
+  const int n = p.n, nb = p.nb;
+  const int b0 = blockIdx.x * kCountSlices;
+  if (b0 >= nb) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ int wcnt[kCountSlices][kBlock / 64];
+  double v[20];
 #pragma unroll
-    for (int i = 0; i < 10; i++) v[i] = 0.0;
-    if (hit) {                                                                                 // :192-204
-      const float* __restrict__ s = which ? p.tgt_xyz + 3 * (size_t)m : p.src_xyz + 3 * (size_t)k;
-      const float sx = s[0], sy = s[1], sz = s[2];
-      const double ax = (double)(2 * sx), ay = (double)(2 * sy), az = (double)(2 * sz);
-      v[0] = ax; v[1] = ay; v[2] = az;
-      v[3] = az * az + ay * ay;     // (0*0 + (-2sz)(-2sz)) + (2sy)(2sy)
-      v[4] = az * az + ax * ax;     // ((2sz)(2sz) + 0*0) + (-2sx)(-2sx)
-      v[5] = ay * ay + ax * ax;     // ((-2sy)(-2sy) + (2sx)(2sx)) + 0*0
-      v[6] = ay * (-ax);            // (3,4): (2sy)(-2sx)
-      v[7] = (-az) * ax;            // (3,5): (-2sz)(2sx)
-      v[8] = az * (-ay);            // (4,5): (2sz)(-2sy)
-      v[9] = 1.0;
+  for (int i = 0; i < 20; i++) v[i] = 0.0;
+#pragma unroll
+  for (int c = 0; c < kCountSlices; c++) {
+    const int k = (b0 + c) * kBlock + (int)threadIdx.x;
+    const int m = (b0 + c < nb && k < n) ? p.match[k] : -1;
+    const bool hit = m >= 0;
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) wcnt[c][wave] = __popcll(b);
+    if (hit) {                                                                                   // :192-204
+#pragma unroll
+      for (int which = 0; which < 2; which++) {
+        if (!(which ? want_target : want_source)) continue;      // uniform
+        const float* __restrict__ s = which ? p.tgt_xyz + 3 * (size_t)m : p.src_xyz + 3 * (size_t)k;
+        const float sx = s[0], sy = s[1], sz = s[2];
+        const double ax = (double)(2 * sx), ay = (double)(2 * sy), az = (double)(2 * sz);
+        double* u = v + 10 * which;
+        u[0] += ax; u[1] += ay; u[2] += az;
+        u[3] += az * az + ay * ay;     // (0*0 + (-2sz)(-2sz)) + (2sy)(2sy)
+        u[4] += az * az + ax * ax;     // ((2sz)(2sz) + 0*0) + (-2sx)(-2sx)
+        u[5] += ay * ay + ax * ax;     // ((-2sy)(-2sy) + (2sx)(2sx)) + 0*0
+        u[6] += ay * (-ax);            // (3,4): (2sy)(-2sx)
+        u[7] += (-az) * ax;            // (3,5): (-2sz)(2sx)
+        u[8] += az * (-ay);            // (4,5): (2sz)(-2sy)
+        u[9] += 1.0;
+      }
     }
-    __syncthreads();
-    block_reduce_atomic<10>(v, info + (size_t)blockIdx.y * kAcc + 10 * which);
   }
+  __syncthreads();
+  if (threadIdx.x < kCountSlices && b0 + (int)threadIdx.x < nb)
+    p.block_count[b0 + threadIdx.x] = ((wcnt[threadIdx.x][0] + wcnt[threadIdx.x][1]) + wcnt[threadIdx.x][2]) + wcnt[threadIdx.x][3];
+  if (!(want_source | want_target)) return;                    // uniform
+  __shared__ double red[kBlock / 64][20];
+#pragma unroll
+  for (int i = 0; i < 20; i++) {
+    double t = v[i];
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+    if (lane == 0) red[wave][i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 20) p.partial[(size_t)blockIdx.x * 32 + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// Exclusive scan of a pair's per-block match counts (a few thousand blocks at most): one workgroup per pair.
-__global__ __launch_bounds__(1024) void k_scan_blocks(const PairDev* __restrict__ P, int* __restrict__ totals) {
+// Exclusive scan of a pair's per-block match counts (a few thousand blocks at most) and, with want_info, the fixed-order total of the information
+// partial vectors k_count_blocks left (info[0..19] of the pair are OVERWRITTEN; info[20], the fitness sum of k_ransac_match, is left alone): one workgroup per pair.
+__global__ __launch_bounds__(1024) void k_scan_blocks(const PairDev* __restrict__ P, int* __restrict__ totals, double* __restrict__ info, int want_info) {
   __shared__ int buf[1024];
   __shared__ int carry;
   const PairDev& p = P[blockIdx.x];
@@ -984,6 +939,22 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const PairDev* __restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+  if (want_info) {                                              // (uniform) 32 values x 32 strided slices of the partial vectors, then the slices in order
+    __shared__ double fin[32][33];
+    const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int nparts = (nb + kCountSlices - 1) / kCountSlices;
+    double q = 0.0;
+    if (val < 20)
+      for (int b = slice; b < nparts; b += 32) q += p.partial[(size_t)b * 32 + val];
+    fin[slice][val] = q;
+    __syncthreads();
+    if (threadIdx.x < 20) {
+      double r = 0.0;
+#pragma unroll
+      for (int sl = 0; sl < 32; sl++) r += fin[sl][threadIdx.x];
+      info[(size_t)blockIdx.x * kAcc + threadIdx.x] = r;
+    }
+  }
 }
 
 // Stable compaction: pairs (match[k], k) in ascending k (CorresApp.cpp:157, file order of corres_*.txt).
@@ -1001,8 +972,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const PairDev* __restrict__ 
   if (m >= 0) {
     int o = p.block_offset[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; w++) o += wcnt[w];
-    p.pairs[2 * o] = m;                                        // (o < n: every match has its own k)
-    p.pairs[2 * o + 1] = k;
+    reinterpret_cast<int2*>(p.pairs)[o] = make_int2(m, k);       // (o < n: every match has its own k; the slices of `pairs` are 16-byte aligned)
   }
 }
 
@@ -1112,7 +1082,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_cells(ChunkDesc D, unsigned* _
     q[a] = (int)floorf((p[a] - G.org[a]) / G.cell);
     q[a] = min(max(q[a], 0), G.dim[a] - 1);
   }
-  const int c = (q[2] * G.dim[1] + q[1]) * G.dim[0] + q[0];
+  const int c = ((q[2] + 2) * (G.dim[1] + 4) + (q[1] + 2)) * (G.dim[0] + 4) + (q[0] + 2);   // two rings of empty cells around the box (struct Grid)
   const unsigned g = (unsigned)(D.pt_off[y] + i);
   key[g] = ((unsigned)y << D.shift) | (unsigned)c;
   idx[g] = g;
@@ -1132,34 +1102,6 @@ __global__ __launch_bounds__(kBlock) void k_chunk_gather(ChunkDesc D, const unsi
   sorted[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
 }
 
-#if ER_NN_ROWMASK
-// One thread per cell of every cloud of the chunk (blockIdx.y = cloud), after the prefix sum: bit j (0-7) = the cells x-1..x+1 of neighbour row j
-// (nn_block's order: dy fastest, the home row left out) hold a point; bit 8 / 9 = the home row's cell x-1 / x+1 does.
-__global__ __launch_bounds__(kBlock) void k_chunk_rowmask(ChunkDesc D, const int* __restrict__ cs_all, unsigned short* __restrict__ mask_all) {
-  const int yc = blockIdx.y;
-  const GridDims G = D.G[yc];
-  const int nx = G.dim[0], ny = G.dim[1], nz = G.dim[2];
-  const int c = blockIdx.x * kBlock + threadIdx.x;
-  if (c >= nx * ny * nz) return;
-  const int* __restrict__ cs = cs_all + D.cs_off[yc];
-  const int x = c % nx, y = (c / nx) % ny, z = c / (nx * ny);
-  const int xa = max(x - 1, 0), xb = min(x + 1, nx - 1);
-  unsigned m = 0;
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const int pass = j < 4 ? j : j + 1;
-    const int dy = pass % 3 - 1, dz = pass / 3 - 1;
-    const int yy = y + dy, zz = z + dz;
-    if (yy < 0 || yy >= ny || zz < 0 || zz >= nz) continue;
-    const int row = (zz * ny + yy) * nx;
-    if (cs[row + xb + 1] - cs[row + xa] > 0) m |= 1u << j;
-  }
-  const int rh = (z * ny + y) * nx;
-  if (x - 1 >= 0 && cs[rh + x] - cs[rh + x - 1] > 0) m |= 0x100u;
-  if (x + 1 < nx && cs[rh + x + 2] - cs[rh + x + 1] > 0) m |= 0x200u;
-  mask_all[D.cs_off[yc] + c] = (unsigned short)m;            // (indexed like cell_start: one spare entry per cloud)
-}
-#endif
 
 // Grow-only scratch of the grid build, one per device, handed out under a mutex (er_cloud_create may be called from
 // several host threads; builds on one device then take turns).
@@ -1482,9 +1424,11 @@ void expand_information(const double* acc, double* I) {
   I[4 * 6 + 5] = I[5 * 6 + 4] = acc[8];
 }
 
-// Iterations enqueued per host visit.  PCL's loop runs 3 iterations on most fragment pairs of the pipeline (the third one
-// meets the stop rule): one chunk usually ends the job; workgroups of a chunk that come after a pair's stop decision return at once.
-constexpr int kIcpChunk = 3;
+// Iterations enqueued per host visit (the first visit; later ones twice as many).  PCL's loop runs 3 iterations on most fragment pairs of the
+// pipeline (the third one meets the stop rule) and 4 on a few: one chunk usually ends the job; workgroups of a chunk that come after a pair's
+// stop decision return at once.
+constexpr int kIcpChunk = 4;
+static int icp_chunk() { const char* e = getenv("ER_ICP_CHUNK"); const int v = e ? atoi(e) : kIcpChunk; return v < 1 ? 1 : (v > 20 ? 20 : v); }   // (A/B switch)
 
 }  // namespace
 
@@ -1503,6 +1447,10 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   for (int i = 0; i < n_clouds; i++) out[i] = nullptr;
   for (int i = 0; i < n_clouds; i++)
     if (counts[i] < 0 || (counts[i] > 0 && (!xyz_host[i] || !normal_host[i]))) return er::fail("er_cloud_create: bad arguments (cloud %d)", i);
+  // the search kernels address candidates, matched-target records and the ICP loop's X by UNSIGNED 32-bit byte offsets (s * 16, i * 32, k * 12: struct
+  // PairDev's hot accesses): a cloud must stay below 2^27 points, or those offsets wrap and the kernels read other memory
+  for (int i = 0; i < n_clouds; i++)
+    if (counts[i] >= (1 << 27)) return er::fail("er_cloud_create: cloud %d has %d points; the limit is 2^27 - 1 (32-bit byte offsets in the search kernels)", i, counts[i]);
   if (!(grid_cell > 0.f)) return er::fail("er_cloud_create: grid_cell must be positive");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -1708,16 +1656,17 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
           hi[a] = ordered_float(got[3 + a]);
         }
       }
+      constexpr int kRing = 4;                                    // two rings of empty cells per axis (struct Grid)
       for (;;) {
         long total = 1;
         for (int a = 0; a < 3; a++) {
           dim[a] = (int)std::floor((hi[a] - lo[a]) / cell) + 1;
-          total *= dim[a];
+          total *= dim[a] + kRing;
         }
         if (total <= (1L << 25)) break;
         cell *= 2.f;
       }
-      const int ncell = dim[0] * dim[1] * dim[2];
+      const int ncell = (dim[0] + kRing) * (dim[1] + kRing) * (dim[2] + kRing);
       max_cells = std::max(max_cells, ncell);
       C.D.cs_off[k] = cs_total;
       cs_total += (long)ncell + 1;
@@ -1728,14 +1677,12 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
       }
       C.D.G[k].cell = cell;
       c->grid.slack = grid_slack(dim, cell);
+      c->grid.pnx = dim[0] + 4;
+      c->grid.pny = dim[1] + 4;
     }
     C.D.cs_off[m] = cs_total;
     C.cells = new CloudSlab();
-#if ER_NN_ROWMASK
-    const size_t cells_bytes = (size_t)cs_total * sizeof(int) + (size_t)cs_total * sizeof(unsigned short);   // [cell_start of the chunk | row masks]
-#else
     const size_t cells_bytes = (size_t)cs_total * sizeof(int);
-#endif
     hipError_t e = hipMalloc(&C.cells->p, cells_bytes);
     if (e != hipSuccess) {
       delete C.cells;
@@ -1750,9 +1697,6 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
       c->cell_start = cs + C.D.cs_off[k];
       c->grid.pts = c->sorted;
       c->grid.cell_start = c->cell_start;
-#if ER_NN_ROWMASK
-      c->grid.rowmask = reinterpret_cast<const unsigned short*>(cs + cs_total) + C.D.cs_off[k];
-#endif
     }
     int bits = 1;
     while ((1L << bits) < (long)max_cells) bits++;
@@ -1769,9 +1713,6 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
     tmp = gs.cub_cap;
     ER_HIP_TRY(hipcub::DeviceScan::InclusiveSum(gs.cub[q], tmp, cs, cs, (int)cs_total, L));
     if (C.total > 0) hipLaunchKernelGGL(k_chunk_gather, dim3(nblocks_of((int)C.total)), dim3(kBlock), 0, L, C.D, k1, x1, (int)C.total, C.sorted);
-#if ER_NN_ROWMASK
-    hipLaunchKernelGGL(k_chunk_rowmask, dim3(nblocks_of(max_cells), m), dim3(kBlock), 0, L, C.D, cs, reinterpret_cast<unsigned short*>(cs + cs_total));
-#endif
     ER_HIP_TRY(hipGetLastError());
     return 0;
   };
@@ -1889,8 +1830,10 @@ int er_icp_align_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, cons
     ER_HIP_TRY(hipMemcpyAsync(g->d_state, g->h_state, (size_t)m * sizeof(IcpDev), hipMemcpyHostToDevice, g->stream));
     int chunk_no = 0;
     while (n_active > 0) {
-      // the first chunk ends the job for most pairs (three iterations); the stragglers then run six iterations per host visit
-      const int chunk_len = chunk_no++ == 0 ? kIcpChunk : 2 * kIcpChunk;
+      // the first chunk ends the job for most pairs; the stragglers then run twice as many iterations per host visit.  A launch pair whose pairs
+      // are all done costs ~12 us (every workgroup leaves at once), a host visit ~60 us plus the ramp of the next launch: chunks err on the long side
+      // (round 5: 4 then 8 iterations instead of 3 then 6 -- the one pair of the bench list that needs a fourth iteration no longer costs a second visit)
+      const int chunk_len = chunk_no++ == 0 ? icp_chunk() : 2 * icp_chunk();
       ER_HIP_TRY(hipMemcpyAsync(g->d_active, g->h_active, (size_t)n_active * sizeof(int), hipMemcpyHostToDevice, g->stream));
       // points per thread of k_icp_iter for THIS chunk: as many slices of 256 points per workgroup as still leave ~4 workgroups per CU in
       // flight -- 8 for a full list, 1 for the two or three stragglers of a hard list on their way to the iteration limit (round 4: the
@@ -1993,9 +1936,10 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
 // Compaction chain of slots [s0, s0 + m) of the group (match already written): per-block counts (+ information terms), per-pair
 // scan, stable compaction; the totals and the information terms come back to the pinned mirrors.  Records `done` on the stream.
 static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done) {
-  hipLaunchKernelGGL(k_count_blocks, dim3(mxb, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0, g->d_info + (size_t)s0 * kAcc, want_source ? 1 : 0,
+  hipLaunchKernelGGL(k_count_blocks, dim3((mxb + kCountSlices - 1) / kCountSlices, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0, want_source ? 1 : 0,
                      want_target ? 1 : 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, g->stream, g->d_pairs + s0, g->d_totals + s0);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, g->stream, g->d_pairs + s0, g->d_totals + s0, g->d_info + (size_t)s0 * kAcc,
+                     (want_source || want_target) ? 1 : 0);
   hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipMemcpyAsync(g->h_totals + s0, g->d_totals + s0, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, g->stream));

@@ -3,10 +3,11 @@
 //
 //   frames (path A, as BASELINE.json prescribes): contiguous frame blocks per GPU into private volumes, then
 //       er_tsdf_allreduce = [agree on the key count: all-reduce(MAX) of one int] -> [all-gather of the touched unit keys,
-//       padded to that count] -> union -> ONE ncclReduce / ncclAllReduce (sum, float) over the [key][sdf*weight | weight]
-//       planes of the union -> import (weight = W, sdf = SW / W).  The running mean with unit weights is a sum
-//       (TSDFVolume.cpp:93-94: sdf' = (sdf w + tsdf) / (w + 1), w' = w + 1), so this equals the sequential result up to the
-//       float32 rounding order: weights exact, sdf within 1e-5.
+//       padded to that count] -> union + who touched what -> ONE ncclReduce / ncclAllReduce (sum, float) over the
+//       [key][sdf*weight | weight] planes of the units two or more ranks touched -> import (weight = W, sdf = SW / W), and one
+//       grouped ncclSend / ncclRecv step for the units only one rank touched (raw, bit for bit; er_merge_protocol.h).  The running
+//       mean with unit weights is a sum (TSDFVolume.cpp:93-94: sdf' = (sdf w + tsdf) / (w + 1), w' = w + 1), so this equals the
+//       sequential result up to the float32 rounding order: weights exact, sdf within 1e-5 (exact in single-toucher units).
 //   units  (the bit-exact alternative): er_tsdf_set_unit_shard in er_tsdf.hip -- no collective at all.
 //   pairs  (path B): independent, no collective (BuildCorrespondence --gpus).
 //
@@ -39,6 +40,10 @@ struct Rccl {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclReduce) Reduce = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   bool ok = false;
   char why[256] = "librccl.so.1 not found";      // dlerror() of the failed load, read ONCE (a second call returns NULL)
@@ -70,10 +75,15 @@ Rccl* rccl() {
     ER_SYM(AllReduce, "ncclAllReduce");
     ER_SYM(Reduce, "ncclReduce");
     ER_SYM(AllGather, "ncclAllGather");
+    ER_SYM(Send, "ncclSend");
+    ER_SYM(Recv, "ncclRecv");
+    ER_SYM(GroupStart, "ncclGroupStart");
+    ER_SYM(GroupEnd, "ncclGroupEnd");
     ER_SYM(GetErrorString, "ncclGetErrorString");
 #undef ER_SYM
-    R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllReduce && R.Reduce && R.AllGather && R.GetErrorString;
-    if (!R.ok) snprintf(R.why, sizeof R.why, "librccl.so.1 lacks one of the eight nccl* entry points");
+    R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllReduce && R.Reduce && R.AllGather && R.Send && R.Recv &&
+           R.GroupStart && R.GroupEnd && R.GetErrorString;
+    if (!R.ok) snprintf(R.why, sizeof R.why, "librccl.so.1 lacks one of the twelve nccl* entry points");
   });
   return R.ok ? &R : nullptr;
 }
@@ -91,8 +101,11 @@ Rccl* rccl() {
 struct er_comm_s {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
-  float* buf = nullptr;        // [union][2][64^3] planes (grow-only)
+  float* buf = nullptr;        // [multi-toucher units][sdf*w | w][64^3] planes of the reduction (grow-only)
   size_t buf_units = 0;
+  float *sbuf = nullptr, *rbuf = nullptr;   // raw single-toucher units on their way out / in (grow-only)
+  size_t sbuf_units = 0, rbuf_units = 0;
+  er::MergeStats last;         // what the last merge moved
   int* ikeys = nullptr;        // device scratch: [1 + max_keys * (world + 1)] ints (grow-only)
   size_t ikeys_cap = 0;
 };
@@ -141,6 +154,32 @@ struct RcclTransport : er::MergeTransport {
       ER_NCCL_TRY(R, R->Reduce(planes, planes, count, ncclFloat32, ncclSum, root, c->comm, S));
     return 0;
   }
+  // the single-toucher units: every send and receive of this rank in ONE group (RCCL pairs them up across the ranks; over xGMI each pair is a
+  // direct link).  A rank with nothing to send or receive issues nothing.
+  int exchange(const float* send, size_t send_count, const std::vector<int>& send_to, float* recv, const std::vector<size_t>& recv_count) override {
+    bool any = !send_to.empty() && send_count > 0;
+    for (size_t n : recv_count) any = any || n > 0;
+    if (!any) return 0;
+    ER_NCCL_TRY(R, R->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    if (send_count > 0)
+      for (int q : send_to) {
+        const ncclResult_t e = R->Send(send, send_count, ncclFloat32, q, c->comm, S);
+        if (e != ncclSuccess) bad = e;
+      }
+    size_t off = 0;
+    for (int q = 0; q < c->world; q++) {
+      const size_t n = recv_count[(size_t)q];
+      if (!n) continue;
+      const ncclResult_t e = R->Recv(recv + off, n, ncclFloat32, q, c->comm, S);
+      if (e != ncclSuccess) bad = e;
+      off += n;
+    }
+    const ncclResult_t e2 = R->GroupEnd();                      // (always closed, whatever a call inside said)
+    if (bad != ncclSuccess || e2 != ncclSuccess)
+      return ::er::fail("er_tsdf_allreduce: ncclSend / ncclRecv failed: %s", R->GetErrorString(bad != ncclSuccess ? bad : e2));
+    return 0;
+  }
 };
 
 // er::MergeVolume over an er_tsdf_t; the planes live in the communicator's grow-only device buffer.
@@ -170,6 +209,26 @@ struct DeviceVolume : er::MergeVolume {
     return er_tsdf_export_weighted(h, uk, nu, c->buf);          // on the volume's stream, like the collectives
   }
   int import_planes(const int* uk, int nu, const float* planes) override { return er_tsdf_import_weighted(h, uk, nu, planes); }
+  static int grow(float** b, size_t* have, int units) {
+    if (*have >= (size_t)units) return 0;
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+    *have = 0;
+    ER_HIP_TRY(hipMalloc((void**)b, (size_t)units * 2 * ER_UNIT_VOX * sizeof(float)));
+    *have = (size_t)units;
+    return 0;
+  }
+  int export_raw(const int* uk, int nu, float** block) override {
+    if (grow(&c->sbuf, &c->sbuf_units, nu)) return 1;
+    *block = c->sbuf;
+    return er_tsdf_export_raw(h, uk, nu, c->sbuf);
+  }
+  int receive_buffer(int nu, float** block) override {
+    if (grow(&c->rbuf, &c->rbuf_units, nu)) return 1;
+    *block = c->rbuf;
+    return 0;
+  }
+  int import_raw(const int* uk, int nu, const float* block) override { return er_tsdf_import_raw(h, uk, nu, block); }
 };
 
 }  // namespace
@@ -240,7 +299,14 @@ int er_comm_create_local(int n, const int* devices, er_comm_t* out) {
     out[i] = c;
   }
   for (int i = 0; i < n; i++)
-    if (comm_scratch(out[i])) return 1;                          // (the caller destroys the communicators it was given)
+    if (comm_scratch(out[i])) {                                  // all or nothing, like every other failure path of this call (the
+      const std::string why = er_last_error();                   // handles used to stay in out[] for the caller to destroy, the earlier paths left NULLs)
+      for (int k = 0; k < n; k++) {
+        er_comm_destroy(out[k]);
+        out[k] = nullptr;
+      }
+      return er::fail("%s", why.c_str());
+    }
   return 0;
 }
 
@@ -248,6 +314,8 @@ int er_comm_destroy(er_comm_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   if (c->buf) (void)hipFree(c->buf);
+  if (c->sbuf) (void)hipFree(c->sbuf);
+  if (c->rbuf) (void)hipFree(c->rbuf);
   if (c->ikeys) (void)hipFree(c->ikeys);
   Rccl* R = rccl();
   if (R && c->comm) (void)R->CommDestroy(c->comm);
@@ -278,7 +346,8 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   std::string why = pre ? er_last_error() : "";                 // (the protocol's later steps may overwrite the thread's message)
   RcclTransport t(R, c, pre && er::tsdf_device(h) != c->device ? nullptr : er::tsdf_stream(h));
   DeviceVolume v(h, c);
-  const int r = er::merge_protocol(t, v, root, union_units, pre ? 1 : 0);
+  c->last = er::MergeStats();
+  const int r = er::merge_protocol(t, v, root, union_units, pre ? 1 : 0, &c->last);
   if (r == er::MERGE_OK) {
     ER_HIP_TRY(hipStreamSynchronize(er::tsdf_stream(h)));
     return 0;
@@ -287,6 +356,16 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
     return er::fail("er_tsdf_allreduce: another rank of the communicator failed before the merge (its own er_last_error() says why); nothing was merged");
   if (pre) return er::fail("%s", why.c_str());
   return 1;                                                     // local / transport failure: the message is already recorded
+}
+
+int er_comm_merge_stats(er_comm_t c, long long stats[8]) {
+  if (!c || !stats) return er::fail("er_comm_merge_stats: NULL argument");
+  const er::MergeStats& m = c->last;
+  stats[0] = m.union_units; stats[1] = m.multi_units; stats[2] = m.single_units; stats[3] = m.sent_units; stats[4] = m.received_units;
+  stats[5] = (long long)(m.reduced_floats * sizeof(float));
+  stats[6] = (long long)(m.sent_floats * sizeof(float));
+  stats[7] = (long long)(m.received_floats * sizeof(float));
+  return 0;
 }
 
 void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi) {

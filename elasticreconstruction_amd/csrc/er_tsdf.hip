@@ -970,29 +970,30 @@ __global__ __launch_bounds__(64) void k_mesh(const float2* __restrict__ pool, co
   if (!pass && lane == 0) slab_count[blockIdx.x] = total;
 }
 
-// Multi-GPU frame split: planes [key][0] = sdf*weight, [key][1] = weight.
-__global__ void k_export_weighted(const float2* __restrict__ pool, const int* __restrict__ slots, float* __restrict__ buf) {
+// Multi-GPU frame split: planes [key][0] = sdf*weight, [key][1] = weight -- what a sum over ranks may add (units several ranks touched);
+// raw != 0: [key][0] = sdf, [key][1] = weight, the unit bit for bit (units only one rank touched travel like this, round 5).
+__global__ void k_export_weighted(const float2* __restrict__ pool, const int* __restrict__ slots, float* __restrict__ buf, int raw) {
   const int q = blockIdx.y;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = slots[q];
   float sw = 0.0f, w = 0.0f;
   if (slot >= 0) {
     const float2 v = pool[(size_t)slot * kUnitVox + l];
-    sw = v.x * v.y;
+    sw = raw ? v.x : v.x * v.y;
     w = v.y;
   }
   buf[((size_t)q * 2 + 0) * kUnitVox + l] = sw;
   buf[((size_t)q * 2 + 1) * kUnitVox + l] = w;
 }
 
-__global__ void k_import_weighted(float2* __restrict__ pool, const int* __restrict__ slots, const float* __restrict__ buf) {
+__global__ void k_import_weighted(float2* __restrict__ pool, const int* __restrict__ slots, const float* __restrict__ buf, int raw) {
   const int q = blockIdx.y;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   const int slot = slots[q];
   if (slot < 0) return;
   const float sw = buf[((size_t)q * 2 + 0) * kUnitVox + l];
   const float w = buf[((size_t)q * 2 + 1) * kUnitVox + l];
-  pool[(size_t)slot * kUnitVox + l] = make_float2(w > 0.0f ? sw / w : 0.0f, w);
+  pool[(size_t)slot * kUnitVox + l] = make_float2(raw ? sw : (w > 0.0f ? sw / w : 0.0f), w);
 }
 
 // Host-driven unit allocation (import of units this GPU never touched).
@@ -1890,26 +1891,39 @@ done:
   return rc;
 }
 
-int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf) {
-  if (!h || !keys_host || !dev_buf) return er::fail("er_tsdf_export_weighted: NULL argument");
+static int export_units(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf, int raw, const char* who) {
+  if (!h || !keys_host || !dev_buf) return er::fail("%s: NULL argument", who);
   if (n_keys <= 0) return 0;
   ER_HIP_TRY(hipSetDevice(h->device));
   if (resolve_slots(h, keys_host, n_keys, false)) return 1;
   hipLaunchKernelGGL(k_export_weighted, dim3(er::kUnitVox / kBlock, n_keys), dim3(kBlock), 0, h->stream, h->pool,
-                     h->slot_scratch, dev_buf);
+                     h->slot_scratch, dev_buf, raw);
   ER_HIP_TRY(hipGetLastError());
   return 0;
 }
 
-int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf) {
-  if (!h || !keys_host || !dev_buf) return er::fail("er_tsdf_import_weighted: NULL argument");
+static int import_units(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf, int raw, const char* who) {
+  if (!h || !keys_host || !dev_buf) return er::fail("%s: NULL argument", who);
   if (n_keys <= 0) return 0;
   ER_HIP_TRY(hipSetDevice(h->device));
   if (resolve_slots(h, keys_host, n_keys, true)) return 1;
   hipLaunchKernelGGL(k_import_weighted, dim3(er::kUnitVox / kBlock, n_keys), dim3(kBlock), 0, h->stream, h->pool,
-                     h->slot_scratch, dev_buf);
+                     h->slot_scratch, dev_buf, raw);
   ER_HIP_TRY(hipGetLastError());
   return check_flags(h);
+}
+
+int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf) {
+  return export_units(h, keys_host, n_keys, dev_buf, 0, "er_tsdf_export_weighted");
+}
+int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf) {
+  return import_units(h, keys_host, n_keys, dev_buf, 0, "er_tsdf_import_weighted");
+}
+int er_tsdf_export_raw(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf) {
+  return export_units(h, keys_host, n_keys, dev_buf, 1, "er_tsdf_export_raw");
+}
+int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf) {
+  return import_units(h, keys_host, n_keys, dev_buf, 1, "er_tsdf_import_raw");
 }
 
 int er_tsdf_set_profiling(er_tsdf_t h, int enable) {

@@ -6,6 +6,9 @@
   Path A (frames)  contiguous frame blocks per rank into private volumes, then ONE exchange step:
                    all-gather of the touched unit keys -> union, ONE reduce(sum) to rank 0 (or all-reduce) over
                    the [key][sdf*weight | weight] planes of the union, per-voxel divide on import.
+                   (merge_volumes below, the torch.distributed CROSS-CHECK, still reduces the planes of the whole union -- the
+                   dense protocol of rounds 2-4; the product path, er_tsdf_allreduce behind AbiComm, reduces only the units two or
+                   more ranks touched and moves the others point to point: csrc/er_merge_protocol.h.)
                    (The running mean with unit weights is a sum: w = sum_g w_g, sdf = sum_g sdf_g*w_g / w;
                    TSDFVolume.cpp:93-94 applied sequentially gives the same value up to float rounding
                    order, hence tolerance 1e-5 instead of bit parity for this mode.)
@@ -155,6 +158,16 @@ class AbiComm:
         n = C.c_int(0)
         _ffi.check(self._lib.er_tsdf_allreduce(vol._h, self._h, int(root), C.byref(n)), "er_tsdf_allreduce")
         return n.value
+
+    def merge_stats(self):
+        """What this rank's last allreduce moved (er_comm_merge_stats): the sum reduction only carries the units two or more ranks touched,
+        units only one rank touched travel point to point, bit for bit, or stay where they are."""
+        import ctypes as C
+        from . import _ffi
+        st = (C.c_longlong * 8)()
+        _ffi.check(self._lib.er_comm_merge_stats(self._h, st), "er_comm_merge_stats")
+        names = ("union_units", "multi_toucher_units", "single_toucher_units", "units_sent", "units_received", "bytes_reduced", "bytes_sent", "bytes_received")
+        return {n: int(v) for n, v in zip(names, st)}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -201,6 +201,15 @@ class TSDFVolume:
         k = np.ascontiguousarray(keys, dtype=np.int32)
         _ffi.check(self._lib.er_tsdf_import_weighted(self._h, _ffi.ptr(k), k.size, C.c_void_p(dev_ptr)), "er_tsdf_import_weighted")
 
+    def export_raw(self, keys, dev_ptr):
+        """[key][sdf | weight] planes, bit for bit: how a unit only one GPU touched travels (er_tsdf_export_raw)."""
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        _ffi.check(self._lib.er_tsdf_export_raw(self._h, _ffi.ptr(k), k.size, C.c_void_p(dev_ptr)), "er_tsdf_export_raw")
+
+    def import_raw(self, keys, dev_ptr):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        _ffi.check(self._lib.er_tsdf_import_raw(self._h, _ffi.ptr(k), k.size, C.c_void_p(dev_ptr)), "er_tsdf_import_raw")
+
     # -- profiling --------------------------------------------------------------------------------
     def set_profiling(self, enable):
         """True / 1: time every k_integrate launch; n > 1: every n-th launch; False / 0: off."""

@@ -151,6 +151,11 @@ int er_mc_table(unsigned char out[256 * 16]);
  * after an external all-reduce(sum) read them back as weight = W, sdf = SW / W. */
 int er_tsdf_export_weighted(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
 int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
+/* The same layout with [key][0] = sdf itself: a unit BIT FOR BIT -- how a unit that only one GPU touched travels (TSDFVolume.cpp:93-94 is a
+ * sum only where frames of two GPUs met; sdf * w / w would round the others for nothing).  import_raw creates the unit if it is absent and
+ * overwrites it otherwise. */
+int er_tsdf_export_raw(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
+int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
 
 /* Multi-GPU, the bit-exact alternative: shard the volume BY UNIT.  Every GPU is fed ALL frames and runs
  * their pre-pass, but only allocates / integrates / reports the units with er_unit_owner(key, world) == rank.  Units are disjoint
@@ -166,11 +171,17 @@ int er_unit_owner(int key, int world);          /* (xi + yi + zi) mod world: dia
  *                                        communicator (ncclCommInitRank; collective: all ranks must call it);
  *   er_comm_create_local                 ONE process, n GPUs, one host thread per GPU afterwards (ncclCommInitAll).
  * er_tsdf_allreduce merges the private volumes of the ranks after each integrated its own contiguous frame block
- * (er_frame_block): agree on the key count, all-gather the touched unit keys, ONE reduction (sum) of the
- * [key][sdf*weight | weight] planes of the union, import with sdf = SW / W -- algebraically the sequential running mean of
- * TSDFVolume.cpp:93-94 (weights exact, sdf within 1e-5: the float32 summation order differs).  Every rank calls it once;
- * root < 0 leaves the merged volume on every rank (ncclAllReduce), otherwise only on `root` (ncclReduce).
- * union_units (nullable) receives the size of the key union. */
+ * (er_frame_block): agree on the key count, all-gather the touched unit keys -- every rank then knows who touched what --,
+ * ONE reduction (sum) of the [key][sdf*weight | weight] planes of the units TWO OR MORE ranks touched, imported with
+ * sdf = SW / W -- algebraically the sequential running mean of TSDFVolume.cpp:93-94 (weights exact, sdf within 1e-5: the
+ * float32 summation order differs) -- and ONE point-to-point step (ncclSend / ncclRecv) that carries the units only ONE rank
+ * touched, bit for bit, to where the result is wanted; a unit that already lives there does not move (round 5; rounds 2-4
+ * reduced the planes of the whole union).  Every rank calls it once; root < 0 leaves the merged volume on every rank
+ * (ncclAllReduce + every owner sends to all), otherwise only on `root` (ncclReduce + owners send to the root).
+ * union_units (nullable) receives the size of the key union; er_comm_merge_stats what the last merge of this communicator
+ * moved: stats[0] union, [1] multi-toucher units (reduced), [2] single-toucher units, [3] units this rank sent, [4] units this
+ * rank received, [5] bytes handed to the reduction, [6] bytes of the block this rank sent (the same block goes to every receiver), [7] bytes
+ * received. */
 typedef struct er_comm_s* er_comm_t;
 #define ER_COMM_ID_BYTES 128
 int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]);
@@ -180,6 +191,7 @@ int er_comm_destroy(er_comm_t c);
 int er_comm_rank(er_comm_t c);
 int er_comm_world(er_comm_t c);
 int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units);
+int er_comm_merge_stats(er_comm_t c, long long stats[8]);
 /* Contiguous frame block [lo, hi) of `rank` (IntegrateApp.cpp:190-226 is the loop being split). */
 void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi);
 
@@ -196,7 +208,8 @@ typedef struct er_cloud_s* er_cloud_t;
 /* pointclouds_[i] after the NaN-normal filter (CorresApp.cpp:94-98): n points, xyz and normals as
  * separate float[3*n] host arrays (AoS xyz xyz ...).  grid_cell = edge of the uniform search grid
  * built over this cloud when it is used as a TARGET; must be >= every max distance queried later
- * (use reg_dist_, CorresApp.cpp:16). */
+ * (use reg_dist_, CorresApp.cpp:16).  n < 2^27 (134 217 728) points: the search kernels address a cloud with 32-bit byte offsets; larger
+ * clouds are refused. */
 int er_cloud_create(const float* xyz_host, const float* normal_host, int n, float grid_cell, int device,
                     er_cloud_t* out);
 /* The clouds of a LIST of fragments in one call (LoadData's loop, CorresApp.cpp:82-110): xyz_host[i] / normal_host[i] hold counts[i] points.

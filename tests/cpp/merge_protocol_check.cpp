@@ -3,7 +3,10 @@
 // transport and host-array volumes (tiny units), world = 1, 2, 3.  Cases: uneven key counts, an empty rank, every rank empty,
 // root = 0 / 1 / 2 / all-reduce (root < 0), a rank whose key query fails (unit pool overflow) and a rank whose export fails:
 // in the failure cases EVERY rank must come back nonzero -- none may wait in a collective for ever (the run itself is the hang test,
-// tests/test_distributed_cpu.py gives it a timeout).  Prints "OK <cases>" and exits 0 on success.
+// tests/test_distributed_cpu.py gives it a timeout).  Round 5 (the sparse merge): the floats handed to the sum reduction must be exactly
+// 2 x unit voxels x (units two or more ranks touched), every unit only ONE rank touched must arrive on the receiving rank(s) BIT FOR BIT (it
+// travels point to point, no sdf * w / w round trip) and must not move at all when it already lives where it is wanted, and the merged volume
+// must equal the dense algebra (w = sum w_g, sdf = sum sdf_g w_g / w) the protocol of rounds 2-4 computed.  Prints "OK <cases>" and exits 0.
 #include "er_merge_protocol.h"
 
 #include <cmath>
@@ -27,7 +30,12 @@ struct Shared {          // one per communicator
   std::vector<float*> fptr;
   std::vector<int> ibuf;
   std::vector<float> fbuf;
-  explicit Shared(int w) : world(w), iptr((size_t)w), fptr((size_t)w) {}
+  std::vector<const float*> xsend;                       // exchange: every rank's send block, its length and its receivers
+  std::vector<size_t> xcount;
+  std::vector<std::vector<int>> xto;
+  size_t reduced_floats = 0, moved_floats = 0;           // what the data-path steps were handed (reduce: per call; exchange: per (sender, receiver))
+  int reduce_calls = 0, exchange_calls = 0;
+  explicit Shared(int w) : world(w), iptr((size_t)w), fptr((size_t)w), xsend((size_t)w), xcount((size_t)w), xto((size_t)w) {}
   // classic generation barrier; `last` runs inside the critical section of the last arriver
   template <class F> void barrier(F last) {
     std::unique_lock<std::mutex> lk(m);
@@ -76,16 +84,41 @@ struct ThreadTransport : er::MergeTransport {
       s.fbuf.assign(count, 0.f);
       for (int q = 0; q < s.world; q++)                  // rank order: a fixed summation order, like a ring would give
         for (size_t i = 0; i < count; i++) s.fbuf[i] += s.fptr[(size_t)q][i];
+      s.reduced_floats += count;
+      s.reduce_calls++;
     });
     if (root < 0 || root == r) std::copy(s.fbuf.begin(), s.fbuf.end(), planes);
     s.barrier([] {});
     return 0;
   }
+  int exchange(const float* send, size_t send_count, const std::vector<int>& send_to, float* recv, const std::vector<size_t>& recv_count) override {
+    s.xsend[(size_t)r] = send;
+    s.xcount[(size_t)r] = send_count;
+    s.xto[(size_t)r] = send_to;
+    s.barrier([&] {
+      s.exchange_calls++;
+      for (int q = 0; q < s.world; q++) s.moved_floats += s.xcount[(size_t)q] * s.xto[(size_t)q].size();
+    });
+    size_t off = 0;
+    int bad = 0;
+    for (int q = 0; q < s.world; q++) {
+      const size_t n = recv_count[(size_t)q];
+      if (!n) continue;
+      const std::vector<int>& to = s.xto[(size_t)q];     // what I expect from q must be what q sends to me
+      if (q == r || n != s.xcount[(size_t)q] || std::find(to.begin(), to.end(), r) == to.end()) bad = 1;
+      else std::copy(s.xsend[(size_t)q], s.xsend[(size_t)q] + n, recv + off);
+      off += n;
+    }
+    for (int q : send_to)                                // ... and whoever I send to must expect exactly that (checked from the sender's side by the receiver above)
+      if (q == r || q < 0 || q >= s.world) bad = 1;
+    s.barrier([] {});
+    return bad;
+  }
 };
 
 struct HostVolume : er::MergeVolume {
   std::map<int, std::vector<float>> sdf, w;              // key -> VOX values
-  std::vector<float> planes;
+  std::vector<float> planes, raw_out, raw_in;
   bool fail_keys = false, fail_export = false;
   size_t unit_voxels() const override { return VOX; }
   int touched_keys(std::vector<int>& keys) override {
@@ -106,6 +139,29 @@ struct HostVolume : er::MergeVolume {
       }
     }
     *out = planes.data();
+    return 0;
+  }
+  int export_raw(const int* uk, int nu, float** out) override {
+    if (fail_export) return 1;
+    raw_out.assign((size_t)nu * 2 * VOX, 0.f);
+    for (int u = 0; u < nu; u++) {
+      if (!sdf.count(uk[u])) return 1;                    // the protocol only asks for units this rank owns
+      std::copy(sdf[uk[u]].begin(), sdf[uk[u]].end(), raw_out.begin() + ((size_t)u * 2) * VOX);
+      std::copy(w[uk[u]].begin(), w[uk[u]].end(), raw_out.begin() + ((size_t)u * 2 + 1) * VOX);
+    }
+    *out = raw_out.data();
+    return 0;
+  }
+  int receive_buffer(int nu, float** out) override {
+    raw_in.assign((size_t)nu * 2 * VOX, -7.f);
+    *out = raw_in.data();
+    return 0;
+  }
+  int import_raw(const int* uk, int nu, const float* p) override {
+    for (int u = 0; u < nu; u++) {
+      sdf[uk[u]].assign(p + ((size_t)u * 2) * VOX, p + ((size_t)u * 2 + 1) * VOX);
+      w[uk[u]].assign(p + ((size_t)u * 2 + 1) * VOX, p + ((size_t)u * 2 + 2) * VOX);
+    }
     return 0;
   }
   int import_planes(const int* uk, int nu, const float* p) override {
@@ -154,13 +210,24 @@ int run_case(const Case& c, int id) {
   std::vector<HostVolume> before = vols;
   Shared sh(W);
   std::vector<int> rc((size_t)W, -1), nu((size_t)W, -1);
+  std::vector<er::MergeStats> stats((size_t)W);
   std::vector<std::thread> th;
   for (int r = 0; r < W; r++)
     th.emplace_back([&, r] {
       ThreadTransport t(sh, r);
-      rc[(size_t)r] = er::merge_protocol(t, vols[(size_t)r], c.root, &nu[(size_t)r], r == c.pre_status_rank ? 1 : 0);
+      rc[(size_t)r] = er::merge_protocol(t, vols[(size_t)r], c.root, &nu[(size_t)r], r == c.pre_status_rank ? 1 : 0, &stats[(size_t)r]);
     });
   for (auto& t : th) t.join();
+  // who touched what, from the volumes as they were before the merge
+  std::map<int, std::vector<int>> touchers;
+  for (int r = 0; r < W; r++)
+    for (auto& kv : before[(size_t)r].sdf) touchers[kv.first].push_back(r);
+  size_t n_multi = 0, n_travel = 0, n_pairs_moved = 0;
+  for (auto& kv : touchers) {
+    if (kv.second.size() >= 2) { n_multi++; continue; }
+    const bool travels = c.root < 0 ? W > 1 : kv.second[0] != c.root;
+    if (travels) { n_travel++; n_pairs_moved += c.root < 0 ? (size_t)(W - 1) : 1; }
+  }
   const bool expect_fail = c.fail_keys_rank >= 0 || c.fail_export_rank >= 0 || c.pre_status_rank >= 0;
   for (int r = 0; r < W; r++) {
     if (expect_fail) {
@@ -173,12 +240,33 @@ int run_case(const Case& c, int id) {
       continue;
     }
     if (rc[(size_t)r] != er::MERGE_OK || nu[(size_t)r] != (int)sw.size()) { fprintf(stderr, "case %d rank %d: rc %d union %d want %zu\n", id, r, rc[(size_t)r], nu[(size_t)r], sw.size()); return 1; }
+    // the sparse merge: ONLY multi-toucher units go through the sum reduction (one call), single-toucher units travel point to point or not at all
+    if (stats[(size_t)r].multi_units != (int)n_multi || stats[(size_t)r].reduced_floats != n_multi * 2 * VOX ||
+        stats[(size_t)r].single_units != (int)(touchers.size() - n_multi)) {
+      fprintf(stderr, "case %d rank %d: stats multi %d reduced %zu single %d, want %zu / %zu / %zu\n", id, r, stats[(size_t)r].multi_units,
+              stats[(size_t)r].reduced_floats, stats[(size_t)r].single_units, n_multi, n_multi * 2 * VOX, touchers.size() - n_multi);
+      return 1;
+    }
+    if (r == 0 && (sh.reduced_floats != n_multi * 2 * VOX || sh.reduce_calls != (n_multi ? 1 : 0) || sh.moved_floats != n_pairs_moved * 2 * VOX ||
+                   sh.exchange_calls != (n_travel ? 1 : 0))) {
+      fprintf(stderr, "case %d: transport saw %zu reduced floats in %d calls, %zu moved floats in %d exchanges; want %zu / %d / %zu / %d\n", id, sh.reduced_floats,
+              sh.reduce_calls, sh.moved_floats, sh.exchange_calls, n_multi * 2 * VOX, n_multi ? 1 : 0, n_pairs_moved * 2 * VOX, n_travel ? 1 : 0);
+      return 1;
+    }
     const bool receives = c.root < 0 || c.root == r;
     if (!receives) {
       if (vols[(size_t)r].sdf != before[(size_t)r].sdf) { fprintf(stderr, "case %d rank %d: non-root volume changed\n", id, r); return 1; }
       continue;
     }
     if (vols[(size_t)r].sdf.size() != sw.size()) { fprintf(stderr, "case %d rank %d: %zu units after the merge, want %zu\n", id, r, vols[(size_t)r].sdf.size(), sw.size()); return 1; }
+    for (auto& kv : touchers)                              // a unit only one rank touched arrives (or stays) exactly as its owner had it
+      if (kv.second.size() == 1) {
+        const HostVolume& o = before[(size_t)kv.second[0]];
+        if (vols[(size_t)r].sdf[kv.first] != o.sdf.at(kv.first) || vols[(size_t)r].w[kv.first] != o.w.at(kv.first)) {
+          fprintf(stderr, "case %d rank %d key %d: a single-toucher unit changed on its way\n", id, r, kv.first);
+          return 1;
+        }
+      }
     for (auto& kv : sw)
       for (size_t i = 0; i < VOX; i++) {
         const double Wd = ww[kv.first][i], Sd = Wd > 0 ? kv.second[i] / Wd : 0.0;
@@ -197,8 +285,10 @@ int main() {
       {2, -1, {4, 11}, -1, -1},          {3, 2, {12, 0, 5}, -1, -1},      {3, -1, {1, 2, 20}, -1, -1},
       {3, 0, {0, 0, 0}, -1, -1},         {2, 0, {23, 23}, -1, -1},                                      // nobody touched anything; identical sets
       {2, 0, {6, 6}, 1, -1},             {3, -1, {6, 2, 9}, 0, -1},       {3, 1, {6, 2, 9}, -1, 2},    // key query / export failure on one rank
-      {2, -1, {0, 4}, -1, 0},
+      {2, -1, {3, 4}, -1, 0},                                                                           // (the failing rank must have something to export: a rank without units exports nothing since round 5)
       {2, 0, {5, 5}, -1, -1, 0},         {3, -1, {4, 0, 7}, -1, -1, 2},                                 // a failure found before the protocol (bad argument on one rank)
+      {3, 0, {3, 3, 3}, -1, -1},         {3, 1, {2, 9, 1}, -1, -1},       {2, -1, {1, 1}, -1, -1},     // few keys: mostly single-toucher units, every root
+      {3, 2, {0, 0, 8}, -1, -1},         {3, 0, {0, 8, 0}, -1, -1},                                     // everything already on the root / everything has to travel
   };
   int id = 0;
   for (const Case& c : cases)

@@ -354,6 +354,76 @@ def test_hard_pairs_at_config2_size_equal_the_reference_ccorresapp(gpu, tmp_path
         c.close()
 
 
+def test_kinfu_like_fragments_at_config2_size(gpu, tmp_path):
+    """the configs[2]-size list on fragments that look like cloud_bin_<i>.pcd -- synth.kinfu_fragment: 50 depth frames of a
+    hand-held sweep integrated into a TSDF volume by this library, zero crossings extracted, normals = the normalised TSDF gradient (NaN at
+    the border of the observed region, filtered like CCorresApp::LoadData does, CorresApp.cpp:93-97), thinned ~ 1 / z^2 (> 10 : 1 density
+    contrast inside one cloud, dozens of points in a near cell, one or two in a far one), odd fragments from depth images with 2 mm noise.
+    (a) 50 pairs over 25 fragments, guesses <= 2 deg / 2 cm off: every pair against the CPU oracle -- inlier counts, iteration counts,
+        converged flags and correspondence index lists EXACT, transforms within 1e-5, information within 1e-9;
+    (b) the same fragments with guesses up to 6 deg / 6 cm off: >= 8 selected pairs (iteration limit, farthest from the truth, ...) against the
+        reference's own compiled CCorresApp (oracle/_ref/libref_corres.so), as the hard-list test above does on the uniform fragments."""
+    from corres_helpers import check_pairs_against_reference, hard_pair_list, select_hard
+    from elasticreconstruction_amd.icp import count_inliers_batch, find_correspondence_batch, icp_align_batch
+    from oracle.pyoracle import RefCorres
+    n_frag, n_pairs = 25, 50
+    frs, stats = [], []
+    for i in range(n_frag):
+        x, n, F, st = synth.kinfu_fragment(i, n_frag, 250000, noise_mm=2.0 if i % 2 else 0.0)
+        ok = ~np.isnan(n).any(axis=1)
+        frs.append((np.ascontiguousarray(x[ok]), np.ascontiguousarray(n[ok]), F))
+        stats.append(st)
+    nan_frac = float(np.mean([st["nan_fraction"] for st in stats]))
+    occ = [synth.cell_occupancy(x) for x, _, _ in frs]
+    assert all(len(x) > 150000 for x, _, _ in frs), [len(x) for x, _, _ in frs]
+    assert 0.005 < nan_frac < 0.3, "NaN normals: %.3f of the points" % nan_frac
+    assert max(o[0] for o in occ) >= 10 * np.mean([o[1] for o in occ]) or max(o[0] for o in occ) >= 40, occ[:3]      # the density contrast is there
+    gc = [Cloud(x, n, 0.03) for x, n, _ in frs]
+    oc = [IcpOracle(x, n, 0.03) for x, n, _ in frs]
+    pairs = synth.config2_pair_list(frs, n_pairs)
+    srcs, tgts = [gc[b] for _, b, _ in pairs], [gc[a] for a, _, _ in pairs]
+    cnts = count_inliers_batch(srcs, tgts, [T for _, _, T in pairs], 0.03)
+    fins, iters, conv, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for _, _, T in pairs], 0.03, 20, 1e-6, 0)
+    lists, infos = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in fins], 0.015, 0.8660, True)
+    worst_T, gt = 0.0, []
+    for k, (a, b, T) in enumerate(pairs):
+        assert int(cnts[k]) == oc[b].count_inliers(oc[a], T, 0.03), "pair %d: inlier count" % k
+        To, ito, co, _ = oc[b].align(oc[a], T.astype(np.float32), 0.03, 20, 1e-6, 0)
+        assert (int(iters[k]), bool(conv[k])) == (ito, co), "pair %d: iterations/converged %s vs %s" % (k, (iters[k], conv[k]), (ito, co))
+        worst_T = max(worst_T, float(np.abs(fins[k] - To).max()))
+        assert np.abs(fins[k] - To).max() <= TOL_T, "pair %d: transform differs by %.3g" % (k, np.abs(fins[k] - To).max())
+        po, io = oc[b].find_correspondence(oc[a], fins[k].astype(np.float64), 0.015, 0.8660, want_info=True)
+        assert np.array_equal(lists[k], po), "pair %d: %d vs %d correspondences" % (k, lists[k].shape[0], po.shape[0])
+        assert np.allclose(infos[k], io, rtol=1e-9, atol=1e-6)
+        gt.append(float(np.abs(fins[k].astype(np.float64) - np.linalg.inv(frs[a][2]) @ frs[b][2]).max()))
+    # extracted surfaces of two different sweeps: the ICP fixed point sits within a voxel of the ground truth (5.9 mm), not on it
+    assert np.median(gt) < 6e-3 and max(gt) < 3e-2, "ground truth missed: median %.3g max %.3g" % (np.median(gt), max(gt))
+    print("kinfu-like list: %d pairs, %.0f points per fragment after the NaN filter (%.1f %% NaN normals), cells max / mean occupancy %d / %.1f, "
+          "mean %.2f ICP iterations (max %d), max |T_gpu - T_oracle| = %.2g, ground-truth error median %.2g max %.2g"
+          % (n_pairs, np.mean([len(x) for x, _, _ in frs]), 100 * nan_frac, max(o[0] for o in occ), np.mean([o[1] for o in occ]),
+             float(np.mean(iters)), int(np.max(iters)), worst_T, np.median(gt), max(gt)))
+    # (b) the hard guesses on the same fragments against the reference's own code
+    hard = hard_pair_list(frs, n_pairs)
+    h_cnts = count_inliers_batch(srcs, tgts, [T for _, _, T in hard], 0.03)
+    h_fins, h_iters, h_conv, _ = icp_align_batch(srcs, tgts, [T.astype(np.float32) for _, _, T in hard], 0.03, 20, 1e-6, 0)
+    h_lists, h_infos = find_correspondence_batch(srcs, tgts, [F.astype(np.float64) for F in h_fins], 0.015, 0.8660, True)
+    h_err = [float(np.abs(F.astype(np.float64) - np.linalg.inv(frs[a][2]) @ frs[b][2]).max()) for F, (a, b, _) in zip(h_fins, hard)]
+    sel = select_hard(h_iters, h_err, want=8)
+    if RefCorres.available():
+        out = check_pairs_against_reference(frs, hard, sel, h_cnts, h_fins, h_iters, h_conv, h_lists, h_infos, str(tmp_path))
+        assert out["pairs"] >= 8
+    else:
+        out = {"against": "oracle/icp_oracle.cpp (the reference build did not travel)", "selected": sel}
+        for k in sel:
+            a, b, T = hard[k]
+            assert int(h_cnts[k]) == oc[b].count_inliers(oc[a], T, 0.03)
+            To, ito, co, _ = oc[b].align(oc[a], T.astype(np.float32), 0.03, 20, 1e-6, 0)
+            assert (int(h_iters[k]), bool(h_conv[k])) == (ito, co) and np.abs(h_fins[k] - To).max() <= TOL_T, "hard pair %d" % k
+            po, io = oc[b].find_correspondence(oc[a], h_fins[k].astype(np.float64), 0.015, 0.8660, want_info=True)
+            assert np.array_equal(h_lists[k], po) and np.allclose(h_infos[k], io, rtol=1e-9, atol=1e-6)
+    print("kinfu-like hard list: iterations %s, converged %d / %d; checked: %s" % ([int(i) for i in h_iters], int(np.sum(h_conv)), n_pairs, out))
+
+
 def test_registration_batch_equals_the_three_stage_calls(gpu, monkeypatch):
     """er_registration_batch (Registration + FindCorrespondence of a pair list in one call, the shares on host threads of their own) against
     the three *_batch calls in sequence with the accept rule of CorresApp.cpp:270 applied in between: pre-check counts, accept flags,

@@ -262,6 +262,35 @@ def test_frame_split_merge_two_virtual_ranks(gpu):
         assert np.array_equal(wf, wm), "merged weights differ in unit %d" % k
         worst = max(worst, float(np.abs(sf - sm).max()))
     assert worst <= 1e-5, "merged tsdf differs by %.3g" % worst
+    # Round 5, the sparse merge (csrc/er_merge_protocol.h) with rank 0 as the root: only the units BOTH blocks touched go through the sum; a unit only
+    # rank 1 touched travels raw (er_tsdf_export_raw -> er_tsdf_import_raw) and must arrive BIT FOR BIT -- and equal the single-volume result exactly,
+    # since no frame of rank 0 ever reached it; the root's own single-toucher units do not move at all.
+    k0, k1 = parts[0].unit_keys(), parts[1].unit_keys()
+    multi = np.intersect1d(k0, k1).astype(np.int32)
+    only1 = np.setdiff1d(k1, k0).astype(np.int32)
+    only0 = np.setdiff1d(k0, k1).astype(np.int32)
+    assert len(multi) > 0 and len(only1) > 0 and len(only0) > 0, (len(multi), len(only0), len(only1))
+    mb = [torch.empty((len(multi), 2, 64 ** 3), dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    for p, b in zip(parts, mb):
+        p.export_weighted(multi, b.data_ptr())
+        p.synchronize()
+    raw = torch.empty((len(only1), 2, 64 ** 3), dtype=torch.float32, device="cuda:0")
+    parts[1].export_raw(only1, raw.data_ptr())
+    parts[1].synchronize()
+    msum = mb[0] + mb[1]
+    root = parts[0]
+    root.import_weighted(multi, msum.data_ptr())
+    root.import_raw(only1, raw.data_ptr())
+    root.synchronize()
+    assert np.array_equal(root.unit_keys(), full.unit_keys())
+    for k in np.concatenate([only0, only1]):
+        sf, wf = full.read_unit(k)
+        sr, wr = root.read_unit(k)
+        assert np.array_equal(wf, wr) and np.array_equal(sf.view(np.uint32), sr.view(np.uint32)), "single-toucher unit %d is not bit-identical" % k
+    for k in multi:
+        sf, wf = full.read_unit(k)
+        sr, wr = root.read_unit(k)
+        assert np.array_equal(wf, wr) and float(np.abs(sf - sr).max()) <= 1e-5
     for v in parts + [full, merged]:
         v.close()
 
