@@ -357,6 +357,45 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
            "single_call_pairs_per_s": nseq / dt1,
            "single_call_8_host_threads_pairs_per_s": n_pairs / dt8}
     res["_pass_s"] = dt
+    # ---- the device-resident hand-off: the same fused call with list buffers that live in HBM (the 83 MB of lists never cross
+    # PCIe), consumed where they are by er_fopt_set_correspondences_dev (the sort by lattice cell pair on the GPU) ----
+    try:
+        from elasticreconstruction_amd.fopt import FragmentOptimizer
+        from elasticreconstruction_amd.icp import DeviceLists, registration_batch_dev
+        dl = DeviceLists(f_srcs, device)
+        ddt = []
+        for _ in range(9):
+            t0 = time.perf_counter()
+            dres = registration_batch_dev(f_srcs, f_tgts, f_T, dl, 0.03, 40000, 0.25, 20, 1e-6, 0, 0.015, 0.8660, want_info=True)
+            ddt.append(time.perf_counter() - t0)
+        ddt = ddt[2:]
+        same = bool(np.array_equal(dres["T"], fused["T"]) and [int(c) for c in dl.counts] == [len(l) for l in fused["lists"]] and
+                    all(np.array_equal(dl.download(k), np.asarray(fused["lists"][k])) for k in (0, n_pairs // 2, n_pairs - 1)))
+        fo = FragmentOptimizer(len(clouds), 8, 3.0, device)
+        for f, (x, n) in enumerate(hosts):
+            fo.SetCloud(f, x, n)
+        ids = [(a, b) for a, b, _ in pairs]
+        t0 = time.perf_counter()
+        ng_dev = fo.SetCorrespondencesDev(ids, dl)
+        t_dev = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        ng_dev = fo.SetCorrespondencesDev(ids, dl)
+        t_dev = min(t_dev, time.perf_counter() - t0)
+        host_lists = [(a, b, np.array(fused["lists"][k])) for k, (a, b) in enumerate(ids)]
+        t0 = time.perf_counter()
+        ng_host = fo.SetCorrespondences(host_lists)
+        t_host = time.perf_counter() - t0
+        fo.close()
+        res["device_hand_off"] = {"pairs_per_s": n_pairs / float(np.median(ddt)), "list_ms": 1e3 * float(np.median(ddt)), "pass_ms": [round(1e3 * t, 3) for t in ddt],
+                                  "equals_the_host_path": same, "list_bytes_kept_in_hbm": int(dl.counts.sum()) * 8,
+                                  "fopt_set_correspondences_ms": {"device_lists": 1e3 * t_dev, "host_lists": 1e3 * t_host, "groups": int(ng_dev),
+                                                                  "groups_equal": bool(ng_dev == ng_host), "correspondences": int(dl.counts.sum())},
+                                  "what": "er_registration_batch with list buffers in HBM (er_device_alloc; the list copies are device-to-device), then "
+                                          "er_fopt_set_correspondences_dev on them (keys + ONE radix sort + run lengths on the GPU) against er_fopt_set_correspondences "
+                                          "on the host copies (a stable_sort per list on one host core, then three uploads)"}
+        dl.close()
+    except Exception as ex:
+        res["device_hand_off"] = {"error": repr(ex)[:400]}
     # RansacCurvature::getFitness over a hypothesis list (down-sampled source, as GlobalRegistration uses it)
     from elasticreconstruction_amd.icp import ransac_fitness_batch
     sub = np.sort(np.random.default_rng(11).choice(hosts[1][0].shape[0], 5000, replace=False))
@@ -392,7 +431,7 @@ def icp_section(n_pairs, device, with_cpu=True, n_frag=25):
     try:
         kfr, kst = [], []
         for i in range(n_frag):
-            x, n, F, st = synth.kinfu_fragment(i, n_frag, 250000, noise_mm=2.0 if i % 2 else 0.0, device=device)
+            x, n, F, st = synth.kinfu_fragment(i, 2 * n_frag, 250000, noise_mm=2.0 if i % 2 else 0.0, device=device)   # sweeps 7.2 degrees apart
             ok = ~np.isnan(n).any(axis=1)
             kfr.append((np.ascontiguousarray(x[ok]), np.ascontiguousarray(n[ok]), F))
             kst.append(st)

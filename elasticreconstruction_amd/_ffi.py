@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("ER_HIP_LIB") or os.path.join(_HERE, "liber_hip.so")
 
 # Every symbol include/er_hip.h declares (tests/test_abi.py checks header == this list == the .so).
 SYMBOLS = [
-    "er_last_error", "er_device_count", "er_abi_version", "er_request_hw_queues", "er_host_alloc", "er_host_free", "er_host_copy_h2d",
+    "er_last_error", "er_device_count", "er_abi_version", "er_request_hw_queues", "er_host_alloc", "er_host_free", "er_host_copy_h2d", "er_device_alloc", "er_device_free", "er_device_copy_d2h",
     "er_tsdf_create", "er_tsdf_destroy", "er_tsdf_set_stream", "er_tsdf_synchronize",
     "er_tsdf_wait_event", "er_tsdf_reset", "er_tsdf_status", "er_tsdf_set_unit_shard", "er_unit_owner",
     "er_tsdf_scale_depth", "er_tsdf_reproject", "er_tsdf_integrate", "er_tsdf_integrate_frames",
@@ -26,7 +26,7 @@ SYMBOLS = [
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
     "er_icp_count_inliers_batch", "er_icp_align_batch", "er_find_correspondence_batch", "er_icp_release_workspaces", "er_registration_batch", "er_ransac_fitness_batch", "er_ransac_inliers",
     "er_fopt_create", "er_fopt_destroy", "er_fopt_set_cloud", "er_fopt_cloud_size", "er_fopt_get_points", "er_fopt_update_pose",
-    "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_group_count", "er_fopt_group_info", "er_fopt_update_normals", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
+    "er_fopt_update_point_pn", "er_fopt_set_correspondences", "er_fopt_set_correspondences_dev", "er_fopt_group_count", "er_fopt_group_info", "er_fopt_update_normals", "er_fopt_assemble_rigid", "er_fopt_assemble_slac",
     "er_fopt_assemble_nonrigid", "er_fopt_factor_slac", "er_fopt_factor_nonrigid", "er_fopt_solve", "er_fopt_debug_shift_diagonal",
 ]
 
@@ -71,6 +71,10 @@ def lib():
     L.er_host_alloc.argtypes = [C.c_size_t]
     L.er_host_free.argtypes = [vp]
     L.er_host_copy_h2d.argtypes = [vp, vp, C.c_size_t]
+    L.er_device_alloc.restype = vp
+    L.er_device_alloc.argtypes = [C.c_size_t, C.c_int]
+    L.er_device_free.argtypes = [vp]
+    L.er_device_copy_d2h.argtypes = [vp, vp, C.c_size_t]
     L.er_tsdf_create.argtypes = [C.c_int, C.c_int, fp, C.c_int, C.c_int, C.POINTER(vp)]
     L.er_tsdf_destroy.argtypes = [vp]
     L.er_tsdf_set_stream.argtypes = [vp, vp]
@@ -134,6 +138,7 @@ def lib():
         L.er_fopt_update_pose.argtypes = [vp, C.c_int, vp]
         L.er_fopt_update_point_pn.argtypes = [vp, C.c_int, vp]
         L.er_fopt_set_correspondences.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.er_fopt_set_correspondences_dev.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.er_fopt_group_count.argtypes = [vp]
         L.er_fopt_assemble_rigid.argtypes = [vp, vp, vp, vp]
         L.er_fopt_assemble_slac.argtypes = [vp, vp, vp, vp, vp]

@@ -68,4 +68,23 @@ int er_host_free(void* p) {
   return 0;
 }
 
+void* er_device_alloc(size_t bytes, int device) {
+  void* p = nullptr;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+    er::fail("er_device_alloc: hipMalloc(%zu) on device %d failed: %s", bytes, device, hipGetErrorString(hipGetLastError()));
+    return nullptr;
+  }
+  return p;
+}
+
+int er_device_free(void* p) {
+  if (p) ER_HIP_TRY(hipFree(p));
+  return 0;
+}
+
+int er_device_copy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
+  ER_HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 }  // extern "C"

@@ -1395,14 +1395,20 @@ int max_points(int i0, int m, const er_cloud_t* src) {
   return mx;
 }
 
-bool is_pinned_host(const void* p) {
+// Where a caller's list buffer lives: 0 = pageable host memory (staged through the group's page-locked block), 1 = page-locked host memory (the copy
+// goes straight there), 2 = DEVICE memory of `device` (round 5: the list stays in HBM -- a device-to-device copy of exactly the list, no PCIe; what a
+// consumer on the same GPU wants, er_fopt_set_correspondences_dev), -1 = device memory of another GPU (refused).
+int buffer_kind(const void* p, int device) {
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) {
     (void)hipGetLastError();                                 // plain malloc memory: "invalid value", not an error for us
-    return false;
+    return 0;
   }
-  return at.type == hipMemoryTypeHost;
+  if (at.type == hipMemoryTypeHost) return 1;
+  if (at.type == hipMemoryTypeDevice) return at.device == device ? 2 : -1;
+  return 0;
 }
+bool is_pinned_host(const void* p) { return buffer_kind(p, -1) == 1; }
 
 // sum A^T A with A = [I | B], B = [[0, 2sz, -2sy], [-2sz, 0, 2sx], [2sy, -2sx, 0]]  (CorresApp.cpp:198-203,
 // RansacCurvature.h:717-721) from its ten distinct terms (k_count_blocks).
@@ -1988,9 +1994,12 @@ int er_ransac_inliers(er_cloud_t src, er_cloud_t tgt, const float* M16, float co
   if (fitness && total > 0) *fitness = g->h_info[20] / (double)total;                               // :697-703
   const int ncopy = std::min(total, capacity);
   if (ncopy > 0) {
-    const bool direct = is_pinned_host(pairs_host);
+    const int kind = buffer_kind(pairs_host, src->device);
+    if (kind < 0) return er::fail("er_ransac_inliers: the list buffer lives on another GPU than the clouds");
+    const bool direct = kind >= 1;                              // page-locked host or device memory
     if (!direct && stage_reserve(g, (size_t)ncopy * 2)) return 1;
-    ER_HIP_TRY(hipMemcpyAsync(direct ? pairs_host : g->stage, g->h_pairs[0].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, g->stream));
+    ER_HIP_TRY(hipMemcpyAsync(direct ? pairs_host : g->stage, g->h_pairs[0].pairs, (size_t)ncopy * 2 * sizeof(int),
+                              kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g->stream));
     ER_HIP_TRY(hipStreamSynchronize(g->stream));
     if (!direct) memcpy(pairs_host, g->stage, (size_t)ncopy * 2 * sizeof(int));
   }
@@ -2013,7 +2022,9 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
   for (int i = 0; i < n; i++) {
     if (capacity[i] > 0 && !pairs_host[i]) return er::fail("er_find_correspondence: NULL pair buffer for pair %d", i);
     if (capacity[i] > 0) {
-      direct[(size_t)i] = is_pinned_host(pairs_host[i]) ? 1 : 0;               // (asked once per pair, not again at copy time)
+      const int kind = buffer_kind(pairs_host[i], device);                     // (asked once per pair, not again at copy time)
+      if (kind < 0) return er::fail("er_find_correspondence: the list buffer of pair %d lives on another GPU than its clouds", i);
+      direct[(size_t)i] = (char)kind;                                           // 1: page-locked host, 2: device memory -- both are copied to directly
       if (!direct[(size_t)i]) stage_need += (size_t)std::min(capacity[i], src[i]->n) * 2;
     }
   }
@@ -2074,8 +2085,8 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
           dst = g->stage + stage_used;
           stage_used += (size_t)ncopy * 2;
         }
-        if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), hipMemcpyDeviceToHost, (i & 1) ? g->copy_stream2 : g->copy_stream) !=
-            hipSuccess) {
+        if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), direct[(size_t)i] == 2 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                           (i & 1) ? g->copy_stream2 : g->copy_stream) != hipSuccess) {
           cleanup();
           return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError()));
         }
@@ -2104,7 +2115,8 @@ int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], d
 // The pairs are independent, so the list is cut into a few contiguous shares and every share runs the three stages on a host thread
 // and a group workspace of its own: the host round trips of one share (accept rule, the states of an ICP chunk, list sizes) and its
 // list copies over PCIe overlap the kernels of the others -- what the reference's "#pragma omp parallel for" does for its CPU loops.
-// Results are those of the three *_batch calls in sequence (same kernels, same per-pair arithmetic).
+// Results are those of the three *_batch calls in sequence (same kernels, same per-pair arithmetic; a share is a shorter list, so the slice count per
+// workgroup of k_icp_iter -- and with it the grouping of the float64 sums -- can differ: last bits of a transform, see include/er_hip.h).
 int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
                           int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
                           int* accepted, float* T_final, int* iterations, int* converged, int* const* pairs_host, const int* capacity,

@@ -164,6 +164,19 @@ class FragmentOptimizer:
         self.n_pairs = n
         return self._lib.er_fopt_group_count(self._h)
 
+    def SetCorrespondencesDev(self, pair_ids, lists):
+        """The same from lists that are ALREADY IN HBM (icp.DeviceLists, filled by registration_batch_dev): pair_ids = [(i, j)] with i the
+        TARGET fragment of list k and j its source (the rows are (target index, source index), the lines of corres_<i>_<j>.txt).  The sort by
+        lattice cell pair runs on the GPU; results are bit-identical to SetCorrespondences on the downloaded lists."""
+        n = len(pair_ids)
+        fi = np.array([p[0] for p in pair_ids], np.int32)
+        fj = np.array([p[1] for p in pair_ids], np.int32)
+        cnt = np.ascontiguousarray(lists.counts[:n], np.int32)
+        _ffi.check(self._lib.er_fopt_set_correspondences_dev(self._h, n, _ffi.ptr(fi), _ffi.ptr(fj), lists.ptrs(), _ffi.ptr(cnt)),
+                   "er_fopt_set_correspondences_dev")
+        self.n_pairs = n
+        return self._lib.er_fopt_group_count(self._h)
+
     # ---- Hessian assembly ---------------------------------------------------------------------------------
     def AssembleRigid(self):
         N = 6 * self.num_

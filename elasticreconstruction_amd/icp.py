@@ -217,6 +217,63 @@ def registration_batch(srcs, tgts, Ts, reg_dist=0.03, reg_num=40000, reg_ratio=0
                 lists=[(l.copy() if copy else l) for l in lists], info=info.reshape(n, 6, 6) if want_info else None)
 
 
+class DeviceLists:
+    """Correspondence lists of a pair list that STAY IN HBM (round 5): one er_device_alloc block cut into one slot per pair (room for |source|
+    rows each), handed to er_registration_batch / er_find_correspondence_batch as their list buffers -- a buffer may be device memory, the
+    copy is then device-to-device -- and on to er_fopt_set_correspondences_dev.  counts[k] = rows of pair k after the call."""
+
+    def __init__(self, srcs, device=0):
+        self._lib = _ffi.lib()
+        self.n = len(srcs)
+        self.cap = np.array([s.n for s in srcs], np.int32)
+        ints = ((np.maximum(self.cap, 1).astype(np.int64) * 2 + 63) // 64) * 64
+        self.offs = np.concatenate([[0], np.cumsum(ints)[:-1]]).astype(np.int64)
+        self.total_ints = int(ints.sum())
+        self.base = self._lib.er_device_alloc(self.total_ints * 4, int(device))
+        if not self.base:
+            raise _ffi.ErError("er_device_alloc: " + self._lib.er_last_error().decode())
+        self.counts = np.zeros(self.n, np.int32)
+
+    def ptrs(self):
+        return (C.c_void_p * max(self.n, 1))(*[self.base + 4 * int(o) for o in self.offs])
+
+    def download(self, k):
+        """One list to the host (when a corres_<i>_<j>.txt is wanted after all)."""
+        m = int(self.counts[k])
+        out = np.empty((m, 2), np.int32)
+        if m:
+            _ffi.check(self._lib.er_device_copy_d2h(_ffi.ptr(out), C.c_void_p(self.base + 4 * int(self.offs[k])), m * 8), "er_device_copy_d2h")
+        return out
+
+    def close(self):
+        if getattr(self, "base", None):
+            self._lib.er_device_free(C.c_void_p(self.base))
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def registration_batch_dev(srcs, tgts, Ts, lists, reg_dist=0.03, reg_num=40000, reg_ratio=0.25, max_iter=20, eps=1e-6, stop_rule=0, corr_dist=0.015,
+                           normal_cos=0.8660, want_info=False):
+    """er_registration_batch with the correspondence lists left in HBM (`lists`: a DeviceLists over the same sources).  Everything else comes
+    back as registration_batch returns it; lists.counts holds the list lengths."""
+    n = len(srcs)
+    Tm = np.ascontiguousarray(Ts, np.float64).reshape(n, 16)
+    counts, acc, its, cv = (np.zeros(n, np.int32) for _ in range(4))
+    F = np.zeros((n, 16), np.float32)
+    info = np.zeros((n, 36), np.float64) if want_info else None
+    _ffi.check(srcs[0]._lib.er_registration_batch(n, _handles(srcs), _handles(tgts), _ffi.ptr(Tm), float(reg_dist), int(reg_num), float(reg_ratio),
+                                                  int(max_iter), float(eps), int(stop_rule), float(corr_dist), float(normal_cos), _ffi.ptr(counts),
+                                                  _ffi.ptr(acc), _ffi.ptr(F), _ffi.ptr(its), _ffi.ptr(cv), lists.ptrs(), _ffi.ptr(lists.cap), _ffi.ptr(lists.counts),
+                                                  _ffi.ptr(info) if want_info else None), "er_registration_batch")
+    return dict(counts=counts, accepted=acc.astype(bool), T=F.reshape(n, 4, 4), iterations=its, converged=cv.astype(bool),
+                info=info.reshape(n, 6, 6) if want_info else None)
+
+
 class CorresApp:
     """CCorresApp (CorresApp.h:12-82).  Defaults from the constructor, CorresApp.cpp:8-24."""
 

@@ -49,6 +49,12 @@ int er_request_hw_queues(int n);
 void* er_host_alloc(size_t bytes);               /* NULL on failure (see er_last_error) */
 int er_host_free(void* p);
 int er_host_copy_h2d(void* dev_dst, const void* host_src, size_t bytes);   /* blocking host -> device copy (current device) */
+/* Device memory for hosts that do not speak HIP themselves: the list buffers of er_find_correspondence_batch / er_registration_batch
+ * may live in HBM (the lists then never cross PCIe) and er_fopt_set_correspondences_dev consumes them there; er_device_copy_d2h fetches
+ * one when a corres_<i>_<j>.txt is to be written after all. */
+void* er_device_alloc(size_t bytes, int device);  /* NULL on failure */
+int er_device_free(void* p);
+int er_device_copy_d2h(void* host_dst, const void* dev_src, size_t bytes);   /* blocking device -> host copy */
 
 /* ------------------------------------------------------------ path A: TSDF ---- */
 typedef struct er_tsdf_s* er_tsdf_t;
@@ -236,15 +242,21 @@ int er_icp_align(er_cloud_t src, er_cloud_t tgt, const float guess[16], double m
 
 /* FindCorrespondence (CorresApp.cpp:144-161, 186-208): pairs (tgt_index, src_index) ascending in
  * src_index, for NN sqdist < dist^2 and normal dot > normal_cos; info36 (nullable) = row-major 6x6
- * information matrix over the untransformed source points. pairs_host holds 2*capacity ints. */
+ * information matrix over the untransformed source points. pairs_host holds 2*capacity ints -- pageable host memory,
+ * page-locked host memory (er_host_alloc: no staging pass) or, since round 5, DEVICE memory of the clouds' GPU (er_device_alloc:
+ * the list stays in HBM, a device-to-device copy of exactly the list; the same holds for every pairs_host of the *_batch forms). */
 int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], double dist, double normal_cos,
                            int* pairs_host, int capacity, int* n_pairs, double* info36);
 
 /* The reference runs its two loops over the pair list with "#pragma omp parallel for" (CorresApp.cpp:121,220).
  * The *_batch forms take the whole list of one loop: n pairs (src[i], tgt[i]) on ONE device, per-pair inputs and
- * outputs as arrays (T: n*16 doubles, guess/out: n*16 floats, info36: n*36 doubles, ...).  Results are identical
- * to n single calls; internally the pairs are software-pipelined over a few independent streams/workspaces so
- * that one pair's host round trip (6x6 solve, convergence test, result copy) overlaps the kernels of the others.
+ * outputs as arrays (T: n*16 doubles, guess/out: n*16 floats, info36: n*36 doubles, ...).  Results are those of n single
+ * calls -- integers (counts, iteration counts, correspondence lists) identical; one caveat for er_icp_align: the 29 float64 sums of an
+ * ICP iteration are added per workgroup of 1..8 slices of 256 points and then in a fixed order, and the library picks that slice count
+ * from the pairs of the list that are still running, so a pair's final transform can differ in its last bits (|dT| ~ 1e-7; the parity
+ * bar is 1e-5) between two lists it is part of (and, in principle, an iteration count at a razor's-edge stop decision; never observed).
+ * For the same list the result is bit-reproducible.  Internally a whole group of pairs runs through every stage in one launch; the ICP
+ * loop's solve and stop rule stay on the device.
  * The single-pair functions above are the n == 1 case of these.  Clouds are immutable: any number of host threads
  * may use the same cloud concurrently (each call borrows its workspaces from a per-device pool). */
 int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double max_dist, int* counts);
@@ -284,7 +296,8 @@ int er_icp_release_workspaces(void);
  *                er_find_correspondence_batch returns them; n_pairs = 0 for a rejected pair.  The `Reduced too much` rule of :164-173
  *                (n_pairs / counts < 0.5) is the caller's: both numbers are returned.
  * The list is cut into ER_ICP_SHARES (default 6, at least ~8 pairs each) contiguous shares that run their three stages on a host thread and workspace each, so one
- * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls. */
+ * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls
+ * (with the er_icp_align caveat above: a share is a shorter list). */
 int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
                           int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
                           int* accepted, float* T_final, int* iterations, int* converged, int* const* pairs_host, const int* capacity,
@@ -315,6 +328,12 @@ int er_fopt_update_point_pn(er_fopt_t h, int frag, const double* ctr_slice_host)
  * the lines of corres_<i>_<j>.txt.  Sorted once by lattice cell pair for the assembly kernels. */
 int er_fopt_set_correspondences(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs_host,
                                 const int* counts);
+/* The same with the lists ALREADY IN HBM on the handle's device (pairs_dev[l] = device pointer to counts[l] rows, e.g. the buffers
+ * er_registration_batch filled): the (cell, cell) keys, ONE stable radix sort over all lists, the run lengths and the gather run on the
+ * GPU; only the group table (a few thousand rows) visits the host.  Same order as the host path -- lists in the given order, groups by
+ * ascending cell pair, rows of a group in list order -- hence bit-identical assembly results.  Row indices are range-checked on the device. */
+int er_fopt_set_correspondences_dev(er_fopt_t h, int n_pairs, const int* frag_i, const int* frag_j, const int* const* pairs_dev,
+                                    const int* counts);
 int er_fopt_group_count(er_fopt_t h);          /* groups = distinct (pair, lattice cell of p_i, lattice cell of p_j) */
 int er_fopt_group_info(er_fopt_t h, int* info4);   /* 4 ints per group: frag_i, frag_j, idx_[0] of p_i's cell, of p_j's cell */
 /* PointCloud::UpdateAllNormal (PointCloud.h:32-36): n_ only, from the fragment's slice of ctr (non-rigid mode, OptApp.cpp:151-153). */

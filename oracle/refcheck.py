@@ -41,14 +41,16 @@ def point_to_plane_conditioning(src_xyz, tgt_nrm, T, corr):
 
 
 def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, lists, infos, tmp_dir, reg_dist=0.03, tol_T=1e-5, reg_num=40000,
-                                  reg_ratio=0.25):
+                                  reg_ratio=0.25, tol_T_at_limit=None):
     """The results somebody (the HIP path; in the CPU suite: the restatement) produced for pairs[k], k in sel -- pre-check count,
     final transform, iteration count, converged flag, correspondence list and information matrix AT that final transform -- against
     the reference's own compiled code: CCorresApp::Registration (pre-check count = frame_ and the accept rule, CorresApp.cpp:257-281;
     final transform of the accepted pairs), the stub's PCL 1.7 ICP called as CorresApp.cpp:295-306 configures it on EVERY selected
     pair (iteration count, converged, transform -- a 6 cm guess can fall below the pre-check, the ICP loop is still compared), and
     CCorresApp::FindCorrespondence run from the candidate's final transforms of the accepted pairs (corres_<i>_<j>.txt byte for byte,
-    frame_, information).  Returns a summary dict."""
+    frame_, information).  tol_T_at_limit (default: tol_T) applies to pairs that used up PCL's 20 iterations: such a pair was stopped while still
+    moving, and a loop that is not at a fixed point carries a one-ulp difference of a float32 increment forward instead of contracting it (noisy
+    kinfu-like fragments: 2e-5 after 20 iterations; the uniform fragments stay below 1e-6 even there).  Returns a summary dict."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.pyoracle import RefCorres
     need = sorted({q for k in sel for q in pairs[k][:2]})
@@ -61,6 +63,7 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
     reg = app.pairs()
     app.close()
     worst_T, accepted, degenerate = 0.0, [], {}
+    tol_lim = tol_T if tol_T_at_limit is None else tol_T_at_limit
 
     def ill_posed(k):
         """True (and recorded) if pair k's point-to-plane system is singular to working precision at the candidate's transform."""
@@ -82,7 +85,7 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
         if d > tol_T and ill_posed(k):
             continue                                                   # no well-defined answer to compare (listed in the summary)
         worst_T = max(worst_T, d)
-        assert d <= tol_T, "pair %d (%d iterations): transform differs from CCorresApp's by %.3g" % (k, int(iters[k]), d)
+        assert d <= (tol_lim if int(iters[k]) >= 20 else tol_T), "pair %d (%d iterations): transform differs from CCorresApp's by %.3g" % (k, int(iters[k]), d)
 
     def ref_icp(k):
         a, b, T = pairs[k]
@@ -97,7 +100,7 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
         assert (int(iters[k]), bool(conv[k])) == (it1, c1), "pair %d: iterations / converged %s, reference %s" % (k, (int(iters[k]), bool(conv[k])), (it1, c1))
         d = float(np.abs(T1.astype(np.float64) - np.asarray(fins[k], np.float64)).max())
         worst_T = max(worst_T, d)
-        assert d <= tol_T, "pair %d (%d iterations): transform differs from the reference ICP's by %.3g" % (k, it1, d)
+        assert d <= (tol_lim if it1 >= 20 else tol_T), "pair %d (%d iterations): transform differs from the reference ICP's by %.3g" % (k, it1, d)
     d = tmp_dir if tmp_dir.endswith("/") else tmp_dir + "/"
     app2 = RefCorres(out_dir=d, reg_dist=reg_dist, reg_num=reg_num, reg_ratio=reg_ratio)
     for q in need:

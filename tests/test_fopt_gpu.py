@@ -328,3 +328,55 @@ def test_slac_with_a_negative_regulariser_is_reported_not_positive_definite(gpu,
     assert np.array_equal(Jb, Jb2) or np.allclose(Jb, Jb2, rtol=1e-12, atol=1e-12 * np.abs(Jb).max())
     assert np.abs(g.Solve(Jb2) - x1).max() <= 1e-9 * np.abs(x1).max()
     g.close()
+
+
+def test_device_resident_correspondence_hand_off(gpu):
+    """VERDICT round 4 (5, 7): BuildCorrespondence's lists reach FragmentOptimizer WITHOUT crossing PCIe twice (CorresApp.cpp:175-184 writes what
+    OptApp.cpp:100-118 reads).  er_registration_batch is handed list buffers that live in HBM (er_device_alloc) -- the lists are then copied device
+    to device -- and er_fopt_set_correspondences_dev sorts them by lattice cell pair on the GPU.  Against the host path on the same pairs:
+    transforms, counts and information matrices identical, every downloaded list identical to the host list, the same (pair, cell, cell) groups
+    in the same order, assembled rigid and SLAC systems equal to 1e-12 (the assembly adds with float64 atomics: no run-to-run bit equality
+    even on one path), and an out-of-range row is refused on the device."""
+    import ctypes as C
+    from elasticreconstruction_amd import _ffi, synth
+    from elasticreconstruction_amd.icp import Cloud, DeviceLists, registration_batch, registration_batch_dev
+    frs = synth.fragment_set(4, 60000, device="cuda:0")
+    clouds = [Cloud(x, n, 0.03) for x, n, _ in frs]
+    ids = [(0, 1), (1, 2), (2, 3), (0, 2), (1, 3), (0, 3)]
+    Ts = [np.linalg.inv(frs[a][2]) @ frs[b][2] @ synth.perturbation(40 + k, 2.0, 0.02) for k, (a, b) in enumerate(ids)]
+    srcs, tgts = [clouds[b] for _, b in ids], [clouds[a] for a, _ in ids]
+    host = registration_batch(srcs, tgts, Ts, want_info=True)
+    dl = DeviceLists(srcs)
+    dev = registration_batch_dev(srcs, tgts, Ts, dl, want_info=True)
+    assert np.array_equal(dev["counts"], host["counts"]) and np.array_equal(dev["accepted"], host["accepted"]) and host["accepted"].all()
+    assert np.array_equal(dev["iterations"], host["iterations"]) and np.array_equal(dev["T"].view(np.uint32), host["T"].view(np.uint32))
+    assert np.allclose(dev["info"], host["info"], rtol=1e-12, atol=0)
+    assert [int(c) for c in dl.counts] == [len(l) for l in host["lists"]] and min(dl.counts) > 10000
+    for k in range(len(ids)):
+        assert np.array_equal(dl.download(k), host["lists"][k]), "list %d differs between the host and the device-resident path" % k
+    g1, g2 = FragmentOptimizer(4, 8, 3.0), FragmentOptimizer(4, 8, 3.0)
+    for g in (g1, g2):
+        for f, (x, n, _) in enumerate(frs):
+            assert g.SetCloud(f, x, n) == -1
+    n1 = g1.SetCorrespondences([(a, b, host["lists"][k]) for k, (a, b) in enumerate(ids)])
+    n2 = g2.SetCorrespondencesDev(ids, dl)
+    assert n1 == n2 > len(ids)
+    gi1, gi2 = np.zeros(4 * n1, np.int32), np.zeros(4 * n2, np.int32)
+    g1._lib.er_fopt_group_info(g1._h, _ffi.ptr(gi1))
+    g2._lib.er_fopt_group_info(g2._h, _ffi.ptr(gi2))
+    assert np.array_equal(gi1, gi2), "the (pair, cell, cell) groups differ"
+    (J1, b1, s1), (J2, b2, s2) = g1.AssembleRigid(), g2.AssembleRigid()
+    assert np.allclose(J1, J2, rtol=0, atol=1e-12 * np.abs(J1).max()) and np.allclose(b1, b2, rtol=0, atol=1e-12 * np.abs(b1).max()) and s1 == pytest.approx(s2, rel=1e-12)
+    Rt = np.stack([np.eye(3).reshape(9) for _ in range(4)])
+    (J1, b1, s1), (J2, b2, s2) = g1.AssembleSLAC(Rt), g2.AssembleSLAC(Rt)
+    assert np.allclose(J1, J2, rtol=0, atol=1e-12 * np.abs(J1).max()) and np.allclose(b1, b2, rtol=0, atol=1e-12 * np.abs(b1).max())
+    assert np.array_equal(J1 != 0, J2 != 0)
+    # an empty list in the middle, then a row that points outside its fragment: refused by the range check ON THE DEVICE
+    dl.counts[1] = 0
+    assert g2.SetCorrespondencesDev(ids, dl) < n2
+    bad = np.array([[len(frs[0][0]) + 5, 0]], np.int32)
+    _ffi.check(g2._lib.er_host_copy_h2d(C.c_void_p(dl.base + 4 * int(dl.offs[1])), _ffi.ptr(bad), 8), "er_host_copy_h2d")
+    dl.counts[1] = 1
+    with pytest.raises(Exception, match="out of range"):
+        g2.SetCorrespondencesDev(ids, dl)
+    dl.close()
