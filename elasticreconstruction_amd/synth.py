@@ -315,6 +315,18 @@ def pair_list(frs, n_pairs, rot, trans, seed0):
     return out
 
 
+def chain_pair_list(frs, n_pairs, rot, trans, seed0):
+    """Pairs over fragments that follow each other along an OPEN path (kinfu_fragment_set over part of a circle): every fragment with its next
+    neighbour, then with the one after, then the third, ... -- no wrap-around from the last fragment to the first.  Same guesses as pair_list."""
+    n_frag, out, step = len(frs), [], 1
+    while len(out) < n_pairs and step < n_frag:
+        for a in range(n_frag - step):
+            if len(out) < n_pairs:
+                out.append((a, a + step, np.linalg.inv(frs[a][2]) @ frs[a + step][2] @ perturbation(seed0 + len(out), rot, trans)))
+        step += 1
+    return out
+
+
 def hard_pair_list(frs, n_pairs):
     """The HARD list of bench.py's icp.hard_set and of tests/test_icp_gpu.py: guesses up to 6 deg / 6 cm off the ground truth -- three
     times the configs[2] perturbation -- so that PCL's 20-iteration budget, the transform criterion and the iteration limit are all
@@ -348,7 +360,7 @@ def kinfu_fragment(i, num, target_points=250000, frames=50, noise_mm=0.0, densit
     into a TSDF volume in the fragment's own cube frame -- first camera at basepose, the kinfu convention -- by THIS library's Integrate
     path, the zero crossings of the volume are extracted (er_tsdf_extract_surface: points on the voxel lattice's edges, 5.9 mm apart), and
     every point gets the normalised TSDF gradient (central differences at its nearest voxel) as its normal -- NaN where a neighbour voxel
-    was never observed, as at the border of what the sweep saw.  Points outside the cube are dropped (PointCloud::LoadFromPCDFile stops
+    was never observed, as at the border of what the sweep saw.  Points outside the cube [0, length) are dropped (PointCloud::LoadFromPCDFile stops
     there); density = "inv_z2" thins the survivors with probability ~ 1 / z^2 of the first camera (what one depth image of the sweep
     gives: dense close to the camera, > 10 x sparser on the far wall), "tsdf" keeps the lattice density.  NOT part of the measured path:
     a generator of realistic inputs that happens to need a GPU.
@@ -389,8 +401,8 @@ def kinfu_fragment(i, num, target_points=250000, frames=50, noise_mm=0.0, densit
         Wt[sl] = torch.from_numpy(w.reshape(64, 64, 64) != 0).to(dev)
     vol.close()
     P = torch.from_numpy(pts[:, :3].copy()).to(dev)
-    inside = ((P >= 0.0) & (P <= length)).all(dim=1)
-    v = torch.round(P.to(torch.float64) / ul).to(torch.int64)
+    inside = ((P >= 0.0) & (P < length)).all(dim=1)           # (PointCloud::GetCoordinate, PointCloud.h:101-110: floor(p / unit) must stay below the resolution --
+    v = torch.round(P.to(torch.float64) / ul).to(torch.int64)    #  a zero crossing ON the cube's far face, voxel 512, is already outside)
     ok = inside & ((v >= 1) & (v <= 510)).all(dim=1)
     vc = v.clamp(1, 510)
     g3, seen = [], Wt[vc[:, 0], vc[:, 1], vc[:, 2]]

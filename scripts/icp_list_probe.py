@@ -6,13 +6,23 @@ import numpy as np
 from elasticreconstruction_amd import synth
 from elasticreconstruction_amd.icp import Cloud, count_inliers_batch, find_correspondence_batch, icp_align_batch
 n_pairs, n_frag, reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50, 25, int(sys.argv[2]) if len(sys.argv) > 2 else 20
-frs = synth.fragment_set(n_frag, 250000, device="cuda:0")
-clouds = [(Cloud(x, n, 0.03, 0), F) for x, n, F in frs]
-pairs = []
-for k in range(n_pairs):
-    a = k % n_frag
-    b = (a + 1 + (k // n_frag) % 3) % n_frag
-    pairs.append((a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(700 + k, 2.0, 0.02)))
+if os.environ.get("ER_PROBE_KINFU", "0") == "1":          # the realistic list of bench.py's icp.realistic leg (synth.kinfu_fragment, sweeps 7.2 degrees apart)
+    frs = []
+    for i in range(n_frag):
+        x, n, F, st = synth.kinfu_fragment(i, 2 * n_frag, 250000, noise_mm=2.0 if i % 2 else 0.0)
+        ok = ~np.isnan(n).any(axis=1)
+        frs.append((np.ascontiguousarray(x[ok]), np.ascontiguousarray(n[ok]), F))
+    clouds = [(Cloud(x, n, 0.03, 0), F) for x, n, F in frs]
+    pairs = synth.chain_pair_list(frs, n_pairs, 2.0, 0.02, 700)
+    os.environ.setdefault("ER_PROBE_HARD", "0")
+else:
+    frs = synth.fragment_set(n_frag, 250000, device="cuda:0")
+    clouds = [(Cloud(x, n, 0.03, 0), F) for x, n, F in frs]
+    pairs = []
+    for k in range(n_pairs):
+        a = k % n_frag
+        b = (a + 1 + (k // n_frag) % 3) % n_frag
+        pairs.append((a, b, np.linalg.inv(clouds[a][1]) @ clouds[b][1] @ synth.perturbation(700 + k, 2.0, 0.02)))
 srcs, tgts = [clouds[b][0] for _, b, _ in pairs], [clouds[a][0] for a, _, _ in pairs]
 Ts = [T for _, _, T in pairs]
 T32 = [T.astype(np.float32) for T in Ts]

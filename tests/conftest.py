@@ -17,7 +17,7 @@ def pytest_configure(config):
 # run FIRST, the widening rows 8(f) last, so that `pytest -m gpu -x` can never lose the hot path's evidence to a failure in a
 # widening row (round 3: tests/test_fopt_gpu.py sorted first, one wrong test in it hid 36 parity tests from the driver's run).
 GPU_ORDER = ("test_tsdf_gpu", "test_icp_gpu", "test_host_programs_gpu", "test_distributed_gpu")
-WIDENING = ("test_ransac_", "test_zero_crossing_", "test_marching_cubes_", "test_fragment_optimizer_program_")    # 8(f) rows inside 8(a) files
+WIDENING = ("test_ransac_", "test_zero_crossing_", "test_marching_cubes_", "test_fragment_optimizer_program_", "test_chain_")    # 8(f) rows inside 8(a) files
 
 
 def pytest_collection_modifyitems(session, config, items):

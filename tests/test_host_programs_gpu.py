@@ -382,3 +382,125 @@ def test_abi_allreduce_on_a_one_rank_communicator_is_the_identity(gpu):
             blocks.append((lo.value, hi.value))
             assert (lo.value, hi.value) == parallel.frame_block(n, r, w)
         assert blocks[0][0] == 0 and blocks[-1][1] == n
+
+
+def test_chain_on_own_outputs_from_depth_frames_to_the_warped_volume(gpu, tmp_path):
+    """every stage consumes what the stage before it wrote (README.txt: Modules; the pipeline's order is
+    fragments -> BuildCorrespondence -> FragmentOptimizer -> Integrate) -- nothing is handed over in memory:
+      1. four 50-frame sweeps of depth images -> one TSDF sub-volume each through the library's Integrate path -> zero crossings + gradient normals
+         -> cloud_bin_<i>.pcd WITH their NaN normals (synth.kinfu_fragment: what pcl_kinfu's extraction leaves);
+      2. bin/BuildCorrespondence --registration --save_xyzn on those files + an initial pair log -> reg_output.log, corres_<i>_<j>.txt, cloud_bin_xyzn_<i>.xyzn;
+      3. bin/FragmentOptimizer --slac on the files of (2) + noisy initial poses -> pose.log, output.ctr;
+      4. bin/Integrate --pose_traj pose.log --ctr output.ctr on the ORIGINAL 200 depth frames -> world.pcd.
+    Checked: every program's input files are accepted by the corresponding reference program (oracle/_ref/*_ref, the reference sources compiled in place)
+    with the same results -- transforms 1e-5, correspondence files after a FindCorrespondence-only pass byte for byte, poses and lattices 1e-6, the final
+    voxel list as a bit-identical point set -- and the end result is RIGHT: the optimised poses are closer to the ground truth than the initial ones and the
+    near-zero voxels of the final volume lie within 1.5 voxels of the analytic room and sphere."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from corres_helpers import REF_BIN as BC_REF, read_outputs, run_program, write_refined_log
+    from test_fopt_oracle import REF_BIN as FO_REF
+    d = str(tmp_path) + "/"
+    NUM, FR, TOTAL = 4, 50, 50
+    base = synth.basepose(3.0)
+    # ---- 1. depth frames -> sub-volumes -> fragments on disk --------------------------------------------------------------------------------
+    F, seg, depth = [], [], []
+    for i in range(NUM):
+        x, n, Fi, st = synth.kinfu_fragment(i, TOTAL, 60000)
+        assert st["nan_normals"] > 0 and len(x) == 60000
+        formats.save_pcd_xyzn(d + "cloud_bin_%d.pcd" % i, x, n, binary=True)
+        W = synth.kinfu_camera_path(i, TOTAL, FR)
+        F.append(Fi)
+        seg.extend(np.linalg.inv(Fi) @ W[j] for j in range(FR))
+        depth.append(synth.to_numpy_u16(synth.render_depth(W, device="cuda:0")))
+    depth = np.concatenate(depth)
+    gt = [np.linalg.inv(F[0]) @ F[i] for i in range(NUM)]                       # fragment poses relative to fragment 0
+    # ---- 2. BuildCorrespondence ---------------------------------------------------------------------------------------------------------------
+    pairs = [formats.FramedTransformation(i, j, NUM, np.linalg.inv(gt[i]) @ gt[j] @ synth.perturbation(31 * i + j, 1.0, 0.01))
+             for (i, j) in [(0, 1), (1, 2), (2, 3), (0, 2), (1, 3)]]
+    formats.save_log(d + "init.log", pairs)
+    a1 = ["--reg_traj", d + "init.log", "--registration", "--save_xyzn", "--output_information"]
+    run_program(os.path.join(BIN, "BuildCorrespondence"), a1, d)
+    log, info, corr = read_outputs(d, pairs)
+    assert all(t.frame > 10000 for t in log) and len(corr) == len(pairs), [t.frame for t in log]
+    for t in log:                                                                 # the ICP pulled every pair onto the ground truth (within a voxel)
+        assert np.abs(t.T - np.linalg.inv(gt[t.id1]) @ gt[t.id2]).max() < 6e-3, (t.id1, t.id2)
+    xyzn = {i: open(d + "cloud_bin_xyzn_%d.xyzn" % i).read() for i in range(NUM)}
+    if os.path.exists(BC_REF):                                                    # the reference program on OUR .pcd files and init.log
+        for k in corr:
+            os.rename(d + "corres_%d_%d.txt" % k, d + "ours_corres_%d_%d.txt" % k)
+        run_program(BC_REF, a1, d)
+        rlog, rinfo, rcorr = read_outputs(d, pairs)
+        assert {i: open(d + "cloud_bin_xyzn_%d.xyzn" % i).read() for i in range(NUM)} == xyzn, "cloud_bin_xyzn_<i>.xyzn differ from the reference program's"
+        for t, r in zip(log, rlog):
+            assert (t.id1, t.id2) == (r.id1, r.id2) and np.abs(t.T - r.T).max() <= 1e-5 and abs(t.frame - r.frame) <= max(3, r.frame // 1000)
+        # FindCorrespondence-only from OUR 8-decimal transforms: byte-identical files
+        write_refined_log(d + "refined.log", log, NUM)
+        a2 = ["--reg_traj", d + "refined.log", "--output_information"]
+        for prog, tag in ((os.path.join(BIN, "BuildCorrespondence"), "ours"), (BC_REF, "ref")):
+            run_program(prog, a2, d)
+            out = read_outputs(d, pairs)
+            if tag == "ours":
+                log2, corr2 = out[0], out[2]
+            else:
+                assert corr2 == out[2] and [(t.id1, t.id2, t.frame) for t in log2] == [(t.id1, t.id2, t.frame) for t in out[0]]
+        os.replace(d + "reg_output.log", d + "reg_pass2.log")
+        for k in corr:
+            os.replace(d + "ours_corres_%d_%d.txt" % k, d + "corres_%d_%d.txt" % k)   # stage 3 reads the registration pass's own files
+        formats.save_log(d + "reg_output.log", log)
+    # ---- 3. FragmentOptimizer --slac ----------------------------------------------------------------------------------------------------------
+    init = [gt[i] @ synth.perturbation(90 + i, 0.4, 0.006) if i else gt[i] for i in range(NUM)]
+    with open(d + "rgbd.log", "w") as fh:                                         # InitIPose, OptApp.cpp:49-72: ipose = basepose * traj[0]^-1 * traj[i] * basepose^-1
+        for f, P in enumerate(init):
+            g = np.linalg.inv(base) @ P @ base
+            fh.write("%d\t%d\t%d\n" % (f, f, f + 1))
+            fh.write("\n".join("%.8f %.8f %.8f %.8f" % tuple(r) for r in g) + "\n")
+    a3 = ["--slac", "--registration", d + "reg_output.log", "--dir", d, "--rgbdslam", d + "rgbd.log", "--interval", "1", "--num", str(NUM), "--resolution", "8",
+          "--length", "3.0", "--iteration", "4", "--blacklistpair", "0"]
+    run_program(os.path.join(BIN, "FragmentOptimizer"), a3 + ["--save_to", d + "output.ctr"], d)
+    pose = [t.T for t in formats.load_log(d + "pose.log")]
+    ctr = np.loadtxt(d + "output.ctr")
+    assert len(pose) == NUM and ctr.shape == (NUM * 729, 3)
+    err0 = max(np.abs(init[i] - gt[i]).max() for i in range(NUM))
+    err1 = max(np.abs(pose[i] - pose[0] @ gt[i]).max() for i in range(NUM))      # (the gauge: everything relative to the optimised pose of fragment 0)
+    assert err1 < 0.5 * err0 and err1 < 4e-3, "SLAC did not pull the poses onto the ground truth: %.3g -> %.3g" % (err0, err1)
+    if os.path.exists(FO_REF):                                                    # the reference program on OUR reg_output.log / corres / xyzn files
+        os.replace(d + "pose.log", d + "pose_ours.log")
+        run_program(FO_REF, a3 + ["--save_to", d + "output_ref.ctr"], d)
+        rpose = [t.T for t in formats.load_log(d + "pose.log")]
+        assert max(np.abs(a - b).max() for a, b in zip(pose, rpose)) < 1e-6 and np.abs(ctr - np.loadtxt(d + "output_ref.ctr")).max() < 1e-6
+        os.replace(d + "pose_ours.log", d + "pose.log")
+    # ---- 4. Integrate with the optimised poses and lattices -------------------------------------------------------------------------------------
+    plog = formats.load_log(d + "pose.log")
+    formats.save_log(d + "pose5.log", plog + [formats.FramedTransformation(NUM, NUM, NUM + 1, plog[-1].T)])   # F + 1 entries: all F frames are integrated (SURVEY.md 8d)
+    n = NUM * FR
+    formats.save_log(d + "seg.log", [formats.FramedTransformation(f, f, f + 1, seg[f]) for f in range(n)] +
+                     [formats.FramedTransformation(n + j, n + j, n + j + 1, seg[-1]) for j in range(FR)])
+    depth.tofile(d + "frames.raw")
+    a4 = ["--pose_traj", "pose5.log", "--seg_traj", "seg.log", "--ctr", "output.ctr", "--num", str(NUM), "--resolution", "8", "--length", "3.0",
+          "--interval", str(FR), "-oni", "frames.raw"]
+    r = run_program(os.path.join(BIN, "Integrate"), a4 + ["--save_to", "world.pcd", "--max_units", "1024"], d)
+    w = formats.load_pcd(d + "world.pcd")
+    w = np.stack([w["x"], w["y"], w["z"], w["intensity"]], 1)
+    assert "%d voxel points have been written." % w.shape[0] in r.stdout and w.shape[0] > 200000
+    ref_int = os.path.join(ROOT, "oracle", "_ref", "Integrate_ref")
+    if os.path.exists(ref_int):                                                   # the reference program on OUR pose.log / output.ctr: the same voxels, bit for bit
+        run_program(ref_int, a4 + ["--save_to", "world_ref.pcd"], d, timeout=900)
+        wr = formats.load_pcd(d + "world_ref.pcd")
+        wr = np.stack([wr["x"], wr["y"], wr["z"], wr["intensity"]], 1)
+        assert np.array_equal(sorted_points(w).view(np.uint32), sorted_points(wr).view(np.uint32)), "world.pcd differs from the reference program's"
+    # the surface of the final volume is where the scene is: voxels next to the zero crossing (|tsdf| < 0.15 = 4.5 mm of the 30 mm band), lifted from the
+    # volume's frame (= fragment 0's cube, up to the optimised pose of fragment 0) into the room
+    near = w[np.abs(w[:, 3]) < 0.15]
+    p = near[:, :3].astype(np.float64) * (3.0 / 512.0)
+    M = F[0] @ np.linalg.inv(pose[0])
+    q = p @ M[:3, :3].T + M[:3, 3]
+    dw = np.minimum(np.abs(q - synth.ROOM_LO), np.abs(q - synth.ROOM_HI)).min(axis=1)
+    ds = np.abs(np.linalg.norm(q - np.asarray(synth.SPHERE_C), axis=1) - synth.SPHERE_R)
+    dist = np.minimum(dw, ds)
+    vox = 3.0 / 512.0
+    assert len(near) > 20000 and np.mean(dist < 1.5 * vox) > 0.97 and np.percentile(dist, 99.5) < 3.0 * vox, \
+        "final surface off the scene: %.3f within 1.5 voxels, 99.5 %% at %.2f voxels" % (np.mean(dist < 1.5 * vox), np.percentile(dist, 99.5) / vox)
+    print("chain: %d correspondences over %d pairs, pose error %.2g -> %.2g, %d near-zero voxels, %.1f %% within 1.5 voxels of the scene (median %.2f voxels)"
+          % (sum(t.frame for t in log), len(log), err0, err1, len(near), 100 * np.mean(dist < 1.5 * vox), np.median(dist) / vox))
