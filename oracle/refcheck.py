@@ -41,7 +41,7 @@ def point_to_plane_conditioning(src_xyz, tgt_nrm, T, corr):
 
 
 def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, lists, infos, tmp_dir, reg_dist=0.03, tol_T=1e-5, reg_num=40000,
-                                  reg_ratio=0.25, tol_T_at_limit=None):
+                                  reg_ratio=0.25, tol_T_at_limit=None, icp_on_rejected=True):
     """The results somebody (the HIP path; in the CPU suite: the restatement) produced for pairs[k], k in sel -- pre-check count,
     final transform, iteration count, converged flag, correspondence list and information matrix AT that final transform -- against
     the reference's own compiled code: CCorresApp::Registration (pre-check count = frame_ and the accept rule, CorresApp.cpp:257-281;
@@ -50,7 +50,10 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
     CCorresApp::FindCorrespondence run from the candidate's final transforms of the accepted pairs (corres_<i>_<j>.txt byte for byte,
     frame_, information).  tol_T_at_limit (default: tol_T) applies to pairs that used up PCL's 20 iterations: such a pair was stopped while still
     moving, and a loop that is not at a fixed point carries a one-ulp difference of a float32 increment forward instead of contracting it (noisy
-    kinfu-like fragments: 2e-5 after 20 iterations; the uniform fragments stay below 1e-6 even there).  Returns a summary dict."""
+    kinfu-like fragments: 2e-5 after 20 iterations; the uniform fragments stay below 1e-6 even there).  icp_on_rejected=False compares ICP loops only
+    for the pairs the pre-check accepts -- what CCorresApp::Registration actually runs: from a guess that leaves 2 % of the points with a neighbour the
+    loop solves near-singular systems, the estimate jumps by decimetres per iteration and a 1e-16 difference in the float64 sums grows tenfold per
+    iteration (profiles/r05f_icp_trace_rejected_pair.txt).  Returns a summary dict."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.pyoracle import RefCorres
     need = sorted({q for k in sel for q in pairs[k][:2]})
@@ -91,6 +94,8 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
         a, b, T = pairs[k]
         return RefCorres.icp(frs[b][0], frs[b][1], frs[a][0], frs[a][1], T.astype(np.float32), reg_dist, 20, 1e-6)
     with_icp = [k for k in sel if fins[k] is not None]                 # (a candidate that follows the reference's flow has no ICP result for rejected pairs)
+    if not icp_on_rejected:
+        with_icp = [k for k in with_icp if k in {q for q, _ in accepted}]
     assert all(fins[k] is not None for k, _ in accepted), "an accepted pair without a final transform"
     with ThreadPoolExecutor(8) as ex:                                  # (ctypes releases the GIL; the stub's ICP is single-threaded)
         ricp = list(ex.map(ref_icp, with_icp))

@@ -450,6 +450,8 @@ def test_chain_on_own_outputs_from_depth_frames_to_the_warped_volume(gpu, tmp_pa
             os.replace(d + "ours_corres_%d_%d.txt" % k, d + "corres_%d_%d.txt" % k)   # stage 3 reads the registration pass's own files
         formats.save_log(d + "reg_output.log", log)
     # ---- 3. FragmentOptimizer --slac ----------------------------------------------------------------------------------------------------------
+    for i in range(NUM):                                                          # stage 3 reads what stage 2 WROTE: cloud_bin_xyzn_<i>.xyzn (OptApp.cpp:86-96 prefers a
+        os.replace(d + "cloud_bin_%d.pcd" % i, d + "stage1_cloud_bin_%d.pcd" % i)   # cloud_bin_<i>.pcd when one is there; the stand-in PCL of the reference build only reads PointXYZRGBNormal files)
     init = [gt[i] @ synth.perturbation(90 + i, 0.4, 0.006) if i else gt[i] for i in range(NUM)]
     with open(d + "rgbd.log", "w") as fh:                                         # InitIPose, OptApp.cpp:49-72: ipose = basepose * traj[0]^-1 * traj[i] * basepose^-1
         for f, P in enumerate(init):
