@@ -1114,6 +1114,7 @@ struct GridScratch {
   size_t n_cap = 0, cub_cap = 0, bounds_cap = 0;
   hipStream_t up[2] = {nullptr, nullptr};                       // uploads: coordinates on one, normals on the other (two DMA engines keep the link busy)
   hipStream_t cs2[2] = {nullptr, nullptr};                      // grid kernels: consecutive chunks alternate between two lanes
+  hipStream_t bs = nullptr;                                     // the bounding boxes of EVERY chunk (stage A): waits for uploads never sit in front of a grid
   hipEvent_t lane_ev = nullptr;
   std::vector<hipEvent_t> ev;                                   // three per chunk of a batch: uploads done (two streams), bounds back
 };
@@ -1468,7 +1469,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   std::lock_guard<std::mutex> lock(gs.mu);
   auto sync_all = [&]() -> hipError_t {
     hipError_t e = hipSuccess;
-    for (hipStream_t st : {gs.up[0], gs.up[1], gs.cs2[0], gs.cs2[1]})
+    for (hipStream_t st : {gs.up[0], gs.up[1], gs.cs2[0], gs.cs2[1], gs.bs})
       if (st) {
         const hipError_t e1 = hipStreamSynchronize(st);
         if (e == hipSuccess) e = e1;
@@ -1494,6 +1495,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   for (int q = 0; q < 2; q++) {
     if (!gs.up[q]) ER_CTRY(hipStreamCreateWithFlags(&gs.up[q], hipStreamNonBlocking));
     if (!gs.cs2[q]) ER_CTRY(hipStreamCreateWithFlags(&gs.cs2[q], hipStreamNonBlocking));
+    if (!gs.bs) ER_CTRY(hipStreamCreateWithFlags(&gs.bs, hipStreamNonBlocking));
   }
   if (!gs.lane_ev) ER_CTRY(hipEventCreateWithFlags(&gs.lane_ev, hipEventDisableTiming));
   // ---- the chunks: consecutive clouds, at most kCloudChunk of them and kChunkPoints points (the first cloud of a chunk always fits) ----
@@ -1579,6 +1581,7 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
   ER_CTRY(hipMemcpyAsync(gs.bounds, h_init, (size_t)n_clouds * 8 * sizeof(int), hipMemcpyHostToDevice, gs.cs2[0]));
   ER_CTRY(hipEventRecord(gs.lane_ev, gs.cs2[0]));
   ER_CTRY(hipStreamWaitEvent(gs.cs2[1], gs.lane_ev, 0));
+  ER_CTRY(hipStreamWaitEvent(gs.bs, gs.lane_ev, 0));            // (the boxes' initial pattern is in place before the first bounds kernel)
   // ---- stage A of a chunk: allocation, uploads (two copy streams), bounding boxes (the chunk's compute lane) ----
   auto stage_a = [&](int ch) -> int {
     Chunk& C = chunks[(size_t)ch];
@@ -1627,7 +1630,10 @@ int er_cloud_create_batch(int n_clouds, const float* const* xyz_host, const floa
         ER_HIP_TRY(hipMemcpyAsync(out[i]->nrm, normal_host[i], (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, gs.up[1]));
       }
     }
-    hipStream_t L = gs.cs2[ch & 1];
+    // Stage A runs on a stream of its own (round 5): on the two grid lanes the upload waits of chunk 2, 4, ... were queued IN FRONT of
+    // chunk 0's grid (in-order streams; every stage A is enqueued before the first stage B), so "built while the later chunks are still uploading" mostly
+    // did not happen.  Stage B of a chunk starts after the HOST has seen the chunk's boxes (ev[3 ch + 2]), hence after its uploads.
+    hipStream_t L = gs.bs;
     for (int q = 0; q < 2; q++) {
       ER_HIP_TRY(hipEventRecord(gs.ev[(size_t)(3 * ch + q)], gs.up[q]));
       ER_HIP_TRY(hipStreamWaitEvent(L, gs.ev[(size_t)(3 * ch + q)], 0));
