@@ -612,14 +612,14 @@ def allpairs_section(n_frag, device, rank=0, world=1, with_cpu=True):
            "phase_ms": {"pre_check_all_pairs": 1e3 * ph[0], "icp_accepted": 1e3 * ph[1], "find_correspondence_accepted": 1e3 * ph[2]},
            "sharding": "pair p -> rank p mod %d, fragments replicated, no collective" % world, "_pass_s": dt}
     if with_cpu:
-        # 24 random pairs + the first four accepted ones against the reference's own compiled CCorresApp (the accept rule of
+        # 14 random pairs + the first four accepted ones (24 + 4 until round 4: the leg took 90 s of the default run) against the reference's own compiled CCorresApp (the accept rule of
         # CorresApp.cpp:257-281 decides on BOTH sides which of them get an ICP and a correspondence list); where that build did not
         # travel, the pre-check counts against the restatement
         try:
             from oracle import refcheck
             from oracle.pyoracle import IcpOracle, RefCorres
             rng = np.random.default_rng(5)
-            pick = sorted(set(int(k) for k in rng.choice(len(mine), 24, replace=False)) | set(int(k) for k in np.nonzero(acc)[0][:4]))
+            pick = sorted(set(int(k) for k in rng.choice(len(mine), 14, replace=False)) | set(int(k) for k in np.nonzero(acc)[0][:4]))
             if RefCorres.available():
                 fins, its, conv, lists, infos = last["fins"], last["iters"], last["conv"], last["lists"], last["infos"]
                 pos = {int(k): q for q, k in enumerate(np.nonzero(acc)[0])}
