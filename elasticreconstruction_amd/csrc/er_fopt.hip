@@ -855,6 +855,8 @@ int er_fopt_set_correspondences_dev(er_fopt_t h, int n_pairs, const int* frag_i,
   for (int l = 0; l < n_pairs; l++) {
     const int i = frag_i[l], j = frag_j[l], m = counts[l];
     if (i < 0 || i >= h->num || j < 0 || j >= h->num || m < 0 || (m > 0 && !pairs_dev[l])) return er::fail("er_fopt_set_correspondences_dev: bad pair %d", l);
+    if (m > 0 && (fn[(size_t)i] == 0 || fn[(size_t)j] == 0 || !h->d_frags))      // (the key kernel reads the fragments' idx_[0] arrays)
+      return er::fail("er_fopt_set_correspondences_dev: pair %d refers to a fragment without a cloud (er_fopt_set_cloud first)", l);
     off[(size_t)l + 1] = off[(size_t)l] + m;
   }
   const long N = off[(size_t)n_pairs];
