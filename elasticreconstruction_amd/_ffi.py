@@ -20,7 +20,7 @@ SYMBOLS = [
     "er_tsdf_extract_world", "er_tsdf_extract_surface", "er_tsdf_extract_mesh", "er_mc_table", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
     "er_tsdf_export_raw", "er_tsdf_import_raw",
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
-    "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_destroy", "er_comm_rank", "er_comm_world",
+    "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_create_loopback", "er_comm_destroy", "er_comm_rank", "er_comm_world",
     "er_tsdf_allreduce", "er_comm_merge_stats", "er_frame_block",
     "er_cloud_create", "er_cloud_create_batch", "er_cloud_destroy", "er_cloud_size",
     "er_icp_count_inliers", "er_icp_align", "er_find_correspondence",
@@ -104,6 +104,7 @@ def lib():
     L.er_comm_unique_id.argtypes = [vp]
     L.er_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.er_comm_create_local.argtypes = [C.c_int, vp, vp]
+    L.er_comm_create_loopback.argtypes = [C.c_int, C.c_int, vp]
     L.er_comm_destroy.argtypes = [vp]
     L.er_comm_rank.argtypes = [vp]
     L.er_comm_world.argtypes = [vp]

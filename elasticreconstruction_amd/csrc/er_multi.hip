@@ -25,6 +25,8 @@
 #include <rccl/rccl.h>   // types and enums only: every function is reached through dlsym
 
 #include <algorithm>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -98,7 +100,40 @@ Rccl* rccl() {
 
 }  // namespace
 
+// ---- loopback communicator (round 5): N ranks = N host threads of ONE process, all on ONE device ----------------------------------------------
+// RCCL refuses two ranks on one GPU and the builder's boxes have one, so until round 5 no N > 1 merge had ever touched a device volume.  The loopback
+// transport runs the SAME protocol header over the SAME device volumes, export / import kernels and plane buffers; only the wire is replaced: the sum
+// reduction is a kernel that adds the ranks' plane buffers in rank order, the point-to-point step is a device-to-device copy, the small host collectives
+// go through a mutex / condition-variable barrier.  It is what `bin/Integrate --gpus N --same_device` and tests/test_tsdf_gpu.py use; it says nothing
+// about xGMI.
+struct ErLoop {
+  int world = 1, device = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0, generation = 0;
+  std::vector<const int*> iptr;
+  std::vector<int> ibuf;
+  std::vector<float*> fptr;
+  std::vector<const float*> xsend;
+  std::vector<size_t> xcount;
+  std::vector<std::vector<int>> xto;
+  explicit ErLoop(int w, int dev) : world(w), device(dev), iptr((size_t)w), fptr((size_t)w), xsend((size_t)w), xcount((size_t)w), xto((size_t)w) {}
+  template <class F> void barrier(F last) {                     // `last` runs inside the critical section of the last arriver
+    std::unique_lock<std::mutex> lk(m);
+    const int gen = generation;
+    if (++arrived == world) {
+      last();
+      arrived = 0;
+      generation++;
+      cv.notify_all();
+    } else {
+      cv.wait(lk, [&] { return generation != gen; });
+    }
+  }
+};
+
 struct er_comm_s {
+  std::shared_ptr<ErLoop> loop;   // set: a loopback communicator (comm stays NULL)
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   float* buf = nullptr;        // [multi-toucher units][sdf*w | w][64^3] planes of the reduction (grow-only)
@@ -179,6 +214,89 @@ struct RcclTransport : er::MergeTransport {
     if (bad != ncclSuccess || e2 != ncclSuccess)
       return ::er::fail("er_tsdf_allreduce: ncclSend / ncclRecv failed: %s", R->GetErrorString(bad != ncclSuccess ? bad : e2));
     return 0;
+  }
+};
+
+// dst[i] = ((src_0[i] + src_1[i]) + ...) + src_{n-1}[i]: the ranks' plane buffers added in rank order (dst may be one of the sources)
+struct LoopSrc { const float* p[16]; };
+__global__ __launch_bounds__(256) void k_loop_sum(LoopSrc S, int n, float* __restrict__ dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    float a = S.p[0][i];
+    for (int q = 1; q < n; q++) a += S.p[q][i];
+    dst[i] = a;
+  }
+}
+
+// er::MergeTransport over an ErLoop: every rank is a host thread of this process, every buffer lives on the one device.
+struct LoopTransport : er::MergeTransport {
+  er_comm_t c;
+  ErLoop& L;
+  hipStream_t S;
+  LoopTransport(er_comm_t comm, hipStream_t s) : c(comm), L(*comm->loop), S(s) {}
+  int rank() const override { return c->rank; }
+  int world() const override { return c->world; }
+  int allreduce_max(int* v, int n) override {
+    L.iptr[(size_t)c->rank] = v;
+    L.barrier([&] {
+      L.ibuf.assign((size_t)n, -2147483647 - 1);
+      for (int q = 0; q < L.world; q++)
+        for (int i = 0; i < n; i++) L.ibuf[(size_t)i] = std::max(L.ibuf[(size_t)i], L.iptr[(size_t)q][i]);
+    });
+    for (int i = 0; i < n; i++) v[i] = L.ibuf[(size_t)i];
+    L.barrier([] {});                                           // nobody overwrites ibuf before everyone has read it
+    return 0;
+  }
+  int allgather(const int* mine, int n, int* all) override {
+    L.iptr[(size_t)c->rank] = mine;
+    L.barrier([&] {
+      L.ibuf.resize((size_t)n * L.world);
+      for (int q = 0; q < L.world; q++) std::copy(L.iptr[(size_t)q], L.iptr[(size_t)q] + n, L.ibuf.begin() + (size_t)q * n);
+    });
+    std::copy(L.ibuf.begin(), L.ibuf.end(), all);
+    L.barrier([] {});
+    return 0;
+  }
+  int reduce_sum(float* planes, size_t count, int root) override {
+    if (L.world > 16) return ::er::fail("er_tsdf_allreduce: the loopback communicator holds at most 16 ranks");
+    int rc = 0;
+    if (hipStreamSynchronize(S) != hipSuccess) rc = 1;         // this rank's export kernel has written `planes`
+    L.fptr[(size_t)c->rank] = planes;
+    L.barrier([] {});
+    const int owner = root < 0 ? 0 : root;                      // the rank that adds; with root < 0 the others copy its result
+    if (c->rank == owner && !rc) {
+      LoopSrc src;
+      for (int q = 0; q < 16; q++) src.p[q] = q < L.world ? L.fptr[(size_t)q] : nullptr;
+      const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 16384);
+      hipLaunchKernelGGL(k_loop_sum, dim3(blocks), dim3(256), 0, S, src, L.world, planes, count);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(S) != hipSuccess) rc = 1;
+    }
+    L.barrier([] {});
+    if (root < 0 && c->rank != owner && !rc) {
+      if (hipMemcpyAsync(planes, L.fptr[(size_t)owner], count * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess || hipStreamSynchronize(S) != hipSuccess) rc = 1;
+    }
+    L.barrier([] {});                                           // the owner's buffer stays untouched until everybody has copied
+    return rc ? ::er::fail("er_tsdf_allreduce (loopback): %s", hipGetErrorString(hipGetLastError())) : 0;
+  }
+  int exchange(const float* send, size_t send_count, const std::vector<int>& send_to, float* recv, const std::vector<size_t>& recv_count) override {
+    int rc = 0;
+    if (hipStreamSynchronize(S) != hipSuccess) rc = 1;         // this rank's raw export has written `send`
+    L.xsend[(size_t)c->rank] = send;
+    L.xcount[(size_t)c->rank] = send_count;
+    L.xto[(size_t)c->rank] = send_to;
+    L.barrier([] {});
+    size_t off = 0;
+    for (int q = 0; q < L.world && !rc; q++) {
+      const size_t n = recv_count[(size_t)q];
+      if (!n) continue;
+      const std::vector<int>& to = L.xto[(size_t)q];           // what I expect from q must be what q sends to me
+      if (q == c->rank || n != L.xcount[(size_t)q] || std::find(to.begin(), to.end(), c->rank) == to.end()) rc = 2;
+      else if (hipMemcpyAsync(recv + off, L.xsend[(size_t)q], n * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess) rc = 1;
+      off += n;
+    }
+    if (!rc && hipStreamSynchronize(S) != hipSuccess) rc = 1;
+    L.barrier([] {});                                           // the senders' blocks stay untouched until everybody has copied
+    if (rc == 2) return ::er::fail("er_tsdf_allreduce (loopback): the ranks disagree about who sends what");
+    return rc ? ::er::fail("er_tsdf_allreduce (loopback): %s", hipGetErrorString(hipGetLastError())) : 0;
   }
 };
 
@@ -310,6 +428,23 @@ int er_comm_create_local(int n, const int* devices, er_comm_t* out) {
   return 0;
 }
 
+int er_comm_create_loopback(int n, int device, er_comm_t* out) {
+  if (n < 1 || n > 16 || !out) return er::fail("er_comm_create_loopback: 1 .. 16 ranks and a handle array are needed");
+  for (int i = 0; i < n; i++) out[i] = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return er::fail("er_comm_create_loopback: device %d is not there", device);
+  std::shared_ptr<ErLoop> L = std::make_shared<ErLoop>(n, device);
+  for (int i = 0; i < n; i++) {
+    er_comm_t c = new er_comm_s();
+    c->loop = L;
+    c->rank = i;
+    c->world = n;
+    c->device = device;
+    out[i] = c;
+  }
+  return 0;
+}
+
 int er_comm_destroy(er_comm_t c) {
   if (!c) return 0;
   (void)hipSetDevice(c->device);
@@ -317,8 +452,10 @@ int er_comm_destroy(er_comm_t c) {
   if (c->sbuf) (void)hipFree(c->sbuf);
   if (c->rbuf) (void)hipFree(c->rbuf);
   if (c->ikeys) (void)hipFree(c->ikeys);
-  Rccl* R = rccl();
-  if (R && c->comm) (void)R->CommDestroy(c->comm);
+  if (c->comm) {
+    Rccl* R = rccl();
+    if (R) (void)R->CommDestroy(c->comm);
+  }
   delete c;
   return 0;
 }
@@ -335,8 +472,8 @@ int er_comm_world(er_comm_t c) { return c ? c->world : -1; }
 // missing, and a HIP / RCCL error inside a collective itself (MERGE_TRANSPORT_FAILURE) -- after those the peers' state is unknown.
 int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   if (!h || !c) return er::fail("er_tsdf_allreduce: NULL argument");
-  Rccl* R = rccl();
-  if (!R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded (%s)", rccl_reason());
+  Rccl* R = c->loop ? nullptr : rccl();
+  if (!c->loop && !R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded (%s)", rccl_reason());
   int pre = 0;
   if (root >= c->world) pre = er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
   else if (er::tsdf_device(h) != c->device)
@@ -344,7 +481,10 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   const hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess && !pre) pre = er::fail("er_tsdf_allreduce: hipSetDevice(%d): %s", c->device, hipGetErrorString(e));
   std::string why = pre ? er_last_error() : "";                 // (the protocol's later steps may overwrite the thread's message)
-  RcclTransport t(R, c, pre && er::tsdf_device(h) != c->device ? nullptr : er::tsdf_stream(h));
+  hipStream_t stream = pre && er::tsdf_device(h) != c->device ? nullptr : er::tsdf_stream(h);
+  RcclTransport t_rccl(R, c, stream);
+  std::unique_ptr<LoopTransport> t_loop(c->loop ? new LoopTransport(c, stream) : nullptr);
+  er::MergeTransport& t = c->loop ? static_cast<er::MergeTransport&>(*t_loop) : static_cast<er::MergeTransport&>(t_rccl);
   DeviceVolume v(h, c);
   c->last = er::MergeStats();
   const int r = er::merge_protocol(t, v, root, union_units, pre ? 1 : 0, &c->last);

@@ -365,15 +365,16 @@ int main(int argc, char* argv[]) {
   parse_argument(argc, argv, "--gpus", gpus);
   parse_argument(argc, argv, "--shard", shard);
   const bool force_merge = find_switch(argc, argv, "--force_merge");
-  // test hook: all workers share ONE device (lets a 1-GPU box run the N-worker unit-shard logic; RCCL refuses two ranks on
-  // one device, so it is only accepted with --shard unit)
+  // all workers share ONE device: lets a 1-GPU box run the N-worker logic.  --shard unit needs no collective; --shard frame merges through the
+  // library's loopback communicator (er_comm_create_loopback: the same protocol, device volumes and kernels, device-to-device copies instead of
+  // RCCL, which refuses two ranks on one device)
   const bool same_device = find_switch(argc, argv, "--same_device");
   if (app.batch_ < 1) app.batch_ = 1;
   if (app.batch_ > ER_MAX_BATCH) app.batch_ = ER_MAX_BATCH;
   if (gpus < 1) gpus = 1;
   if (shard != "frame" && shard != "unit") { fprintf(stderr, "Integrate: --shard must be frame or unit\n"); return 1; }
   const bool unit_shard = shard == "unit";
-  if (same_device && !unit_shard && gpus > 1) { fprintf(stderr, "Integrate: --same_device needs --shard unit\n"); return 1; }
+  if (same_device && !unit_shard && gpus > 16) { fprintf(stderr, "Integrate: --same_device --shard frame takes at most 16 workers\n"); return 1; }
   if (!same_device && gpus > 1 && er_device_count() > 0 && app.device_ + gpus > er_device_count()) {
     fprintf(stderr, "Integrate: --gpus %d from --device %d, but %d HIP devices are visible\n", gpus, app.device_, er_device_count());
     return 1;
@@ -393,7 +394,8 @@ int main(int argc, char* argv[]) {
   if (merge) {
     std::vector<int> devs((size_t)gpus);
     for (int g = 0; g < gpus; g++) devs[(size_t)g] = app.device_ + g;
-    if (er_comm_create_local(gpus, devs.data(), comms.data()) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return 1; }
+    const int crc = same_device ? er_comm_create_loopback(gpus, app.device_, comms.data()) : er_comm_create_local(gpus, devs.data(), comms.data());
+    if (crc != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); return 1; }
   }
 
   // The frame ids Execute can let through (IntegrateApp.cpp:200-216,230-233): [first, last].  --shard frame cuts this range
@@ -432,7 +434,12 @@ int main(int argc, char* argv[]) {
     if (merge) {
       int nu = 0;
       if (er_tsdf_allreduce(w.volume_, comms[(size_t)g], 0, &nu) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); wrc[(size_t)g] = 1; }
-      else if (g == 0) fprintf(stderr, "Integrate: merged %d GPU volumes over RCCL, %d units in the union\n", gpus, nu);
+      else if (g == 0) {
+        long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)er_comm_merge_stats(comms[0], st);
+        fprintf(stderr, "Integrate: merged %d GPU volumes over %s, %d units in the union (%lld reduced, %lld of %lld single-toucher units received by the root)\n", gpus,
+                same_device ? "the loopback transport (one device)" : "RCCL", nu, st[1], st[4], st[2]);
+      }
     }
   };
   if (gpus == 1) {

@@ -173,3 +173,49 @@ class AbiComm:
         if getattr(self, "_h", None):
             self._lib.er_comm_destroy(self._h)
             self._h = None
+
+
+class LoopbackComms:
+    """n ranks of ONE process on ONE device (er_comm_create_loopback): the product's merge protocol over real device volumes without RCCL -- the sum
+    reduction is a kernel that adds the ranks' plane buffers in rank order, the point-to-point step device-to-device copies.  allreduce(vols, root) calls
+    er_tsdf_allreduce for every rank from a thread of its own (ctypes releases the GIL), as `bin/Integrate --gpus N --same_device` does."""
+
+    def __init__(self, n, device=0):
+        import ctypes as C
+        from . import _ffi
+        self._lib = _ffi.lib()
+        self.n = int(n)
+        arr = (C.c_void_p * self.n)()
+        _ffi.check(self._lib.er_comm_create_loopback(self.n, int(device), arr), "er_comm_create_loopback")
+        self._h = [C.c_void_p(arr[i]) for i in range(self.n)]
+
+    def allreduce(self, vols, root=0):
+        """vols[r] = rank r's volume.  Returns the union size (the same on every rank)."""
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+        from . import _ffi
+        assert len(vols) == self.n
+
+        def one(r):
+            n = C.c_int(0)
+            rc = self._lib.er_tsdf_allreduce(vols[r]._h, self._h[r], int(root), C.byref(n))
+            return rc, n.value, (self._lib.er_last_error().decode() if rc else "")
+        with ThreadPoolExecutor(self.n) as ex:
+            out = list(ex.map(one, range(self.n)))
+        bad = [o for o in out if o[0]]
+        if bad:
+            raise _ffi.ErError("er_tsdf_allreduce (loopback): " + bad[0][2])
+        return out[0][1]
+
+    def merge_stats(self, rank=0):
+        import ctypes as C
+        from . import _ffi
+        st = (C.c_longlong * 8)()
+        _ffi.check(self._lib.er_comm_merge_stats(self._h[rank], st), "er_comm_merge_stats")
+        names = ("union_units", "multi_toucher_units", "single_toucher_units", "units_sent", "units_received", "bytes_reduced", "bytes_sent", "bytes_received")
+        return {n: int(v) for n, v in zip(names, st)}
+
+    def close(self):
+        for h in getattr(self, "_h", []):
+            self._lib.er_comm_destroy(h)
+        self._h = []

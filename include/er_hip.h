@@ -193,6 +193,10 @@ typedef struct er_comm_s* er_comm_t;
 int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]);
 int er_comm_create(const unsigned char id[ER_COMM_ID_BYTES], int rank, int world, int device, er_comm_t* out);
 int er_comm_create_local(int n, const int* devices, er_comm_t* out /* n handles */);
+/* n <= 16 ranks = n host threads of this process, ALL on one device, no RCCL: the same merge protocol over the same device volumes and
+ * export / import kernels, the sum reduction as a kernel that adds the ranks' plane buffers in rank order, the point-to-point step as
+ * device-to-device copies.  For boxes with one GPU (RCCL refuses two ranks on one device): `Integrate --gpus N --same_device`, tests. */
+int er_comm_create_loopback(int n, int device, er_comm_t* out /* n handles */);
 int er_comm_destroy(er_comm_t c);
 int er_comm_rank(er_comm_t c);
 int er_comm_world(er_comm_t c);

@@ -73,6 +73,51 @@ for G in (1, 2, 4, 8):
     print("configs[3] G=%d: %s" % (G, json.dumps(p)), flush=True)
 out["configs[3]"] = res3
 
+# ---- the REAL merge of configs[3] with 8 ranks on this one GPU (loopback communicator: the protocol, the device volumes, the export / import kernels and the
+# plane buffers of er_tsdf_allreduce; a summing kernel and device-to-device copies where RCCL would be) -- everything of the 8-rank merge except the wire ----
+try:
+    from elasticreconstruction_amd import parallel
+    G = 8
+    per = -(-N // (G * 50)) * 50
+    vols, full = [], TSDFVolume(max_units=2048, device=0)
+    for r in range(G):
+        sc = synth.make_scenario(per, interval=50, warp=True, frame_offset=r * per, total_frames=N, revolutions=N / 3000.0, radius_drift=1.5, room=(-1.5, 4.5), device=dev)
+        w = synth.warp_arrays(sc)
+        v = TSDFVolume(max_units=2048 if r == 0 else 1024, device=0)
+        px = sc["depth"].shape[1]
+        for lo in range(0, per, 200):
+            hi = lo + 200
+            gi = w["grid_index"][lo:hi]
+            g0, g1 = int(gi.min()), int(gi.max()) + 1
+            ws = dict(ctr=w["ctr"][g0:g1], resolution=w["resolution"], length=w["length"], grid_index=gi - g0, seg=w["seg"][lo:hi], madj=w["madj"][lo:hi])
+            for tgt in (v, full):
+                tgt.IntegrateFrames(None, sc["traj"][lo:hi], ws, device_ptr=sc["depth"].data_ptr() + lo * px * 2)
+        v.synchronize(); full.synchronize()
+        vols.append(v)
+        del sc
+    comms = parallel.LoopbackComms(G)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nu = comms.allreduce(vols, root=0)
+    t_merge = time.perf_counter() - t0
+    st = comms.merge_stats(0)
+    worst, wdiff = 0.0, 0
+    keys = full.unit_keys()
+    same_keys = bool(np.array_equal(keys, vols[0].unit_keys()))
+    for k in keys[:: max(1, len(keys) // 120)]:               # every ninth unit or so: 120 units x 2 MiB x 2 read back
+        sf, wf = full.read_unit(k)
+        sm, wm = vols[0].read_unit(k)
+        wdiff += int((wf != wm).sum())
+        worst = max(worst, float(np.abs(sf - sm).max()))
+    out["loopback_merge_8_ranks"] = {"union": int(nu), "merge_ms_without_a_wire": round(1e3 * t_merge, 2), "stats_root": st, "keys_equal_single_volume": same_keys,
+                                     "weight_mismatches_in_sampled_units": wdiff, "max_abs_sdf_diff_in_sampled_units": worst}
+    print("loopback merge of configs[3], 8 ranks on one GPU:", json.dumps(out["loopback_merge_8_ranks"]), flush=True)
+    comms.close()
+    for v in vols + [full]:
+        v.close()
+except Exception as ex:
+    print("loopback merge failed:", repr(ex), flush=True)
+
 # ---- configs[1]: every rank one 3000-frame revolution (bench.py --gpus G: frame_offset = rank * 3000 of a G x 3000-frame trajectory) ------------------
 res1 = {}
 for G in (1, 2, 8):

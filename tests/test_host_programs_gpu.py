@@ -320,6 +320,7 @@ def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
        * --gpus 1 --force_merge: the frame-split merge of er_tsdf_allreduce -- key exchange + ONE ncclReduce issued from
          liber_hip.so over a one-rank RCCL communicator -- must leave the volume as it was: weights exact, sdf within 1e-5
          (sdf*w / w re-rounds), same point set up to that tolerance;
+       * --gpus 3 --same_device: three workers on this GPU, frame blocks, the merge over the loopback communicator: same points within 1e-5;
        * --gpus 3 --shard unit --same_device: three workers, each fed every frame and owning a third of the units, no
          collective: world.pcd BYTE-identical to the single-GPU program's (same points, same ascending-key order)."""
     d = str(tmp_path)
@@ -344,6 +345,15 @@ def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
         assert np.array_equal(a[:, :3], b[:, :3]) and np.abs(a[:, 3] - b[:, 3]).max() <= 1e-5
     else:
         assert abs(a.shape[0] - b.shape[0]) <= 1e-4 * a.shape[0]
+    # --gpus 3 --same_device (frame shard): three workers on this one GPU, contiguous frame blocks, merged by er_tsdf_allreduce over the loopback
+    # communicator -- the protocol, the device volumes and the export / import kernels of the real thing, device-to-device copies for the wire
+    looped, r = run(["--gpus", "3", "--same_device"], "wl.pcd")
+    assert "merged 3 GPU volumes over the loopback transport" in r.stderr
+    c = sorted_points(looped)
+    if a.shape == c.shape:
+        assert np.array_equal(a[:, :3], c[:, :3]) and np.abs(a[:, 3] - c[:, 3]).max() <= 1e-5
+    else:
+        assert abs(a.shape[0] - c.shape[0]) <= 1e-4 * a.shape[0]
     sharded, _ = run(["--gpus", "3", "--shard", "unit", "--same_device"], "wu.pcd")
     assert np.array_equal(one.view(np.uint32), sharded.view(np.uint32)), "unit-shard world.pcd differs from the single-GPU one"
     with open(os.path.join(d, "w1.pcd"), "rb") as f1, open(os.path.join(d, "wu.pcd"), "rb") as f2:
