@@ -22,6 +22,7 @@ def run_block(sc, max_units, step):
     """integrate a scenario's frames in steps of `step`; returns (keys, seconds of the second pass)"""
     depth, px = sc["depth"], sc["depth"].shape[1]
     warp = synth.warp_arrays(sc)
+    torch.cuda.synchronize()                                   # (the frames are rendered on torch's stream)
     vol = TSDFVolume(max_units=max_units, device=0)
     dt = None
     for rep in range(2):
@@ -83,6 +84,7 @@ try:
     for r in range(G):
         sc = synth.make_scenario(per, interval=50, warp=True, frame_offset=r * per, total_frames=N, revolutions=N / 3000.0, radius_drift=1.5, room=(-1.5, 4.5), device=dev)
         w = synth.warp_arrays(sc)
+        torch.cuda.synchronize()
         v = TSDFVolume(max_units=2048 if r == 0 else 1024, device=0)
         px = sc["depth"].shape[1]
         for lo in range(0, per, 200):

@@ -303,6 +303,7 @@ def test_frame_split_merge_with_four_loopback_ranks_on_one_gpu(gpu):
     borders, most units belong to one block.  Against ONE volume that integrated the same four blocks: key sets equal, weights exact, sdf within 1e-5 in
     the units two or more ranks touched and BIT-IDENTICAL in the units one rank touched (they travel raw); er_comm_merge_stats consistent with the key
     sets; with root < 0 every rank ends with the same bits."""
+    import torch
     from elasticreconstruction_amd import parallel
     G, per = 4, 100
     full = TSDFVolume(max_units=2048)
@@ -311,6 +312,7 @@ def test_frame_split_merge_with_four_loopback_ranks_on_one_gpu(gpu):
         sc = synth.make_scenario(per, interval=50, warp=True, frame_offset=r * per, total_frames=G * per, revolutions=1.0, radius_drift=1.5,
                                  room=(-1.5, 4.5), device="cuda:0")
         blocks.append((sc, synth.warp_arrays(sc)))
+        torch.cuda.synchronize()                               # the frames are rendered on torch's stream: finished before the library's streams read them
         full.IntegrateFrames(None, sc["traj"], blocks[-1][1], device_ptr=sc["depth"].data_ptr())
         full.synchronize()
     for root in (0, -1):
