@@ -2048,7 +2048,12 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
     if (group_describe(g, i0, m, src, tgt, T, true)) return 1;
     ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, (size_t)m * kAcc * sizeof(double), g->stream));
-    const int nsub = (m + kCorrSub - 1) / kCorrSub;
+    // sub-groups exist to put the list copies of one behind the kernels of the next (PCIe); when every list of this group stays in HBM there is nothing
+    // to hide and the whole group is ONE sub-group: 4 launches instead of 4 per 8 pairs, no partly filled last waves in between
+    bool all_dev = true;
+    for (int q = 0; q < m; q++) all_dev = all_dev && (capacity[i0 + q] <= 0 || direct[(size_t)(i0 + q)] == 2);
+    const int sub = all_dev ? std::max(m, 1) : kCorrSub;
+    const int nsub = (m + sub - 1) / sub;
     while ((int)g->sub_ev.size() < nsub) {
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return er::fail("er_find_correspondence: hipEventCreate failed");
@@ -2057,7 +2062,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     std::vector<hipEvent_t>& evs = g->sub_ev;
     auto cleanup = [&]() {};
     auto enqueue = [&](int s) -> int {
-      const int s0 = s * kCorrSub, ms = std::min(kCorrSub, m - s0);
+      const int s0 = s * sub, ms = std::min(sub, m - s0);
       int mxb = 1;
       for (int q = 0; q < ms; q++) mxb = std::max(mxb, g->h_pairs[s0 + q].nb);
       hipLaunchKernelGGL(k_find_corr, dim3(mxb, ms), dim3(kBlock), 0, g->stream, g->d_pairs + s0, (float)dist, dist * dist, normal_cos);
@@ -2066,7 +2071,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     if (enqueue(0)) { cleanup(); return 1; }
     for (int s = 0; s < nsub; s++) {
       if (s + 1 < nsub && enqueue(s + 1)) { cleanup(); return 1; }
-      const int s0 = s * kCorrSub, ms = std::min(kCorrSub, m - s0);
+      const int s0 = s * sub, ms = std::min(sub, m - s0);
       if (hipEventSynchronize(evs[(size_t)s]) != hipSuccess) { cleanup(); return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError())); }
       for (int q = 0; q < ms; q++) {
         const int i = i0 + s0 + q;
