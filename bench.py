@@ -871,6 +871,16 @@ class DryVolume:
             with np.errstate(divide="ignore", invalid="ignore"):
                 self.units[int(k)] = (np.where(w > 0, sw / w, np.float32(0)).astype(np.float32), w)
 
+    def export_raw(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            buf[q, 0], buf[q, 1] = self.units[int(k)]
+
+    def import_raw(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            self.units[int(k)] = (buf[q, 0].copy(), buf[q, 1].copy())
+
     def close(self):
         self.units = {}
 

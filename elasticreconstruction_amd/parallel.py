@@ -6,15 +6,15 @@
   Path A (frames)  contiguous frame blocks per rank into private volumes, then ONE exchange step:
                    all-gather of the touched unit keys -> union, ONE reduce(sum) to rank 0 (or all-reduce) over
                    the [key][sdf*weight | weight] planes of the union, per-voxel divide on import.
-                   (merge_volumes below, the torch.distributed CROSS-CHECK, still reduces the planes of the whole union -- the
-                   dense protocol of rounds 2-4; the product path, er_tsdf_allreduce behind AbiComm, reduces only the units two or
-                   more ranks touched and moves the others point to point: csrc/er_merge_protocol.h.)
+                   (Since round 5 only the units two or more ranks touched go through the sum; a unit one rank touched travels raw,
+                   bit for bit, from its owner to where the result is wanted: csrc/er_merge_protocol.h -- er_tsdf_allreduce behind
+                   AbiComm is the product path, merge_volumes below the torch.distributed cross-check of the same protocol.)
                    (The running mean with unit weights is a sum: w = sum_g w_g, sdf = sum_g sdf_g*w_g / w;
                    TSDFVolume.cpp:93-94 applied sequentially gives the same value up to float rounding
                    order, hence tolerance 1e-5 instead of bit parity for this mode.)
 
-The functions only need an object with unit_keys() / export_weighted(keys, ptr) / import_weighted(keys, ptr)
-/ synchronize(), so the CPU tests can drive the identical protocol over gloo with a host-memory volume.
+The functions only need an object with unit_keys() / export_weighted(keys, ptr) / import_weighted(keys, ptr) / export_raw(keys, ptr) /
+import_raw(keys, ptr) / synchronize(), so the CPU tests can drive the identical protocol over gloo with a host-memory volume.
 """
 import numpy as np
 
@@ -43,11 +43,11 @@ def _agree_max(values, dist, device):
     return [int(v) for v in t.cpu()]
 
 
-def union_keys(local_keys, dist, device, status=0):
-    """Union of the per-rank touched unit keys (sorted int32 numpy): the ranks first AGREE on the padded length -- one
-    all_reduce(MAX) of {key count, status} -- then exchange the keys in ONE fixed-size all-gather (padded with -1), so every
-    rank issues the same collectives with the same shapes whatever it touched (csrc/er_merge_protocol.h, steps 2-3).
-    status != 0 on any rank makes every rank raise MergeError after the first collective."""
+def gather_keys(local_keys, dist, device, status=0):
+    """Every rank's touched unit keys on every rank: the ranks first AGREE on the padded length -- one all_reduce(MAX) of {key count, status} --
+    then exchange the keys in ONE fixed-size all-gather (padded with -1), so every rank issues the same collectives with the same shapes
+    whatever it touched (csrc/er_merge_protocol.h, steps 2-3).  status != 0 on any rank makes every rank raise MergeError after the first
+    collective.  Returns [sorted int32 numpy array of rank q's keys for q in range(world)]."""
     import torch
     world = dist.get_world_size()
     keys = np.ascontiguousarray(local_keys, np.int32)
@@ -55,23 +55,55 @@ def union_keys(local_keys, dist, device, status=0):
     if any_failed:
         raise MergeError("a rank failed before the merge (its unit pool or hash table overflowed?); nothing was merged")
     if max_keys <= 0:
-        return np.zeros(0, np.int32)
+        return [np.zeros(0, np.int32) for _ in range(world)]
     pad = torch.full((max_keys,), -1, dtype=torch.int32)
     if keys.size:
         pad[:keys.size] = torch.from_numpy(keys)
     pad = pad.to(device)
     allk = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(allk, pad)                               # (list form: also supported by gloo in the CPU tests)
-    u = torch.unique(torch.stack(allk))
-    return u[u >= 0].to(torch.int32).cpu().numpy()
+    out = []
+    for t in allk:
+        a = np.unique(t.cpu().numpy())
+        out.append(a[a >= 0].astype(np.int32))
+    return out
+
+
+def union_keys(local_keys, dist, device, status=0):
+    """Sorted union of the per-rank touched unit keys (gather_keys, then the union)."""
+    per_rank = gather_keys(local_keys, dist, device, status)
+    return np.unique(np.concatenate(per_rank)).astype(np.int32) if per_rank else np.zeros(0, np.int32)
+
+
+def merge_plan(per_rank_keys, rank, root):
+    """Who touched what (csrc/er_merge_protocol.h step 3, the same arithmetic): (union, multi, send, recv) with multi = the keys two or more ranks
+    touched (they go through the sum), send = this rank's single-toucher keys that have to travel (to `root`, or to everybody for root < 0),
+    recv = {owner: keys} of the single-toucher units that arrive here.  All arrays sorted."""
+    world = len(per_rank_keys)
+    allk = np.concatenate(per_rank_keys) if world else np.zeros(0, np.int32)
+    union, cnt = np.unique(allk, return_counts=True)
+    multi = union[cnt >= 2].astype(np.int32)
+    single = set(int(k) for k in union[cnt == 1])
+    send, recv = np.zeros(0, np.int32), {}
+    for q in range(world):
+        own = np.array(sorted(int(k) for k in per_rank_keys[q] if int(k) in single), np.int32)
+        travels = own.size > 0 and (world > 1 if root < 0 else q != root)
+        if not travels:
+            continue
+        if q == rank:
+            send = own
+        elif root < 0 or root == rank:
+            recv[q] = own
+    return union.astype(np.int32), multi, send, recv
 
 
 def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
     """Frame-split merge over torch.distributed -- the cross-check of the product path (er_tsdf_allreduce, same protocol:
-    csrc/er_merge_protocol.h).  mode "reduce" (default): ONE reduce(sum) to `root` -- the "final reduce of per-GPU TSDF
-    volume-unit weights" of BASELINE.json; afterwards `root` holds the complete volume (the other ranks keep
-    their partial volumes).  mode "all_reduce": every rank ends with the complete volume (about 1.75x the
-    link traffic of the reduce on a ring).  Returns the union size.
+    csrc/er_merge_protocol.h, since round 5 including its sparse data path).  mode "reduce" (default): ONE reduce(sum) to `root` over the
+    [key][sdf*weight | weight] planes of the units TWO OR MORE ranks touched -- the "final reduce of per-GPU TSDF volume-unit weights" of
+    BASELINE.json -- and one send per owner of the units only ONE rank touched, raw, bit for bit; afterwards `root` holds the complete volume
+    (the other ranks keep their partial volumes).  mode "all_reduce": an all-reduce and one broadcast per owner; every rank ends with the
+    complete volume.  Returns the union size.
     A rank-local failure (vol.unit_keys() / export raising, e.g. "raise max_units") is carried through the next collective
     as a status: every rank raises MergeError together instead of the healthy ones blocking in the reduction.
     sync_stream: callable that orders the communication stream after the volume's kernels and vice versa.  None (default)
@@ -79,43 +111,80 @@ def merge_volumes(vol, dist, device, sync_stream=None, mode="reduce", root=0):
     the collective is ordered on) is drained before the import -- two host waits, once per job."""
     import torch
     local_error = None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    all_mode = mode == "all_reduce"
     try:
         keys = vol.unit_keys()
     except Exception as ex:                                   # unit pool / hash table overflow on THIS rank
         keys, local_error = np.zeros(0, np.int32), ex
     try:
-        union = union_keys(keys, dist, device, status=1 if local_error else 0)
+        per_rank = gather_keys(keys, dist, device, status=1 if local_error else 0)
     except MergeError:
         if local_error:
             raise local_error
         raise
+    union, multi, send, recv = merge_plan(per_rank, rank, -1 if all_mode else root)
     if union.size == 0:
         return 0
-    buf = None
-    try:
-        buf = torch.empty((union.size, 2, 64 ** 3), dtype=torch.float32, device=device)
-        vol.export_weighted(union, buf.data_ptr())
+    plane = 2 * 64 ** 3
+
+    def wait_volume():
         if sync_stream:
             sync_stream()
         else:
-            vol.synchronize()                                # k_export_weighted has written buf
+            vol.synchronize()
+
+    def wait_comm():
+        if sync_stream:
+            sync_stream()
+        elif getattr(device, "type", str(device)) != "cpu" and str(device) != "cpu":
+            torch.cuda.current_stream(device).synchronize()
+
+    buf = sbuf = None
+    rbuf = {}
+    try:
+        if multi.size:
+            buf = torch.empty((multi.size, 2, 64 ** 3), dtype=torch.float32, device=device)
+            vol.export_weighted(multi, buf.data_ptr())
+        if send.size:
+            sbuf = torch.empty((send.size, 2, 64 ** 3), dtype=torch.float32, device=device)
+            vol.export_raw(send, sbuf.data_ptr())
+        for q, ks in recv.items():
+            rbuf[q] = torch.empty((ks.size, 2, 64 ** 3), dtype=torch.float32, device=device)
+        wait_volume()                                        # the export kernels have written buf / sbuf
     except Exception as ex:
         local_error = ex
     if _agree_max([1 if local_error else 0], dist, device)[0]:
         if local_error:
             raise local_error
         raise MergeError("a rank failed while exporting its planes; nothing was merged")
-    if mode == "all_reduce":
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)           # the ONLY data-path collective of the pipeline
-    else:
-        dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
-    if sync_stream:
-        sync_stream()
-    elif getattr(device, "type", str(device)) != "cpu" and str(device) != "cpu":
-        torch.cuda.current_stream(device).synchronize()      # the reduce has landed in buf
-    if mode == "all_reduce" or dist.get_rank() == root:
-        vol.import_weighted(union, buf.data_ptr())
+    if multi.size:                                           # (the same decision on every rank: `multi` is a function of the gathered keys)
+        if all_mode:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)       # the ONLY arithmetic collective of the pipeline
+        else:
+            dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM)
+    # the single-toucher units: owners in ascending rank order, so that every rank issues matching calls in the same order
+    single_cnt = [int(np.setdiff1d(per_rank[q], multi).size) for q in range(world)]
+    for q in range(world):
+        if single_cnt[q] == 0:
+            continue
+        if all_mode:
+            if world > 1:
+                t = sbuf if q == rank else rbuf[q]
+                dist.broadcast(t, src=q)
+        elif q != root:
+            if q == rank:
+                dist.send(sbuf, dst=root)
+            elif rank == root:
+                dist.recv(rbuf[q], src=q)
+    wait_comm()                                              # the reduce / the received units have landed
+    if all_mode or rank == root:
+        if multi.size:
+            vol.import_weighted(multi, buf.data_ptr())
+        for q, ks in recv.items():
+            vol.import_raw(ks, rbuf[q].data_ptr())
     vol.synchronize()
+    del plane
     return int(union.size)
 
 

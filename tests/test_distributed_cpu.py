@@ -54,6 +54,16 @@ class HostVolume:
                 s = np.where(w > 0, sw / w, np.float32(0)).astype(np.float32)
             self.units[int(k)] = (s, w)
 
+    def export_raw(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            buf[q, 0], buf[q, 1] = self.units[int(k)]               # (only asked for units this rank owns)
+
+    def import_raw(self, keys, ptr):
+        buf = self._view(ptr, len(keys))
+        for q, k in enumerate(keys):
+            self.units[int(k)] = (buf[q, 0].copy(), buf[q, 1].copy())
+
     def synchronize(self):
         pass
 
@@ -94,6 +104,8 @@ def _worker(rank, world, port, q):
     # pair sharding: every pair exactly once, results back in order
     mine = {p: (p, rank) for p in parallel.pair_shard(7, rank, world)}
     gathered = parallel.gather_pair_results(mine, 7, dist)
+    keysets = [None] * world
+    dist.all_gather_object(keysets, [int(k) for k in local_keys])
     if rank == 0:
         full = HostVolume()
         full.integrate_with_oracle(depth, poses)
@@ -104,7 +116,13 @@ def _worker(rank, world, port, q):
             sf, wf = full.units[int(k)]
             wbad += int((w != wf).sum())
             worst = max(worst, float(np.abs(s - sf).max()))
+        # round 5, the sparse merge: a unit only ONE rank touched travels raw and must equal the single-volume result BIT FOR BIT (no frame of the
+        # other rank ever reached it), in the reduce AND in the all-reduce mode
+        single = sorted(set(keysets[0]) ^ set(keysets[1]))
+        raw_exact = all(np.array_equal(v.units[k][0].view(np.uint32), full.units[k][0].view(np.uint32)) and np.array_equal(v.units[k][1], full.units[k][1])
+                        for v in (vol, vol_ar) for k in single)
         q.put(dict(failure_kinds=kinds, ok_keys=ok_keys, worst=worst, wbad=wbad, n_union=n_union, n_local=len(local_keys), modes_agree=bool(same),
+                   single_units=len(single), multi_units=len(set(keysets[0]) & set(keysets[1])), raw_exact=bool(raw_exact),
                    pairs=[g[0] for g in gathered], owners=[g[1] for g in gathered]))
     dist.barrier()
     dist.destroy_process_group()
@@ -129,6 +147,7 @@ def test_frame_split_merge_and_pair_shard_world2_gloo():
     assert res["wbad"] == 0, "merged weights must be exact (integer-valued floats)"
     assert res["worst"] <= 1e-5, "merged tsdf off by %.3g" % res["worst"]
     assert res["n_union"] >= res["n_local"] > 0 and res["modes_agree"]
+    assert res["single_units"] > 0 and res["multi_units"] > 0 and res["raw_exact"], (res["single_units"], res["multi_units"], res["raw_exact"])
     assert res["pairs"] == list(range(7)) and res["owners"] == [0, 1, 0, 1, 0, 1, 0]
 
 
