@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
   const int lo_tiles_x = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_tiles = lo_tiles_x * ((rows + (1 << kLoShift) - 1) >> kLoShift);
   const int n_items = plan->n_units * kItemsPerUnit;
   // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
-  // its own (one atomic per item and workgroup; the grid is 4 persistent workgroups per CU): longest-processing-time-
+  // its own (one atomic per item and workgroup; the grid is 3 persistent workgroups per CU): longest-processing-time-
   // first scheduling.  The culling and the full / sure shortcuts make the real cost of an item unpredictable, and with a static
   // deal the kernel lasted as long as its unluckiest workgroup: taking 22 % of the instructions out of the kernel (the full
   // path) did not shorten it at all.  History: with the static deal the queue made the kernel 13 % faster and the JOB 5 %
@@ -617,10 +617,7 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
       m_full = __ballot(keep && full);
     }
     // Frame loop in two halves: project() computes the pixel under every voxel of the four register rows and issues the depth
-    // gathers, finish() does the arithmetic that needs the samples.  -DER_FRAME_PIPELINE software-pipelines the loop over two
-    // frames (the gathers of frame n+1 in flight during the update of frame n; the waits become "all but the newest four
-    // loads"): measured, no gain -- 124.9 k vs 125.4 k frames/s, 108 VGPRs instead of 98 (profiles/r02x_ab_frame_pipeline.txt) --
-    // so the sequential order is the default.  Frames reach every voxel in ascending order either way.
+    // gathers, finish() does the arithmetic that needs the samples; the loop below overlaps the two halves of consecutive frames.
     auto project = [&](int f, float (&dp)[kRows]) {
       const FrameXform fx = frames[f];
       const float* __restrict__ sc = scaled + (size_t)f * (pixels + kScaledPad);
@@ -675,40 +672,77 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
         (void)upd;
       }
     };
-    while (m) {
-      {
-        // a run of consecutive FULL frames (in the mask's order): n updates with tsdf = 1 of every voxel of the patch
-        const unsigned long long nf = m & ~m_full;
-        const unsigned long long run = nf ? (m & ((nf & (0ull - nf)) - 1ull)) : m;
-        if (run) {                                                       // wave-uniform
-          const int n = __popcll(run);
-          m &= ~run;
-          bool nontrivial = false;
+    // Software pipeline over the frames that need a projection (round 5, the one change to this loop that paid): the projection and the four depth gathers
+    // of the NEXT such frame are issued before the current frame's samples are used.  A probe build with shader-clock stamps had shown 3100 ticks per
+    // (wave, frame) visit for ~730 issue cycles -- the wave sat on its gathers once per frame.  Runs of full frames need no samples and are applied where
+    // they fall in the ascending order, so every voxel still sees its frames one by one in frame order.  Two stages per trip with alternating sample
+    // registers (a rotating copy would have to wait for the data it copies); the last frame is finished after the loop.  Measured, interleaved on one box
+    // (profiles/r05n_ab_frame_pipeline.txt): k_integrate 0.234 -> 0.203 ms per launch inside the three-stream pipeline, 167.4 k -> 170.0 k frames/s; and
+    // with THREE persistent workgroups per CU instead of four -- each wave now hides its own latency, the freed registers go to the pre-pass kernels --
+    // 174.3 k (two: 172.0 k).  A fully symmetric variant (two sample sets in flight at every stage top, so that the compiler's waits are "all but the newest
+    // four" in both stages; in this one the first stage still waits for everything before its projection) measured the same and is 15 % more code.
+    // Round 2 had tried the same idea on the kernel of its day and found nothing (profiles/r02x_ab_frame_pipeline.txt): the exact update dominated a visit then.
+    {
+      unsigned long long mn = m & ~m_full, mf = m & m_full;
+      auto apply_full = [&](unsigned long long run) {
+        const int n = __popcll(run);
+        bool nontrivial = false;
 #pragma unroll
-          for (int r = 0; r < kRows; r++) nontrivial = nontrivial | !(voxel_free_trivial(S[r], W[r]) & (W[r] < 8388608.0f));
-          if (__ballot(nontrivial) == 0ull) {                            // (S W + 1) / (W + 1) == 1 exactly, W + n exact below 2^24
+        for (int r = 0; r < kRows; r++) nontrivial = nontrivial | !(voxel_free_trivial(S[r], W[r]) & (W[r] < 8388608.0f));
+        if (__ballot(nontrivial) == 0ull) {                              // (S W + 1) / (W + 1) == 1 exactly, W + n exact below 2^24
+#pragma unroll
+          for (int r = 0; r < kRows; r++) {
+            S[r] = 1.0f;
+            W[r] = W[r] + (float)n;
+          }
+        } else {                                                         // a voxel that was inside the truncation band before: the n divisions, in order
+          for (int q = 0; q < n; q++) {
 #pragma unroll
             for (int r = 0; r < kRows; r++) {
-              S[r] = 1.0f;
-              W[r] = W[r] + (float)n;
-            }
-          } else {                                                       // a voxel that was inside the truncation band before: the n divisions, in order
-            for (int q = 0; q < n; q++) {
-#pragma unroll
-              for (int r = 0; r < kRows; r++) {
-                S[r] = div_inrange(S[r] * W[r] + 1.0f, W[r] + 1.0f);
-                W[r] = W[r] + 1.0f;
-              }
+              S[r] = div_inrange(S[r] * W[r] + 1.0f, W[r] + 1.0f);
+              W[r] = W[r] + 1.0f;
             }
           }
-          continue;
         }
+      };
+      auto runs_before = [&](int f) {
+        const unsigned long long run = f < 64 ? (mf & ((1ull << f) - 1ull)) : mf;   // the full frames before the next projected one
+        if (run) {                                                       // wave-uniform
+          mf &= ~run;
+          apply_full(run);
+        }
+      };
+      if (mn) {
+        float dpa[kRows], dpb[kRows];
+        int pf = __builtin_ctzll(mn);
+        mn &= mn - 1;
+        project(pf, dpa);
+        bool last_in_b = false;
+        for (;;) {                                                       // two stages per trip: the sample registers alternate; the last frame is finished after the loop
+          runs_before(pf);
+          if (mn == 0ull) break;                                         // (pf's samples are in dpa)
+          int nf = __builtin_ctzll(mn);
+          mn &= mn - 1;
+          project(nf, dpb);
+          finish(pf, dpa);
+          pf = nf;
+          runs_before(pf);
+          if (mn == 0ull) {                                              // (pf's samples are in dpb)
+            last_in_b = true;
+            break;
+          }
+          nf = __builtin_ctzll(mn);
+          mn &= mn - 1;
+          project(nf, dpa);
+          finish(pf, dpb);
+          pf = nf;
+        }
+        float dpl[kRows];
+#pragma unroll
+        for (int r = 0; r < kRows; r++) dpl[r] = last_in_b ? dpb[r] : dpa[r];
+        finish(pf, dpl);                                                 // the last projected frame: nothing left to prefetch
       }
-      const int f = __builtin_ctzll(m);
-      m &= m - 1;
-      float dp[kRows];
-      project(f, dp);
-      finish(f, dp);
+      runs_before(64);                                                   // the full frames after the last projected one
     }
 #pragma unroll
     for (int r = 0; r < kRows; r++)
@@ -1228,12 +1262,13 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
   int* nbatch = h->counters + kNbatchSlot[p];
 
 #ifndef ER_INT_BLOCKS_PER_CU
-#define ER_INT_BLOCKS_PER_CU 4
+#define ER_INT_BLOCKS_PER_CU 3
 #endif
   constexpr int kIntBlocksPerCu = ER_INT_BLOCKS_PER_CU;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
                                            // space next to them (round 2, four rows per lane: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s;
                                            // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; four rows with the plan records: 2 -> 153.3 k,
-                                           // 3 -> 158.5 k, 4 -> 159.2 k, 5 -> 155.2 k; profiles/r02G_*, r03i_ab_rows8.txt, r03D_ab_rows4_again.txt)
+                                           // 3 -> 158.5 k, 4 -> 159.2 k, 5 -> 155.2 k; profiles/r02G_*, r03i_ab_rows8.txt, r03D_ab_rows4_again.txt;
+                                           // round 5, with the frame loop software-pipelined: 2 -> 172.0 k, 3 -> 174.3 k, 4 -> 170.0 k, 5 -> 169.6 k)
   const int wide_grid = h->n_cu * kIntBlocksPerCu;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);
