@@ -219,12 +219,54 @@ def _bench_dry_run(nproc, extra, timeout=420):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    import tempfile
+    full = os.path.join(tempfile.mkdtemp(prefix="er_bench_dry_"), "bench_full.json")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--dry-run"] + extra
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--dry-run", "--full-json", full] + extra
     env = dict(os.environ, OMP_NUM_THREADS="1", ER_ORACLE_QUIET="1")
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return json_line(r.stdout)
+    compact = json_line(r.stdout)
+    check_compact_line(r.stdout, compact)
+    with open(full) as fh:
+        out = json.load(fh)
+    # the compact line is made FROM the full object: the headline numbers agree
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better", "vs_baseline"):
+        assert compact[k] == out[k], k
+    assert abs(compact["value"] - out["value"]) <= 1e-6 * out["value"] and abs(compact["ms_per_step"] - out["ms_per_step"]) <= 1e-6 * out["ms_per_step"]
+    return out
+
+
+COMPACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"}
+
+
+def check_compact_line(stdout, c):
+    """BENCH_r05.json parsed as null because the one stdout line had grown to 22 KB.  The LAST stdout line must be a JSON
+    object under 4 KB with the contract's keys, and roofline.frac must recompute from the line itself."""
+    import json
+    last = [l for l in stdout.splitlines() if l.strip()][-1]
+    assert len(last) < 4096, "compact line is %d bytes" % len(last)
+    assert json.loads(last) == c
+    assert COMPACT_KEYS <= set(c), COMPACT_KEYS - set(c)
+    assert {"workload", "baseline_config", "frames_per_step", "volume_units_touched", "inputs"} <= set(c["config"])
+    assert c["config"]["workload"].startswith("configs[") and len(c["config"]["workload"]) < 100
+    rf = c["roofline"]
+    assert {"bound", "kernel", "frac", "achieved", "peak", "unit", "kernel_frac", "algorithmic_bytes_per_pass", "traffic", "avg_launch_ms"} <= set(rf)
+    assert rf["bound"] == "hbm" and rf["kernel"] == "k_integrate" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s"
+    frac = rf["algorithmic_bytes_per_pass"] / (c["ms_per_step"] * c["steps"] * 1e-3) / 8e12
+    assert abs(rf["frac"] - frac) <= 1e-5 * frac, (rf["frac"], frac)
+    assert abs(rf["achieved"] / rf["peak"] - rf["frac"]) <= 1e-5 * frac
+    # k_integrate priced with its own bytes over its own launch time
+    assert abs(rf["kernel_frac"] - rf["kernel_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 8e12) <= 1e-5 * rf["kernel_frac"]
+
+    def no_prose(x, path="line"):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                no_prose(v, path + "." + k)
+        elif isinstance(x, str):
+            assert len(x) <= 100, "%s carries %d characters of text" % (path, len(x))
+    no_prose(c)
 
 
 def test_bench_dry_run_four_ranks_through_the_drivers_command_line():
@@ -252,6 +294,25 @@ def test_bench_dry_run_four_ranks_through_the_drivers_command_line():
     assert out["roofline"]["voxel_updates_per_pass"] == 2 * 100 * 64 ** 3
     assert out["icp"]["pairs"] == 20 and "4 GPUs x 5 pairs" in out["icp"]["sharding"]
     assert "cpu_baseline" not in out and "other_configs" not in out
+
+
+def test_compact_line_of_a_full_headline_object_stays_under_4k():
+    """The compact line from the LARGEST object bench.py has ever produced (profiles/r05o_bench_default.json, 22 KB: the line the driver could
+    not parse in round 5) is under 4 KB, keeps the headline, roofline, cpu_baseline, parity, ICP and other-config figures, and drops the prose."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05o_bench_default.json")) as fh:
+        out = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
+    line = bench.compact_line(out)
+    assert len(line) < 4096, len(line)
+    c = json.loads(line)
+    check_compact_line(line, c)
+    assert abs(c["value"] - out["value"]) < 1e-6 * out["value"] and c["config"]["workload"] == "configs[1]" and c["config"]["inputs"] == "hbm_resident"
+    assert c["cpu_baseline"]["kind"] == "reference" and c["cpu_baseline"]["cores"] == 8 and c["cpu_baseline"]["value"] > 0
+    assert c["parity_checked"]["bit_exact"] is True
+    assert c["icp"]["pairs_per_s"] > 0 and c["icp"]["realistic_pairs_per_s"] > 0 and c["icp"]["cpu_baseline"]["kind"] == "reference"
+    assert set(c["other_configs"]) == {"configs[3]", "configs[4]"} and c["other_configs"]["configs[3]"]["bit_exact"] is True
 
 
 def test_bench_dry_run_config4_and_config5_two_ranks():
