@@ -137,7 +137,9 @@ def compact_line(out):
         c["config"]["merge_impl"] = cfg["merge_impl"].split(" ")[0]
     ms = _get(cfg, "merge_stats")
     if isinstance(ms, dict):
-        c["config"]["merge_bytes"] = {k: ms[k] for k in ("reduced_bytes", "raw_bytes", "band_bytes", "units_reduced", "units_raw") if k in ms}
+        c["config"]["merge"] = {k: ms[k] for k in ("impl", "multi_toucher_units", "single_toucher_units", "bytes_sent", "bytes_received", "bytes_reduced",
+                                                   "ring_equivalent_bytes") if k in ms}
+        c["config"]["merge_result"] = (cfg.get("merge_result") or "").split(" ")[0]
     kint = _get(rf, "kernels", "k_integrate") or {}
     c["roofline"] = {"bound": rf.get("bound"), "kernel": rf.get("kernel"), "frac": rf.get("frac"), "achieved": rf.get("achieved"),
                      "peak": rf.get("peak"), "unit": rf.get("unit"), "algorithmic_bytes_per_pass": rf.get("algorithmic_bytes_per_pass"),
@@ -212,6 +214,28 @@ def compact_line(out):
     return line
 
 
+class QuietStdout:
+    """File descriptor 1 points at stderr for the whole run and comes back for the ONE line: RCCL prints a version banner through C stdio (seen
+    in the first round-6 GPU run, flushed at process exit, i.e. AFTER the JSON line), the reference's code logs through printf / cout, and with
+    N > 1 every rank's stdout lands in the same pipe.  Ranks other than 0 never get it back."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def restore(self):
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)                 # whatever C stdio still holds goes where fd 1 points NOW (stderr)
+        except OSError:
+            pass
+        os.dup2(self._saved, 1)
+
+
+_quiet = None
+
+
 def emit(out, full_path):
     """Full object -> file (and stderr), compact line -> stdout, LAST."""
     try:
@@ -226,7 +250,11 @@ def emit(out, full_path):
         sys.stderr.write("bench.py: could not write %s: %s\n" % (full_path, ex))
     sys.stderr.write("bench.py full result object:\n" + json.dumps(out, indent=1) + "\n")
     sys.stderr.flush()
+    if _quiet is not None:
+        _quiet.restore()
     print(compact_line(out), flush=True)
+    if _quiet is not None:
+        os.dup2(2, 1)                                      # (anything a library prints at exit stays off the line's pipe)
 
 
 def main():
@@ -261,6 +289,9 @@ def main():
     ap.add_argument("--merge-impl", choices=["torch", "abi"], default="abi",
                     help="frame-split merge through liber_hip.so's own RCCL calls (er_tsdf_allreduce: the product path, what "
                          "bin/Integrate --gpus uses; default) or through torch.distributed (parallel.merge_volumes, the cross-check)")
+    ap.add_argument("--merge-root", type=int, default=-2,
+                    help="where the frame-split merge leaves the result (--merge-impl abi): -2 = distributed by unit owner (default, what bin/Integrate "
+                         "--gpus N does), r >= 0 = gathered on rank r, -1 = on every rank")
     ap.add_argument("--icp-pairs", type=int, default=50,
                     help="also time N fragment pairs per GPU through Registration + FindCorrespondence (configs[2] shape) and add an "
                          "'icp' object with BASELINE.json's second figure, pairs/s (0 = skip)")
@@ -276,6 +307,8 @@ def main():
                     help="where rank 0 writes the FULL result object (per-phase tables, definitions, A/B leftovers, the children's objects); "
                          "stdout carries only the compact line (< 4 KB) made from it by compact_line()")
     args = ap.parse_args()
+    global _quiet
+    _quiet = QuietStdout()
 
     import numpy as np
     import torch
@@ -370,11 +403,16 @@ def main():
             merge_note = merge_note or "er_comm_create failed on another rank"
             args.merge_impl = "torch"
 
+    # the product's merge (er_tsdf_allreduce, round 6: reduce-scatter by unit owner) leaves the merged volume DISTRIBUTED -- every unit complete on
+    # exactly one rank, which is all SaveWorld needs (bin/Integrate --gpus N assembles world.pcd from the ranks' extractions); --merge-root 0 gathers
+    # it on rank 0 inside the timed region instead.  The torch cross-check and the dry run know the rooted form only.
+    distributed = comm is not None and not dry and args.merge_root == -2
+
     def merge(vol):
-        """Frame-split merge: key all-gather + ONE reduce(sum) to rank 0 over the sdf*w / w planes."""
+        """Frame-split merge inside the timed region."""
         from elasticreconstruction_amd import parallel
         if comm is not None:
-            return comm.allreduce(vol, root=0)
+            return comm.allreduce(vol, root=args.merge_root if not dry else 0)
         return parallel.merge_volumes(vol, dist, dev)
 
     max_units = 4096 if big_room else (640 if world == 1 else 1024)
@@ -435,9 +473,15 @@ def main():
         vol.set_profiling(False)
     n_pass = len(pass_s)
     dt = float(np.median(pass_s))
-    # unit weights add exactly, so after the merge rank 0 holds the job-wide number of voxel updates of ONE pass
-    sum_w = vol.sum_weight() / world
+    # unit weights add exactly: after a merge gathered on rank 0 it holds the job-wide number of voxel updates of ONE pass; after a distributed merge
+    # every unit lives on exactly one rank and the ranks' sums add up to it (one small all-reduce, outside the timed region)
+    sum_w = vol.sum_weight()
     n_units = vol.unit_count()
+    if use_dist and distributed:
+        t = torch.tensor([sum_w, float(n_units)], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        sum_w, n_units = float(t[0].item()), int(round(float(t[1].item())))
+    sum_w /= world
 
     # ---- streamed: the same K steps with the frames in page-locked HOST memory (PCIe inside the timed region) ----
     streamed = None
@@ -526,7 +570,7 @@ def main():
                        "baseline_config": args.config, "warp": warp_on,
                        "frames_per_step": S, "frames_per_gpu": n_frames, "volume_units_touched": n_units,
                        "covers_all_of_configs1": bool(args.config == 2 and n_frames == CONFIG2_FRAMES),
-                       "parallelism": "frame-block shard x%d + one final reduce to rank 0" % world if world > 1 else "single GPU",
+                       "parallelism": "frame-block shard x%d + merge by unit owner" % world if world > 1 else "single GPU",
                        "inputs": "HOST memory, copied over PCIe inside the timed region (not the headline configuration)"
                        if args.host_input else "resident in HBM before the timed region"},
             "timing": {"passes": n_pass, "timed_region_s": float(sum(pass_s)), "pass_ms": {"min": 1e3 * min(pass_s), "median": 1e3 * dt, "max": 1e3 * max(pass_s)},
@@ -538,6 +582,7 @@ def main():
             out["config"]["merge_union_units"] = n_union
             out["config"]["merge_impl"] = args.merge_impl + (" (er_tsdf_allreduce: liber_hip.so's own RCCL calls)" if args.merge_impl == "abi" else " (parallel.merge_volumes over torch.distributed)")
             out["config"]["rccl_ranks"] = world
+            out["config"]["merge_result"] = "distributed by unit owner" if distributed else "on rank %d" % max(args.merge_root, 0)
             if comm is not None and hasattr(comm, "merge_stats"):
                 # rank 0's view of the LAST merge: the sum reduction carries only the units two or more ranks touched, the others travel raw, point to
                 # point, or stay where they are (csrc/er_merge_protocol.h; with one rank nothing moves at all)

@@ -117,18 +117,27 @@ struct ErLoop {
   std::vector<const float*> xsend;
   std::vector<size_t> xcount;
   std::vector<std::vector<int>> xto;
-  explicit ErLoop(int w, int dev) : world(w), device(dev), iptr((size_t)w), fptr((size_t)w), xsend((size_t)w), xcount((size_t)w), xto((size_t)w) {}
-  template <class F> void barrier(F last) {                     // `last` runs inside the critical section of the last arriver
+  std::vector<std::vector<size_t>> voff, vcnt;                  // exchange_v: every rank's per-receiver offsets and counts
+  int pending_vote = 0, result_vote = 0;
+  explicit ErLoop(int w, int dev)
+      : world(w), device(dev), iptr((size_t)w), fptr((size_t)w), xsend((size_t)w), xcount((size_t)w), xto((size_t)w), voff((size_t)w), vcnt((size_t)w) {}
+  // `last` runs inside the critical section of the last arriver.  Returns the OR of every rank's `vote`: how a failure that only ONE rank saw
+  // (a kernel launch, a copy) reaches all of them before anybody decides to skip a later step the others would wait in.
+  template <class F> int barrier(F last, int vote = 0) {
     std::unique_lock<std::mutex> lk(m);
     const int gen = generation;
+    pending_vote |= vote;
     if (++arrived == world) {
       last();
+      result_vote = pending_vote;
+      pending_vote = 0;
       arrived = 0;
       generation++;
       cv.notify_all();
     } else {
       cv.wait(lk, [&] { return generation != gen; });
     }
+    return result_vote;                                         // (stable until every rank has entered the NEXT barrier, which needs this one to have returned)
   }
 };
 
@@ -140,7 +149,13 @@ struct er_comm_s {
   size_t buf_units = 0;
   float *sbuf = nullptr, *rbuf = nullptr;   // raw single-toucher units on their way out / in (grow-only)
   size_t sbuf_units = 0, rbuf_units = 0;
-  er::MergeStats last;         // what the last merge moved
+  er::MergeStats last;         // what the last merge moved (ring protocol)
+  er::OwnerMergeStats last_owner;   // ... (owner protocol)
+  int last_impl = 0;           // 0 = ring (er::merge_protocol), 1 = owner (er::merge_protocol_owner)
+  float* vbuf[2] = {nullptr, nullptr};      // owner merge: incoming records of step 1 / step 3 (grow-only)
+  size_t vbuf_floats[2] = {0, 0};
+  float* xbuf = nullptr;       // owner merge: outgoing records (grow-only)
+  size_t xbuf_floats = 0;
   int* ikeys = nullptr;        // device scratch: [1 + max_keys * (world + 1)] ints (grow-only)
   size_t ikeys_cap = 0;
 };
@@ -215,8 +230,38 @@ struct RcclTransport : er::MergeTransport {
       return ::er::fail("er_tsdf_allreduce: ncclSend / ncclRecv failed: %s", R->GetErrorString(bad != ncclSuccess ? bad : e2));
     return 0;
   }
+  // owner merge: a block of its own per receiver, every send and receive of this rank in ONE group -- over xGMI every (sender, owner) pair is a
+  // direct link, so the seven links of a GPU carry their records at the same time (a ring reduction crosses them one after the other)
+  int exchange_v(const float* send, const std::vector<size_t>& send_off, const std::vector<size_t>& send_count, float* recv,
+                 const std::vector<size_t>& recv_count) override {
+    bool any = false;
+    for (size_t n : send_count) any = any || n > 0;
+    for (size_t n : recv_count) any = any || n > 0;
+    if (!any) return 0;
+    ER_NCCL_TRY(R, R->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int q = 0; q < c->world; q++) {
+      if (!send_count[(size_t)q]) continue;
+      const ncclResult_t e = R->Send(send + send_off[(size_t)q], send_count[(size_t)q], ncclFloat32, q, c->comm, S);
+      if (e != ncclSuccess) bad = e;
+    }
+    size_t off = 0;
+    for (int q = 0; q < c->world; q++) {
+      const size_t n = recv_count[(size_t)q];
+      if (!n) continue;
+      const ncclResult_t e = R->Recv(recv + off, n, ncclFloat32, q, c->comm, S);
+      if (e != ncclSuccess) bad = e;
+      off += n;
+    }
+    const ncclResult_t e2 = R->GroupEnd();
+    if (bad != ncclSuccess || e2 != ncclSuccess)
+      return ::er::fail("er_tsdf_allreduce: ncclSend / ncclRecv failed: %s", R->GetErrorString(bad != ncclSuccess ? bad : e2));
+    ER_HIP_TRY(hipStreamSynchronize(S));                        // the owner's next step reads the records from the host's point of view
+    return 0;
+  }
 };
 
+// (RcclTransport::exchange_v is defined below the class: it shares the group logic)
 // dst[i] = ((src_0[i] + src_1[i]) + ...) + src_{n-1}[i]: the ranks' plane buffers added in rank order (dst may be one of the sources)
 struct LoopSrc { const float* p[16]; };
 __global__ __launch_bounds__(256) void k_loop_sum(LoopSrc S, int n, float* __restrict__ dst, size_t count) {
@@ -261,21 +306,23 @@ struct LoopTransport : er::MergeTransport {
     int rc = 0;
     if (hipStreamSynchronize(S) != hipSuccess) rc = 1;         // this rank's export kernel has written `planes`
     L.fptr[(size_t)c->rank] = planes;
-    L.barrier([] {});
+    rc = L.barrier([] {}, rc);                                  // (from here on rc is the SAME on every rank: nobody skips a barrier the others wait in)
     const int owner = root < 0 ? 0 : root;                      // the rank that adds; with root < 0 the others copy its result
+    int mine = 0;
     if (c->rank == owner && !rc) {
       LoopSrc src;
       for (int q = 0; q < 16; q++) src.p[q] = q < L.world ? L.fptr[(size_t)q] : nullptr;
       const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 16384);
       hipLaunchKernelGGL(k_loop_sum, dim3(blocks), dim3(256), 0, S, src, L.world, planes, count);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(S) != hipSuccess) rc = 1;
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(S) != hipSuccess) mine = 1;
     }
-    L.barrier([] {});
+    rc = L.barrier([] {}, rc | mine);
+    mine = 0;
     if (root < 0 && c->rank != owner && !rc) {
-      if (hipMemcpyAsync(planes, L.fptr[(size_t)owner], count * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess || hipStreamSynchronize(S) != hipSuccess) rc = 1;
+      if (hipMemcpyAsync(planes, L.fptr[(size_t)owner], count * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess || hipStreamSynchronize(S) != hipSuccess) mine = 1;
     }
-    L.barrier([] {});                                           // the owner's buffer stays untouched until everybody has copied
-    return rc ? ::er::fail("er_tsdf_allreduce (loopback): %s", hipGetErrorString(hipGetLastError())) : 0;
+    rc = L.barrier([] {}, rc | mine);                           // the owner's buffer stays untouched until everybody has copied
+    return rc ? ::er::fail("er_tsdf_allreduce (loopback): a rank of the communicator failed in the sum step (%s)", hipGetErrorString(hipGetLastError())) : 0;
   }
   int exchange(const float* send, size_t send_count, const std::vector<int>& send_to, float* recv, const std::vector<size_t>& recv_count) override {
     int rc = 0;
@@ -283,25 +330,50 @@ struct LoopTransport : er::MergeTransport {
     L.xsend[(size_t)c->rank] = send;
     L.xcount[(size_t)c->rank] = send_count;
     L.xto[(size_t)c->rank] = send_to;
-    L.barrier([] {});
+    rc = L.barrier([] {}, rc);
+    int mine = 0;
     size_t off = 0;
-    for (int q = 0; q < L.world && !rc; q++) {
+    for (int q = 0; q < L.world && !rc && !mine; q++) {
       const size_t n = recv_count[(size_t)q];
       if (!n) continue;
       const std::vector<int>& to = L.xto[(size_t)q];           // what I expect from q must be what q sends to me
-      if (q == c->rank || n != L.xcount[(size_t)q] || std::find(to.begin(), to.end(), c->rank) == to.end()) rc = 2;
-      else if (hipMemcpyAsync(recv + off, L.xsend[(size_t)q], n * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess) rc = 1;
+      if (q == c->rank || n != L.xcount[(size_t)q] || std::find(to.begin(), to.end(), c->rank) == to.end()) mine = 2;
+      else if (hipMemcpyAsync(recv + off, L.xsend[(size_t)q], n * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess) mine = 1;
       off += n;
     }
-    if (!rc && hipStreamSynchronize(S) != hipSuccess) rc = 1;
-    L.barrier([] {});                                           // the senders' blocks stay untouched until everybody has copied
-    if (rc == 2) return ::er::fail("er_tsdf_allreduce (loopback): the ranks disagree about who sends what");
-    return rc ? ::er::fail("er_tsdf_allreduce (loopback): %s", hipGetErrorString(hipGetLastError())) : 0;
+    if (!rc && !mine && hipStreamSynchronize(S) != hipSuccess) mine = 1;
+    rc = L.barrier([] {}, rc | mine);                           // the senders' blocks stay untouched until everybody has copied
+    if (rc & 2) return ::er::fail("er_tsdf_allreduce (loopback): the ranks disagree about who sends what");
+    return rc ? ::er::fail("er_tsdf_allreduce (loopback): a rank of the communicator failed in the point-to-point step (%s)", hipGetErrorString(hipGetLastError())) : 0;
+  }
+  int exchange_v(const float* send, const std::vector<size_t>& send_off, const std::vector<size_t>& send_count, float* recv,
+                 const std::vector<size_t>& recv_count) override {
+    int rc = 0;
+    if (hipStreamSynchronize(S) != hipSuccess) rc = 1;         // this rank's records are written
+    L.xsend[(size_t)c->rank] = send;
+    L.voff[(size_t)c->rank] = send_off;
+    L.vcnt[(size_t)c->rank] = send_count;
+    rc = L.barrier([] {}, rc);
+    int mine = 0;
+    size_t off = 0;
+    for (int q = 0; q < L.world && !rc && !mine; q++) {
+      const size_t n = recv_count[(size_t)q];
+      if (!n) continue;
+      if (q == c->rank || n != L.vcnt[(size_t)q][(size_t)c->rank]) mine = 2;   // what I expect from q must be what q sends to me
+      else if (hipMemcpyAsync(recv + off, L.xsend[(size_t)q] + L.voff[(size_t)q][(size_t)c->rank], n * sizeof(float), hipMemcpyDeviceToDevice, S) != hipSuccess) mine = 1;
+      off += n;
+    }
+    for (int q = 0; q < L.world && !rc && !mine; q++)          // ... and nobody may send me what I do not expect
+      if (q != c->rank && L.vcnt[(size_t)q][(size_t)c->rank] != recv_count[(size_t)q]) mine = 2;
+    if (!rc && !mine && hipStreamSynchronize(S) != hipSuccess) mine = 1;
+    rc = L.barrier([] {}, rc | mine);
+    if (rc & 2) return ::er::fail("er_tsdf_allreduce (loopback): the ranks disagree about who sends what");
+    return rc ? ::er::fail("er_tsdf_allreduce (loopback): a rank of the communicator failed in the record exchange (%s)", hipGetErrorString(hipGetLastError())) : 0;
   }
 };
 
 // er::MergeVolume over an er_tsdf_t; the planes live in the communicator's grow-only device buffer.
-struct DeviceVolume : er::MergeVolume {
+struct DeviceVolume : er::OwnerMergeVolume {
   er_tsdf_t h;
   er_comm_t c;
   DeviceVolume(er_tsdf_t vol, er_comm_t comm) : h(vol), c(comm) {}
@@ -347,6 +419,46 @@ struct DeviceVolume : er::MergeVolume {
     return 0;
   }
   int import_raw(const int* uk, int nu, const float* block) override { return er_tsdf_import_raw(h, uk, nu, block); }
+  // ---- owner merge: band records (er_tsdf.hip) ----
+  static int grow_floats(float** b, size_t* have, size_t floats) {
+    if (*have >= floats) return 0;
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+    *have = 0;
+    const size_t cap = floats + floats / 8 + 1024;
+    ER_HIP_TRY(hipMalloc((void**)b, cap * sizeof(float)));
+    *have = cap;
+    return 0;
+  }
+  int band_counts(const int* uk, int nu, int* counts) override { return er_tsdf_band_counts(h, uk, nu, counts); }
+  size_t band_record_floats(int count) const override { return (size_t)er_tsdf_band_record_words(count); }
+  int export_band(const int* uk, const int* counts, int nu, float** block) override {
+    size_t total = 0;
+    for (int i = 0; i < nu; i++) total += band_record_floats(counts[i]);
+    if (grow_floats(&c->xbuf, &c->xbuf_floats, total)) return 1;
+    *block = c->xbuf;
+    return er_tsdf_export_band(h, uk, counts, nu, c->xbuf);
+  }
+  int band_receive_buffer(size_t floats, int which, float** block) override {
+    if (grow_floats(&c->vbuf[which & 1], &c->vbuf_floats[which & 1], floats)) return 1;
+    *block = c->vbuf[which & 1];
+    return 0;
+  }
+  int merge_band(const int* uk, int nu, const std::vector<std::vector<const float*>>& src, const int* self_pos) override {
+    std::vector<int> nsrc((size_t)nu);
+    std::vector<const void*> recs((size_t)nu * 16, nullptr);
+    for (int i = 0; i < nu; i++) {
+      nsrc[(size_t)i] = (int)src[(size_t)i].size();
+      if (nsrc[(size_t)i] > 16) return ::er::fail("er_tsdf_allreduce: unit %d has %d touchers besides its owner (at most 16)", uk[i], nsrc[(size_t)i]);
+      for (int k = 0; k < nsrc[(size_t)i]; k++) recs[(size_t)i * 16 + (size_t)k] = src[(size_t)i][(size_t)k];
+    }
+    return er_tsdf_merge_band(h, uk, nu, nsrc.data(), self_pos, recs.data());
+  }
+  int import_band(const int* uk, int nu, const std::vector<const float*>& recs) override {
+    std::vector<const void*> r(recs.begin(), recs.end());
+    return er_tsdf_import_band(h, uk, nu, r.data());
+  }
+  int drop_units(const int* uk, int nu) override { return er_tsdf_drop_units(h, uk, nu); }
 };
 
 }  // namespace
@@ -451,6 +563,9 @@ int er_comm_destroy(er_comm_t c) {
   if (c->buf) (void)hipFree(c->buf);
   if (c->sbuf) (void)hipFree(c->sbuf);
   if (c->rbuf) (void)hipFree(c->rbuf);
+  if (c->xbuf) (void)hipFree(c->xbuf);
+  if (c->vbuf[0]) (void)hipFree(c->vbuf[0]);
+  if (c->vbuf[1]) (void)hipFree(c->vbuf[1]);
   if (c->ikeys) (void)hipFree(c->ikeys);
   if (c->comm) {
     Rccl* R = rccl();
@@ -474,8 +589,14 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   if (!h || !c) return er::fail("er_tsdf_allreduce: NULL argument");
   Rccl* R = c->loop ? nullptr : rccl();
   if (!c->loop && !R) return er::fail("er_tsdf_allreduce: librccl.so.1 could not be loaded (%s)", rccl_reason());
+  // which protocol: the owner merge (round 6; reduce-scatter by unit, band records, rank-ordered sums) unless ER_MERGE_IMPL=ring asks for round 5's
+  // ring reduction of whole planes; a distributed result (root == ER_MERGE_DISTRIBUTED) only exists in the owner merge
+  const char* impl_env = getenv("ER_MERGE_IMPL");
+  const bool ring = impl_env && std::string(impl_env) == "ring";
   int pre = 0;
-  if (root >= c->world) pre = er::fail("er_tsdf_allreduce: root %d not in [0,%d)", root, c->world);
+  if (root >= c->world || root < ER_MERGE_DISTRIBUTED) pre = er::fail("er_tsdf_allreduce: root %d not in [0,%d) and neither ER_MERGE_ALL nor ER_MERGE_DISTRIBUTED", root, c->world);
+  else if (ring && root == ER_MERGE_DISTRIBUTED) pre = er::fail("er_tsdf_allreduce: ER_MERGE_IMPL=ring cannot leave the result distributed (root = ER_MERGE_DISTRIBUTED)");
+  else if (!ring && c->world > 17) pre = er::fail("er_tsdf_allreduce: the owner merge adds at most 17 ranks per unit (ER_MERGE_IMPL=ring has no such limit)");
   else if (er::tsdf_device(h) != c->device)
     pre = er::fail("er_tsdf_allreduce: the volume lives on device %d, the communicator on %d", er::tsdf_device(h), c->device);
   const hipError_t e = hipSetDevice(c->device);
@@ -487,7 +608,10 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   er::MergeTransport& t = c->loop ? static_cast<er::MergeTransport&>(*t_loop) : static_cast<er::MergeTransport&>(t_rccl);
   DeviceVolume v(h, c);
   c->last = er::MergeStats();
-  const int r = er::merge_protocol(t, v, root, union_units, pre ? 1 : 0, &c->last);
+  c->last_owner = er::OwnerMergeStats();
+  c->last_impl = ring ? 0 : 1;
+  const int r = ring ? er::merge_protocol(t, v, root, union_units, pre ? 1 : 0, &c->last)
+                     : er::merge_protocol_owner(t, v, root, union_units, pre ? 1 : 0, &c->last_owner);
   if (r == er::MERGE_OK) {
     ER_HIP_TRY(hipStreamSynchronize(er::tsdf_stream(h)));
     return 0;
@@ -498,8 +622,29 @@ int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units) {
   return 1;                                                     // local / transport failure: the message is already recorded
 }
 
+int er_comm_merge_stats_owner(er_comm_t c, long long stats[12]) {
+  if (!c || !stats) return er::fail("er_comm_merge_stats_owner: NULL argument");
+  const er::OwnerMergeStats& m = c->last_owner;
+  stats[0] = c->last_impl;
+  stats[1] = m.union_units; stats[2] = m.multi_units; stats[3] = m.single_units; stats[4] = m.owned_units; stats[5] = m.owned_multi; stats[6] = m.dropped_units;
+  stats[7] = (long long)(m.sent_floats[0] * sizeof(float));
+  stats[8] = (long long)(m.received_floats[0] * sizeof(float));
+  stats[9] = (long long)(m.sent_floats[1] * sizeof(float));
+  stats[10] = (long long)(m.received_floats[1] * sizeof(float));
+  stats[11] = (long long)(m.dense_floats * sizeof(float));
+  return 0;
+}
+
 int er_comm_merge_stats(er_comm_t c, long long stats[8]) {
   if (!c || !stats) return er::fail("er_comm_merge_stats: NULL argument");
+  if (c->last_impl == 1) {                                        // the owner merge in the ring protocol's terms
+    const er::OwnerMergeStats& o = c->last_owner;
+    stats[0] = o.union_units; stats[1] = o.multi_units; stats[2] = o.single_units; stats[3] = o.dropped_units; stats[4] = o.owned_multi;
+    stats[5] = 0;                                                 // nothing goes through a reduction collective
+    stats[6] = (long long)((o.sent_floats[0] + o.sent_floats[1]) * sizeof(float));
+    stats[7] = (long long)((o.received_floats[0] + o.received_floats[1]) * sizeof(float));
+    return 0;
+  }
   const er::MergeStats& m = c->last;
   stats[0] = m.union_units; stats[1] = m.multi_units; stats[2] = m.single_units; stats[3] = m.sent_units; stats[4] = m.received_units;
   stats[5] = (long long)(m.reduced_floats * sizeof(float));

@@ -1030,6 +1030,119 @@ __global__ void k_import_weighted(float2* __restrict__ pool, const int* __restri
   pool[(size_t)slot * kUnitVox + l] = make_float2(raw ? sw : (w > 0.0f ? sw / w : 0.0f), w);
 }
 
+// ---- band records (round 6: the owner merge of the frame split, csrc/er_merge_protocol.h) ----------------------------------------------------
+// A unit as its OBSERVED voxels only (weight != 0: the truncation band of the surfaces that crossed it, ~0.2 of a touched unit):
+//   words [0, 128)         exclusive prefix of the observed-voxel counts of the unit's 128 chunks of 2048 voxels (a chunk = one wave's share)
+//   words [128, 8320)      occupancy bitmap, bit (l & 63) of the 64-bit word l >> 6 <-> voxel l (k fastest, like the pool)
+//   words [8320, ...)      {sdf_, weight_} of the observed voxels in voxel order
+// A never-updated voxel is (+0, 0) in the pool (TSDFVolumeUnit.cpp:4-21 zero-fills, TSDFVolume.cpp:93-94 writes both), so a record restores a unit bit for bit.
+constexpr int kBandChunk = 2048;
+constexpr int kBandChunks = kUnitVox / kBandChunk;          // 128
+constexpr int kBandBitmapWords = kUnitVox / 32;             // 8192
+constexpr int kBandHeader = kBandChunks + kBandBitmapWords; // 8320 words = 33 280 bytes per record before its values
+constexpr int kBandMaxSrc = 16;
+
+__global__ __launch_bounds__(256) void k_band_count(const float2* __restrict__ pool, const int* __restrict__ slots, int* __restrict__ chunk_cnt) {
+  const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int slot = slots[q];
+  int n = 0;
+  if (slot >= 0) {
+    const float2* __restrict__ u = pool + (size_t)slot * kUnitVox + (size_t)chunk * kBandChunk;
+#pragma unroll 8
+    for (int it = 0; it < kBandChunk / 64; it++) n += __popcll(__ballot(u[it * 64 + lane].y != 0.0f));
+  }
+  if (lane == 0) chunk_cnt[q * kBandChunks + chunk] = n;
+}
+
+__global__ __launch_bounds__(256) void k_band_pack(const float2* __restrict__ pool, const int* __restrict__ slots, const int* __restrict__ chunk_cnt,
+                                                   const long* __restrict__ rec_off, uint32_t* __restrict__ out) {
+  const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int slot = slots[q];
+  uint32_t* __restrict__ rec = out + rec_off[q];
+  int before = (lane < chunk ? chunk_cnt[q * kBandChunks + lane] : 0) + (lane + 64 < chunk ? chunk_cnt[q * kBandChunks + 64 + lane] : 0);
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) rec[chunk] = (uint32_t)before;
+  float2* __restrict__ vals = reinterpret_cast<float2*>(rec + kBandHeader);
+  unsigned long long* __restrict__ bits = reinterpret_cast<unsigned long long*>(rec + kBandChunks) + (size_t)chunk * (kBandChunk / 64);
+  const float2* __restrict__ u = pool + (size_t)(slot < 0 ? 0 : slot) * kUnitVox + (size_t)chunk * kBandChunk;
+  int off = before;
+#pragma unroll 4
+  for (int it = 0; it < kBandChunk / 64; it++) {
+    const float2 v = slot < 0 ? make_float2(0.f, 0.f) : u[it * 64 + lane];
+    const bool on = v.y != 0.0f;
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) bits[it] = b;
+    if (on) vals[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
+    off += __popcll(b);
+  }
+}
+
+struct BandItem {
+  int slot, nsrc, self_pos, pad;
+  const uint32_t* rec[kBandMaxSrc];
+};
+
+// The owner's sum of one unit: its own voxels and the records of the other touchers IN RANK ORDER (self_pos = records that come before its own):
+//   SW = sum_r fl(sdf_r * w_r), W = sum_r w_r, sdf = SW / W   -- TSDFVolume.cpp:93-94 as a sum, what k_export_weighted + a rank-ordered reduction +
+// k_import_weighted compute, with the order fixed by the key sets (this translation unit is compiled with -ffp-contract=off: product, then sum).
+__global__ __launch_bounds__(256) void k_band_merge(float2* __restrict__ pool, const BandItem* __restrict__ items) {
+  const BandItem& item = items[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + wave;
+  __shared__ int off[4][kBandMaxSrc];
+  const int nsrc = item.nsrc, self_pos = item.self_pos;
+  if (lane < nsrc) off[wave][lane] = (int)item.rec[lane][chunk];
+  float2* __restrict__ u = pool + (size_t)item.slot * kUnitVox + (size_t)chunk * kBandChunk;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int it = 0; it < kBandChunk / 64; it++) {
+    float sw = 0.0f, w = 0.0f;
+    const float2 own = u[it * 64 + lane];
+    for (int s = 0; s <= nsrc; s++) {
+      if (s == self_pos) {
+        sw += own.x * own.y;
+        w += own.y;
+      }
+      if (s == nsrc) break;
+      const unsigned long long b = reinterpret_cast<const unsigned long long*>(item.rec[s] + kBandChunks)[(size_t)chunk * (kBandChunk / 64) + it];
+      const int o = off[wave][s];
+      if ((b >> lane) & 1ull) {
+        const float2 v = reinterpret_cast<const float2*>(item.rec[s] + kBandHeader)[o + __popcll(b & below)];
+        sw += v.x * v.y;
+        w += v.y;
+      }
+      if (lane == 0) off[wave][s] = o + __popcll(b);
+    }
+    u[it * 64 + lane] = w > 0.0f ? make_float2(sw / w, w) : make_float2(0.0f, 0.0f);
+  }
+}
+
+// record -> unit, bit for bit (every voxel is written: an unobserved one becomes (+0, 0))
+__global__ __launch_bounds__(256) void k_band_import(float2* __restrict__ pool, const int* __restrict__ slots, const uint32_t* const* __restrict__ recs) {
+  const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int chunk = blockIdx.x * 4 + wave;
+  const int slot = slots[q];
+  if (slot < 0) return;
+  const uint32_t* __restrict__ rec = recs[q];
+  float2* __restrict__ u = pool + (size_t)slot * kUnitVox + (size_t)chunk * kBandChunk;
+  const float2* __restrict__ vals = reinterpret_cast<const float2*>(rec + kBandHeader);
+  const unsigned long long* __restrict__ bits = reinterpret_cast<const unsigned long long*>(rec + kBandChunks) + (size_t)chunk * (kBandChunk / 64);
+  int off = (int)rec[chunk];
+  for (int it = 0; it < kBandChunk / 64; it++) {
+    const unsigned long long b = bits[it];
+    u[it * 64 + lane] = ((b >> lane) & 1ull) ? vals[off + __popcll(b & ((1ull << lane) - 1ull))] : make_float2(0.0f, 0.0f);
+    off += __popcll(b);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_zero_units(float2* __restrict__ pool, const int* __restrict__ slots) {
+  const int slot = slots[blockIdx.y];
+  if (slot < 0) return;
+  float4* __restrict__ u = reinterpret_cast<float4*>(pool + (size_t)slot * kUnitVox);
+  u[blockIdx.x * 256 + threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // Host-driven unit allocation (import of units this GPU never touched).
 __global__ void k_ensure_units(const int* __restrict__ keys, int n, int* __restrict__ ht_key, int* __restrict__ ht_slot,
                                int cap_mask, int hash_shift, int* __restrict__ unit_key, int max_units,
@@ -1121,6 +1234,11 @@ struct er_tsdf_s {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   double ms_total = 0.0;
   long launches = 0, frames_done = 0;
+  // round 6 (owner merge): units this GPU handed to their owner -- zeroed, still in the table, hidden from every key / count / extraction query until
+  // the next frame is integrated or the unit is imported again -- and the grow-only device scratch of the band kernels
+  std::vector<int> dropped;                         // sorted
+  void* band_scratch = nullptr;
+  size_t band_scratch_cap = 0;
 };
 
 hipStream_t er::tsdf_stream(er_tsdf_s* h) { return h->stream; }
@@ -1184,9 +1302,12 @@ int sorted_units(er_tsdf_t h, std::vector<int>& keys, std::vector<int>& slots) {
   n = std::min(n, h->max_units);
   std::vector<int> uk((size_t)n);
   if (n) ER_HIP_TRY(hipMemcpy(uk.data(), h->unit_key, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-  std::vector<std::pair<int, int>> ks((size_t)n);
-  for (int s = 0; s < n; s++) ks[(size_t)s] = std::make_pair(uk[(size_t)s], s);
+  std::vector<std::pair<int, int>> ks;
+  ks.reserve((size_t)n);
+  for (int s = 0; s < n; s++)
+    if (!std::binary_search(h->dropped.begin(), h->dropped.end(), uk[(size_t)s])) ks.push_back(std::make_pair(uk[(size_t)s], s));   // (handed to their owner)
   std::sort(ks.begin(), ks.end());
+  n = (int)ks.size();
   keys.resize((size_t)n);
   slots.resize((size_t)n);
   for (int s = 0; s < n; s++) {
@@ -1194,6 +1315,25 @@ int sorted_units(er_tsdf_t h, std::vector<int>& keys, std::vector<int>& slots) {
     slots[(size_t)s] = ks[(size_t)s].second;
   }
   return 0;
+}
+
+int ensure_band_scratch(er_tsdf_t h, size_t bytes) {
+  if (bytes <= h->band_scratch_cap) return 0;
+  if (h->band_scratch) (void)hipFree(h->band_scratch);
+  h->band_scratch = nullptr;
+  h->band_scratch_cap = 0;
+  const size_t cap = std::max<size_t>(bytes, (size_t)1 << 20);
+  ER_HIP_TRY(hipMalloc(&h->band_scratch, cap));
+  h->band_scratch_cap = cap;
+  return 0;
+}
+
+void undrop(er_tsdf_t h, const int* keys, int n) {
+  if (h->dropped.empty()) return;
+  for (int i = 0; i < n; i++) {
+    auto it = std::lower_bound(h->dropped.begin(), h->dropped.end(), keys[i]);
+    if (it != h->dropped.end() && *it == keys[i]) h->dropped.erase(it);
+  }
 }
 
 // Host staging layout of one batch's constants inside the pinned buffer of its parity.
@@ -1475,7 +1615,7 @@ int er_tsdf_destroy(er_tsdf_t h) {
     if (h->aux_stream[a]) (void)hipStreamSynchronize(h->aux_stream[a]);
   std::vector<void*> ptrs = {h->pool, h->ht_key, h->ht_slot, h->unit_key, h->counters, h->stats, h->lambda, h->T12, h->seg12, h->madj12,
                              h->grid_index, h->dsum, h->ctr_dev[0], h->ctr_dev[1], h->key_scratch,
-                             h->slot_scratch};
+                             h->slot_scratch, h->band_scratch};
   for (int q = 0; q < kDepth; q++)
     for (void* x : {(void*)h->ht_mask[q], (void*)h->batch[q], (void*)h->scaled[q], (void*)h->depth_stage[q], h->dstage[q], (void*)h->tile_max[q], (void*)h->tile_lo[q], (void*)h->tile_lo_fine[q],
                     (void*)h->plan_rec[q], (void*)h->plan[q]})
@@ -1634,6 +1774,7 @@ int er_tsdf_integrate_frames(er_tsdf_t h, int n, const uint16_t* depth, int dept
   if (!h || !depth || !T) return er::fail("er_tsdf_integrate_frames: NULL argument");
   if (n < 0) return er::fail("er_tsdf_integrate_frames: negative frame count");
   ER_HIP_TRY(hipSetDevice(h->device));
+  if (n > 0) h->dropped.clear();                              // (handed-over units are zeroed: from here on they are this GPU's new contribution)
   if (warp) {
     if (!warp->ctr || !warp->grid_index || !warp->seg || !warp->madj || warp->num_grids <= 0 || warp->resolution <= 0)
       return er::fail("er_tsdf_integrate_frames: incomplete er_warp");
@@ -1701,6 +1842,7 @@ int er_tsdf_reset(er_tsdf_t h) {
   ER_HIP_TRY(hipStreamSynchronize(s));
   for (int q = 0; q < kDepth; q++) h->used[q] = h->reset_pending[q] = false;
   h->batch_no = 0;
+  h->dropped.clear();
   return 0;
 }
 
@@ -1733,6 +1875,7 @@ int er_tsdf_unit_count(er_tsdf_t h, int* count) {
   ER_HIP_TRY(hipSetDevice(h->device));
   if (check_flags(h)) return 1;
   ER_HIP_TRY(hipMemcpy(count, h->counters + C_NUNITS, sizeof(int), hipMemcpyDeviceToHost));
+  *count -= (int)h->dropped.size();                             // units handed to their owner by a distributed merge
   return 0;
 }
 
@@ -1749,6 +1892,7 @@ int er_tsdf_read_unit(er_tsdf_t h, int key, float* sdf_host, float* weight_host)
   if (!h) return er::fail("er_tsdf_read_unit: NULL handle");
   ER_HIP_TRY(hipSetDevice(h->device));
   if (check_flags(h)) return 1;
+  if (std::binary_search(h->dropped.begin(), h->dropped.end(), key)) return er::fail("er_tsdf_read_unit: unit %d was handed to its owner by the last merge", key);
   if (resolve_slots(h, &key, 1, false)) return 1;
   int slot = -1;
   ER_HIP_TRY(hipMemcpyAsync(&slot, h->slot_scratch, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1941,6 +2085,7 @@ static int import_units(er_tsdf_t h, const int* keys_host, int n_keys, const flo
   if (!h || !keys_host || !dev_buf) return er::fail("%s: NULL argument", who);
   if (n_keys <= 0) return 0;
   ER_HIP_TRY(hipSetDevice(h->device));
+  undrop(h, keys_host, n_keys);
   if (resolve_slots(h, keys_host, n_keys, true)) return 1;
   hipLaunchKernelGGL(k_import_weighted, dim3(er::kUnitVox / kBlock, n_keys), dim3(kBlock), 0, h->stream, h->pool,
                      h->slot_scratch, dev_buf, raw);
@@ -1959,6 +2104,118 @@ int er_tsdf_export_raw(er_tsdf_t h, const int* keys_host, int n_keys, float* dev
 }
 int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf) {
   return import_units(h, keys_host, n_keys, dev_buf, 1, "er_tsdf_import_raw");
+}
+
+// ---- band records behind the C ABI (the device half of er_merge_protocol.h's OwnerMergeVolume) ------------------------------------------------
+long er_tsdf_band_record_words(int count) { return (long)kBandHeader + 2L * (long)std::max(count, 0); }
+
+static int band_chunk_counts(er_tsdf_t h, const int* keys_host, int n, std::vector<int>& chunk, const char* who) {
+  if (resolve_slots(h, keys_host, n, false)) return 1;
+  if (ensure_band_scratch(h, (size_t)n * kBandChunks * sizeof(int) + (size_t)n * sizeof(long) + 64)) return 1;
+  int* d_cnt = (int*)h->band_scratch;
+  hipLaunchKernelGGL(k_band_count, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt);
+  ER_HIP_TRY(hipGetLastError());
+  chunk.resize((size_t)n * kBandChunks);
+  std::vector<int> slots((size_t)n);
+  ER_HIP_TRY(hipMemcpyAsync(chunk.data(), d_cnt, chunk.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(slots.data(), h->slot_scratch, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; i++)
+    if (slots[(size_t)i] < 0 || std::binary_search(h->dropped.begin(), h->dropped.end(), keys_host[i])) return er::fail("%s: this GPU holds no unit with key %d", who, keys_host[i]);
+  return 0;
+}
+
+int er_tsdf_band_counts(er_tsdf_t h, const int* keys_host, int n, int* counts_host) {
+  if (!h || (n > 0 && (!keys_host || !counts_host))) return er::fail("er_tsdf_band_counts: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> chunk;
+  if (band_chunk_counts(h, keys_host, n, chunk, "er_tsdf_band_counts")) return 1;
+  for (int i = 0; i < n; i++) {
+    int c = 0;
+    for (int k = 0; k < kBandChunks; k++) c += chunk[(size_t)i * kBandChunks + k];
+    counts_host[i] = c;
+  }
+  return 0;
+}
+
+int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* counts_host, int n, void* dev_block) {
+  if (!h || (n > 0 && (!keys_host || !counts_host || !dev_block))) return er::fail("er_tsdf_export_band: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> chunk;
+  if (band_chunk_counts(h, keys_host, n, chunk, "er_tsdf_export_band")) return 1;
+  std::vector<long> off((size_t)n);
+  long at = 0;
+  for (int i = 0; i < n; i++) {
+    int c = 0;
+    for (int k = 0; k < kBandChunks; k++) c += chunk[(size_t)i * kBandChunks + k];
+    if (c != counts_host[i]) return er::fail("er_tsdf_export_band: unit %d holds %d observed voxels, the caller planned for %d (the volume changed since er_tsdf_band_counts)", keys_host[i], c, counts_host[i]);
+    off[(size_t)i] = at;
+    at += er_tsdf_band_record_words(c);
+  }
+  int* d_cnt = (int*)h->band_scratch;                            // (still holds the chunk counts of exactly this key list)
+  long* d_off = (long*)((char*)h->band_scratch + (((size_t)n * kBandChunks * sizeof(int) + 15) & ~(size_t)15));
+  ER_HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_band_pack, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt, d_off, (uint32_t*)dev_block);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));                   // (off is a host temporary; the block is complete when this returns)
+  return 0;
+}
+
+int er_tsdf_merge_band(er_tsdf_t h, const int* keys_host, int n, const int* nsrc, const int* self_pos, const void* const* recs) {
+  if (!h || (n > 0 && (!keys_host || !nsrc || !self_pos || !recs))) return er::fail("er_tsdf_merge_band: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (resolve_slots(h, keys_host, n, false)) return 1;
+  std::vector<int> slots((size_t)n);
+  ER_HIP_TRY(hipMemcpyAsync(slots.data(), h->slot_scratch, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  std::vector<BandItem> items((size_t)n);
+  for (int i = 0; i < n; i++) {
+    if (slots[(size_t)i] < 0) return er::fail("er_tsdf_merge_band: the owner holds no unit with key %d", keys_host[i]);
+    if (nsrc[i] < 0 || nsrc[i] > kBandMaxSrc || self_pos[i] < 0 || self_pos[i] > nsrc[i])
+      return er::fail("er_tsdf_merge_band: unit %d has %d records (at most %d), own position %d", keys_host[i], nsrc[i], kBandMaxSrc, self_pos[i]);
+    BandItem& b = items[(size_t)i];
+    b.slot = slots[(size_t)i];
+    b.nsrc = nsrc[i];
+    b.self_pos = self_pos[i];
+    b.pad = 0;
+    for (int k = 0; k < kBandMaxSrc; k++) b.rec[k] = k < nsrc[i] ? (const uint32_t*)recs[(size_t)i * kBandMaxSrc + k] : nullptr;
+  }
+  if (ensure_band_scratch(h, items.size() * sizeof(BandItem))) return 1;
+  ER_HIP_TRY(hipMemcpyAsync(h->band_scratch, items.data(), items.size() * sizeof(BandItem), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_band_merge, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, (const BandItem*)h->band_scratch);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int er_tsdf_import_band(er_tsdf_t h, const int* keys_host, int n, const void* const* recs) {
+  if (!h || (n > 0 && (!keys_host || !recs))) return er::fail("er_tsdf_import_band: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  undrop(h, keys_host, n);
+  if (resolve_slots(h, keys_host, n, true)) return 1;
+  if (ensure_band_scratch(h, (size_t)n * sizeof(void*))) return 1;
+  ER_HIP_TRY(hipMemcpyAsync(h->band_scratch, recs, (size_t)n * sizeof(void*), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_band_import, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, (const uint32_t* const*)h->band_scratch);
+  ER_HIP_TRY(hipGetLastError());
+  return check_flags(h);                                         // (synchronises: recs may be a host temporary)
+}
+
+int er_tsdf_drop_units(er_tsdf_t h, const int* keys_host, int n) {
+  if (!h || (n > 0 && !keys_host)) return er::fail("er_tsdf_drop_units: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  if (resolve_slots(h, keys_host, n, false)) return 1;
+  hipLaunchKernelGGL(k_zero_units, dim3(kUnitVox / 2 / 256, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->dropped.insert(h->dropped.end(), keys_host, keys_host + n);
+  std::sort(h->dropped.begin(), h->dropped.end());
+  h->dropped.erase(std::unique(h->dropped.begin(), h->dropped.end()), h->dropped.end());
+  return 0;
 }
 
 int er_tsdf_set_profiling(er_tsdf_t h, int enable) {

@@ -13,9 +13,11 @@
 // New, additive: --device <gpu> (0), --max_units <n> (2048), --batch <frames fused per launch> (64),
 //   --gpus <N>            N GPUs (devices --device ... --device + N - 1), one host thread per GPU
 //   --shard frame|unit    frame (default, what BASELINE.json names): the active frame range is cut into N contiguous blocks,
-//                         every GPU integrates its block into a private volume, then ONE RCCL reduce(sum) of the
-//                         [sdf*weight | weight] planes of the key union to the first GPU (er_tsdf_allreduce; weights exact,
-//                         sdf within 1e-5 of the single-GPU run: float32 summation order);
+//                         every GPU integrates its block into a private volume, then er_tsdf_allreduce merges them: every volume
+//                         unit goes to the GPU that observed most of it, which adds the other GPUs' band records in rank order
+//                         (weights exact, sdf within 1e-5 of the single-GPU run: float32 summation order).  The merged volume stays
+//                         DISTRIBUTED -- SaveWorld is per unit (TSDFVolume.cpp:104-132): world.pcd is assembled from the GPUs'
+//                         extractions in ascending key order -- unless --merge_root <g> gathers it on GPU g first;
 //                         unit: every GPU is fed all frames and owns the units with er_unit_owner(key, N) == its rank
 //                         (er_tsdf_set_unit_shard): no collective, world.pcd BIT-identical to the single-GPU run
 //   --force_merge         with --gpus 1: run the frame-split merge anyway (exercises the RCCL path on a 1-GPU box)
@@ -61,7 +63,7 @@ int print_help() {
   std::cout << "    -oni <raw_file> | --depth_raw <raw_file> : 640x480 uint16 frames; --depth_list <txt> : 16-bit PNG per line" << std::endl;
   std::cout << "MI355X options:" << std::endl;
   std::cout << "    --device <gpu> (0)  --max_units <n> (2048)  --batch <frames> (64)" << std::endl;
-  std::cout << "    --gpus <N> (1)  --shard frame|unit (frame: frame blocks + one RCCL reduce; unit: bit-exact, no collective)  --force_merge" << std::endl;
+  std::cout << "    --gpus <N> (1)  --shard frame|unit (frame: frame blocks + the merge by unit owner over RCCL; unit: bit-exact, no collective)  --merge_root <g>  --force_merge" << std::endl;
   return 0;
 }
 
@@ -365,6 +367,8 @@ int main(int argc, char* argv[]) {
   parse_argument(argc, argv, "--gpus", gpus);
   parse_argument(argc, argv, "--shard", shard);
   const bool force_merge = find_switch(argc, argv, "--force_merge");
+  int merge_root = ER_MERGE_DISTRIBUTED;                                // --merge_root <g>: gather the merged volume on worker g before SaveWorld
+  parse_argument(argc, argv, "--merge_root", merge_root);
   // all workers share ONE device: lets a 1-GPU box run the N-worker logic.  --shard unit needs no collective; --shard frame merges through the
   // library's loopback communicator (er_comm_create_loopback: the same protocol, device volumes and kernels, device-to-device copies instead of
   // RCCL, which refuses two ranks on one device)
@@ -373,6 +377,11 @@ int main(int argc, char* argv[]) {
   if (app.batch_ > ER_MAX_BATCH) app.batch_ = ER_MAX_BATCH;
   if (gpus < 1) gpus = 1;
   if (shard != "frame" && shard != "unit") { fprintf(stderr, "Integrate: --shard must be frame or unit\n"); return 1; }
+  if (merge_root != ER_MERGE_DISTRIBUTED && (merge_root < 0 || merge_root >= gpus)) { fprintf(stderr, "Integrate: --merge_root must name one of the %d workers\n", gpus); return 1; }
+  {
+    const char* impl = getenv("ER_MERGE_IMPL");                          // round 5's ring protocol cannot leave the result distributed
+    if (impl && std::string(impl) == "ring" && merge_root == ER_MERGE_DISTRIBUTED) merge_root = 0;
+  }
   const bool unit_shard = shard == "unit";
   if (same_device && !unit_shard && gpus > 16) { fprintf(stderr, "Integrate: --same_device --shard frame takes at most 16 workers\n"); return 1; }
   if (!same_device && gpus > 1 && er_device_count() > 0 && app.device_ + gpus > er_device_count()) {
@@ -433,12 +442,13 @@ int main(int argc, char* argv[]) {
     // reports that through the merge's first collective and ALL ranks return an error together (er_merge_protocol.h) -- nobody hangs
     if (merge) {
       int nu = 0;
-      if (er_tsdf_allreduce(w.volume_, comms[(size_t)g], 0, &nu) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); wrc[(size_t)g] = 1; }
+      if (er_tsdf_allreduce(w.volume_, comms[(size_t)g], merge_root, &nu) != 0) { fprintf(stderr, "Integrate: %s\n", er_last_error()); wrc[(size_t)g] = 1; }
       else if (g == 0) {
         long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         (void)er_comm_merge_stats(comms[0], st);
-        fprintf(stderr, "Integrate: merged %d GPU volumes over %s, %d units in the union (%lld reduced, %lld of %lld single-toucher units received by the root)\n", gpus,
-                same_device ? "the loopback transport (one device)" : "RCCL", nu, st[1], st[4], st[2]);
+        fprintf(stderr, "Integrate: merged %d GPU volumes over %s, %d units in the union (%lld touched by two or more GPUs, %lld by one), %s\n", gpus,
+                same_device ? "the loopback transport (one device)" : "RCCL", nu, st[1], st[2],
+                merge_root == ER_MERGE_DISTRIBUTED ? "left distributed by unit owner" : ("gathered on GPU " + std::to_string(merge_root)).c_str());
       }
     }
   };
@@ -457,8 +467,9 @@ int main(int argc, char* argv[]) {
     last_id = std::max(last_id, apps[(size_t)g].frame_id_);
   }
   if (rc == 0) {
-    if (unit_shard && gpus > 1) { if (!SaveWorldSharded(apps, app.pcd_filename_)) rc = 1; }
-    else if (!apps[0].SaveWorld()) rc = 1;
+    // every worker holds a disjoint set of finished units (--shard unit, or the frame-split merge left distributed): one list in key order
+    if (gpus > 1 && (unit_shard || (merge && merge_root == ER_MERGE_DISTRIBUTED))) { if (!SaveWorldSharded(apps, app.pcd_filename_)) rc = 1; }
+    else if (!apps[(size_t)(merge && merge_root >= 0 ? merge_root : 0)].SaveWorld()) rc = 1;
   }
   std::cout << "Total " << last_id << " frames processed." << std::endl;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -200,6 +200,27 @@ def gather_pair_results(local_results, n_pairs, dist):
     return out
 
 
+MERGE_ALL, MERGE_DISTRIBUTED = -1, -2        # er_hip.h: ER_MERGE_ALL, ER_MERGE_DISTRIBUTED
+
+
+def _merge_stats(lib, handle):
+    """er_comm_merge_stats + er_comm_merge_stats_owner of one communicator handle as a dict."""
+    import ctypes as C
+    from . import _ffi
+    st = (C.c_longlong * 8)()
+    _ffi.check(lib.er_comm_merge_stats(handle, st), "er_comm_merge_stats")
+    names = ("union_units", "multi_toucher_units", "single_toucher_units", "units_sent", "units_received", "bytes_reduced", "bytes_sent", "bytes_received")
+    out = {n: int(v) for n, v in zip(names, st)}
+    so = (C.c_longlong * 12)()
+    _ffi.check(lib.er_comm_merge_stats_owner(handle, so), "er_comm_merge_stats_owner")
+    out["impl"] = "owner" if so[0] == 1 else "ring"
+    if so[0] == 1:
+        out.update({"units_owned": int(so[4]), "units_summed_here": int(so[5]), "units_handed_over": int(so[6]),
+                    "to_owners_bytes_sent": int(so[7]), "to_owners_bytes_received": int(so[8]),
+                    "to_root_bytes_sent": int(so[9]), "to_root_bytes_received": int(so[10]), "ring_equivalent_bytes": int(so[11])})
+    return out
+
+
 class AbiComm:
     """The frame-split merge through liber_hip.so's OWN RCCL calls (er_comm_* / er_tsdf_allreduce, what bin/Integrate --gpus
     uses) for a one-process-per-GPU job: rank 0 draws the 128-byte communicator id, torch.distributed only carries it to the
@@ -221,7 +242,8 @@ class AbiComm:
         self._h = h
 
     def allreduce(self, vol, root=0):
-        """root < 0: merged volume on every rank; else only on `root`.  Returns the size of the key union."""
+        """root >= 0: the merged volume on `root`; MERGE_ALL (-1): on every rank; MERGE_DISTRIBUTED (-2): every unit complete on its owner, nothing
+        gathered (er_hip.h).  Returns the size of the key union."""
         import ctypes as C
         from . import _ffi
         n = C.c_int(0)
@@ -229,14 +251,8 @@ class AbiComm:
         return n.value
 
     def merge_stats(self):
-        """What this rank's last allreduce moved (er_comm_merge_stats): the sum reduction only carries the units two or more ranks touched,
-        units only one rank touched travel point to point, bit for bit, or stay where they are."""
-        import ctypes as C
-        from . import _ffi
-        st = (C.c_longlong * 8)()
-        _ffi.check(self._lib.er_comm_merge_stats(self._h, st), "er_comm_merge_stats")
-        names = ("union_units", "multi_toucher_units", "single_toucher_units", "units_sent", "units_received", "bytes_reduced", "bytes_sent", "bytes_received")
-        return {n: int(v) for n, v in zip(names, st)}
+        """What this rank's last allreduce moved (er_comm_merge_stats / er_comm_merge_stats_owner)."""
+        return _merge_stats(self._lib, self._h)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -277,14 +293,36 @@ class LoopbackComms:
         return out[0][1]
 
     def merge_stats(self, rank=0):
+        return _merge_stats(self._lib, self._h[rank])
+
+    def allreduce_failing(self, vols, root=0):
+        """Like allreduce, but returns every rank's (rc, message) instead of raising: the collective-failure tests."""
         import ctypes as C
-        from . import _ffi
-        st = (C.c_longlong * 8)()
-        _ffi.check(self._lib.er_comm_merge_stats(self._h[rank], st), "er_comm_merge_stats")
-        names = ("union_units", "multi_toucher_units", "single_toucher_units", "units_sent", "units_received", "bytes_reduced", "bytes_sent", "bytes_received")
-        return {n: int(v) for n, v in zip(names, st)}
+        from concurrent.futures import ThreadPoolExecutor
+
+        def one(r):
+            n = C.c_int(0)
+            rc = self._lib.er_tsdf_allreduce(vols[r]._h, self._h[r], int(root), C.byref(n))
+            return rc, (self._lib.er_last_error().decode() if rc else "")
+        with ThreadPoolExecutor(self.n) as ex:
+            return list(ex.map(one, range(self.n)))
 
     def close(self):
         for h in getattr(self, "_h", []):
             self._lib.er_comm_destroy(h)
         self._h = []
+
+
+class LocalComms(LoopbackComms):
+    """One process, n DISTINCT GPUs, one RCCL communicator each (er_comm_create_local = ncclCommInitAll) and one host thread per rank: what
+    `bin/Integrate --gpus N` does, for tests on a box with several GPUs (tests/test_distributed_gpu.py).  Same interface as LoopbackComms."""
+
+    def __init__(self, devices):
+        import ctypes as C
+        from . import _ffi
+        self._lib = _ffi.lib()
+        self.n = len(devices)
+        dv = (C.c_int * self.n)(*[int(d) for d in devices])
+        arr = (C.c_void_p * self.n)()
+        _ffi.check(self._lib.er_comm_create_local(self.n, dv, arr), "er_comm_create_local")
+        self._h = [C.c_void_p(arr[i]) for i in range(self.n)]

@@ -210,6 +210,40 @@ class TSDFVolume:
         k = np.ascontiguousarray(keys, dtype=np.int32)
         _ffi.check(self._lib.er_tsdf_import_raw(self._h, _ffi.ptr(k), k.size, C.c_void_p(dev_ptr)), "er_tsdf_import_raw")
 
+    # band records (round 6, the owner merge): a unit as its observed voxels only -- include/er_hip.h
+    def band_counts(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        out = np.zeros(k.size, np.int32)
+        _ffi.check(self._lib.er_tsdf_band_counts(self._h, _ffi.ptr(k), k.size, _ffi.ptr(out)), "er_tsdf_band_counts")
+        return out
+
+    def band_record_words(self, count):
+        return int(self._lib.er_tsdf_band_record_words(int(count)))
+
+    def export_band(self, keys, counts, dev_ptr):
+        k, c = np.ascontiguousarray(keys, dtype=np.int32), np.ascontiguousarray(counts, dtype=np.int32)
+        _ffi.check(self._lib.er_tsdf_export_band(self._h, _ffi.ptr(k), _ffi.ptr(c), k.size, C.c_void_p(dev_ptr)), "er_tsdf_export_band")
+
+    def import_band(self, keys, rec_ptrs):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        r = (C.c_void_p * k.size)(*[int(p) for p in rec_ptrs])
+        _ffi.check(self._lib.er_tsdf_import_band(self._h, _ffi.ptr(k), k.size, r), "er_tsdf_import_band")
+
+    def merge_band(self, keys, srcs, self_pos):
+        """srcs[u] = device pointers of the other touchers' records of unit keys[u] in rank order; self_pos[u] of them come before this volume's own voxels."""
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        ns = np.asarray([len(x) for x in srcs], np.int32)
+        sp = np.ascontiguousarray(self_pos, dtype=np.int32)
+        r = (C.c_void_p * (16 * k.size))()
+        for u, x in enumerate(srcs):
+            for q, ptr in enumerate(x):
+                r[16 * u + q] = int(ptr)
+        _ffi.check(self._lib.er_tsdf_merge_band(self._h, _ffi.ptr(k), k.size, _ffi.ptr(ns), _ffi.ptr(sp), r), "er_tsdf_merge_band")
+
+    def drop_units(self, keys):
+        k = np.ascontiguousarray(keys, dtype=np.int32)
+        _ffi.check(self._lib.er_tsdf_drop_units(self._h, _ffi.ptr(k), k.size), "er_tsdf_drop_units")
+
     # -- profiling --------------------------------------------------------------------------------
     def set_profiling(self, enable):
         """True / 1: time every k_integrate launch; n > 1: every n-th launch; False / 0: off."""

@@ -162,6 +162,22 @@ int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const
  * overwrites it otherwise. */
 int er_tsdf_export_raw(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
 int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
+/* Round 6, BAND RECORDS: a unit as its observed voxels only (weight_ != 0 -- the truncation band of the surfaces that crossed it, about a fifth of a
+ * touched unit; a never-updated voxel is (+0, 0), TSDFVolumeUnit.cpp:4-21, so a record restores a unit bit for bit).  A record is
+ * er_tsdf_band_record_words(count) 32-bit words: [128 chunk prefixes | 8192 words of occupancy bitmap | count x {sdf_, weight_}], DEVICE memory, 8-byte
+ * aligned.  band_counts: observed voxels of each unit this GPU holds (a key it does not hold is an error).  export_band: the records of the given
+ * units back to back into dev_block (counts as band_counts returned them; a volume that changed in between is an error).  merge_band: the OWNER's
+ * step of the frame-split merge -- unit keys[u] becomes the sum of its own voxels and nsrc[u] <= 16 records (recs[16 u + k], the other GPUs' in rank
+ * order; self_pos[u] of them come before its own voxels in that order): SW = sum fl(sdf_r w_r), W = sum w_r, sdf = SW / W, TSDFVolume.cpp:93-94 as a
+ * sum in an order fixed by the arguments.  import_band: create / overwrite units from records.  drop_units: this GPU hands the units over -- they
+ * are zeroed and disappear from er_tsdf_unit_count / unit_keys / read_unit / the extractions until the next integrated frame or import touches
+ * them.  All of them run on the handle's stream and return when the device work is done. */
+long er_tsdf_band_record_words(int count);
+int er_tsdf_band_counts(er_tsdf_t h, const int* keys_host, int n_keys, int* counts_host);
+int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* counts_host, int n_keys, void* dev_block);
+int er_tsdf_merge_band(er_tsdf_t h, const int* keys_host, int n_keys, const int* nsrc, const int* self_pos, const void* const* recs);
+int er_tsdf_import_band(er_tsdf_t h, const int* keys_host, int n_keys, const void* const* recs);
+int er_tsdf_drop_units(er_tsdf_t h, const int* keys_host, int n_keys);
 
 /* Multi-GPU, the bit-exact alternative: shard the volume BY UNIT.  Every GPU is fed ALL frames and runs
  * their pre-pass, but only allocates / integrates / reports the units with er_unit_owner(key, world) == rank.  Units are disjoint
@@ -177,17 +193,26 @@ int er_unit_owner(int key, int world);          /* (xi + yi + zi) mod world: dia
  *                                        communicator (ncclCommInitRank; collective: all ranks must call it);
  *   er_comm_create_local                 ONE process, n GPUs, one host thread per GPU afterwards (ncclCommInitAll).
  * er_tsdf_allreduce merges the private volumes of the ranks after each integrated its own contiguous frame block
- * (er_frame_block): agree on the key count, all-gather the touched unit keys -- every rank then knows who touched what --,
- * ONE reduction (sum) of the [key][sdf*weight | weight] planes of the units TWO OR MORE ranks touched, imported with
- * sdf = SW / W -- algebraically the sequential running mean of TSDFVolume.cpp:93-94 (weights exact, sdf within 1e-5: the
- * float32 summation order differs) -- and ONE point-to-point step (ncclSend / ncclRecv) that carries the units only ONE rank
- * touched, bit for bit, to where the result is wanted; a unit that already lives there does not move (round 5; rounds 2-4
- * reduced the planes of the whole union).  Every rank calls it once; root < 0 leaves the merged volume on every rank
- * (ncclAllReduce + every owner sends to all), otherwise only on `root` (ncclReduce + owners send to the root).
- * union_units (nullable) receives the size of the key union; er_comm_merge_stats what the last merge of this communicator
- * moved: stats[0] union, [1] multi-toucher units (reduced), [2] single-toucher units, [3] units this rank sent, [4] units this
- * rank received, [5] bytes handed to the reduction, [6] bytes of the block this rank sent (the same block goes to every receiver), [7] bytes
- * received. */
+ * (er_frame_block).  Every rank calls it once.  Since round 6 it is the OWNER MERGE (csrc/er_merge_protocol.h: merge_protocol_owner), a
+ * reduce-scatter by volume unit:
+ *   agree on the key count; all-gather the touched unit keys with their observed-voxel counts -- every rank then knows who touched what and how
+ *   much; every unit of the union gets an OWNER, the toucher that observed most of it; every other toucher sends the owner a band record of
+ *   its voxels (above) in ONE grouped ncclSend / ncclRecv step -- each (sender, owner) pair is an xGMI link of its own --; the owner adds the
+ *   records to its own voxels IN RANK ORDER in one kernel: weights exact, sdf within 1e-5 of the sequential running mean of TSDFVolume.cpp:93-94
+ *   (the float32 summation order differs from the frame order), and bit-reproducible: the order is a function of the key sets, not of the wire;
+ *   the non-owners drop their copies.
+ * root == ER_MERGE_DISTRIBUTED stops there: the merged volume stays distributed, every unit complete on exactly one rank (SaveWorld is per unit,
+ * TSDFVolume.cpp:104-132: bin/Integrate --gpus N concatenates the ranks' extractions by key).  root >= 0: the owners then send their finished
+ * units, as band records, to `root` in a second grouped step; root == ER_MERGE_ALL (-1): to every other rank.  Units only ONE rank touched are
+ * that rank's: they stay where they are (distributed) or travel bit for bit (records restore a unit exactly).
+ * ER_MERGE_IMPL=ring in the environment of EVERY rank selects round 5's protocol instead (ONE ncclReduce / ncclAllReduce over whole
+ * [sdf*weight | weight] planes of the units two or more ranks touched, summed in RCCL's order; raw point-to-point for the others; root >= 0 or -1 only).
+ * union_units (nullable) receives the size of the key union; er_comm_merge_stats what the last merge of this communicator moved: stats[0] union,
+ * [1] multi-toucher units, [2] single-toucher units, [3] units this rank sent (owner merge: handed over), [4] units this rank received (owner merge:
+ * summed here), [5] bytes handed to a reduction collective (owner merge: 0), [6] bytes this rank sent, [7] bytes received.  er_comm_merge_stats_owner:
+ * [0] protocol of the last merge (0 ring, 1 owner), [1] union, [2] multi-toucher, [3] single-toucher, [4] units this rank owns afterwards, [5] of
+ * which it summed, [6] units it handed over, [7] / [8] bytes sent / received in the step to the owners, [9] / [10] in the step to the root /
+ * everybody, [11] bytes round 5's ring reduction would have been handed for the same key sets (2 MiB per multi-toucher unit). */
 typedef struct er_comm_s* er_comm_t;
 #define ER_COMM_ID_BYTES 128
 int er_comm_unique_id(unsigned char id[ER_COMM_ID_BYTES]);
@@ -200,8 +225,11 @@ int er_comm_create_loopback(int n, int device, er_comm_t* out /* n handles */);
 int er_comm_destroy(er_comm_t c);
 int er_comm_rank(er_comm_t c);
 int er_comm_world(er_comm_t c);
+#define ER_MERGE_ALL (-1)
+#define ER_MERGE_DISTRIBUTED (-2)
 int er_tsdf_allreduce(er_tsdf_t h, er_comm_t c, int root, int* union_units);
 int er_comm_merge_stats(er_comm_t c, long long stats[8]);
+int er_comm_merge_stats_owner(er_comm_t c, long long stats[12]);
 /* Contiguous frame block [lo, hi) of `rank` (IntegrateApp.cpp:190-226 is the loop being split). */
 void er_frame_block(int n_frames, int rank, int world, int* lo, int* hi);
 

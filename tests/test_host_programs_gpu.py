@@ -315,49 +315,84 @@ def test_fragment_optimizer_program_equals_reference_program(gpu, tmp_path):
     assert np.abs(blocked - np.loadtxt(os.path.join(d4, "out_nonrigid.ctr"))).max() < 1e-6
 
 
-def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
-    """bin/Integrate --gpus on the one GPU of this box:
-       * --gpus 1 --force_merge: the frame-split merge of er_tsdf_allreduce -- key exchange + ONE ncclReduce issued from
-         liber_hip.so over a one-rank RCCL communicator -- must leave the volume as it was: weights exact, sdf within 1e-5
-         (sdf*w / w re-rounds), same point set up to that tolerance;
-       * --gpus 3 --same_device: three workers on this GPU, frame blocks, the merge over the loopback communicator: same points within 1e-5;
-       * --gpus 3 --shard unit --same_device: three workers, each fed every frame and owning a third of the units, no
-         collective: world.pcd BYTE-identical to the single-GPU program's (same points, same ascending-key order)."""
-    d = str(tmp_path)
+def _same_world(a, b):
+    """SaveWorld keeps |sdf| < 0.98: a voxel whose sdf sits at the threshold may flip under the 1e-5 re-rounding of a merged unit; everything else must be
+    the same voxel with an intensity within 1e-5."""
+    if a.shape == b.shape:
+        assert np.array_equal(a[:, :3], b[:, :3]) and np.abs(a[:, 3] - b[:, 3]).max() <= 1e-5
+    else:
+        assert abs(a.shape[0] - b.shape[0]) <= 1e-4 * a.shape[0]
+
+
+def integrate_multi_gpu_case(d, gpus_args, same_device):
+    """bin/Integrate with `gpus_args` (+ --same_device on a one-GPU box) in both shard modes against the single-GPU program (also called by
+    tests/test_distributed_gpu.py with real devices):
+       * --shard frame (default): frame blocks per worker, er_tsdf_allreduce leaves the merged volume DISTRIBUTED by unit owner (round 6), world.pcd is
+         assembled from the owners' extractions in ascending key order: the same points within 1e-5;
+       * --merge_root 0: the same merge gathered on the first GPU before SaveWorld; ER_MERGE_IMPL=ring: round 5's protocol -- all the same points;
+       * --shard unit: every worker is fed every frame and owns a third of the units, no collective: world.pcd BYTE-identical to the single-GPU one."""
     sc = synth.make_scenario(12, interval=4, warp=True, amplitude=0.004, seed=21)
     depth = synth.to_numpy_u16(sc["depth"])
     write_integrate_inputs(d, sc, depth)
     args = ["--pose_traj", "pose.log", "--seg_traj", "seg.log", "--ctr", "grids.ctr", "--num", "3", "--resolution", "8",
             "--length", "3.0", "--interval", "4", "-oni", "frames.raw", "--max_units", "512"]
+    sd = ["--same_device"] if same_device else []
 
-    def run(extra, out):
-        r = subprocess.run([os.path.join(BIN, "Integrate")] + args + extra + ["--save_to", out], cwd=d, capture_output=True, text=True, timeout=300)
+    def run(extra, out, env=None):
+        r = subprocess.run([os.path.join(BIN, "Integrate")] + args + extra + ["--save_to", out], cwd=d, capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **(env or {})))
         assert r.returncode == 0, r.stdout + r.stderr
         p = formats.load_pcd(os.path.join(d, out))
         return np.stack([p["x"], p["y"], p["z"], p["intensity"]], 1), r
     one, _ = run([], "w1.pcd")
-    merged, r = run(["--gpus", "1", "--force_merge"], "wm.pcd")
-    assert "merged 1 GPU volumes over RCCL" in r.stderr
-    # SaveWorld keeps |sdf| < 0.98: a voxel whose sdf sits at the threshold may flip under the 1e-5 re-rounding; everything
-    # else must be the same voxel with an intensity within 1e-5
-    a, b = sorted_points(one), sorted_points(merged)
-    if a.shape == b.shape:
-        assert np.array_equal(a[:, :3], b[:, :3]) and np.abs(a[:, 3] - b[:, 3]).max() <= 1e-5
-    else:
-        assert abs(a.shape[0] - b.shape[0]) <= 1e-4 * a.shape[0]
-    # --gpus 3 --same_device (frame shard): three workers on this one GPU, contiguous frame blocks, merged by er_tsdf_allreduce over the loopback
-    # communicator -- the protocol, the device volumes and the export / import kernels of the real thing, device-to-device copies for the wire
-    looped, r = run(["--gpus", "3", "--same_device"], "wl.pcd")
-    assert "merged 3 GPU volumes over the loopback transport" in r.stderr
-    c = sorted_points(looped)
-    if a.shape == c.shape:
-        assert np.array_equal(a[:, :3], c[:, :3]) and np.abs(a[:, 3] - c[:, 3]).max() <= 1e-5
-    else:
-        assert abs(a.shape[0] - c.shape[0]) <= 1e-4 * a.shape[0]
-    sharded, _ = run(["--gpus", "3", "--shard", "unit", "--same_device"], "wu.pcd")
+    a = sorted_points(one)
+    where = "the loopback transport" if same_device else "RCCL"
+    n = gpus_args[1]
+    looped, r = run(gpus_args + sd, "wl.pcd")
+    assert "merged %s GPU volumes over %s" % (n, where) in r.stderr and "left distributed" in r.stderr, r.stderr
+    _same_world(a, sorted_points(looped))
+    # world.pcd of the distributed result lists the units in ascending key order like the single-GPU program: same order of the points up to the
+    # threshold flips
+    if looped.shape == one.shape:
+        assert np.array_equal(looped[:, :3], one[:, :3])
+    rooted, r = run(gpus_args + sd + ["--merge_root", "0"], "wr.pcd")
+    assert "gathered on GPU 0" in r.stderr, r.stderr
+    _same_world(a, sorted_points(rooted))
+    assert np.array_equal(sorted_points(rooted).view(np.uint32), sorted_points(looped).view(np.uint32)), "gathered and distributed results differ"
+    ring, r = run(gpus_args + sd + ["--merge_root", "0"], "wg.pcd", env={"ER_MERGE_IMPL": "ring"})
+    _same_world(a, sorted_points(ring))
+    sharded, _ = run(gpus_args + ["--shard", "unit"] + sd, "wu.pcd")
     assert np.array_equal(one.view(np.uint32), sharded.view(np.uint32)), "unit-shard world.pcd differs from the single-GPU one"
     with open(os.path.join(d, "w1.pcd"), "rb") as f1, open(os.path.join(d, "wu.pcd"), "rb") as f2:
         assert f1.read() == f2.read()
+    return one, run
+
+
+def test_integrate_program_multi_gpu_modes(gpu, tmp_path):
+    """bin/Integrate --gpus on the one GPU of this box: --gpus 3 --same_device in every mode (integrate_multi_gpu_case), and
+    --gpus 1 --force_merge: er_tsdf_allreduce on a one-rank RCCL communicator must leave the volume as it was."""
+    one, run = integrate_multi_gpu_case(str(tmp_path), ["--gpus", "3"], same_device=True)
+    merged, r = run(["--gpus", "1", "--force_merge"], "wm.pcd")
+    assert "merged 1 GPU volumes over RCCL" in r.stderr
+    assert np.array_equal(sorted_points(one).view(np.uint32), sorted_points(merged).view(np.uint32))     # one rank: nothing is summed, nothing moves
+
+
+def build_correspondence_multi_gpu_case(d, gpus):
+    """bin/BuildCorrespondence --gpus N (pair p -> GPU p mod N, no collective) writes the same files as with one GPU."""
+    from corres_helpers import run_program, standard_pairs, write_scene
+    d = d + "/"
+    fr = write_scene(d)
+    pairs = standard_pairs(fr, d)
+    ours = os.path.join(BIN, "BuildCorrespondence")
+    a1 = ["--reg_traj", d + "init.log", "--registration", "--reg_dist", "0.04", "--output_information"]
+    run_program(ours, a1, d)
+    log1, info1, corr1 = _bc_outputs(d, pairs)
+    txt1 = open(d + "reg_output.log").read()
+    run_program(ours, a1 + ["--gpus", str(gpus)], d)
+    log2, info2, corr2 = _bc_outputs(d, pairs)
+    assert open(d + "reg_output.log").read() == txt1 and corr1 == corr2
+    for x, y in zip(info1, info2):
+        assert x.frame == y.frame and np.array_equal(x.info, y.info)
 
 
 def test_abi_allreduce_on_a_one_rank_communicator_is_the_identity(gpu):
@@ -381,7 +416,7 @@ def test_abi_allreduce_on_a_one_rank_communicator_is_the_identity(gpu):
     assert nu.value == len(before) and L.er_comm_world(comm[0]) == 1 and L.er_comm_rank(comm[0]) == 0
     for k, (s0, w0) in before.items():
         s1, w1 = vol.read_unit(k)
-        assert np.array_equal(w0, w1) and np.abs(s1 - s0).max() <= 1e-5
+        assert np.array_equal(w0, w1) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))    # one rank: every unit is its own, nothing is summed
     L.er_comm_destroy(comm[0])
     vol.close()
     for n, w in ((10000, 8), (3000, 4), (7, 3), (2, 4)):

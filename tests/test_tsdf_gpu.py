@@ -295,76 +295,42 @@ def test_frame_split_merge_two_virtual_ranks(gpu):
         v.close()
 
 
-def test_frame_split_merge_with_four_loopback_ranks_on_one_gpu(gpu):
-    """The product's merge -- er_tsdf_allreduce: csrc/er_merge_protocol.h over the DEVICE volumes, the export / import kernels and the plane buffers -- with
-    FOUR ranks on this one GPU (er_comm_create_loopback: host threads, the sum reduction as a kernel that adds the ranks' buffers in rank order, the
-    point-to-point step as device-to-device copies; RCCL refuses two ranks on one device, so until round 5 no N > 1 merge had touched a device volume).
-    Scene: a quarter each of one revolution through the 6 m room with the radius drifting (the configs[3] shape): neighbouring blocks share units at their
-    borders, most units belong to one block.  Against ONE volume that integrated the same four blocks: key sets equal, weights exact, sdf within 1e-5 in
-    the units two or more ranks touched and BIT-IDENTICAL in the units one rank touched (they travel raw); er_comm_merge_stats consistent with the key
-    sets; with root < 0 every rank ends with the same bits."""
-    import torch
+@pytest.mark.parametrize("impl, root", [("owner", -2), ("owner", 0), ("owner", -1), ("ring", 0), ("ring", -1)])
+def test_frame_split_merge_with_four_loopback_ranks_on_one_gpu(gpu, impl, root):
+    """The product's merge -- er_tsdf_allreduce: csrc/er_merge_protocol.h over the DEVICE volumes and their kernels -- with FOUR ranks on this one GPU
+    (er_comm_create_loopback: host threads, device-to-device copies for the wire; RCCL refuses two ranks on one device).  Round 6: the OWNER merge
+    (reduce-scatter by unit over band records, sums in rank order in the owner's kernel) with the result left distributed (-2), gathered on rank 0, or
+    on every rank (-1); and round 5's ring protocol (ER_MERGE_IMPL=ring: whole planes through one sum, raw units point to point) for comparison.
+    tests/helpers.py::check_frame_split_merge holds the assertions; tests/test_distributed_gpu.py runs the same checker over RCCL when the box has
+    two or more GPUs."""
     from elasticreconstruction_amd import parallel
-    G, per = 4, 100
-    full = TSDFVolume(max_units=2048)
-    blocks = []
-    for r in range(G):
-        sc = synth.make_scenario(per, interval=50, warp=True, frame_offset=r * per, total_frames=G * per, revolutions=1.0, radius_drift=1.5,
-                                 room=(-1.5, 4.5), device="cuda:0")
-        blocks.append((sc, synth.warp_arrays(sc)))
-        torch.cuda.synchronize()                               # the frames are rendered on torch's stream: finished before the library's streams read them
-        full.IntegrateFrames(None, sc["traj"], blocks[-1][1], device_ptr=sc["depth"].data_ptr())
-        full.synchronize()
-    for root in (0, -1):
-        vols = [TSDFVolume(max_units=2048) for _ in range(G)]
-        for v, (sc, w) in zip(vols, blocks):
-            v.IntegrateFrames(None, sc["traj"], w, device_ptr=sc["depth"].data_ptr())
-            v.synchronize()
-        keysets = [set(int(k) for k in v.unit_keys()) for v in vols]
-        touch = {}
-        for r, ks in enumerate(keysets):
-            for k in ks:
-                touch.setdefault(k, []).append(r)
-        multi = sorted(k for k, t in touch.items() if len(t) >= 2)
-        single = sorted(k for k, t in touch.items() if len(t) == 1)
-        assert len(multi) > 20 and len(single) > 100 and max(len(t) for t in touch.values()) >= 2
-        comms = parallel.LoopbackComms(G)
-        nu = comms.allreduce(vols, root=root)
-        assert nu == len(touch) == full.unit_count()
-        st = [comms.merge_stats(r) for r in range(G)]
-        unit_bytes = 2 * 64 ** 3 * 4
-        for r in range(G):
-            assert (st[r]["union_units"], st[r]["multi_toucher_units"], st[r]["single_toucher_units"]) == (len(touch), len(multi), len(single))
-            assert st[r]["bytes_reduced"] == len(multi) * unit_bytes
-            mine = [k for k in single if touch[k] == [r]]
-            travels = (lambda k: True) if root < 0 else (lambda k: touch[k] != [root])
-            assert st[r]["units_sent"] == len([k for k in mine if travels(k)])
-            want_recv = len([k for k in single if touch[k] != [r]]) if (root < 0 or r == root) else 0
-            assert st[r]["units_received"] == want_recv and st[r]["bytes_received"] == want_recv * unit_bytes
-        receivers = range(G) if root < 0 else [root]
-        for r in receivers:
-            assert np.array_equal(vols[r].unit_keys(), full.unit_keys())
-            worst = 0.0
-            for k in single:
-                sf, wf = full.read_unit(k)
-                sm, wm = vols[r].read_unit(k)
-                assert np.array_equal(wf, wm) and np.array_equal(sf.view(np.uint32), sm.view(np.uint32)), "single-toucher unit %d changed on its way to rank %d" % (k, r)
-            for k in multi:
-                sf, wf = full.read_unit(k)
-                sm, wm = vols[r].read_unit(k)
-                assert np.array_equal(wf, wm), "merged weights differ in unit %d" % k
-                worst = max(worst, float(np.abs(sf - sm).max()))
-            assert worst <= 1e-5, "merged tsdf differs by %.3g on rank %d" % (worst, r)
-        if root < 0:                                           # one sum, copied: every rank holds the same bits
-            helpers.assert_volumes_identical(vols[0], vols[G - 1], "all-reduce: rank 0 vs rank %d" % (G - 1))
-        else:                                                  # the other ranks keep their partial volumes
-            assert set(int(k) for k in vols[1].unit_keys()) == keysets[1]
-        print("loopback merge, root %d: union %d = %d multi-toucher (reduced) + %d single-toucher (%d received by rank 0), max |dsdf| %.2g"
-              % (root, len(touch), len(multi), len(single), st[0]["units_received"], worst))
-        comms.close()
-        for v in vols:
-            v.close()
-    full.close()
+    out = helpers.check_frame_split_merge(lambda: parallel.LoopbackComms(4), [0, 0, 0, 0], root, impl, repeat=2 if (impl, root) == ("owner", -2) else 1)
+    print("loopback merge:", out)
+    if impl == "owner" and root == -2:
+        assert out["moved_MB"] < 0.45 * out["ring_equivalent_MB"], out        # records, not planes
+
+
+def test_owner_merge_failure_on_one_loopback_rank_reaches_all(gpu):
+    """A failure only ONE rank sees must not leave the others waiting (the loopback steps now agree on their status inside their
+    barriers; tests/cpp/merge_protocol_check.cpp injects the failures BEFORE a collective).  Here rank 1's volume is too small for the units the gather
+    to every rank sends it: its unit pool runs out in the import after the last collective -- rank 1 reports it, every call returns."""
+    from elasticreconstruction_amd import parallel
+    blocks = helpers.merge_blocks(4, 50, [0, 0, 0, 0])
+    vols = []
+    for r, (sc, w) in enumerate(blocks):
+        v = TSDFVolume(max_units=2048)
+        v.IntegrateFrames(None, sc["traj"], w, device_ptr=sc["depth"].data_ptr())
+        v.synchronize()
+        vols.append(v)
+    small = TSDFVolume(max_units=vols[1].unit_count() + 1)
+    small.IntegrateFrames(None, blocks[1][0]["traj"], blocks[1][1], device_ptr=blocks[1][0]["depth"].data_ptr())
+    small.synchronize()
+    comms = parallel.LoopbackComms(4)
+    res = comms.allreduce_failing([vols[0], small, vols[2], vols[3]], root=parallel.MERGE_ALL)
+    assert res[1][0] != 0 and "pool" in res[1][1], res
+    comms.close()
+    for v in vols + [small]:
+        v.close()
 
 
 def test_config1_identity_trajectory_properties(gpu):
