@@ -114,11 +114,11 @@ def lib():
     L.er_comm_merge_stats_owner.argtypes = [vp, vp]
     L.er_tsdf_band_record_words.argtypes = [C.c_int]
     L.er_tsdf_band_record_words.restype = C.c_long
-    L.er_tsdf_band_counts.argtypes = [vp, ip, C.c_int, ip]
-    L.er_tsdf_export_band.argtypes = [vp, ip, ip, C.c_int, vp]
-    L.er_tsdf_merge_band.argtypes = [vp, ip, C.c_int, ip, ip, vp]
-    L.er_tsdf_import_band.argtypes = [vp, ip, C.c_int, vp]
-    L.er_tsdf_drop_units.argtypes = [vp, ip, C.c_int]
+    L.er_tsdf_band_counts.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_export_band.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.er_tsdf_merge_band.argtypes = [vp, vp, C.c_int, vp, vp, vp]
+    L.er_tsdf_import_band.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_drop_units.argtypes = [vp, vp, C.c_int]
     L.er_frame_block.restype = None
     L.er_frame_block.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip]
     L.er_tsdf_set_profiling.argtypes = [vp, C.c_int]

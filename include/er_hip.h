@@ -283,12 +283,11 @@ int er_find_correspondence(er_cloud_t src, er_cloud_t tgt, const double T[16], d
 /* The reference runs its two loops over the pair list with "#pragma omp parallel for" (CorresApp.cpp:121,220).
  * The *_batch forms take the whole list of one loop: n pairs (src[i], tgt[i]) on ONE device, per-pair inputs and
  * outputs as arrays (T: n*16 doubles, guess/out: n*16 floats, info36: n*36 doubles, ...).  Results are those of n single
- * calls -- integers (counts, iteration counts, correspondence lists) identical; one caveat for er_icp_align: the 29 float64 sums of an
- * ICP iteration are added per workgroup of 1..8 slices of 256 points and then in a fixed order, and the library picks that slice count
- * from the pairs of the list that are still running, so a pair's final transform can differ in its last bits (|dT| ~ 1e-7; the parity
- * bar is 1e-5) between two lists it is part of (and, in principle, an iteration count at a razor's-edge stop decision; never observed).
- * For the same list the result is bit-reproducible.  Internally a whole group of pairs runs through every stage in one launch; the ICP
- * loop's solve and stop rule stay on the device.
+ * calls, bit for bit: integers (counts, iteration counts, correspondence lists) and -- since round 6 -- every float of every transform.  The 29
+ * float64 sums of an ICP iteration are added per wave of 64 consecutive points (a function of the pair alone) and from there on as 64-bit fixed-point
+ * integers whose power-of-two scales come from certain bounds of the data, so the totals do not depend on how the library groups the work: not on the
+ * list a pair is part of, its position, ER_ICP_GROUP or the shares of er_registration_batch (rounds 4-5: they did, in the last bits).
+ * Internally a whole group of pairs runs through every stage in one launch; the ICP loop's solve and stop rule stay on the device.
  * The single-pair functions above are the n == 1 case of these.  Clouds are immutable: any number of host threads
  * may use the same cloud concurrently (each call borrows its workspaces from a per-device pool). */
 int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T, double max_dist, int* counts);
@@ -328,8 +327,7 @@ int er_icp_release_workspaces(void);
  *                er_find_correspondence_batch returns them; n_pairs = 0 for a rejected pair.  The `Reduced too much` rule of :164-173
  *                (n_pairs / counts < 0.5) is the caller's: both numbers are returned.
  * The list is cut into ER_ICP_SHARES (default 6, at least ~8 pairs each) contiguous shares that run their three stages on a host thread and workspace each, so one
- * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls
- * (with the er_icp_align caveat above: a share is a shorter list). */
+ * share's host round trips and PCIe list copies overlap the kernels of the others; the results are those of the three *_batch calls, bit for bit. */
 int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, const double* T_guess, double reg_dist, int reg_num, double reg_ratio,
                           int max_iter, double transformation_epsilon, int stop_rule, double corr_dist, double normal_cos, int* counts,
                           int* accepted, float* T_final, int* iterations, int* converged, int* const* pairs_host, const int* capacity,

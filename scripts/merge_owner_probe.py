@@ -42,18 +42,31 @@ integrate_all(lambda r: [full])
 keys = [int(k) for k in full.unit_keys()]
 sample = keys[:: max(1, len(keys) // 150)]
 ref = {k: full.read_unit(k) for k in sample}
-out = {"ranks": G, "frames": N, "union_units": len(keys), "sum_weight": full.sum_weight()}
+obs = one = wmax = 0
+for k in sample:                                            # what a band record could still shed: observed voxels whose sdf is exactly 1 (free space in front of a surface)
+    s_, w_ = ref[k]
+    obs += int((w_ != 0).sum())
+    one += int(((w_ != 0) & (s_ == 1.0)).sum())
+    wmax = max(wmax, float(w_.max()))
+out = {"ranks": G, "frames": N, "union_units": len(keys), "sum_weight": full.sum_weight(),
+       "sampled_units": len(sample), "observed_fraction": obs / (len(sample) * 64.0 ** 3), "observed_with_sdf_exactly_1": one / max(obs, 1), "max_weight": wmax}
+print(json.dumps(out), flush=True)
 for impl, root in (("owner", parallel.MERGE_DISTRIBUTED), ("owner", 0), ("ring", 0)):
     os.environ["ER_MERGE_IMPL"] = impl
     vols = [TSDFVolume(max_units=2048, device=0) for _ in range(G)]
     integrate_all(lambda r: [vols[r]])
     comms = parallel.LoopbackComms(G)
     times = []
-    for rep in range(1):
+    for rep in range(2):                                    # the second merge meets warm plane / record buffers: that one is timed
+        if rep:
+            for v in vols:
+                v.reset()
+            integrate_all(lambda r: [vols[r]])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nu = comms.allreduce(vols, root=root)
         times.append(time.perf_counter() - t0)
+    times = times[1:]
     st = [comms.merge_stats(r) for r in range(G)]
     have = [set(int(k) for k in v.unit_keys()) for v in vols]
     where = {k: [r for r in range(G) if k in have[r]] for k in keys}

@@ -183,7 +183,7 @@ def check_frame_split_merge(make_comms, devices, root, impl="owner", per=100, ma
                     lo = sum(band_record_bytes(count[(k, r)]) for k in multi for r in touch[k]) - sum(band_record_bytes(best[k]) for k in multi)
                     assert to_owner == lo == sum(s["to_owners_bytes_received"] for s in st)
                     assert sum(s["to_root_bytes_sent"] for s in st) > 0
-                    assert sum(s["to_root_bytes_received"] for s in st) == sum(s["to_root_bytes_sent"] for s in st) * (G - 1 if root < 0 else 1)
+                    assert sum(s["to_root_bytes_received"] for s in st) == sum(s["to_root_bytes_sent"] for s in st)      # (sent counts every receiver)
                 summary["ring_equivalent_MB"] = st[0]["ring_equivalent_bytes"] / 1e6
                 summary["moved_MB"] = sum(s["bytes_sent"] for s in st) / 1e6
             else:
