@@ -19,7 +19,7 @@ SYMBOLS = [
     "er_tsdf_unit_count", "er_tsdf_unit_keys", "er_tsdf_read_unit", "er_tsdf_sum_weight",
     "er_tsdf_extract_world", "er_tsdf_extract_surface", "er_tsdf_extract_mesh", "er_mc_table", "er_tsdf_export_weighted", "er_tsdf_import_weighted",
     "er_tsdf_export_raw", "er_tsdf_import_raw",
-    "er_tsdf_band_record_words", "er_tsdf_band_counts", "er_tsdf_export_band", "er_tsdf_merge_band", "er_tsdf_import_band", "er_tsdf_drop_units",
+    "er_tsdf_band_sizes", "er_tsdf_export_band", "er_tsdf_merge_band", "er_tsdf_import_band", "er_tsdf_drop_units",
     "er_tsdf_set_profiling", "er_tsdf_get_profile",
     "er_comm_unique_id", "er_comm_create", "er_comm_create_local", "er_comm_create_loopback", "er_comm_destroy", "er_comm_rank", "er_comm_world",
     "er_tsdf_allreduce", "er_comm_merge_stats", "er_comm_merge_stats_owner", "er_frame_block",
@@ -112,9 +112,7 @@ def lib():
     L.er_tsdf_allreduce.argtypes = [vp, vp, C.c_int, ip]
     L.er_comm_merge_stats.argtypes = [vp, vp]
     L.er_comm_merge_stats_owner.argtypes = [vp, vp]
-    L.er_tsdf_band_record_words.argtypes = [C.c_int]
-    L.er_tsdf_band_record_words.restype = C.c_long
-    L.er_tsdf_band_counts.argtypes = [vp, vp, C.c_int, vp]
+    L.er_tsdf_band_sizes.argtypes = [vp, vp, C.c_int, vp]
     L.er_tsdf_export_band.argtypes = [vp, vp, vp, C.c_int, vp]
     L.er_tsdf_merge_band.argtypes = [vp, vp, C.c_int, vp, vp, vp]
     L.er_tsdf_import_band.argtypes = [vp, vp, C.c_int, vp]

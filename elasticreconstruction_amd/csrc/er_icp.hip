@@ -149,7 +149,13 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 //   A two-bin task list on top of the compacted one: within the noise (profiles/r04v_ab_compact_tasks.txt).
 // What the counters say binds it (profiles/r04w_icp_pmc_compact.txt): VALU issue, and within it the straight-line part every query runs.
 #ifndef ER_NN_TASKCAP
-#define ER_NN_TASKCAP (kBlock * 4)
+#define ER_NN_TASKCAP (kBlock * 8)
+#endif
+// Round 6: a surviving range goes to the task list in PIECES of at most ER_NN_PIECE candidates.  Phase 1 hands one task to a lane per trip of its loop,
+// and a wave is busy as long as its longest task: with whole rows as tasks -- up to three cells, 60 and more candidates in the dense cells of a
+// kinfu-like fragment against 6 on average in uniform surfels -- one lane scanned for fifteen trips while 63 waited.  (0 = whole ranges, rounds 3-5.)
+#ifndef ER_NN_PIECE
+#define ER_NN_PIECE 8
 #endif
 #ifndef ER_NN_OCC
 #define ER_NN_OCC 1
@@ -212,6 +218,32 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
     }
   }
   return key;
+}
+
+// Appends the candidate range [s0, s0 + n) of query `tid` to the workgroup's task list, in pieces; what does not fit is scanned here.
+template <int kU>
+__device__ __forceinline__ void push_range(NnShared& sh, const Grid& g, int s0, int n, int tid, float qx, float qy, float qz, unsigned long long& key) {
+#if ER_NN_PIECE > 0
+  const int np = (n + ER_NN_PIECE - 1) / ER_NN_PIECE;
+  int t = n < (1 << 23) ? atomicAdd(&sh.ntask, np) : kTaskCap;
+  for (int k = 0; k < np; k++, t++, s0 += ER_NN_PIECE, n -= ER_NN_PIECE) {
+    const int m = min(n, ER_NN_PIECE);
+    if (t < kTaskCap) {
+      sh.task_s0[t] = s0;
+      sh.task_nq[t] = (m << 8) | tid;
+    } else {
+      key = scan_range<kU>(g, s0, s0 + m, qx, qy, qz, key);
+    }
+  }
+#else
+  const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
+  if (t < kTaskCap) {
+    sh.task_s0[t] = s0;
+    sh.task_nq[t] = (n << 8) | tid;
+  } else {                                                  // the task list is full (or the range does not fit the packing): scan it here
+    key = scan_range<kU>(g, s0, s0 + n, qx, qy, qz, key);
+  }
+#endif
 }
 
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
@@ -305,15 +337,7 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int n = r_n[j];
-      if (n > 0) {
-        const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
-        if (t < kTaskCap) {
-          sh.task_s0[t] = r_s0[j];
-          sh.task_nq[t] = (n << 8) | tid;
-        } else {                                              // the task list is full (or the range does not fit the packing): scan it here
-          key = scan_range<kU>(g, r_s0[j], r_s0[j] + n, qx, qy, qz, key);
-        }
-      }
+      if (n > 0) push_range<kU>(sh, g, r_s0[j], n, tid, qx, qy, qz, key);
     }
   }
   sh.best[tid] = key;
@@ -402,15 +426,7 @@ __device__ __forceinline__ int nn_block_seeded(NnShared& sh, const Grid& g, bool
 #pragma unroll
     for (int j = 0; j < 9; j++) {
       const int n = r_n[j];
-      if (n > 0) {
-        const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
-        if (t < kTaskCap) {
-          sh.task_s0[t] = r_s0[j];
-          sh.task_nq[t] = (n << 8) | tid;
-        } else {
-          key = scan_range<kU>(g, r_s0[j], r_s0[j] + n, qx, qy, qz, key);
-        }
-      }
+      if (n > 0) push_range<kU>(sh, g, r_s0[j], n, tid, qx, qy, qz, key);
     }
   }
   sh.best[tid] = key;

@@ -430,8 +430,9 @@ struct DeviceVolume : er::OwnerMergeVolume {
     *have = cap;
     return 0;
   }
-  int band_counts(const int* uk, int nu, int* counts) override { return er_tsdf_band_counts(h, uk, nu, counts); }
-  size_t band_record_floats(int count) const override { return (size_t)er_tsdf_band_record_words(count); }
+  // (the protocol's "count" of a unit is its record size in words here: the owner is the toucher with the LARGEST record, the plan needs sizes only)
+  int band_counts(const int* uk, int nu, int* counts) override { return er_tsdf_band_sizes(h, uk, nu, counts); }
+  size_t band_record_floats(int count) const override { return (size_t)count; }
   int export_band(const int* uk, const int* counts, int nu, float** block) override {
     size_t total = 0;
     for (int i = 0; i < nu; i++) total += band_record_floats(counts[i]);

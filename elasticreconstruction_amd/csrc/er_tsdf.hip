@@ -1031,51 +1031,103 @@ __global__ void k_import_weighted(float2* __restrict__ pool, const int* __restri
 }
 
 // ---- band records (round 6: the owner merge of the frame split, csrc/er_merge_protocol.h) ----------------------------------------------------
-// A unit as its OBSERVED voxels only (weight != 0: the truncation band of the surfaces that crossed it, ~0.2 of a touched unit):
-//   words [0, 128)         exclusive prefix of the observed-voxel counts of the unit's 128 chunks of 2048 voxels (a chunk = one wave's share)
-//   words [128, 8320)      occupancy bitmap, bit (l & 63) of the 64-bit word l >> 6 <-> voxel l (k fastest, like the pool)
-//   words [8320, ...)      {sdf_, weight_} of the observed voxels in voxel order
+// A unit as its OBSERVED voxels only (weight != 0; measured on configs[3]: 0.28 of a touched unit), and of those the sdf only where it is not exactly 1
+// -- free space in front of a surface: every frame wrote tsdf = 1 there, so the running mean is 1.0f to the bit; 81 % of the observed voxels --, and the
+// weight, a frame count, as 16 bits when every weight of the unit fits (flag bit 0 otherwise: float32 weights).  32-bit words:
+//   [0] flags  [1] observed voxels  [2] band voxels (observed, sdf != 1)  [3] 0
+//   [4, 132)          exclusive prefix of the observed-voxel counts of the unit's 128 chunks of 2048 voxels (a chunk = one wave's share)
+//   [132, 260)        ... of the band-voxel counts
+//   [260, 8452)       observed bitmap, bit (l & 63) of the 64-bit word l >> 6 <-> voxel l (k fastest, like the pool)
+//   [8452, 16644)     sdf-is-one bitmap (a subset of the observed one)
+//   then              the weights of the observed voxels in voxel order (uint16, or float32 with flag bit 0), padded to an even number of words,
+//   then              the sdf_ of the band voxels in voxel order (float32), padded to an even number of words.
 // A never-updated voxel is (+0, 0) in the pool (TSDFVolumeUnit.cpp:4-21 zero-fills, TSDFVolume.cpp:93-94 writes both), so a record restores a unit bit for bit.
 constexpr int kBandChunk = 2048;
 constexpr int kBandChunks = kUnitVox / kBandChunk;          // 128
 constexpr int kBandBitmapWords = kUnitVox / 32;             // 8192
-constexpr int kBandHeader = kBandChunks + kBandBitmapWords; // 8320 words = 33 280 bytes per record before its values
+constexpr int kBandObsPrefix = 4, kBandBandPrefix = kBandObsPrefix + kBandChunks, kBandObsBits = kBandBandPrefix + kBandChunks,
+              kBandOneBits = kBandObsBits + kBandBitmapWords, kBandHeader = kBandOneBits + kBandBitmapWords;   // 16 644 words before the values
 constexpr int kBandMaxSrc = 16;
+constexpr uint32_t kOneBits = 0x3f800000u;
 
-__global__ __launch_bounds__(256) void k_band_count(const float2* __restrict__ pool, const int* __restrict__ slots, int* __restrict__ chunk_cnt) {
+__host__ __device__ inline long band_weight_words(int obs, int wide) { return wide ? (long)((obs + 1) & ~1) : 2L * ((obs + 3) / 4); }
+__host__ __device__ inline long band_record_words(int obs, int band, int wide) { return (long)kBandHeader + band_weight_words(obs, wide) + (long)((band + 1) & ~1); }
+
+// counts[q][0..127] observed, [128..255] band voxels per chunk; wide[q] |= 1 if a weight does not fit 16 bits
+__global__ __launch_bounds__(256) void k_band_count(const float2* __restrict__ pool, const int* __restrict__ slots, int* __restrict__ counts, int* __restrict__ wide) {
   const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + wave;
   const int slot = slots[q];
-  int n = 0;
+  int n = 0, nb = 0, w = 0;
   if (slot >= 0) {
     const float2* __restrict__ u = pool + (size_t)slot * kUnitVox + (size_t)chunk * kBandChunk;
 #pragma unroll 8
-    for (int it = 0; it < kBandChunk / 64; it++) n += __popcll(__ballot(u[it * 64 + lane].y != 0.0f));
+    for (int it = 0; it < kBandChunk / 64; it++) {
+      const float2 v = u[it * 64 + lane];
+      const bool on = v.y != 0.0f;
+      n += __popcll(__ballot(on));
+      nb += __popcll(__ballot(on && __float_as_uint(v.x) != kOneBits));
+      w |= (on && !(v.y >= 1.0f && v.y <= 65535.0f && v.y == floorf(v.y))) ? 1 : 0;
+    }
   }
-  if (lane == 0) chunk_cnt[q * kBandChunks + chunk] = n;
+  if (lane == 0) {
+    counts[q * 2 * kBandChunks + chunk] = n;
+    counts[q * 2 * kBandChunks + kBandChunks + chunk] = nb;
+  }
+  if (__any(w) && lane == 0) atomicOr(&wide[q], 1);
 }
 
-__global__ __launch_bounds__(256) void k_band_pack(const float2* __restrict__ pool, const int* __restrict__ slots, const int* __restrict__ chunk_cnt,
-                                                   const long* __restrict__ rec_off, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_band_pack(const float2* __restrict__ pool, const int* __restrict__ slots, const int* __restrict__ counts,
+                                                   const int* __restrict__ wide, const long* __restrict__ rec_off, uint32_t* __restrict__ out) {
   const int q = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + wave;
   const int slot = slots[q];
   uint32_t* __restrict__ rec = out + rec_off[q];
-  int before = (lane < chunk ? chunk_cnt[q * kBandChunks + lane] : 0) + (lane + 64 < chunk ? chunk_cnt[q * kBandChunks + 64 + lane] : 0);
-  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
-  if (lane == 0) rec[chunk] = (uint32_t)before;
-  float2* __restrict__ vals = reinterpret_cast<float2*>(rec + kBandHeader);
-  unsigned long long* __restrict__ bits = reinterpret_cast<unsigned long long*>(rec + kBandChunks) + (size_t)chunk * (kBandChunk / 64);
+  const int* __restrict__ co = counts + q * 2 * kBandChunks;
+  int before = (lane < chunk ? co[lane] : 0) + (lane + 64 < chunk ? co[64 + lane] : 0);
+  int before_b = (lane < chunk ? co[kBandChunks + lane] : 0) + (lane + 64 < chunk ? co[kBandChunks + 64 + lane] : 0);
+  int total = co[lane] + co[64 + lane], total_b = co[kBandChunks + lane] + co[kBandChunks + 64 + lane];
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    before_b += __shfl_xor(before_b, o);
+    total += __shfl_xor(total, o);
+    total_b += __shfl_xor(total_b, o);
+  }
+  const int is_wide = wide[q] & 1;
+  if (lane == 0) {
+    rec[kBandObsPrefix + chunk] = (uint32_t)before;
+    rec[kBandBandPrefix + chunk] = (uint32_t)before_b;
+    if (chunk == 0) {
+      rec[0] = (uint32_t)is_wide;
+      rec[1] = (uint32_t)total;
+      rec[2] = (uint32_t)total_b;
+      rec[3] = 0u;
+    }
+  }
+  uint32_t* __restrict__ wts = rec + kBandHeader;
+  float* __restrict__ sdf = reinterpret_cast<float*>(rec + kBandHeader + band_weight_words(total, is_wide));
+  unsigned long long* __restrict__ bits = reinterpret_cast<unsigned long long*>(rec + kBandObsBits) + (size_t)chunk * (kBandChunk / 64);
+  unsigned long long* __restrict__ ones = reinterpret_cast<unsigned long long*>(rec + kBandOneBits) + (size_t)chunk * (kBandChunk / 64);
   const float2* __restrict__ u = pool + (size_t)(slot < 0 ? 0 : slot) * kUnitVox + (size_t)chunk * kBandChunk;
-  int off = before;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int off = before, off_b = before_b;
 #pragma unroll 4
   for (int it = 0; it < kBandChunk / 64; it++) {
     const float2 v = slot < 0 ? make_float2(0.f, 0.f) : u[it * 64 + lane];
-    const bool on = v.y != 0.0f;
-    const unsigned long long b = __ballot(on);
-    if (lane == 0) bits[it] = b;
-    if (on) vals[off + __popcll(b & ((1ull << lane) - 1ull))] = v;
+    const bool on = v.y != 0.0f, one = on && __float_as_uint(v.x) == kOneBits;
+    const unsigned long long b = __ballot(on), b1 = __ballot(one);
+    if (lane == 0) {
+      bits[it] = b;
+      ones[it] = b1;
+    }
+    if (on) {
+      const int at = off + __popcll(b & below);
+      if (is_wide) reinterpret_cast<float*>(wts)[at] = v.y;
+      else reinterpret_cast<unsigned short*>(wts)[at] = (unsigned short)v.y;
+      if (!one) sdf[off_b + __popcll((b & ~b1) & below)] = v.x;
+    }
     off += __popcll(b);
+    off_b += __popcll(b & ~b1);
   }
 }
 
@@ -1084,6 +1136,23 @@ struct BandItem {
   const uint32_t* rec[kBandMaxSrc];
 };
 
+// voxel (chunk, it, lane) of a record: {sdf, weight} or (0, 0); o / ob = the wave's running offsets into the record's weights / band values
+__device__ __forceinline__ float2 band_fetch(const uint32_t* __restrict__ rec, int chunk, int it, int lane, unsigned long long below, int& o, int& ob) {
+  const unsigned long long b = reinterpret_cast<const unsigned long long*>(rec + kBandObsBits)[(size_t)chunk * (kBandChunk / 64) + it];
+  const unsigned long long b1 = reinterpret_cast<const unsigned long long*>(rec + kBandOneBits)[(size_t)chunk * (kBandChunk / 64) + it];
+  float2 v = make_float2(0.0f, 0.0f);
+  if ((b >> lane) & 1ull) {
+    const int is_wide = (int)(rec[0] & 1u), total = (int)rec[1];
+    const uint32_t* __restrict__ wts = rec + kBandHeader;
+    const int at = o + __popcll(b & below);
+    v.y = is_wide ? reinterpret_cast<const float*>(wts)[at] : (float)reinterpret_cast<const unsigned short*>(wts)[at];
+    v.x = ((b1 >> lane) & 1ull) ? 1.0f : reinterpret_cast<const float*>(rec + kBandHeader + band_weight_words(total, is_wide))[ob + __popcll((b & ~b1) & below)];
+  }
+  o += __popcll(b);
+  ob += __popcll(b & ~b1);
+  return v;
+}
+
 // The owner's sum of one unit: its own voxels and the records of the other touchers IN RANK ORDER (self_pos = records that come before its own):
 //   SW = sum_r fl(sdf_r * w_r), W = sum_r w_r, sdf = SW / W   -- TSDFVolume.cpp:93-94 as a sum, what k_export_weighted + a rank-ordered reduction +
 // k_import_weighted compute, with the order fixed by the key sets (this translation unit is compiled with -ffp-contract=off: product, then sum).
@@ -1091,9 +1160,12 @@ __global__ __launch_bounds__(256) void k_band_merge(float2* __restrict__ pool, c
   const BandItem& item = items[blockIdx.y];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int chunk = blockIdx.x * 4 + wave;
-  __shared__ int off[4][kBandMaxSrc];
+  __shared__ int off[4][kBandMaxSrc][2];
   const int nsrc = item.nsrc, self_pos = item.self_pos;
-  if (lane < nsrc) off[wave][lane] = (int)item.rec[lane][chunk];
+  if (lane < nsrc) {
+    off[wave][lane][0] = (int)item.rec[lane][kBandObsPrefix + chunk];
+    off[wave][lane][1] = (int)item.rec[lane][kBandBandPrefix + chunk];
+  }
   float2* __restrict__ u = pool + (size_t)item.slot * kUnitVox + (size_t)chunk * kBandChunk;
   const unsigned long long below = (1ull << lane) - 1ull;
   for (int it = 0; it < kBandChunk / 64; it++) {
@@ -1105,14 +1177,14 @@ __global__ __launch_bounds__(256) void k_band_merge(float2* __restrict__ pool, c
         w += own.y;
       }
       if (s == nsrc) break;
-      const unsigned long long b = reinterpret_cast<const unsigned long long*>(item.rec[s] + kBandChunks)[(size_t)chunk * (kBandChunk / 64) + it];
-      const int o = off[wave][s];
-      if ((b >> lane) & 1ull) {
-        const float2 v = reinterpret_cast<const float2*>(item.rec[s] + kBandHeader)[o + __popcll(b & below)];
-        sw += v.x * v.y;
-        w += v.y;
+      int o = off[wave][s][0], ob = off[wave][s][1];
+      const float2 v = band_fetch(item.rec[s], chunk, it, lane, below, o, ob);
+      sw += v.x * v.y;                                           // (an unobserved voxel adds +0: the same bits as skipping it)
+      w += v.y;
+      if (lane == 0) {
+        off[wave][s][0] = o;
+        off[wave][s][1] = ob;
       }
-      if (lane == 0) off[wave][s] = o + __popcll(b);
     }
     u[it * 64 + lane] = w > 0.0f ? make_float2(sw / w, w) : make_float2(0.0f, 0.0f);
   }
@@ -1126,14 +1198,9 @@ __global__ __launch_bounds__(256) void k_band_import(float2* __restrict__ pool, 
   if (slot < 0) return;
   const uint32_t* __restrict__ rec = recs[q];
   float2* __restrict__ u = pool + (size_t)slot * kUnitVox + (size_t)chunk * kBandChunk;
-  const float2* __restrict__ vals = reinterpret_cast<const float2*>(rec + kBandHeader);
-  const unsigned long long* __restrict__ bits = reinterpret_cast<const unsigned long long*>(rec + kBandChunks) + (size_t)chunk * (kBandChunk / 64);
-  int off = (int)rec[chunk];
-  for (int it = 0; it < kBandChunk / 64; it++) {
-    const unsigned long long b = bits[it];
-    u[it * 64 + lane] = ((b >> lane) & 1ull) ? vals[off + __popcll(b & ((1ull << lane) - 1ull))] : make_float2(0.0f, 0.0f);
-    off += __popcll(b);
-  }
+  int o = (int)rec[kBandObsPrefix + chunk], ob = (int)rec[kBandBandPrefix + chunk];
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int it = 0; it < kBandChunk / 64; it++) u[it * 64 + lane] = band_fetch(rec, chunk, it, lane, below, o, ob);
 }
 
 __global__ __launch_bounds__(256) void k_zero_units(float2* __restrict__ pool, const int* __restrict__ slots) {
@@ -2107,57 +2174,64 @@ int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const floa
 }
 
 // ---- band records behind the C ABI (the device half of er_merge_protocol.h's OwnerMergeVolume) ------------------------------------------------
-long er_tsdf_band_record_words(int count) { return (long)kBandHeader + 2L * (long)std::max(count, 0); }
-
-static int band_chunk_counts(er_tsdf_t h, const int* keys_host, int n, std::vector<int>& chunk, const char* who) {
+// chunk counts of the given units -> host: obs[n], band[n], wide[n]; the device copies stay in the band scratch ([counts n x 256 | wide n | offsets n]).
+static int band_unit_counts(er_tsdf_t h, const int* keys_host, int n, std::vector<int>& obs, std::vector<int>& band, std::vector<int>& wide, const char* who) {
   if (resolve_slots(h, keys_host, n, false)) return 1;
-  if (ensure_band_scratch(h, (size_t)n * kBandChunks * sizeof(int) + (size_t)n * sizeof(long) + 64)) return 1;
+  const size_t cnt_bytes = (size_t)n * 2 * kBandChunks * sizeof(int), wide_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
+  if (ensure_band_scratch(h, cnt_bytes + wide_bytes + (size_t)n * sizeof(long) + 64)) return 1;
   int* d_cnt = (int*)h->band_scratch;
-  hipLaunchKernelGGL(k_band_count, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt);
+  int* d_wide = (int*)((char*)h->band_scratch + cnt_bytes);
+  ER_HIP_TRY(hipMemsetAsync(d_wide, 0, (size_t)n * sizeof(int), h->stream));
+  hipLaunchKernelGGL(k_band_count, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt, d_wide);
   ER_HIP_TRY(hipGetLastError());
-  chunk.resize((size_t)n * kBandChunks);
-  std::vector<int> slots((size_t)n);
-  ER_HIP_TRY(hipMemcpyAsync(chunk.data(), d_cnt, chunk.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  std::vector<int> chunk((size_t)n * 2 * kBandChunks), slots((size_t)n);
+  wide.assign((size_t)n, 0);
+  ER_HIP_TRY(hipMemcpyAsync(chunk.data(), d_cnt, cnt_bytes, hipMemcpyDeviceToHost, h->stream));
+  ER_HIP_TRY(hipMemcpyAsync(wide.data(), d_wide, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipMemcpyAsync(slots.data(), h->slot_scratch, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   ER_HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; i++)
-    if (slots[(size_t)i] < 0 || std::binary_search(h->dropped.begin(), h->dropped.end(), keys_host[i])) return er::fail("%s: this GPU holds no unit with key %d", who, keys_host[i]);
-  return 0;
-}
-
-int er_tsdf_band_counts(er_tsdf_t h, const int* keys_host, int n, int* counts_host) {
-  if (!h || (n > 0 && (!keys_host || !counts_host))) return er::fail("er_tsdf_band_counts: NULL argument");
-  if (n <= 0) return 0;
-  ER_HIP_TRY(hipSetDevice(h->device));
-  std::vector<int> chunk;
-  if (band_chunk_counts(h, keys_host, n, chunk, "er_tsdf_band_counts")) return 1;
+  obs.assign((size_t)n, 0);
+  band.assign((size_t)n, 0);
   for (int i = 0; i < n; i++) {
-    int c = 0;
-    for (int k = 0; k < kBandChunks; k++) c += chunk[(size_t)i * kBandChunks + k];
-    counts_host[i] = c;
+    if (slots[(size_t)i] < 0 || std::binary_search(h->dropped.begin(), h->dropped.end(), keys_host[i])) return er::fail("%s: this GPU holds no unit with key %d", who, keys_host[i]);
+    for (int k = 0; k < kBandChunks; k++) {
+      obs[(size_t)i] += chunk[(size_t)i * 2 * kBandChunks + k];
+      band[(size_t)i] += chunk[(size_t)i * 2 * kBandChunks + kBandChunks + k];
+    }
   }
   return 0;
 }
 
-int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* counts_host, int n, void* dev_block) {
-  if (!h || (n > 0 && (!keys_host || !counts_host || !dev_block))) return er::fail("er_tsdf_export_band: NULL argument");
+int er_tsdf_band_sizes(er_tsdf_t h, const int* keys_host, int n, int* words_host) {
+  if (!h || (n > 0 && (!keys_host || !words_host))) return er::fail("er_tsdf_band_sizes: NULL argument");
   if (n <= 0) return 0;
   ER_HIP_TRY(hipSetDevice(h->device));
-  std::vector<int> chunk;
-  if (band_chunk_counts(h, keys_host, n, chunk, "er_tsdf_export_band")) return 1;
+  std::vector<int> obs, band, wide;
+  if (band_unit_counts(h, keys_host, n, obs, band, wide, "er_tsdf_band_sizes")) return 1;
+  for (int i = 0; i < n; i++) words_host[i] = (int)band_record_words(obs[(size_t)i], band[(size_t)i], wide[(size_t)i] & 1);
+  return 0;
+}
+
+int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* words_host, int n, void* dev_block) {
+  if (!h || (n > 0 && (!keys_host || !words_host || !dev_block))) return er::fail("er_tsdf_export_band: NULL argument");
+  if (n <= 0) return 0;
+  ER_HIP_TRY(hipSetDevice(h->device));
+  std::vector<int> obs, band, wide;
+  if (band_unit_counts(h, keys_host, n, obs, band, wide, "er_tsdf_export_band")) return 1;
   std::vector<long> off((size_t)n);
   long at = 0;
   for (int i = 0; i < n; i++) {
-    int c = 0;
-    for (int k = 0; k < kBandChunks; k++) c += chunk[(size_t)i * kBandChunks + k];
-    if (c != counts_host[i]) return er::fail("er_tsdf_export_band: unit %d holds %d observed voxels, the caller planned for %d (the volume changed since er_tsdf_band_counts)", keys_host[i], c, counts_host[i]);
+    const long w = band_record_words(obs[(size_t)i], band[(size_t)i], wide[(size_t)i] & 1);
+    if (w != (long)words_host[i]) return er::fail("er_tsdf_export_band: the record of unit %d takes %ld words, the caller planned for %d (the volume changed since er_tsdf_band_sizes)", keys_host[i], w, words_host[i]);
     off[(size_t)i] = at;
-    at += er_tsdf_band_record_words(c);
+    at += w;
   }
-  int* d_cnt = (int*)h->band_scratch;                            // (still holds the chunk counts of exactly this key list)
-  long* d_off = (long*)((char*)h->band_scratch + (((size_t)n * kBandChunks * sizeof(int) + 15) & ~(size_t)15));
+  const size_t cnt_bytes = (size_t)n * 2 * kBandChunks * sizeof(int), wide_bytes = ((size_t)n * sizeof(int) + 15) & ~(size_t)15;
+  int* d_cnt = (int*)h->band_scratch;                            // (still holds the counts of exactly this key list)
+  int* d_wide = (int*)((char*)h->band_scratch + cnt_bytes);
+  long* d_off = (long*)((char*)h->band_scratch + cnt_bytes + wide_bytes);
   ER_HIP_TRY(hipMemcpyAsync(d_off, off.data(), (size_t)n * sizeof(long), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_band_pack, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt, d_off, (uint32_t*)dev_block);
+  hipLaunchKernelGGL(k_band_pack, dim3(kBandChunks / 4, n), dim3(256), 0, h->stream, h->pool, h->slot_scratch, d_cnt, d_wide, d_off, (uint32_t*)dev_block);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipStreamSynchronize(h->stream));                   // (off is a host temporary; the block is complete when this returns)
   return 0;

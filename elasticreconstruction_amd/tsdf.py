@@ -211,14 +211,12 @@ class TSDFVolume:
         _ffi.check(self._lib.er_tsdf_import_raw(self._h, _ffi.ptr(k), k.size, C.c_void_p(dev_ptr)), "er_tsdf_import_raw")
 
     # band records (round 6, the owner merge): a unit as its observed voxels only -- include/er_hip.h
-    def band_counts(self, keys):
+    def band_sizes(self, keys):
+        """Record size in 32-bit words of each of the given units (er_tsdf_band_sizes)."""
         k = np.ascontiguousarray(keys, dtype=np.int32)
         out = np.zeros(k.size, np.int32)
-        _ffi.check(self._lib.er_tsdf_band_counts(self._h, _ffi.ptr(k), k.size, _ffi.ptr(out)), "er_tsdf_band_counts")
+        _ffi.check(self._lib.er_tsdf_band_sizes(self._h, _ffi.ptr(k), k.size, _ffi.ptr(out)), "er_tsdf_band_sizes")
         return out
-
-    def band_record_words(self, count):
-        return int(self._lib.er_tsdf_band_record_words(int(count)))
 
     def export_band(self, keys, counts, dev_ptr):
         k, c = np.ascontiguousarray(keys, dtype=np.int32), np.ascontiguousarray(counts, dtype=np.int32)

@@ -162,19 +162,19 @@ int er_tsdf_import_weighted(er_tsdf_t h, const int* keys_host, int n_keys, const
  * overwrites it otherwise. */
 int er_tsdf_export_raw(er_tsdf_t h, const int* keys_host, int n_keys, float* dev_buf);
 int er_tsdf_import_raw(er_tsdf_t h, const int* keys_host, int n_keys, const float* dev_buf);
-/* Round 6, BAND RECORDS: a unit as its observed voxels only (weight_ != 0 -- the truncation band of the surfaces that crossed it, about a fifth of a
- * touched unit; a never-updated voxel is (+0, 0), TSDFVolumeUnit.cpp:4-21, so a record restores a unit bit for bit).  A record is
- * er_tsdf_band_record_words(count) 32-bit words: [128 chunk prefixes | 8192 words of occupancy bitmap | count x {sdf_, weight_}], DEVICE memory, 8-byte
- * aligned.  band_counts: observed voxels of each unit this GPU holds (a key it does not hold is an error).  export_band: the records of the given
- * units back to back into dev_block (counts as band_counts returned them; a volume that changed in between is an error).  merge_band: the OWNER's
- * step of the frame-split merge -- unit keys[u] becomes the sum of its own voxels and nsrc[u] <= 16 records (recs[16 u + k], the other GPUs' in rank
- * order; self_pos[u] of them come before its own voxels in that order): SW = sum fl(sdf_r w_r), W = sum w_r, sdf = SW / W, TSDFVolume.cpp:93-94 as a
- * sum in an order fixed by the arguments.  import_band: create / overwrite units from records.  drop_units: this GPU hands the units over -- they
- * are zeroed and disappear from er_tsdf_unit_count / unit_keys / read_unit / the extractions until the next integrated frame or import touches
- * them.  All of them run on the handle's stream and return when the device work is done. */
-long er_tsdf_band_record_words(int count);
-int er_tsdf_band_counts(er_tsdf_t h, const int* keys_host, int n_keys, int* counts_host);
-int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* counts_host, int n_keys, void* dev_block);
+/* Round 6, BAND RECORDS: a unit as its observed voxels only (weight_ != 0: the truncation band and the free space in front of it, about a quarter of a
+ * touched unit), the sdf_ only where it is not exactly 1 (free space: four observed voxels out of five) and the weight_ as 16 bits when every weight of
+ * the unit is a frame count below 65536.  A never-updated voxel is (+0, 0) (TSDFVolumeUnit.cpp:4-21), so a record restores a unit bit for bit.
+ * Records are DEVICE memory, 8-byte aligned, a whole number of 32-bit words (layout: csrc/er_tsdf.hip, "band records").  band_sizes: the record size in
+ * words of each unit this GPU holds (a key it does not hold is an error).  export_band: the records of the given units back to back into dev_block
+ * (sizes as band_sizes returned them; a volume that changed in between is an error).  merge_band: the OWNER's step of the frame-split merge -- unit
+ * keys[u] becomes the sum of its own voxels and nsrc[u] <= 16 records (recs[16 u + k], the other GPUs' in rank order; self_pos[u] of them come before
+ * its own voxels in that order): SW = sum fl(sdf_r w_r), W = sum w_r, sdf = SW / W, TSDFVolume.cpp:93-94 as a sum in an order fixed by the arguments.
+ * import_band: create / overwrite units from records.  drop_units: this GPU hands the units over -- they are zeroed and disappear from
+ * er_tsdf_unit_count / unit_keys / read_unit / the extractions until the next integrated frame or import touches them.  All of them run on the handle's
+ * stream and return when the device work is done. */
+int er_tsdf_band_sizes(er_tsdf_t h, const int* keys_host, int n_keys, int* words_host);
+int er_tsdf_export_band(er_tsdf_t h, const int* keys_host, const int* words_host, int n_keys, void* dev_block);
 int er_tsdf_merge_band(er_tsdf_t h, const int* keys_host, int n_keys, const int* nsrc, const int* self_pos, const void* const* recs);
 int er_tsdf_import_band(er_tsdf_t h, const int* keys_host, int n_keys, const void* const* recs);
 int er_tsdf_drop_units(er_tsdf_t h, const int* keys_host, int n_keys);

@@ -92,8 +92,20 @@ def merge_blocks(G, per, devices):
     return out
 
 
-def band_record_bytes(count):
-    return 4 * (128 + 8192 + 2 * int(count))
+def band_record_words(sdf, w):
+    """Size of a unit's band record (csrc/er_tsdf.hip, "band records"): header + weights of the observed voxels (16 bits each when every weight is a frame
+    count below 65536) + sdf of the observed voxels whose sdf is not exactly 1, both padded to an even number of 32-bit words."""
+    import numpy as np
+    on = w != 0
+    obs = int(np.count_nonzero(on))
+    band = int(np.count_nonzero(on & (sdf.view(np.uint32) != 0x3f800000)))
+    wo = w[on]
+    wide = bool(obs and ((wo < 1).any() or (wo > 65535).any() or (wo != np.floor(wo)).any()))
+    return 16644 + (((obs + 1) & ~1) if wide else 2 * ((obs + 3) // 4)) + ((band + 1) & ~1)
+
+
+def band_record_bytes(words):
+    return 4 * int(words)
 
 
 def check_frame_split_merge(make_comms, devices, root, impl="owner", per=100, max_units=2048, repeat=1):
@@ -138,10 +150,10 @@ def check_frame_split_merge(make_comms, devices, root, impl="owner", per=100, ma
             single = sorted(k for k, t in touch.items() if len(t) == 1)
             assert sorted(touch) == full_keys
             assert len(multi) > 20 and len(single) > 100
-            count = {(k, r): int(np.count_nonzero(before[r][k][1])) for k, t in touch.items() for r in t}
-            for r in range(G):                                    # er_tsdf_band_counts against the read-back volumes
+            count = {(k, r): band_record_words(*before[r][k]) for k, t in touch.items() for r in t}      # (the protocol's "count" of a unit: its record size)
+            for r in range(G):                                    # er_tsdf_band_sizes against the read-back volumes
                 ks = sorted(before[r])
-                assert [int(c) for c in vols[r].band_counts(ks)] == [count[(k, r)] for k in ks]
+                assert [int(c) for c in vols[r].band_sizes(ks)] == [count[(k, r)] for k in ks]
             comms = make_comms()
             nu = comms.allreduce(vols, root=root)
             assert nu == len(touch)
