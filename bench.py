@@ -50,7 +50,7 @@ FRAME_BYTES_FIXED = 640 * 480 * (2 + 4)        # raw read + scaled write/read on
 
 
 from bench_dry import DryComm, DryVolume
-from bench_extras import (allpairs_section, cpu_baseline, fopt_section, icp_section, other_configs, parity_check,
+from bench_extras import (allpairs_section, boundary_section, cpu_baseline, fopt_section, icp_section, other_configs, parity_check,
                           sampled_parity)
 
 
@@ -303,6 +303,9 @@ def main():
     ap.add_argument("--other-configs", type=int, default=1,
                     help="(default run only: --config 2, one GPU, frames resident) also run 'bench.py --config 4' and '--config 5' as child "
                          "processes after the headline measurement and attach a summary of their JSON lines as 'other_configs' (0 = skip)")
+    ap.add_argument("--boundary", type=int, default=1,
+                    help="(default run only) also time the drop-in PROGRAMS end to end -- bin/Integrate on configs[1] from files, bin/BuildCorrespondence on "
+                         "the 50-pair list -- beside the reference's own programs on a bounded sample (0 = skip)")
     ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"),
                     help="where rank 0 writes the FULL result object (per-phase tables, definitions, A/B leftovers, the children's objects); "
                          "stdout carries only the compact line (< 4 KB) made from it by compact_line()")
@@ -739,8 +742,13 @@ def main():
             out["icp"] = icp
             if world == 1 and args.config == 2 and not dry:
                 out["fragment_optimizer"] = fopt_section(local)
+        if world == 1 and args.config == 2 and args.boundary and warp_on and n_frames == CONFIG2_FRAMES and not dry:
+            vol.close()                                              # (the programs bring their own volumes)
+            vol = None
+            out["boundary"] = boundary_section(sc, depth, local)
         if world == 1 and args.config == 2 and args.other_configs and not args.host_input and not args.force_merge and not dry:
-            vol.close()
+            if vol is not None:
+                vol.close()
             vol = None
             out["other_configs"] = other_configs(local)
         emit(out, args.full_json)

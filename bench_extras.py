@@ -729,3 +729,116 @@ def other_configs(device):
             if os.path.exists(full):
                 os.remove(full)
     return res
+
+
+def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pairs=4):
+    """SURVEY.md 8b / VERDICT round 5 (7): the throughput a pipeline script sees at the drop-in boundary -- process start, file reads, the GPU work, file
+    writes -- for the two programs, each beside the reference's OWN program (oracle/_ref/*_ref, compiled in place) on a bounded sample of the same files:
+      bin/Integrate            configs[1] (all frames of `sc`) from a raw uint16 stream, pose.log / seg.log / .ctr in, world.pcd out; and its first
+                               `png_frames` frames from a --depth_list of 16-bit PNGs (inflated ahead by 8 host threads);
+      Integrate_ref            the first `ref_frames` frames of the same raw stream (8 OpenMP threads as hard-coded);
+      bin/BuildCorrespondence  the 50-pair / 25-fragment list of configs[2]: cloud_bin_<i>.pcd in, reg_output.log / .info and 50 corres_<i>_<j>.txt out;
+      BuildCorrespondence_ref  the first `ref_pairs` pairs of the same list (it still loads all 25 fragments).
+    Wall times of subprocess.run; inputs live in /dev/shm when it has room (page cache either way)."""
+    import shutil
+    import subprocess
+    import numpy as np
+    from elasticreconstruction_amd import formats, synth
+    res = {}
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 8e9 else None
+    d = tempfile.mkdtemp(prefix="er_boundary_", dir=base)
+    bin_dir = os.path.join(ROOT, "elasticreconstruction_amd", "bin")
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    env = dict(os.environ, ER_ORACLE_QUIET="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+
+    def timed(cmd, cwd, reps=1):
+        best, rc, err = None, 0, ""
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=600)
+            dt = time.perf_counter() - t0
+            rc, err = r.returncode, r.stderr.decode()[-300:]
+            best = dt if best is None else min(best, dt)
+        return best, rc, err
+
+    try:
+        n, I = sc["n"], sc["interval"]
+        host = synth.to_numpy_u16(depth)
+
+        def write_inputs(tag, m):
+            num = m // I
+            pose = [formats.FramedTransformation(i, i, i + 1, sc["pose"][i]) for i in range(num)]
+            seg = [formats.FramedTransformation(i, i, i + 1, sc["seg"][i]) for i in range(m)]
+            formats.save_log(os.path.join(d, "pose_%s.log" % tag), pose + [formats.FramedTransformation(num, num, num + 1, sc["pose"][num - 1])])
+            formats.save_log(os.path.join(d, "seg_%s.log" % tag), seg + [formats.FramedTransformation(m + j, m + j, m + j + 1, sc["seg"][m - 1]) for j in range(I)])
+            formats.save_ctr(os.path.join(d, "g_%s.ctr" % tag), sc["grids"][:num])
+            return ["--pose_traj", "pose_%s.log" % tag, "--seg_traj", "seg_%s.log" % tag, "--ctr", "g_%s.ctr" % tag, "--num", str(num),
+                    "--resolution", str(sc["resolution"]), "--length", str(sc["length"]), "--interval", str(I)]
+        host.tofile(os.path.join(d, "frames.raw"))
+        a_full = write_inputs("full", n)
+        dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_full + ["-oni", "frames.raw", "--save_to", "world.pcd", "--max_units", "1024"], d, reps=2)
+        res["integrate"] = {"frames": n, "source": "raw uint16 stream (%.1f GB)" % (host.nbytes / 1e9), "wall_s": dt, "frames_per_s": n / dt, "rc": rc}
+        if rc:
+            res["integrate"]["stderr"] = err
+        try:
+            from PIL import Image
+            m = min(n, max(I, png_frames // I * I))
+            t0 = time.perf_counter()
+            with open(os.path.join(d, "list.txt"), "w") as f:
+                for i in range(m):
+                    Image.fromarray(host[i].reshape(480, 640)).save(os.path.join(d, "f%05d.png" % i), compress_level=1)
+                    f.write("f%05d.png\n" % i)
+            t_png = time.perf_counter() - t0
+            a_png = write_inputs("png", m)
+            dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=2)
+            res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": 8, "png_written_in_s": t_png}
+            dt1, rc1, _ = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024",
+                                                                                 "--decode_threads", "1"], d)
+            res["integrate_png"]["one_decode_thread_frames_per_s"] = m / dt1
+        except Exception as ex:
+            res["integrate_png"] = {"error": repr(ex)[:200]}
+        ref_bin = os.path.join(ref_dir, "Integrate_ref")
+        if os.path.exists(ref_bin):
+            m = min(n, max(I, ref_frames // I * I))
+            host[:m].tofile(os.path.join(d, "frames_ref.raw"))
+            a_ref = write_inputs("ref", m)
+            dt, rc, err = timed([ref_bin] + a_ref + ["-oni", "frames_ref.raw", "--save_to", "world_ref.pcd"], d)
+            res["integrate_reference_program"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "threads": 8}
+        # ---- BuildCorrespondence ----
+        frs = synth.fragment_set(25, 250000, device="cuda:%d" % device)
+        for i, (x, nn, _) in enumerate(frs):
+            formats.save_pcd_xyzn(os.path.join(d, "cloud_bin_%d.pcd" % i), x, nn, binary=True)
+        pairs = synth.config2_pair_list(frs, 50)
+        log = [formats.FramedTransformation(a, b, len(frs), T) for a, b, T in pairs]
+        formats.save_log(os.path.join(d, "init.log"), log)
+        formats.save_log(os.path.join(d, "init_ref.log"), log[:ref_pairs])
+        bc = ["--registration", "--reg_dist", "0.03", "--output_information"]
+        dt, rc, err = timed([os.path.join(bin_dir, "BuildCorrespondence"), "--reg_traj", os.path.join(d, "init.log")] + bc, d, reps=2)
+        out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("corres_"))
+        res["build_correspondence"] = {"pairs": len(pairs), "fragments": len(frs), "wall_s": dt, "pairs_per_s": len(pairs) / dt, "rc": rc,
+                                       "pcd_bytes_read": sum(os.path.getsize(os.path.join(d, "cloud_bin_%d.pcd" % i)) for i in range(len(frs))),
+                                       "corres_txt_bytes_written": out_bytes}
+        if rc:
+            res["build_correspondence"]["stderr"] = err
+        ref_bin = os.path.join(ref_dir, "BuildCorrespondence_ref")
+        if os.path.exists(ref_bin):
+            dt, rc, err = timed([ref_bin, "--reg_traj", os.path.join(d, "init_ref.log")] + bc, d)
+            res["build_correspondence_reference_program"] = {"pairs": ref_pairs, "wall_s": dt, "pairs_per_s": ref_pairs / dt, "rc": rc, "threads": 8,
+                                                             "note": "loads all %d fragments, then %d pairs" % (len(frs), ref_pairs)}
+    except Exception as ex:
+        res["error"] = repr(ex)[:300]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    g = lambda *k: _dig(res, *k)
+    res["compact"] = {"integrate_fps": g("integrate", "frames_per_s"), "integrate_png_fps": g("integrate_png", "frames_per_s"),
+                      "integrate_ref_fps": g("integrate_reference_program", "frames_per_s"), "bc_pairs_per_s": g("build_correspondence", "pairs_per_s"),
+                      "bc_ref_pairs_per_s": g("build_correspondence_reference_program", "pairs_per_s")}
+    return res
+
+
+def _dig(d, *path):
+    for p in path:
+        if not isinstance(d, dict) or d.get(p) is None:
+            return None
+        d = d[p]
+    return d

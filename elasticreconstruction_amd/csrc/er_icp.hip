@@ -149,13 +149,7 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 //   A two-bin task list on top of the compacted one: within the noise (profiles/r04v_ab_compact_tasks.txt).
 // What the counters say binds it (profiles/r04w_icp_pmc_compact.txt): VALU issue, and within it the straight-line part every query runs.
 #ifndef ER_NN_TASKCAP
-#define ER_NN_TASKCAP (kBlock * 8)
-#endif
-// Round 6: a surviving range goes to the task list in PIECES of at most ER_NN_PIECE candidates.  Phase 1 hands one task to a lane per trip of its loop,
-// and a wave is busy as long as its longest task: with whole rows as tasks -- up to three cells, 60 and more candidates in the dense cells of a
-// kinfu-like fragment against 6 on average in uniform surfels -- one lane scanned for fifteen trips while 63 waited.  (0 = whole ranges, rounds 3-5.)
-#ifndef ER_NN_PIECE
-#define ER_NN_PIECE 8
+#define ER_NN_TASKCAP (kBlock * 4)
 #endif
 #ifndef ER_NN_OCC
 #define ER_NN_OCC 1
@@ -218,32 +212,6 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
     }
   }
   return key;
-}
-
-// Appends the candidate range [s0, s0 + n) of query `tid` to the workgroup's task list, in pieces; what does not fit is scanned here.
-template <int kU>
-__device__ __forceinline__ void push_range(NnShared& sh, const Grid& g, int s0, int n, int tid, float qx, float qy, float qz, unsigned long long& key) {
-#if ER_NN_PIECE > 0
-  const int np = (n + ER_NN_PIECE - 1) / ER_NN_PIECE;
-  int t = n < (1 << 23) ? atomicAdd(&sh.ntask, np) : kTaskCap;
-  for (int k = 0; k < np; k++, t++, s0 += ER_NN_PIECE, n -= ER_NN_PIECE) {
-    const int m = min(n, ER_NN_PIECE);
-    if (t < kTaskCap) {
-      sh.task_s0[t] = s0;
-      sh.task_nq[t] = (m << 8) | tid;
-    } else {
-      key = scan_range<kU>(g, s0, s0 + m, qx, qy, qz, key);
-    }
-  }
-#else
-  const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
-  if (t < kTaskCap) {
-    sh.task_s0[t] = s0;
-    sh.task_nq[t] = (n << 8) | tid;
-  } else {                                                  // the task list is full (or the range does not fit the packing): scan it here
-    key = scan_range<kU>(g, s0, s0 + n, qx, qy, qz, key);
-  }
-#endif
 }
 
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
@@ -337,7 +305,15 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int n = r_n[j];
-      if (n > 0) push_range<kU>(sh, g, r_s0[j], n, tid, qx, qy, qz, key);
+      if (n > 0) {
+        const int t = n < (1 << 23) ? atomicAdd(&sh.ntask, 1) : kTaskCap;
+        if (t < kTaskCap) {
+          sh.task_s0[t] = r_s0[j];
+          sh.task_nq[t] = (n << 8) | tid;
+        } else {                                              // the task list is full (or the range does not fit the packing): scan it here
+          key = scan_range<kU>(g, r_s0[j], r_s0[j] + n, qx, qy, qz, key);
+        }
+      }
     }
   }
   sh.best[tid] = key;
@@ -354,94 +330,13 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
 }
 
-// Round 6: the search of ICP iterations >= 1, SEEDED with the previous iteration's match and cooperative from the start.
-// The increment of an ICP iteration moves a query by millimetres, so the point it matched last time is an excellent -- and, being a real target point,
-// always VALID -- upper bound for its nearest neighbour now: d_seed is measured first, and with that bound in hand nothing has to be scanned inline to
-// learn one.  All nine rows of the 27-neighbourhood (the home row is just the row with e2 = 0) are trimmed by the same face tests and pushed to the
-// workgroup's task list; phase 1 scans them with every lane busy.  nn_block's inline scans -- own cell, then left / right -- run as long as the fullest
-// cell any of a wave's 64 queries sits in (kinfu-like fragments: 71 points against 20 on average, uniform surfels 25 against 6), which is where its
-// candidate instructions go; here a 71-point cell is eighteen task slots spread over 256 lanes.  A query without a seed (no match within the radius
-// last time: the part of the source that does not overlap the target) keeps the radius as its bound and pushes whatever its rows hold.
-// Same result as nn_block, bit for bit: both return the exact lexicographic (distance, index) minimum over the points inside the bound.
-#ifndef ER_ICP_SEED
-#define ER_ICP_SEED 1
-#endif
-template <int kU = kUnroll>
-__device__ __forceinline__ int nn_block_seeded(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2, int seed,
-                                               const float4* tgt_xn, float& best_d) {
-  const int tid = threadIdx.x;
-  __syncthreads();                                            // the previous call's readers are done with `sh`
-  if (tid == 0) sh.ntask = 0;
-  const float ux = (qx - g.org[0]) / g.cell, uy = (qy - g.org[1]) / g.cell, uz = (qz - g.org[2]) / g.cell;
-  const float cx = floorf(ux), cy = floorf(uy), cz = floorf(uz);
-  const bool inside = active && cx >= -1.f && cx <= (float)g.dim[0] && cy >= -1.f && cy <= (float)g.dim[1] && cz >= -1.f && cz <= (float)g.dim[2];
-  const int ix = inside ? (int)cx : 0, iy = inside ? (int)cy : 0, iz = inside ? (int)cz : 0;
-  __syncthreads();                                            // (sh.ntask is zero)
-  unsigned long long key = kNoHit;
-  const int pnx = g.pnx, pny = g.pny;
-  int home = ((iz + 2) * pny + (iy + 2)) * pnx + (ix + 1);   // the cell LEFT of the query's own cell
-#if ER_NN_OCC
-  const bool live = inside && ER_GP(const ER_GLOBAL unsigned char*, g.occ)[(unsigned)(home + 1)] != 0;
-#else
-  const bool live = inside;
-#endif
-  if (live) {
-    float bound = limit2 * 1.0001f + g.slack;
-    if (seed >= 0) {
-      const f4v t = *(const ER_GLOBAL f4v*)((const ER_GLOBAL char*)tgt_xn + (unsigned)seed * 32u);
-      const float dx = qx - t.x, dy = qy - t.y, dz = qz - t.z;
-      const float d = ((dx * dx) + dy * dy) + dz * dz;
-      key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)seed;
-      bound = fminf(bound, d * 1.0001f + g.slack);           // (fminf drops a NaN distance: the radius stays the bound)
-    }
-    const float xlo = (ux - cx) * g.cell, xhi = g.cell - xlo, ylo = (uy - cy) * g.cell, yhi = g.cell - ylo, zlo = (uz - cz) * g.cell,
-                zhi = g.cell - zlo;
-    const float xl2 = xlo * xlo, xr2 = xhi * xhi, yl2 = ylo * ylo, yh2 = yhi * yhi, zl2 = zlo * zlo, zh2 = zhi * zhi;
-    sh.q[0][tid] = qx;
-    sh.q[1][tid] = qy;
-    sh.q[2][tid] = qz;
-    const ER_GLOBAL char* csb = (const ER_GLOBAL char*)g.cell_start;
-    asm volatile("" : "+v"(home));
-    int r_s0[9], r_n[9];
-#pragma unroll
-    for (int j0 = 0; j0 < 9; j0 += 3) {                         // three rows' bounds in flight at a time
-      i4v rb[3];
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++) {
-        const int j = j0 + jj, dy = j % 3 - 1, dz = j / 3 - 1;
-        rb[jj] = *(const ER_GLOBAL i4v*)(csb + (unsigned)(home + (dz * pny + dy) * pnx) * 4u);
-      }
-#pragma unroll
-      for (int jj = 0; jj < 3; jj++) {
-        const int j = j0 + jj, dy = j % 3 - 1, dz = j / 3 - 1;
-        const float e2 = (dy < 0 ? yl2 : (dy > 0 ? yh2 : 0.f)) + (dz < 0 ? zl2 : (dz > 0 ? zh2 : 0.f));
-        const bool wl = xl2 + e2 <= bound, wr = xr2 + e2 <= bound;
-        const int s0 = wl ? rb[jj].x : rb[jj].y, s1 = wr ? rb[jj].w : rb[jj].z;
-        r_s0[j] = s0;
-        r_n[j] = e2 <= bound ? s1 - s0 : 0;
-        asm volatile("" : "+v"(r_s0[j]), "+v"(r_n[j]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int j = 0; j < 9; j++) {
-      const int n = r_n[j];
-      if (n > 0) push_range<kU>(sh, g, r_s0[j], n, tid, qx, qy, qz, key);
-    }
-  }
-  sh.best[tid] = key;
-  __syncthreads();
-  const int nt = min(sh.ntask, kTaskCap);
-  for (int t = tid; t < nt; t += kBlock) {
-    const int s0 = sh.task_s0[t], nq = sh.task_nq[t], q = nq & 255;
-    const unsigned long long k = scan_range<kU>(g, s0, s0 + (nq >> 8), sh.q[0][q], sh.q[1][q], sh.q[2][q], kNoHit);
-    atomicMin(&sh.best[q], k);
-  }
-  __syncthreads();
-  key = sh.best[tid];
-  best_d = __uint_as_float((unsigned)(key >> 32));
-  return (int)(unsigned)(key & 0xffffffffull);
-}
+// Round 6, tried and taken out again (profiles/r06e_ab_icp_seeds_and_pieces.txt; parity green, transforms bit-identical for every variant):
+//   * ICP iterations >= 1 SEEDED with the previous iteration's match (a valid upper bound before anything is scanned) and cooperative from the start -- all
+//     nine rows trimmed and pushed, no inline scan: ICP phase of the 50-pair list 2.26 -> 2.57 ms, kinfu-like list 3.95 -> 5.2 ms.  A task is scanned by ONE
+//     lane, so the own cell as a task is as long as the own cell inline, and it pays a push, five LDS reads and a 64-bit LDS atomic on top;
+//   * ranges pushed in PIECES of eight candidates (so that a 60-candidate row is eight lanes' work instead of one lane's fifteen trips): every phase
+//     15-50 % slower -- the per-task overhead (LDS atomic add, two stores, five loads, atomicMin) outweighs two trips of candidate arithmetic.
+// The search stays bound by VALU issue in its straight-line part and by LDS traffic per task, not by the imbalance of the scans.
 
 using NnSh = NnShared;
 constexpr int kPrecheckUnroll = 3;   // candidates per trip of the any-hit pre-check (see nn_block)
@@ -546,7 +441,6 @@ struct PairDev {
   Mat12d T;                      // transform of the pre-check / FindCorrespondence (Matrix4d, rows 0..2)
   float* X;                      // [3 n]   ICP: the source as the loop transforms it (cell-sorted order)
   int* match;                    // [n]     FindCorrespondence: NN index or -1, file order
-  int* seed;                     // [n]     ICP: the previous iteration's match of every query (cell-sorted order), or -1 (nn_block_seeded)
   int* block_count;              // [nb]
   int* block_offset;             // [nb]
   int* pairs;                    // [2 n]   compacted (target index, source index) list
@@ -835,18 +729,7 @@ __global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restric
       }
     }
     float d;
-#if ER_ICP_SEED
-    int i;
-    if (first) {                                               // (wave-uniform)
-      i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
-    } else {
-      const int seed = k < n ? ER_GP(gp_i, p.seed)[k] : -1;
-      i = nn_block_seeded(sh, p.g, k < n, sx, sy, sz, radius * radius, seed, p.tgt_xn, d);
-    }
-    if (k < n) ER_GP(gp_iw, p.seed)[k] = i;
-#else
     const int i = nn_block(sh, p.g, k < n, sx, sy, sz, radius * radius, d);
-#endif
     double w[32];
 #pragma unroll
     for (int t = 0; t < 32; t++) w[t] = 0.0;
@@ -1360,7 +1243,7 @@ struct Group {
   int *d_active = nullptr, *d_counts = nullptr, *d_totals = nullptr;
   double *d_info = nullptr, *d_fit = nullptr;      // kAcc per pair; 2 per pair
   float* X = nullptr;
-  int *match = nullptr, *seed = nullptr, *pairs = nullptr, *block_count = nullptr, *block_offset = nullptr;
+  int *match = nullptr, *pairs = nullptr, *block_count = nullptr, *block_offset = nullptr;
   double* partial = nullptr;
   // pinned host mirrors
   PairDev* h_pairs = nullptr;
@@ -1372,11 +1255,11 @@ struct Group {
 };
 
 void group_free_slabs(Group* g) {
-  void* ptrs[] = {g->X, g->match, g->seed, g->pairs, g->block_count, g->block_offset, g->partial};
+  void* ptrs[] = {g->X, g->match, g->pairs, g->block_count, g->block_offset, g->partial};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   g->X = nullptr;
-  g->match = g->seed = g->pairs = g->block_count = g->block_offset = nullptr;
+  g->match = g->pairs = g->block_count = g->block_offset = nullptr;
   g->partial = nullptr;
   g->cap_points = g->cap_blocks = g->cap_parts = 0;
 }
@@ -1455,7 +1338,6 @@ int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t part
     group_free_slabs(g);
     ER_HIP_TRY(hipMalloc((void**)&g->X, std::max<size_t>(cp, 1) * 3 * sizeof(float)));
     ER_HIP_TRY(hipMalloc((void**)&g->match, std::max<size_t>(cp, 1) * sizeof(int)));
-    ER_HIP_TRY(hipMalloc((void**)&g->seed, std::max<size_t>(cp, 1) * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&g->pairs, std::max<size_t>(cp, 1) * 2 * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&g->block_count, std::max<size_t>(cb, 1) * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&g->block_offset, std::max<size_t>(cb, 1) * sizeof(int)));
@@ -1602,7 +1484,7 @@ int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_clou
     P.n = s->n; P.nb = nblocks_of(s->n); P.nbi = nparts_of(s->n, pts); P.pts = pts;
     icp_fixed_point_scales(s->n, t, P.fx_scale, P.fx_inv);
     if (scratch) {
-      P.X = g->X + 3 * op; P.match = g->match + op; P.seed = g->seed + op; P.pairs = g->pairs + 2 * op;
+      P.X = g->X + 3 * op; P.match = g->match + op; P.pairs = g->pairs + 2 * op;
       P.block_count = g->block_count + ob; P.block_offset = g->block_offset + ob;
       P.partial = g->partial + 32 * oq;
       op += (size_t)((s->n + 3) & ~3); ob += (size_t)P.nb; oq += (size_t)P.nbi;

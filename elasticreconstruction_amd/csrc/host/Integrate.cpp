@@ -9,7 +9,7 @@
 // so the depth stream comes from one of (additive flags):
 //   -oni <file> | --depth_raw <file>   raw stream of 640x480 little-endian uint16 frames, FrameID = 1,2,...
 //                                      (-oni with a real OpenNI recording is rejected with a clear message)
-//   --depth_list <txt>                 one 16-bit grayscale PNG path per line, line i = frame i
+//   --depth_list <txt>                 one 16-bit grayscale PNG path per line, line i = frame i (inflated ahead by --decode_threads <n> (8) host threads)
 // New, additive: --device <gpu> (0), --max_units <n> (2048), --batch <frames fused per launch> (64),
 //   --gpus <N>            N GPUs (devices --device ... --device + N - 1), one host thread per GPU
 //   --shard frame|unit    frame (default, what BASELINE.json names): the active frame range is cut into N contiguous blocks,
@@ -33,6 +33,8 @@
 #include <memory>
 #include <algorithm>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -97,11 +99,21 @@ struct RawStream : DepthSource {
   }
 };
 
+// 16-bit PNG list.  Inflating one 640 x 480 frame takes a host core 3-5 ms -- two orders of magnitude more than the GPU needs to integrate it -- so the
+// files are decoded AHEAD by a few host threads (--decode_threads, default 8): thread-safe claim of the next file, a ring of finished frames, next()
+// hands them out strictly in list order (the frame ids and their order are the reference's, IntegrateApp.cpp:190-226).
 struct PngList : DepthSource {
   std::vector<std::string> files;
   size_t at = 0;
-  int cols, rows;
-  PngList(const std::string& list, int c, int r, long first_id = 1) : cols(c), rows(r) {
+  int cols, rows, nthreads;
+  struct Slot { std::vector<uint16_t> px; long idx = -1; bool ready = false, ok = false; };
+  std::vector<Slot> ring;
+  std::vector<std::thread> workers;
+  std::mutex m;
+  std::condition_variable cv_ready, cv_free;
+  size_t next_claim = 0;
+  bool stop = false, started = false;
+  PngList(const std::string& list, int c, int r, long first_id = 1, int threads = 8) : cols(c), rows(r), nthreads(std::max(1, std::min(threads, 64))) {
     at = first_id > 1 ? (size_t)(first_id - 1) : 0;
     FILE* f = fopen(list.c_str(), "r");
     if (!f) return;
@@ -117,10 +129,59 @@ struct PngList : DepthSource {
     }
     fclose(f);
   }
+  ~PngList() override {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      stop = true;
+    }
+    cv_free.notify_all();
+    for (auto& t : workers) t.join();
+  }
+  void start() {
+    started = true;
+    next_claim = at;
+    ring.resize((size_t)nthreads * 2);
+    for (int t = 0; t < nthreads; t++)
+      workers.emplace_back([this] {
+        std::vector<uint16_t> px;
+        for (;;) {
+          size_t i;
+          {
+            std::unique_lock<std::mutex> lk(m);
+            cv_free.wait(lk, [&] { return stop || (next_claim < files.size() && ring[next_claim % ring.size()].idx < 0); });
+            if (stop || next_claim >= files.size()) return;
+            i = next_claim++;
+            ring[i % ring.size()].idx = (long)i;               // claimed: not ready yet
+            if (next_claim >= files.size()) cv_free.notify_all();   // (the others can leave)
+          }
+          int w = 0, h = 0;
+          const bool ok = erfmt::load_png16(files[i], w, h, px) && w == cols && h == rows;
+          {
+            std::lock_guard<std::mutex> lk(m);
+            Slot& s = ring[i % ring.size()];
+            s.px.swap(px);
+            s.ok = ok;
+            s.ready = true;
+          }
+          cv_ready.notify_all();
+        }
+      });
+  }
   bool next(std::vector<uint16_t>& frame, int& frame_id) override {
     if (at >= files.size()) return false;
-    int w = 0, h = 0;
-    if (!erfmt::load_png16(files[at], w, h, frame) || w != cols || h != rows) {
+    if (!started) start();
+    bool ok;
+    {
+      std::unique_lock<std::mutex> lk(m);
+      Slot& s = ring[at % ring.size()];
+      cv_ready.wait(lk, [&] { return s.idx == (long)at && s.ready; });
+      frame.swap(s.px);
+      ok = s.ok;
+      s.idx = -1;
+      s.ready = false;
+    }
+    cv_free.notify_all();
+    if (!ok) {
       fprintf(stderr, "Cannot read %dx%d 16-bit depth PNG %s\n", cols, rows, files[at].c_str());
       return false;
     }
@@ -333,6 +394,8 @@ int main(int argc, char* argv[]) {
                  "raw uint16 frames (--depth_raw) or 16-bit PNGs (--depth_list))" << std::endl;
     return -1;
   }
+  int decode_threads = 8;                                               // --decode_threads <n>: host threads that inflate the PNGs of --depth_list ahead
+  parse_argument(argc, argv, "--decode_threads", decode_threads);
   const size_t px = (size_t)app.cols_ * app.rows_;
   long source_frames = 0;
   if (!list_file.empty()) {
@@ -344,7 +407,7 @@ int main(int argc, char* argv[]) {
     return -1;
   }
   auto open_source = [&](long first_id) -> std::unique_ptr<DepthSource> {
-    if (!list_file.empty()) return std::unique_ptr<DepthSource>(new PngList(list_file, app.cols_, app.rows_, first_id));
+    if (!list_file.empty()) return std::unique_ptr<DepthSource>(new PngList(list_file, app.cols_, app.rows_, first_id, decode_threads));
     return std::unique_ptr<DepthSource>(new RawStream(raw_file, px, first_id));
   };
 
