@@ -16,7 +16,7 @@
 // Queries run in the SOURCE cloud's own cell-sorted order (thread t takes sorted[t]), so the lanes of a wave
 // walk the same few target cells together (coalesced / broadcast candidate loads); results are written back
 // by original index.  The NN search is block-cooperative (see nn_block); candidates stream from L2 as 16-byte loads.
-// Every stage processes a whole GROUP of pairs per launch (blockIdx.y = pair, round 3; "pair groups" below):
+// Every stage processes a whole GROUP of pairs per launch (blockIdx.y = pair; "pair groups" below):
 //   k_count_inliers   transform (float64 -> float32) + NN + count           (Registration pre-check)
 //   k_icp_iter        one ICP iteration: [apply guess / last increment] + NN + point-to-plane rows -> 27+2 float64 sums
 //                     (4 points per thread -> wave shuffle -> LDS -> per-workgroup partial)
@@ -45,10 +45,8 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kAcc = 32;   // 21 ATA + 6 ATb + sum d^2 + count (+ padding)
 
-// The pair descriptors (PairDev) carry their pointers through MEMORY, so the compiler cannot know that they point into global memory and
-// emits FLAT loads for them: 64-bit address arithmetic in the VALU for every access, and a load that counts on BOTH wait counters
-// (a wave that waits for an LDS result then also waits for its outstanding candidate loads).  The hot accesses go through these
-// explicitly global pointer types instead (round 4): global_load with a scalar base and a 32-bit offset, vmcnt only.
+// PairDev carries its pointers through memory, so the compiler emits FLAT loads for them (64-bit VALU address arithmetic, both wait counters).
+// The hot accesses go through explicitly GLOBAL pointer types: global_load with a scalar base and a 32-bit offset, vmcnt only.
 #ifndef ER_ICP_GLOBAL_PTR
 #define ER_ICP_GLOBAL_PTR 1
 #endif
@@ -65,18 +63,10 @@ typedef ER_GLOBAL float* gp_fw;
 typedef ER_GLOBAL int* gp_iw;
 #define ER_GP(type, ptr) ((type)(ptr))
 
-// Three steps on the straight-line part of nn_block that round 4 prepared and round 5 measured (profiles/r05a_ab_nn_prepared_variants.txt; parity green for
-// all of them, none outside the 0.5 % run-to-run spread of the 50-pair list, so none is in the source any more -- commits 8857abb..2b7f283 have them):
-//   a 10-bit "which neighbour rows of this cell hold points" mask per target cell, wave-uniform skip of empty rows   -0.8 % (one more dependent load)
-//   one LDS atomic per wave for the tasks of all eight rows (ballots + mbcnt)                                         +-0
-//   the query's cell coordinates by a reciprocal instead of three divisions (pruning margin widened by one rounding)   +0.4 %
-// Round 5: the grid carries TWO RINGS OF EMPTY CELLS around the cloud's bounding box (cell (x, y, z) of the box is cell (x + 2, y + 2, z + 2) of the
-// array).  A query is searched only if its home cell lies within one cell of the box, so with two rings every cell of its 27-neighbourhood EXISTS:
-// the has-a-left / own / right-cell flags, the y / z range tests of the eight neighbour rows and the clamps of their x ranges (rounds 1-4) are gone, and
-// the four bounds L, O, R, E of a row's three cells x-1, x, x+1 are four CONSECUTIVE ints of cell_start -- one 16-byte load per row instead of two 4-byte
-// loads behind a clamped index each.  Same candidate sets (ring cells hold no point), same cell-sorted order of the points (padded cell ids order like the
-// plain ones).  Measured against the clamped search (profiles/r05b_ab_padded_grid.txt): ~100 VALU and ~130 SALU instructions fewer per slice in the image,
-// the ICP phase of the 50-pair list 2.33 -> 2.27 ms, the hard list 6.45 k -> 6.7 k pairs/s, every path-B parity test unchanged.
+// The grid carries TWO RINGS OF EMPTY CELLS around the cloud's bounding box (cell (x, y, z) of the box is cell (x + 2, y + 2, z + 2) of the array).  A query is
+// searched only if its home cell lies within one cell of the box, so every cell of its 27-neighbourhood EXISTS -- no flags, range tests or clamps -- and
+// the four bounds L, O, R, E of a row's three cells x-1, x, x+1 are four consecutive ints of cell_start: one 16-byte load per row.
+// (What was tried on this search and dropped, with numbers: profiles/HISTORY.md "Path B: the search, rounds 3-6".)
 #ifndef ER_NN_PAD_BATCH
 #define ER_NN_PAD_BATCH 4      // rows whose four bounds are in flight at a time (4 registers per row; 8 = all rows: +11 VGPRs, within the noise)
 #endif
@@ -100,9 +90,8 @@ struct Grid {
 // D = 2.5e-7 x (largest extent + 2 cells) + 4e-9, and sqrt(3) D for the rows and corners that combine two or three axes.  With S^2 = B (1 + r) + A,
 // a skipped point has a true distance >= S - sqrt(3) D, its float32 squared distance is >= (S - sqrt(3) D)^2 (1 - 3e-7), and
 // 2 S sqrt(3) D <= (r / 4) S^2 + 12 D^2 / r  gives  (S - sqrt(3) D)^2 (1 - 3e-7) >= B  as soon as  A >= 1.2001e5 D^2  (r = 1e-4); the code takes 1.3e5.
-// Until round 4 the absolute part was a constant 1e-12, which covers D only for best distances below a micrometre or above several millimetres:
-// in between, a nearest neighbour sitting straight behind a face, with a competitor in an already scanned cell that is farther by less than
-// ~0.2 um, could be skipped (about once in 1e9 queries on fragment data; tests/test_icp_gpu.py builds such queries on purpose).
+// (A constant absolute part would cover D only for best distances below a micrometre or above several millimetres; tests/test_icp_gpu.py builds the
+// queries in between on purpose.)
 inline float grid_slack(const int dim[3], float cell) {
   const int big = std::max(dim[0], std::max(dim[1], dim[2]));
   const double D = 2.5e-7 * (double)(big + 2) * (double)cell + 4e-9;
@@ -112,42 +101,23 @@ inline float grid_slack(const int dim[3], float cell) {
 struct Mat12d { double m[12]; };
 struct Mat12f { float m[12]; };
 
-// Exact 1-NN of q among target points inside the 27 neighbouring cells: float32 squared distance
-// ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties -> lower original index.  limit2 = squared search radius:
-// callers discard anything farther, so rows of cells lying entirely beyond the radius are skipped (margin: 1e-4
+// Exact 1-NN of q among the target points of the 27 neighbouring cells: float32 squared distance ((dx*dx) + dy*dy) + dz*dz (FLANN L2_Simple), ties ->
+// lower original index.  limit2 = squared search radius: callers discard anything farther, so cells lying entirely beyond it are skipped (margin: 1e-4
 // relative plus an absolute part sized from the grid's extent, see grid_slack).
-//
 // Block-cooperative, two phases (one query per thread, kBlock queries per workgroup):
-//   phase 0  every thread scans the HOME row of its query (the three cells x-1..x+1 of its own (y,z) row, one
-//            contiguous range) and learns a first best distance; the eight neighbouring rows that can still hold
-//            a closer point (distance from q to the row's cell slab <= best so far) are appended to an LDS task
-//            list as (query, row) pairs -- since round 4 as (query, candidate range) pairs, empty ranges dropped;
-//   phase 1  the threads of the workgroup share the task list -- one row scan per thread and trip -- and fold the
-//            results into the query's packed (distance bits, index) key with a 64-bit LDS atomicMin, which IS the
-//            lexicographic (distance, index) minimum.
-// Why: only ~1.7 of the 8 neighbour rows survive the test for an average query, but in a SIMT loop a wave runs
-// every row that ANY of its 64 lanes needs -- practically all of them.  Compacting the surviving (query, row)
-// pairs across the workgroup removes that waste (NN pass over 253 k queries: 34 -> 21 us).  Candidates are scanned
-// kUnroll at a time (the 16-byte loads are issued together; the index is clamped to the row's last candidate,
-// whose repeat cannot change the result).
+//   phase 0  the thread scans its query's own cell, then the left / right cell of the home row if its face is closer than the best so far; the eight
+//            neighbour rows are trimmed by the same face tests and their NON-EMPTY ranges go to an LDS task list as (first candidate, count, query);
+//   phase 1  the workgroup shares the list -- one range per thread and trip -- folding results into the query's packed (distance bits, index) key with a
+//            64-bit LDS atomicMin, which IS the lexicographic (distance, index) minimum.
+// Why: ~1.7 of the 8 neighbour rows survive for an average query, but a SIMT loop runs every row ANY lane needs; compacting the survivors across the
+// workgroup removes that waste.  Candidates are scanned kUnroll at a time (the 16-byte loads are issued together).  What bounds it (counters,
+// profiles/r04w_*, r05f_*): VALU issue in the straight-line part every query runs (~360 of ~735 instructions per slice of 64 queries) and LDS traffic per task.
 #ifndef ER_ICP_UNROLL
 #define ER_ICP_UNROLL 4
 #endif
 constexpr int kUnroll = ER_ICP_UNROLL;
 constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 0xffffffffull;   // (FLT_MAX, -1)
 
-// ---- what round 4 tried on this search and did not keep (parity green every time; all of them behind their macros in commit 09fbe87) ------
-//   LDS staging (commit 5632ff7, -DER_NN_STAGE): the 256 cell-sorted queries of a workgroup need only ~450 distinct target points, so the workgroup
-//     built the set of rows it can touch in an LDS hash table, loaded those ranges once and searched from LDS.  45 % SLOWER (k_count_inliers 1301
-//     against 691 us per 50-pair launch, profiles/r04c_*): the search is short of VALU issue slots, not waiting for its loads; staging adds 30 %
-//     instructions, its 43 KB of LDS leave 3 workgroups per CU instead of 8, the table sees 0.9 bank-conflict cycles per LDS instruction.
-//   One task per non-empty CELL, binned by trip count (commit 86e1e31, -DER_NN_CELLTASKS): 19 % slower (6.49 against 5.45 ms per list,
-//     profiles/r04d_*): four cell bounds per surviving row, per-cell tests and three list counters cost what the shorter scans saved.
-//   A tournament on the 32-bit distance bits for groups of four candidates (commit 25fd209, -DER_NN_TOURNAMENT): 7 % slower
-//     (profiles/r04i_ab_tournament.txt): the packed distance arithmetic pays 16 register moves per group.
-//   Two / eight candidates per trip instead of four: 10 % / 7 % slower (profiles/r04t_ab_scan_unroll.txt); three only pays in the any-hit pre-check.
-//   A two-bin task list on top of the compacted one: within the noise (profiles/r04v_ab_compact_tasks.txt).
-// What the counters say binds it (profiles/r04w_icp_pmc_compact.txt): VALU issue, and within it the straight-line part every query runs.
 #ifndef ER_NN_TASKCAP
 #define ER_NN_TASKCAP (kBlock * 4)
 #endif
@@ -156,18 +126,6 @@ constexpr unsigned long long kNoHit = ((unsigned long long)0x7f7fffffu << 32) | 
 #endif
 constexpr int kTaskCap = ER_NN_TASKCAP;   // (query, row) tasks of phase 1 held in LDS; a task beyond that is scanned by the thread that found it
 
-// Round 4, last step (the round-3 (query, row) list it replaces: -DER_NN_COMPACT=0 in commit 09fbe87): the thread that finds a surviving
-// neighbour row also fetches the row's two cell bounds -- all eight rows at once, sixteen independent loads behind ONE wait -- and appends only
-// the NON-EMPTY ranges as (first candidate, count, query) tasks.  Why: 55-63 % of the queries of a Registration pair at its initial guess have no target point within reg_dist at all; their bound
-// never shrinks, all eight rows survive, and most of those rows are empty -- 6.1 row tasks per query of which 1.6-2.2 hold candidates (0.7 of
-// 1.7 once the pair is aligned).  An empty task costs nothing by itself, but it takes the lane a real task could have had: a wave of 64 tasks
-// runs as long as its longest.  The candidate SETS are unchanged: same result, bit for bit.
-// MEASURED (profiles/r04v_ab_compact_tasks.txt): 5.05 -> 4.80 ms per 50-pair list (pre-check 0.51 -> 0.44, ICP 2.59 -> 2.37, correspondences
-// unchanged), i.e. +5 %, where the SIMT model (scripts/icp_simt_sim.py) promised half the candidate slots.  The counters of both builds
-// (profiles/r04w_icp_pmc_compact.txt) say why: VALU instructions per wave fell by 8 % / 3.5 % / -5 % only (k_count_inliers / k_icp_iter /
-// k_find_corr) -- of the ~870 VALU instructions a wave spends per slice of 64 queries in the pre-check, ~500 are the FIXED part (transform,
-// cell, the bounds of the home row, the eight row tests and pushes: counted in the ISA), which no scan order touches.  A two-bin list (tasks
-// of at most two trips apart from the longer ones) measured within the noise of this one (4.74-4.79 ms) and was not kept.
 struct NnShared {
   unsigned long long best[kBlock];
   float q[3][kBlock];
@@ -176,14 +134,11 @@ struct NnShared {
   int ntask;
 };
 
-// Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum.
-// The reference scan: every candidate against the packed (distance bits, index) key -- exact by construction, 51 VALU instructions per trip
-// of four candidates, 20 of them the selection (four 64-bit compares, eight selects, eight moves that pair distance and index).
-// Round 6 (ER_NN_NOCLAMP): the kU loads of a trip are NOT clamped to the range any more.  A trip that starts inside [s0, s1) may read up to kU - 1
-// entries past s1: they are points of the cells that follow in the cell-sorted array -- REAL points of the same cloud, so the packed (distance, index)
-// minimum over the wider set is still the exact nearest neighbour (the set that must be looked at is contained in it) -- or, behind the cloud's last
-// point, the kSentinel entries er_cloud_create appends (x = y = z = +inf: their distance is inf / NaN, whose bit pattern never wins).  That takes an add
-// and a min per candidate out of the loop (8 of ~62 VALU instructions per trip of four); the loads use immediate offsets from one address.
+// Candidates [s0, s1) of the cell-sorted target against the query: the packed (distance bits, index) minimum -- every candidate against the key, exact by
+// construction; ~54 VALU instructions per trip of four, 20 of them the selection.
+// The kU loads of a trip are NOT clamped to the range: a trip that starts inside [s0, s1) may read up to kU - 1 entries past s1.  Those are points of the
+// cells that follow in the cell-sorted array -- REAL points of the same cloud, so the minimum over the wider set is still the exact nearest neighbour --
+// or, behind the cloud's last point, the kSentinel entries of +inf er_cloud_create appends (distance inf / NaN: a bit pattern that never wins).
 #ifndef ER_NN_NOCLAMP
 #define ER_NN_NOCLAMP 1
 #endif
@@ -215,17 +170,12 @@ __device__ __forceinline__ unsigned long long scan_range(const Grid& g, int s0, 
 }
 
 // Every thread of the workgroup must call this (it synchronises); `active` = this thread carries a query.
-// Returns the index (or -1) and the squared distance of the nearest target point.
-// Round 3: the HOME row is no longer scanned as one range of three cells -- the query's own cell first, then the left / right
-// cell only if its face is closer than the best so far -- and the neighbour rows carry the same two flags, so a typical query
-// looks at about half the candidates (a cell is skipped only when every point in it is provably farther than the best: its
-// nearest face already is, with the same 1e-4 relative margin as the row test; ties cannot hide there).
-// hit2 >= 0 (the Registration pre-check only, round 4): the caller does not need the NEAREST point, only whether ANY target point lies closer
-// than sqrt(hit2) -- "count the points whose nearest neighbour is within reg_dist" is "count the points that have a neighbour within
-// reg_dist" -- so a query stops as soon as it holds a candidate below hit2 (its remaining cells and row tasks are dropped); the returned
-// distance is then that candidate's, not the minimum.  Queries without such a candidate run the full exact search as before.
-// kU = candidates per trip of the scans: 4 for the kernels that need the nearest neighbour, 3 for the any-hit pre-check (measured, round 4:
-// pre-check 0.58 -> 0.51 ms per list with 3, the ICP iterations 2.56 -> 2.63 ms: profiles/r04t_ab_scan_unroll.txt).
+// Returns the index (or -1) and the squared distance of the nearest target point.  A cell is skipped only when every point in it is provably
+// farther than the best so far: its nearest face already is, with the 1e-4 relative margin of grid_slack; ties cannot hide there.
+// hit2 >= 0 (the Registration pre-check): the caller only needs to know whether ANY target point lies closer than sqrt(hit2) -- "count the points
+// whose nearest neighbour is within reg_dist" is "count the points that have a neighbour within reg_dist" -- so a query stops as soon as it holds a
+// candidate below hit2; the returned distance is then that candidate's, not the minimum.  Queries without one run the full exact search.
+// kU = candidates per trip: 4 where the nearest neighbour is needed, 3 in the any-hit pre-check (profiles/r04t_ab_scan_unroll.txt).
 template <int kU = kUnroll>
 __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active, float qx, float qy, float qz, float limit2,
                                         float& best_d, float hit2 = -1.f) {
@@ -240,9 +190,9 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   __syncthreads();                                            // (sh.ntask is zero)
   unsigned long long key = kNoHit;
 #if ER_NN_OCC
-  // Round 6: a query whose whole 27-neighbourhood is empty (55-63 % of the queries of a fragment pair: the part of the source that does not overlap the
-  // target) has no neighbour within the radius, and that is all the search would find out after its eight row tests.  One byte per cell says so up
-  // front (written by k_chunk_occ when the grid is built); the queries come in the source's cell order, so whole waves leave here.
+  // A query whose whole 27-neighbourhood is empty (55-63 % of the queries of a fragment pair: the part of the source that does not overlap the target)
+  // has no neighbour within the radius; one byte per cell (k_chunk_occ) says so before the row tests.  Queries come in the source's cell order: whole
+  // waves leave here (9-10 % of the ICP phase, profiles/r06c_*).
   const bool live = inside && ER_GP(const ER_GLOBAL unsigned char*, g.occ)[(unsigned)(((iz + 2) * g.pny + (iy + 2)) * g.pnx + (ix + 2))] != 0;
 #else
   const bool live = inside;
@@ -329,14 +279,6 @@ __device__ __forceinline__ int nn_block(NnShared& sh, const Grid& g, bool active
   best_d = __uint_as_float((unsigned)(key >> 32));
   return (int)(unsigned)(key & 0xffffffffull);              // 0xffffffff -> -1
 }
-
-// Round 6, tried and taken out again (profiles/r06e_ab_icp_seeds_and_pieces.txt; parity green, transforms bit-identical for every variant):
-//   * ICP iterations >= 1 SEEDED with the previous iteration's match (a valid upper bound before anything is scanned) and cooperative from the start -- all
-//     nine rows trimmed and pushed, no inline scan: ICP phase of the 50-pair list 2.26 -> 2.57 ms, kinfu-like list 3.95 -> 5.2 ms.  A task is scanned by ONE
-//     lane, so the own cell as a task is as long as the own cell inline, and it pays a push, five LDS reads and a 64-bit LDS atomic on top;
-//   * ranges pushed in PIECES of eight candidates (so that a 60-candidate row is eight lanes' work instead of one lane's fifteen trips): every phase
-//     15-50 % slower -- the per-task overhead (LDS atomic add, two stores, five loads, atomicMin) outweighs two trips of candidate arithmetic.
-// The search stays bound by VALU issue in its straight-line part and by LDS traffic per task, not by the imbalance of the scans.
 
 using NnSh = NnShared;
 constexpr int kPrecheckUnroll = 3;   // candidates per trip of the any-hit pre-check (see nn_block)
@@ -665,6 +607,28 @@ __global__ __launch_bounds__(kBlock) void k_count_inliers(const PairDev* __restr
   }
 }
 
+// v (finite, |v| < 2^126) as a signed 128-bit integer, truncated towards zero below the units (hi: signed high word, lo: low word, two's complement).
+__device__ __forceinline__ void to_fixed128(double v, long long& hi, unsigned long long& lo) {
+  hi = 0;
+  lo = 0;
+  const double a = fabs(v);
+  if (!(a > 0.0) || !(a < 8.0e37)) return;                       // 0, NaN, inf (cannot happen under the host's bound)
+  int e;
+  const double f = frexp(a, &e);                                 // a = f 2^e, 0.5 <= f < 1
+  const unsigned long long m = (unsigned long long)ldexp(f, 53); // 2^52 <= m < 2^53, exact
+  const int sh = e - 53;                                         // a = m 2^sh
+  unsigned long long mh = 0, ml = 0;
+  if (sh >= 64) mh = m << (sh - 64);
+  else if (sh > 0) { mh = m >> (64 - sh); ml = m << sh; }
+  else if (sh > -64) ml = m >> (-sh);
+  if (v < 0.0) {                                                 // negate
+    ml = ~ml + 1ull;
+    mh = ~mh + (ml == 0ull ? 1ull : 0ull);
+  }
+  hi = (long long)mh;
+  lo = ml;
+}
+
 // One ICP iteration of every ACTIVE pair of the group in one launch (blockIdx.y -> active[y] = the pair's slot):
 //   iteration 0: X <- guess * source (IterativeClosestPoint::transformCloud, float32; a plain copy for an identity guess);
 //   later:       X <- delta * X (the previous iteration's increment, float32);
@@ -692,15 +656,20 @@ __global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restric
   // l >> 1 -- and the wave adds it to ITS row of the LDS accumulator.  The row values are live only between the NN search and the
   // butterfly, so the kernel keeps the register footprint of the plain NN kernels (occupancy is what the latency-bound search
   // needs: with thread-private float64 sums carried across the slices the kernel held 126 VGPRs = 4 waves per SIMD).
-  // Round 6: the sums ACROSS waves are exact.  A wave's 29 totals of one slice (float64, butterfly order: a function of the slice's 64 points alone) are
-  // rounded ONCE to 64-bit fixed point -- a power-of-two scale per sum, sized on the host from certain bounds (PairDev::fx_scale: every term is bounded by
-  // the target's extent, the search radius and the largest normal component, the number of terms by the source's size, so the total stays below 2^61) --
-  // and from there on everything is integer addition: associative, so a pair's sums, and with them its transform and its iteration count, no longer
-  // depend on `pts`, on the chunking of the loop, on the list the pair is part of or on ER_ICP_SHARES (rounds 4-5: they did, in the last bits; VERDICT
-  // round 5 weak 3).  The quantisation (half a unit of 2^-shift per wave and slice) is below the float64 rounding of a sequential sum of the same terms.
-  __shared__ long long part[kBlock / 64][32];
+  // The sums ACROSS waves are exact.  A wave's 29 totals of one slice (float64, butterfly order: a function of the slice's 64 points alone) are converted
+  // to 128-bit fixed point -- a power-of-two scale per sum, sized on the host from certain bounds (icp_fixed_point_scales: the total stays below 2^121);
+  // with 120 bits the conversion is exact for anything but denormal dust -- and from there on everything is integer addition: associative, so a
+  // pair's sums, its transform and its iteration count do not depend on `pts`, the chunking of the loop, the list the pair is part of or ER_ICP_SHARES.
+  // (64 bits were not enough: a scale sized for the worst case leaves the point-to-plane residual sums A^T b -- terms of 1e-3 that cancel -- a
+  // quantisation noise 300 x float64's, and on ill-posed pairs, where the solve divides noise by noise, 385 of configs[4]'s 2367 accepted pairs then
+  // wandered for all 20 iterations instead of 12: profiles/r06g_allpairs_fixed_point_width.txt.)
+  // The conversion waits until the slices are done: the wave totals of every slice are parked in LDS (8 KB) and converted after the loop, where the
+  // registers of the search are free (inside the loop the 128-bit shifts pushed the kernel 12 bytes over its 80-VGPR budget).
+  __shared__ double dslice[kIcpPtsMax][kBlock / 64][32];
+  __shared__ unsigned long long part_lo[kBlock / 32][32];
+  __shared__ long long part_hi[kBlock / 32][32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane < 32) part[wave][lane] = 0;                       // (each wave only ever touches its own row: no barrier needed until the end)
+  for (int t = threadIdx.x; t < kIcpPtsMax * (kBlock / 64) * 32; t += kBlock) (&dslice[0][0][0])[t] = 0.0;   // (the first barrier of nn_block orders this)
   __shared__ double sfx[32];                                 // the scales wait in LDS: two registers less across the search (the kernel sits on its 80)
   if (threadIdx.x < 32) sfx[threadIdx.x] = p.fx_scale[threadIdx.x];
   for (int c = 0; c < pts; c++) {
@@ -765,14 +734,41 @@ __global__ __launch_bounds__(kBlock, 6) void k_icp_iter(const PairDev* __restric
       }
     }
     w[0] += __shfl_xor(w[0], 1);
-    if ((lane & 1) == 0) part[wave][lane >> 1] += __double2ll_rn(w[0] * sfx[lane >> 1]);
+    if ((lane & 1) == 0) dslice[c][wave][lane >> 1] = w[0];
+  }
+  __syncthreads();
+  {
+    const int slot = threadIdx.x & 31, g = threadIdx.x >> 5;     // 8 groups of 32 threads: group g converts slice g of this workgroup
+    unsigned long long lo = 0;
+    long long hi = 0;
+    if (slot < 29 && g < pts) {
+      const double fx = sfx[slot];
+#pragma unroll
+      for (int w2 = 0; w2 < kBlock / 64; w2++) {
+        long long qh;
+        unsigned long long ql;
+        to_fixed128(dslice[g][w2][slot] * fx, qh, ql);           // (a power-of-two scale: the product is exact)
+        const unsigned long long nlo = lo + ql;
+        hi += qh + (long long)(nlo < lo);
+        lo = nlo;
+      }
+    }
+    part_lo[g][slot] = lo;
+    part_hi[g][slot] = hi;
   }
   __syncthreads();
   if (threadIdx.x < 29) {
-    long long q = 0;
+    unsigned long long lo = 0;
+    long long hi = 0;
 #pragma unroll
-    for (int w2 = 0; w2 < kBlock / 64; w2++) q += part[w2][threadIdx.x];
-    reinterpret_cast<long long*>(p.partial)[(size_t)blockIdx.x * 32 + threadIdx.x] = q;
+    for (int g = 0; g < kBlock / 32; g++) {
+      const unsigned long long nlo = lo + part_lo[g][threadIdx.x];
+      hi += part_hi[g][threadIdx.x] + (long long)(nlo < lo);
+      lo = nlo;
+    }
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(p.partial) + ((size_t)blockIdx.x * 32 + threadIdx.x) * 2;
+    out[0] = lo;
+    out[1] = (unsigned long long)hi;
   }
 }
 
@@ -785,23 +781,35 @@ __global__ __launch_bounds__(kBlock) void k_icp_final(const PairDev* __restrict_
   const int slot = active[blockIdx.x];
   IcpDev* st = S + slot;
   if (st->done) return;
-  const long long* __restrict__ partial = reinterpret_cast<const long long*>(P[slot].partial);
+  const unsigned long long* __restrict__ partial = reinterpret_cast<const unsigned long long*>(P[slot].partial);
   const int nparts = (P[slot].nb + pts - 1) / pts;
   const int val = threadIdx.x & 31, slice = threadIdx.x >> 5;   // 32 x 8
-  long long q = 0;                                              // (integer sums: any order gives the same total)
+  unsigned long long lo = 0;                                    // (128-bit integer sums: any order gives the same total)
+  long long hi = 0;
   if (val < 29) {
-#pragma unroll 8
-    for (int b = slice; b < nparts; b += 8) q += partial[(size_t)b * 32 + val];
+    for (int b = slice; b < nparts; b += 8) {
+      const unsigned long long nlo = lo + partial[((size_t)b * 32 + val) * 2];
+      hi += (long long)partial[((size_t)b * 32 + val) * 2 + 1] + (long long)(nlo < lo);
+      lo = nlo;
+    }
   }
-  __shared__ long long fin[8][32];
-  fin[slice][val] = q;
+  __shared__ unsigned long long fin_lo[8][32];
+  __shared__ long long fin_hi[8][32];
+  fin_lo[slice][val] = lo;
+  fin_hi[slice][val] = hi;
   __syncthreads();
   __shared__ double tot[32];
   if (threadIdx.x < 29) {
-    long long r = 0;
+    unsigned long long l = 0;
+    long long h = 0;
 #pragma unroll
-    for (int sl = 0; sl < 8; sl++) r += fin[sl][threadIdx.x];
-    tot[threadIdx.x] = (double)r * P[slot].fx_inv[threadIdx.x];
+    for (int sl = 0; sl < 8; sl++) {
+      const unsigned long long nl = l + fin_lo[sl][threadIdx.x];
+      h += fin_hi[sl][threadIdx.x] + (long long)(nl < l);
+      l = nl;
+    }
+    // value = h 2^64 + l (two's complement): two roundings to float64, far below the wave sums' own
+    tot[threadIdx.x] = (ldexp((double)h, 64) + (double)l) * P[slot].fx_inv[threadIdx.x];
   }
   __syncthreads();
   if (threadIdx.x == 0) dev_icp_decide(tot, st, prm);
@@ -894,11 +902,9 @@ __global__ __launch_bounds__(kBlock) void k_ransac_match(const PairDev* __restri
 // :723-731 with which = 1):  info[0..2] = sum 2sx,2sy,2sz; [3..5] = sum (4sz^2+4sy^2),(4sz^2+4sx^2),(4sy^2+4sx^2);
 // [6..8] = sum -4sysx, -4szsx, -4szsy; [9] = count   (the distinct terms of sum A^T A, A = [I | 2*skew-like(s)]); info is
 // kAcc doubles per pair (source terms at 0, target terms at 10).
-// Round 5: a workgroup takes kCountSlices consecutive blocks, keeps the twenty sums thread-private across them and leaves ONE partial vector per
-// workgroup in the pair's `partial` scratch (free here: the ICP loop that owns it has ended); k_scan_blocks adds the partial vectors in a fixed order.
-// Rounds 1-4 reduced every block of 256 points by itself and added its ten sums to the pair's accumulator with float64 atomics: 977 workgroups x 10
-// atomics per pair on 10 addresses -- the kernel took 86 us per 8-pair launch, 0.60 ms per 50-pair list, more than the pre-check's NN search
-// (profiles/r05b_icp_three_call_kernel_stats.txt), and its result depended on the order the atomics arrived in.
+// A workgroup takes kCountSlices consecutive blocks, keeps the twenty sums thread-private across them and leaves ONE partial vector per workgroup in the
+// pair's `partial` scratch (free here: the ICP loop that owns it has ended); k_scan_blocks adds the partial vectors in a fixed order: no float64
+// atomics, a result that does not depend on arrival order.
 constexpr int kCountSlices = 8;
 __global__ __launch_bounds__(kBlock) void k_count_blocks(const PairDev* __restrict__ P, int want_source, int want_target) {
   const PairDev& p = P[blockIdx.y];
@@ -1341,7 +1347,7 @@ int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t part
     ER_HIP_TRY(hipMalloc((void**)&g->pairs, std::max<size_t>(cp, 1) * 2 * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&g->block_count, std::max<size_t>(cb, 1) * sizeof(int)));
     ER_HIP_TRY(hipMalloc((void**)&g->block_offset, std::max<size_t>(cb, 1) * sizeof(int)));
-    ER_HIP_TRY(hipMalloc((void**)&g->partial, std::max<size_t>(cq, 1) * 32 * sizeof(double)));
+    ER_HIP_TRY(hipMalloc((void**)&g->partial, std::max<size_t>(cq, 1) * 64 * sizeof(double)));   // 32 x 16 bytes per part (k_icp_iter's 128-bit sums)
     g->cap_points = cp;
     g->cap_blocks = cb;
     g->cap_parts = cq;
@@ -1432,10 +1438,10 @@ int batch_prologue(int n, const er_cloud_t* src, const er_cloud_t* tgt, double r
   return 0;
 }
 
-// Power-of-two scales of k_icp_iter's fixed-point partial sums: scale_k = 2^(60 - ilogb(T_k)) with T_k a CERTAIN bound of |sum k| -- n_source terms,
+// Power-of-two scales of k_icp_iter's 128-bit fixed-point partial sums: scale_k = 2^(120 - ilogb(T_k)) with T_k a CERTAIN bound of |sum k| -- n_source terms,
 // each bounded through  |s| <= M (a matched source point lies within the radius of a target point, i.e. within the target's box + radius),
 // |normal component| <= nm (k_chunk_bounds), |d - s| <= r, |e| = |n . (d - s)| <= 3 nm (r + 1e-4 M) (the float32 expression cancels terms of size nm M) --
-// so the int64 total cannot overflow (|sum| * scale < 2^61) whatever the points are.
+// so the 128-bit total cannot overflow (|sum| * scale < 2^121) whatever the points are.
 void icp_fixed_point_scales(int n_src, const er_cloud_s* t, double* scale, double* inv) {
   double M = 0.0;
   const double r = 1.01 * (double)t->radius_cap;
@@ -1450,7 +1456,7 @@ void icp_fixed_point_scales(int n_src, const er_cloud_s* t, double* scale, doubl
     double sc = 0.0;
     if (k < 29) {
       const double b = T[cls[k]];
-      sc = (std::isfinite(b) && b > 0.0) ? std::ldexp(1.0, 60 - std::ilogb(b)) : 0.0;
+      sc = (std::isfinite(b) && b > 0.0) ? std::ldexp(1.0, 120 - std::ilogb(b)) : 0.0;
     }
     scale[k] = sc;
     inv[k] = sc > 0.0 ? 1.0 / sc : 0.0;
@@ -1459,7 +1465,7 @@ void icp_fixed_point_scales(int n_src, const er_cloud_s* t, double* scale, doubl
 
 // Fills the descriptors of pairs [i0, i0 + m) of the caller's lists into slots 0..m-1 and cuts the scratch slabs (scratch = false:
 // the pre-check needs none).  T16: one row-major float64 4x4 per pair, or NULL.
-int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_cloud_t* tgt, const double* T16, bool scratch) {
+int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_cloud_t* tgt, const double* T16, bool scratch, int* const* pairs_direct = nullptr) {
   size_t points = 0, blocks = 0, parts = 0;
   // (the per-workgroup partial sums of k_icp_iter: room for one slice of 256 points per workgroup, the finest split icp_pts below can pick)
   const int pts = 1;
@@ -1486,7 +1492,8 @@ int group_describe(Group* g, int i0, int m, const er_cloud_t* src, const er_clou
     if (scratch) {
       P.X = g->X + 3 * op; P.match = g->match + op; P.pairs = g->pairs + 2 * op;
       P.block_count = g->block_count + ob; P.block_offset = g->block_offset + ob;
-      P.partial = g->partial + 32 * oq;
+      P.partial = g->partial + 64 * oq;
+      if (pairs_direct && pairs_direct[i0 + q]) P.pairs = pairs_direct[i0 + q];   // k_compact writes the list where the caller wants it (see er_find_correspondence_batch)
       op += (size_t)((s->n + 3) & ~3); ob += (size_t)P.nb; oq += (size_t)P.nbi;
     }
   }
@@ -1500,17 +1507,30 @@ int max_points(int i0, int m, const er_cloud_t* src) {
   return mx;
 }
 
+// ER_ICP_DIRECT_LISTS=0 restores the copy per list (A/B).
+static bool direct_lists() {
+  static const bool on = [] { const char* e = getenv("ER_ICP_DIRECT_LISTS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // Where a caller's list buffer lives: 0 = pageable host memory (staged through the group's page-locked block), 1 = page-locked host memory (the copy
 // goes straight there), 2 = DEVICE memory of `device` (round 5: the list stays in HBM -- a device-to-device copy of exactly the list, no PCIe; what a
 // consumer on the same GPU wants, er_fopt_set_correspondences_dev), -1 = device memory of another GPU (refused).
-int buffer_kind(const void* p, int device) {
+int buffer_kind(const void* p, int device, void** device_view = nullptr) {
   hipPointerAttribute_t at;
+  if (device_view) *device_view = nullptr;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) {
     (void)hipGetLastError();                                 // plain malloc memory: "invalid value", not an error for us
     return 0;
   }
-  if (at.type == hipMemoryTypeHost) return 1;
-  if (at.type == hipMemoryTypeDevice) return at.device == device ? 2 : -1;
+  if (at.type == hipMemoryTypeHost) {
+    if (device_view) *device_view = at.devicePointer;       // page-locked host memory is mapped into the device's address space
+    return 1;
+  }
+  if (at.type == hipMemoryTypeDevice) {
+    if (device_view && at.device == device) *device_view = const_cast<void*>(p);
+    return at.device == device ? 2 : -1;
+  }
   return 0;
 }
 bool is_pinned_host(const void* p) { return buffer_kind(p, -1) == 1; }
@@ -2134,13 +2154,21 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
   if (n == 0) return 0;
   size_t stage_need = 0;
   std::vector<char> direct((size_t)n, 0);                      // destination is page-locked: the list is copied straight into it
+  // Round 6: a list whose buffer the GPU can address -- page-locked host memory (mapped into the device's address space) or device memory -- and that
+  // has room for the largest possible list (one pair per source point) is written THERE by k_compact: no copy at all, the PCIe writes leave with the
+  // kernel's stores.  The separate hipMemcpyAsync per list it replaces ran in one of two modes nobody chose -- 83 MB of lists in 1.6 ms or in 4.4 ms
+  // (51 or 20 GB/s), whole processes long, flipping after unrelated calls (profiles/r06h_realistic_probe.txt; BENCH_r05's kinfu-like figure sat in the
+  // slow mode) -- and even the fast mode only started after the kernels of its sub-group had finished.
+  std::vector<int*> written((size_t)n, nullptr);
   for (int i = 0; i < n; i++) {
     if (capacity[i] > 0 && !pairs_host[i]) return er::fail("er_find_correspondence: NULL pair buffer for pair %d", i);
     if (capacity[i] > 0) {
-      const int kind = buffer_kind(pairs_host[i], device);                     // (asked once per pair, not again at copy time)
+      void* view = nullptr;
+      const int kind = buffer_kind(pairs_host[i], device, &view);              // (asked once per pair, not again at copy time)
       if (kind < 0) return er::fail("er_find_correspondence: the list buffer of pair %d lives on another GPU than its clouds", i);
       direct[(size_t)i] = (char)kind;                                           // 1: page-locked host, 2: device memory -- both are copied to directly
       if (!direct[(size_t)i]) stage_need += (size_t)std::min(capacity[i], src[i]->n) * 2;
+      if (kind > 0 && view && capacity[i] >= src[i]->n && ((uintptr_t)view & 7u) == 0 && direct_lists()) written[(size_t)i] = static_cast<int*>(view);
     }
   }
   GroupLease L;
@@ -2155,12 +2183,12 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     const int m = std::min(G, n - i0);
     ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));          // the previous group's lists have left the slabs
     ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
-    if (group_describe(g, i0, m, src, tgt, T, true)) return 1;
+    if (group_describe(g, i0, m, src, tgt, T, true, written.data())) return 1;
     ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, (size_t)m * kAcc * sizeof(double), g->stream));
     // sub-groups exist to put the list copies of one behind the kernels of the next (PCIe); when every list of this group stays in HBM there is nothing
     // to hide and the whole group is ONE sub-group: 4 launches instead of 4 per 8 pairs, no partly filled last waves in between
     bool all_dev = true;
-    for (int q = 0; q < m; q++) all_dev = all_dev && (capacity[i0 + q] <= 0 || direct[(size_t)(i0 + q)] == 2);
+    for (int q = 0; q < m; q++) all_dev = all_dev && (capacity[i0 + q] <= 0 || direct[(size_t)(i0 + q)] == 2 || written[(size_t)(i0 + q)]);
     const int sub = all_dev ? std::max(m, 1) : kCorrSub;
     const int nsub = (m + sub - 1) / sub;
     while ((int)g->sub_ev.size() < nsub) {
@@ -2198,7 +2226,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream2, evs[(size_t)s], 0));
       for (int q = 0; q < ms; q++) {
         const int i = i0 + s0 + q, ncopy = std::min(n_pairs[i], capacity[i]);
-        if (ncopy <= 0) continue;
+        if (ncopy <= 0 || written[(size_t)i]) continue;          // (written in place by k_compact)
         int* dst = pairs_host[i];
         if (!direct[(size_t)i]) {
           staged[(size_t)i] = (long)stage_used;

@@ -505,21 +505,16 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
-// Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in
-// kRows = 4 register rows of 64 -- a 4 x 8 x 8 box (see the mapping below; round 1: four rows of 64 voxels, lane = k).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform
-// loop: the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
-// Items come from a work queue in cost order (k_plan).  Schedules measured on MI355X (profiles/r01_ab_variants.txt,
-// r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt; ms per 50-frame launch in round 1): whole slabs 0.565; quarter
-// slabs dealt round-robin 0.497; XCD-local sweeps 0.647; per-XCD dynamic queues with stealing 1.25; the global queue below.
-// Round 3 asked the same two questions of the final kernel (profiles/r03z_queue_variants.txt): one queue per XCD (each unit swept by
-// the 64 workgroups of one XCD, so that its depth tiles stay in that L2) 0.415 ms against 0.263 ms for the global queue; claiming
-// one or two items ahead (to take the claim's latency off the critical path) 0.345 / 0.385 ms.  The global queue, claimed when the
-// workgroup is free, stays.
+// Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in kRows = 4 register rows of 64 -- a
+// 4 x 8 x 8 box (mapping below).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform loop:
+// the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
+// Items come from ONE global work queue in cost order (k_plan), claimed when the workgroup is free.  (Static deals, per-XCD queues and look-ahead
+// claims were all measured slower: profiles/HISTORY.md "Path A: the schedule of k_integrate".)
 #ifndef ER_INT_MIN_BLOCKS
 #define ER_INT_MIN_BLOCKS 4
 #endif
-constexpr int kIntMinBlocks = ER_INT_MIN_BLOCKS;          // register budget: 4 workgroups of 4 waves per CU guaranteed (94 VGPRs with four rows per lane; the
-                                          // eight-row kernel of mid round 3 needed 144)
+constexpr int kIntMinBlocks = ER_INT_MIN_BLOCKS;          // register budget: room for 4 workgroups of 4 waves per CU (the kernel uses 93 VGPRs); the grid launches
+                                          // ER_INT_BLOCKS_PER_CU = 3 of them per CU -- the freed registers go to the co-running pre-pass kernels
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 }  // namespace
@@ -542,17 +537,11 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
   const int pixels = cols * rows;
   const int lo_tiles_x = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_tiles = lo_tiles_x * ((rows + (1 << kLoShift) - 1) >> kLoShift);
   const int n_items = plan->n_units * kItemsPerUnit;
-  // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with
-  // its own (one atomic per item and workgroup; the grid is 3 persistent workgroups per CU): longest-processing-time-
-  // first scheduling.  The culling and the full / sure shortcuts make the real cost of an item unpredictable, and with a static
-  // deal the kernel lasted as long as its unluckiest workgroup: taking 22 % of the instructions out of the kernel (the full
-  // path) did not shorten it at all.  History: with the static deal the queue made the kernel 13 % faster and the JOB 5 %
-  // slower (the idle tail was where the pre-pass streams got their share of the SIMDs); together with the full path it is
-  // +2.6 % for the job and -20 % for the kernel (profiles/r02z_ab_dynamic_items.txt, r02G_ab_full_path_and_queue.txt).
-  // (Measured in round 3, profiles/r03A_ab_item_barrier.txt: bare s_barrier instructions instead of __syncthreads(), which also drains
-  //  vmcnt -- no difference; ONE barrier per item with the claim passed through two alternating LDS words -- 15 % slower: the wave of
-  //  thread 0 then claims while the other waves still work, and a claim that is made before the workgroup is free costs more than the
-  //  barrier it saves, like the look-ahead variants in profiles/r03z_queue_variants.txt.)
+  // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with its own (one atomic per
+  // item and workgroup; 3 persistent workgroups per CU): longest-processing-time-first.  The culling and the full / sure shortcuts make the real cost of
+  // an item unpredictable; with a static deal the kernel lasted as long as its unluckiest workgroup.  Two barriers per item on purpose: they keep the
+  // four boxes of an item -- neighbours in the volume, hence in every depth image -- in step on one CU (barrier-free hand-outs measured 1.7 x the time
+  // per frame visit, profiles/r05m_*).
   __shared__ int s_item;
   for (;;) {
     __syncthreads();                                                     // everybody is done with the previous s_item
@@ -563,16 +552,8 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     const PlanRec rec = plan_rec[item >> 8];                              // (wave-uniform: one 16-byte scalar load)
     // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments per
     // access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs x 16 x 16
-    // voxels.  History of the shape (each step bit-identical by construction: the culling is exact): round 1 a strip of four whole
-    // rows of 64 voxels (2.3 x 37.5 cm) 114.8 k frames/s -> round 2 a 16 x 16 square of one slab 123.6 k -> the 4 x 8 x 8 box +1 %
-    // (tighter pixel hull for the culling and the "inside" verdict, fewer idle lanes at surfaces and frustum borders, far fewer
-    // patches that cross a surface: profiles/r02k_ab_compact_patches.txt, r02z_ab_box_patch.txt) -> round 3 an 8 x 8 x 8 cube with
-    // eight rows per lane (the per-(patch, frame) work that does not depend on the number of rows is paid half as often: 69.2 M
-    // instead of 72.6 M wave-instructions per launch, +3.3 % for the job at 144 VGPRs and two workgroups per CU, profiles/
-    // r03i_ab_rows8.txt) -> and back to the box: wall-clock stamps (profiles/r03C_item_times.txt) showed that a 50-frame launch has
-    // only ~2500 items for 512 workgroups and that the longest ones -- patches crossing the surface, the exact update for every frame
-    // -- last 150-180 us of a 270 us kernel; four rows halve them, and at 94 VGPRs four workgroups per CU hide each other's
-    // latencies: 0.201 ms alone (0.263), 0.233 ms in the pipeline (0.314), 159 k frames/s (151 k), profiles/r03D_ab_rows4_again.txt.
+    // voxels.  A compact box has a tight pixel hull (culling, the "inside" verdict), few idle lanes at surfaces and frustum borders and few patches
+    // that cross a surface; four rows per lane keep the longest items short and the kernel at 93 VGPRs (shapes tried: profiles/HISTORY.md).
     const int i = ((item >> 4) & 15) * 4;
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
     const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
@@ -672,16 +653,11 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
         (void)upd;
       }
     };
-    // Software pipeline over the frames that need a projection (round 5, the one change to this loop that paid): the projection and the four depth gathers
-    // of the NEXT such frame are issued before the current frame's samples are used.  A probe build with shader-clock stamps had shown 3100 ticks per
-    // (wave, frame) visit for ~730 issue cycles -- the wave sat on its gathers once per frame.  Runs of full frames need no samples and are applied where
-    // they fall in the ascending order, so every voxel still sees its frames one by one in frame order.  Two stages per trip with alternating sample
-    // registers (a rotating copy would have to wait for the data it copies); the last frame is finished after the loop.  Measured, interleaved on one box
-    // (profiles/r05n_ab_frame_pipeline.txt): k_integrate 0.234 -> 0.203 ms per launch inside the three-stream pipeline, 167.4 k -> 170.0 k frames/s; and
-    // with THREE persistent workgroups per CU instead of four -- each wave now hides its own latency, the freed registers go to the pre-pass kernels --
-    // 174.3 k (two: 172.0 k).  A fully symmetric variant (two sample sets in flight at every stage top, so that the compiler's waits are "all but the newest
-    // four" in both stages; in this one the first stage still waits for everything before its projection) measured the same and is 15 % more code.
-    // Round 2 had tried the same idea on the kernel of its day and found nothing (profiles/r02x_ab_frame_pipeline.txt): the exact update dominated a visit then.
+    // Software pipeline over the frames that need a projection: the projection and the four depth gathers of the NEXT such frame are issued before the
+    // current frame's samples are used (a wave used to sit on its gathers once per frame: 3100 ticks per visit for ~730 issue cycles).  Runs of full
+    // frames need no samples and are applied where they fall in the ascending order, so every voxel still sees its frames one by one in frame order.
+    // Two stages per trip with alternating sample registers (a rotating copy would have to wait for the data it copies); the last frame is finished
+    // after the loop.  +4 % for the job together with three instead of four persistent workgroups per CU (profiles/r05n_ab_frame_pipeline.txt).
     {
       unsigned long long mn = m & ~m_full, mf = m & m_full;
       auto apply_full = [&](unsigned long long run) {
@@ -1472,10 +1448,7 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
 #define ER_INT_BLOCKS_PER_CU 3
 #endif
   constexpr int kIntBlocksPerCu = ER_INT_BLOCKS_PER_CU;       // persistent workgroups fed by the queue.  Fewer than fit: the pre-pass kernels need register
-                                           // space next to them (round 2, four rows per lane: 5 -> 133.1 k, 4 -> 135.4 k, 3 -> 135.7 k frames/s;
-                                           // round 3, eight rows: 2 -> 140.7 k, 3 -> 139.4 k; four rows with the plan records: 2 -> 153.3 k,
-                                           // 3 -> 158.5 k, 4 -> 159.2 k, 5 -> 155.2 k; profiles/r02G_*, r03i_ab_rows8.txt, r03D_ab_rows4_again.txt;
-                                           // round 5, with the frame loop software-pipelined: 2 -> 172.0 k, 3 -> 174.3 k, 4 -> 170.0 k, 5 -> 169.6 k)
+                                           // space next to them (2 -> 172.0 k, 3 -> 174.3 k, 4 -> 170.0 k, 5 -> 169.6 k frames/s, profiles/r05n_*)
   const int wide_grid = h->n_cu * kIntBlocksPerCu;
   uint32_t* zsrc = nullptr;
   char* dst = static_cast<char*>(h->dstage[p]);

@@ -40,8 +40,20 @@ def point_to_plane_conditioning(src_xyz, tgt_nrm, T, corr):
     return float(max(w[0], 0.0) / w[-1])
 
 
+def point_to_plane_conditioning_at(frs, pair, G, reg_dist):
+    """point_to_plane_conditioning of a pair at state G with the correspondences an ICP iteration would use there (exact NN within reg_dist, cKDTree)."""
+    from scipy.spatial import cKDTree
+    a, b, _ = pair
+    G = np.asarray(G, np.float64)
+    q = np.asarray(frs[b][0], np.float64) @ G[:3, :3].T + G[:3, 3]
+    dist, j = cKDTree(np.asarray(frs[a][0], np.float64)).query(q, distance_upper_bound=reg_dist)
+    ok = np.isfinite(dist)
+    corr = np.stack([j[ok], np.nonzero(ok)[0]], 1)
+    return point_to_plane_conditioning(frs[b][0], frs[a][1], G, corr)
+
+
 def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, lists, infos, tmp_dir, reg_dist=0.03, tol_T=1e-5, reg_num=40000,
-                                  reg_ratio=0.25, tol_T_at_limit=None, icp_on_rejected=True):
+                                  reg_ratio=0.25, tol_T_at_limit=None, icp_on_rejected=True, step_fn=None):
     """The results somebody (the HIP path; in the CPU suite: the restatement) produced for pairs[k], k in sel -- pre-check count,
     final transform, iteration count, converged flag, correspondence list and information matrix AT that final transform -- against
     the reference's own compiled code: CCorresApp::Registration (pre-check count = frame_ and the accept rule, CorresApp.cpp:257-281;
@@ -53,7 +65,11 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
     kinfu-like fragments: 2e-5 after 20 iterations; the uniform fragments stay below 1e-6 even there).  icp_on_rejected=False compares ICP loops only
     for the pairs the pre-check accepts -- what CCorresApp::Registration actually runs: from a guess that leaves 2 % of the points with a neighbour the
     loop solves near-singular systems, the estimate jumps by decimetres per iteration and a 1e-16 difference in the float64 sums grows tenfold per
-    iteration (profiles/r05f_icp_trace_rejected_pair.txt).  Returns a summary dict."""
+    iteration (profiles/r05f_icp_trace_rejected_pair.txt).
+    step_fn(k, guess float32 4x4) -> (T, iterations, converged): the candidate's ICP limited to ONE iteration (round 6).  When given, the pairs a
+    whole-loop comparison is weakest on -- those that use up the 20 iterations, and the rejected ones whose loops are skipped -- are compared STEP BY STEP
+    instead: from states of the reference's own trajectory (after 0, 1, 5, 12, 19 iterations; 0, 1, 2 for a rejected pair) both sides run one iteration
+    and must land within 1e-6 (1e-5 for a rejected pair) of each other: an error in the loop body cannot hide behind the loop's sensitivity.  Returns a summary dict."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle.pyoracle import RefCorres
     need = sorted({q for k in sel for q in pairs[k][:2]})
@@ -106,6 +122,29 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
         d = float(np.abs(T1.astype(np.float64) - np.asarray(fins[k], np.float64)).max())
         worst_T = max(worst_T, d)
         assert d <= (tol_lim if it1 >= 20 else tol_T), "pair %d (%d iterations): transform differs from the reference ICP's by %.3g" % (k, it1, d)
+    steps_compared, worst_step = 0, 0.0
+    if step_fn is not None:
+        acc_set = {q for q, _ in accepted}
+        at_limit = [k for k in with_icp if int(iters[k]) >= 20 and k not in degenerate]
+        rejected = [k for k in sel if k not in acc_set]
+        for k, states, tol in [(k, (0, 1, 5, 12, 19), 1e-6) for k in at_limit] + [(k, (0, 1, 2), 1e-5) for k in rejected]:
+            a, b, T = pairs[k]
+            for j in states:
+                if j == 0:
+                    G = T.astype(np.float32)
+                else:
+                    G, itj, _, _ = RefCorres.icp(frs[b][0], frs[b][1], frs[a][0], frs[a][1], T.astype(np.float32), reg_dist, j, 1e-6)
+                    if itj < j:
+                        break                                          # the reference's loop ended before state j
+                Tr, itr, cr, _ = RefCorres.icp(frs[b][0], frs[b][1], frs[a][0], frs[a][1], np.asarray(G, np.float32), reg_dist, 1, 1e-6)
+                Tc, itc, cc = step_fn(k, np.asarray(G, np.float32))
+                assert int(itc) == int(itr), "pair %d, one iteration from the reference's state %d: %d iterations, reference %d" % (k, j, itc, itr)
+                dstep = float(np.abs(np.asarray(Tc, np.float64) - Tr.astype(np.float64)).max())
+                if dstep > tol and point_to_plane_conditioning_at(frs, pairs[k], G, reg_dist) < 1e-7:
+                    continue                                           # (a singular system has no answer to compare)
+                assert dstep <= tol, "pair %d, one iteration from the reference's state %d: |dT| = %.3g" % (k, j, dstep)
+                worst_step = max(worst_step, dstep)
+                steps_compared += 1
     d = tmp_dir if tmp_dir.endswith("/") else tmp_dir + "/"
     app2 = RefCorres(out_dir=d, reg_dist=reg_dist, reg_num=reg_num, reg_ratio=reg_ratio)
     for q in need:
@@ -134,7 +173,8 @@ def check_pairs_against_reference(frs, pairs, sel, cnts, fins, iters, conv, list
                                                       "along that direction in the reference as here -- pre-check count and correspondence file at the candidate's "
                                                       "transform are still compared"} for k, v in degenerate.items()},
             "iterations": [int(iters[k]) for k in with_icp], "converged": [bool(conv[k]) for k in with_icp], "max_abs_T_diff": worst_T,
-            "tolerance_T": tol_T, "correspondence_rows_compared": n_rows,
+            "tolerance_T": tol_T, "tolerance_T_at_the_iteration_limit": tol_lim, "single_iterations_compared": steps_compared, "max_abs_T_diff_single_iteration": worst_step,
+            "correspondence_rows_compared": n_rows,
             "against": "the reference's CCorresApp compiled in place (oracle/_ref/libref_corres.so): pre-check count + accept rule, ICP iteration "
                        "count / converged / transform, corres_<i>_<j>.txt byte for byte, information matrix"}
 

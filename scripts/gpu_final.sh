@@ -19,21 +19,21 @@ echo "# HEAD $HEAD_ID" > gpurun_out/smoke_$TAG.log
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" >> gpurun_out/smoke_$TAG.log 2>&1; SRC=$?; echo "smoke exit $SRC" >> gpurun_out/smoke_$TAG.log; tail -2 gpurun_out/smoke_$TAG.log
 echo "== t=${SECONDS}s bench"
 BT=$((LIMIT - SECONDS - 5)); [ $BT -gt 300 ] && BT=300; [ $BT -lt 20 ] && BT=20
-if [ "${GATE_BENCH:-1}" = "1" ]; then timeout $BT python bench.py > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; BRC=$?; else BRC=0; fi
+if [ "${GATE_BENCH:-1}" = "1" ]; then timeout $BT python bench.py --full-json gpurun_out/bench_full_$TAG.json > gpurun_out/bench_default_$TAG.json 2> gpurun_out/bench_default_$TAG.err; BRC=$?; else BRC=0; fi
 python - "$TAG" "$HEAD_ID" <<'PY'
 import json, sys
 tag, head = sys.argv[1], sys.argv[2]
 p = "gpurun_out/bench_default_%s.json" % tag
 try:
-    line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [l for l in open(p).read().splitlines() if l.strip()]
+    d = json.loads(lines[-1])                                  # the LAST stdout line is the compact line (< 4 KB) the driver parses
+    assert len(lines[-1]) < 4096, "compact line is %d bytes" % len(lines[-1])
     d["gate_head"] = head
-    open(p, "w").write(json.dumps(d) + "\n")
-    r, i = d.get("roofline", {}), d.get("icp", {})
-    print("bench: %.1f frames/s, frac %.3f, whole_job_frac %.3f, icp %.0f pairs/s, hard %.0f, parity %s / %s / %s" % (
-        d["value"], r.get("frac") or 0, r.get("whole_job_frac") or 0, i.get("pairs_per_s") or 0, (i.get("hard_set") or {}).get("pairs_per_s") or 0,
-        (d.get("parity_checked") or {}).get("bit_exact"), (i.get("parity_checked_reference") or {}).get("ok"),
-        ((i.get("hard_set") or {}).get("parity_checked_reference") or {}).get("ok")))
+    open(p, "w").write(json.dumps(d, separators=(",", ":")) + "\n")
+    r, i, o = d.get("roofline", {}), d.get("icp", {}), d.get("other_configs", {})
+    print("bench: %.1f frames/s, frac %.3f, kernel_frac %.3f, icp %.0f / hard %.0f / kinfu-like %.0f pairs/s, configs[3] %.0f; parity %s / %s / %s; line %d bytes" % (
+        d["value"], r.get("frac") or 0, r.get("kernel_frac") or 0, i.get("pairs_per_s") or 0, i.get("hard_pairs_per_s") or 0, i.get("realistic_pairs_per_s") or 0,
+        (o.get("configs[3]") or {}).get("value") or 0, (d.get("parity_checked") or {}).get("bit_exact"), i.get("parity_ref_ok"), i.get("hard_ref_ok"), len(lines[-1])))
 except Exception as ex:
     print("bench: no JSON line (%s)" % ex)
 PY
