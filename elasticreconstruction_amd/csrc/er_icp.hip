@@ -1001,7 +1001,9 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const PairDev* __restrict_
   }
 }
 
-// Stable compaction: pairs (match[k], k) in ascending k (CorresApp.cpp:157, file order of corres_*.txt).
+// Stable compaction: pairs (match[k], k) in ascending k (CorresApp.cpp:157, file order of corres_*.txt).  p.pairs may be the caller's own buffer --
+// device memory or page-locked host memory (er_find_correspondence_batch) -- in which case the list is complete where it is wanted when the kernel ends.
+// (Staging the block's matches in LDS and storing them as aligned 16-byte bursts changed nothing for a host destination: profiles/r06l_fc_modes.txt.)
 __global__ __launch_bounds__(kBlock) void k_compact(const PairDev* __restrict__ P) {
   const PairDev& p = P[blockIdx.y];
   const int n = p.n;
@@ -1016,7 +1018,7 @@ __global__ __launch_bounds__(kBlock) void k_compact(const PairDev* __restrict__ 
   if (m >= 0) {
     int o = p.block_offset[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; w++) o += wcnt[w];
-    reinterpret_cast<int2*>(p.pairs)[o] = make_int2(m, k);       // (o < n: every match has its own k; the slices of `pairs` are 16-byte aligned)
+    reinterpret_cast<int2*>(p.pairs)[o] = make_int2(m, k);       // (o < n: every match has its own k; the buffer is 8-byte aligned)
   }
 }
 
@@ -1238,7 +1240,9 @@ Grid grid_of(const er_cloud_s* c) { return c->grid; }
 // The pool is never freed behind the HIP runtime's back (er_icp_release_workspaces does it).
 struct Group {
   int device = 0;
-  hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;   // two copy streams: list copies alternate between them
+  hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;   // copy streams: list copies alternate between them ...
+  hipStream_t copy_more[2] = {nullptr, nullptr};    // ... and two more (round 6; created on first use): which SDMA engine a stream's copies run on is the
+                                                    // runtime's choice, and two streams that share one engine move 83 MB of lists in 4.4 instead of 1.6 ms
   hipEvent_t ev = nullptr, ev2 = nullptr;
   std::vector<hipEvent_t> sub_ev;  // one per sub-group of er_find_correspondence_batch (grown on demand)
   int cap_pairs = 0;
@@ -1288,6 +1292,11 @@ void group_destroy(Group* g) {
   if (g->stream) (void)hipStreamSynchronize(g->stream);
   if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
   if (g->copy_stream2) (void)hipStreamSynchronize(g->copy_stream2);
+  for (hipStream_t x : g->copy_more)
+    if (x) {
+      (void)hipStreamSynchronize(x);
+      (void)hipStreamDestroy(x);
+    }
   group_free_slabs(g);
   group_free_pairs(g);
   if (g->stage) (void)hipHostFree(g->stage);
@@ -1339,6 +1348,8 @@ int group_reserve(Group* g, int pairs, size_t points, size_t blocks, size_t part
     ER_HIP_TRY(hipStreamSynchronize(g->stream));
     if (g->copy_stream) ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
     if (g->copy_stream2) ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
+    for (hipStream_t x : g->copy_more)
+      if (x) ER_HIP_TRY(hipStreamSynchronize(x));
     const size_t cp = std::max(points + points / 8, g->cap_points), cb = std::max(blocks + blocks / 8, g->cap_blocks),
                  cq = std::max(parts + parts / 8, g->cap_parts);
     group_free_slabs(g);
@@ -1408,6 +1419,8 @@ struct GroupLease {             // RAII: the group of one API call
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->copy_stream) (void)hipStreamSynchronize(g->copy_stream);
     if (g->copy_stream2) (void)hipStreamSynchronize(g->copy_stream2);
+    for (hipStream_t x : g->copy_more)
+      if (x) (void)hipStreamSynchronize(x);
     std::lock_guard<std::mutex> lock(pool().mu);
     pool().idle.push_back(g);
   }
@@ -1507,10 +1520,19 @@ int max_points(int i0, int m, const er_cloud_t* src) {
   return mx;
 }
 
-// ER_ICP_DIRECT_LISTS=0 restores the copy per list (A/B).
-static bool direct_lists() {
-  static const bool on = [] { const char* e = getenv("ER_ICP_DIRECT_LISTS"); return !(e && e[0] == '0'); }();
-  return on;
+// Lists are written in place by k_compact when the GPU can address the destination: device memory (no device-to-device copy) and page-locked host
+// memory (no hipMemcpyAsync).  For a host destination that is 2.1-2.5 ms per 50-pair list whatever the state of the process: the copies it replaces
+// took 1.6-1.9 ms when their two streams ran on separate SDMA engines and 4.3-4.7 ms when they shared one -- the runtime's choice, whole processes
+// long (profiles/r06h_realistic_probe.txt, r06l_fc_modes.txt).  ER_ICP_DIRECT_LISTS=0 copies everything, =d only device destinations are written in place.
+static int direct_lists() {
+  static const int mode = [] { const char* e = getenv("ER_ICP_DIRECT_LISTS"); return e ? (e[0] == '0' ? 0 : (e[0] == 'd' ? 1 : 2)) : 2; }();
+  return mode;                                                 // 0: never, 1: device destinations, 2: device and page-locked host destinations
+}
+// Copy streams the list copies of one call are dealt to when lists ARE copied (pageable or too small destinations): ER_ICP_COPY_STREAMS = 1 .. 4,
+// default 2 (four streams: 2.5-3.0 ms whatever the engines do, two: 1.6 or 4.4 ms; profiles/r06j_fc_modes.txt).
+static int list_copy_streams() {
+  static const int n = [] { const char* e = getenv("ER_ICP_COPY_STREAMS"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+  return n;
 }
 
 // Where a caller's list buffer lives: 0 = pageable host memory (staged through the group's page-locked block), 1 = page-locked host memory (the copy
@@ -2154,11 +2176,10 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
   if (n == 0) return 0;
   size_t stage_need = 0;
   std::vector<char> direct((size_t)n, 0);                      // destination is page-locked: the list is copied straight into it
-  // Round 6: a list whose buffer the GPU can address -- page-locked host memory (mapped into the device's address space) or device memory -- and that
-  // has room for the largest possible list (one pair per source point) is written THERE by k_compact: no copy at all, the PCIe writes leave with the
-  // kernel's stores.  The separate hipMemcpyAsync per list it replaces ran in one of two modes nobody chose -- 83 MB of lists in 1.6 ms or in 4.4 ms
-  // (51 or 20 GB/s), whole processes long, flipping after unrelated calls (profiles/r06h_realistic_probe.txt; BENCH_r05's kinfu-like figure sat in the
-  // slow mode) -- and even the fast mode only started after the kernels of its sub-group had finished.
+  // A list whose buffer the GPU can address and that has room for the largest possible list (one pair per source point) can be written THERE by k_compact:
+  // no copy at all (direct_lists()).  The copies of the other lists are dealt to up to four copy streams: with two, both could land on ONE SDMA engine --
+  // 83 MB of lists in 4.4 instead of 1.6 ms (20 against 51 GB/s), whole processes long, flipping after unrelated calls created more streams
+  // (profiles/r06h_realistic_probe.txt; BENCH_r05's kinfu-like figure sat in the slow mode).
   std::vector<int*> written((size_t)n, nullptr);
   for (int i = 0; i < n; i++) {
     if (capacity[i] > 0 && !pairs_host[i]) return er::fail("er_find_correspondence: NULL pair buffer for pair %d", i);
@@ -2168,7 +2189,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       if (kind < 0) return er::fail("er_find_correspondence: the list buffer of pair %d lives on another GPU than its clouds", i);
       direct[(size_t)i] = (char)kind;                                           // 1: page-locked host, 2: device memory -- both are copied to directly
       if (!direct[(size_t)i]) stage_need += (size_t)std::min(capacity[i], src[i]->n) * 2;
-      if (kind > 0 && view && capacity[i] >= src[i]->n && ((uintptr_t)view & 7u) == 0 && direct_lists()) written[(size_t)i] = static_cast<int*>(view);
+      if (kind > 0 && view && capacity[i] >= src[i]->n && ((uintptr_t)view & 7u) == 0 && direct_lists() >= (kind == 2 ? 1 : 2)) written[(size_t)i] = static_cast<int*>(view);
     }
   }
   GroupLease L;
@@ -2179,10 +2200,14 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
   size_t stage_used = 0;
   const int G = group_cfg();
   int rc = 0;
+  const int ncs = list_copy_streams();
+  for (int q = 0; q < 2 && q + 2 < ncs; q++)
+    if (!g->copy_more[q]) ER_HIP_TRY(hipStreamCreateWithFlags(&g->copy_more[q], hipStreamNonBlocking));
+  hipStream_t cs[4] = {g->copy_stream, ncs > 1 ? g->copy_stream2 : g->copy_stream, ncs > 2 ? g->copy_more[0] : g->copy_stream,
+                       ncs > 3 ? g->copy_more[1] : (ncs > 1 ? g->copy_stream2 : g->copy_stream)};
   for (int i0 = 0; i0 < n; i0 += G) {
     const int m = std::min(G, n - i0);
-    ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));          // the previous group's lists have left the slabs
-    ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
+    for (int q = 0; q < 4; q++) ER_HIP_TRY(hipStreamSynchronize(cs[q]));          // the previous group's lists have left the slabs
     if (group_describe(g, i0, m, src, tgt, T, true, written.data())) return 1;
     ER_HIP_TRY(hipMemsetAsync(g->d_info, 0, (size_t)m * kAcc * sizeof(double), g->stream));
     // sub-groups exist to put the list copies of one behind the kernels of the next (PCIe); when every list of this group stays in HBM there is nothing
@@ -2222,8 +2247,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
         if (n_pairs[i] > capacity[i]) rc = er::fail("er_find_correspondence: %d pairs exceed the capacity %d", n_pairs[i], capacity[i]);
       }
       // copies of this sub-group's lists on the copy stream (its kernels are done: evs[s] has been waited for)
-      ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream, evs[(size_t)s], 0));
-      ER_HIP_TRY(hipStreamWaitEvent(g->copy_stream2, evs[(size_t)s], 0));
+      for (int q = 0; q < ncs; q++) ER_HIP_TRY(hipStreamWaitEvent(cs[q], evs[(size_t)s], 0));
       for (int q = 0; q < ms; q++) {
         const int i = i0 + s0 + q, ncopy = std::min(n_pairs[i], capacity[i]);
         if (ncopy <= 0 || written[(size_t)i]) continue;          // (written in place by k_compact)
@@ -2234,7 +2258,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
           stage_used += (size_t)ncopy * 2;
         }
         if (hipMemcpyAsync(dst, g->h_pairs[s0 + q].pairs, (size_t)ncopy * 2 * sizeof(int), direct[(size_t)i] == 2 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
-                           (i & 1) ? g->copy_stream2 : g->copy_stream) != hipSuccess) {
+                           cs[i % ncs]) != hipSuccess) {
           cleanup();
           return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError()));
         }
@@ -2242,8 +2266,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     }
     cleanup();
   }
-  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream));
-  ER_HIP_TRY(hipStreamSynchronize(g->copy_stream2));
+  for (int q = 0; q < 4; q++) ER_HIP_TRY(hipStreamSynchronize(cs[q]));
   for (int i = 0; i < n; i++)
     if (staged[(size_t)i] >= 0) memcpy(pairs_host[i], g->stage + staged[(size_t)i], (size_t)std::min(n_pairs[i], capacity[i]) * 2 * sizeof(int));
   return rc;

@@ -23,7 +23,9 @@ for k in ("k_count_inliers", "k_icp_iter", "k_find_corr"):
     print("   VALU instructions per wave %.0f; VALU issue share = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x cycles) = %.2f" % (g("SQ_INSTS_VALU") / g("SQ_WAVES"), g("SQ_ACTIVE_INST_VALU") * 4 / simd_cycles))
     print("   wave cycles: waiting for anything %.2f, waiting for an instruction to issue %.2f, any instruction active %.2f" % (
         g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_ANY") / g("SQ_WAVE_CYCLES")))
-    print("   occupancy = wave cycles / (1024 SIMDs x cycles) = %.1f waves per SIMD" % (g("SQ_WAVE_CYCLES") / simd_cycles * 1.0))
+    # SQ_WAVE_CYCLES (like SQ_WAIT_* and SQ_ACTIVE_INST_*) counts QUAD-cycles (MI355X_MICROARCH.md): x 4 for resident waves per SIMD.  The round-5 files
+    # (r05f_icp_pmc_*) printed this figure without the factor -- their "1.1 - 1.6 waves per SIMD" are 4.4 - 6.4, at a launch bound of 6.
+    print("   occupancy = SQ_WAVE_CYCLES x 4 / (1024 SIMDs x cycles) = %.1f waves per SIMD" % (g("SQ_WAVE_CYCLES") * 4.0 / simd_cycles))
     print("   per wave: VMEM reads %.0f, LDS instructions %.0f (bank-conflict cycles / LDS instruction %.2f), SMEM %.0f" % (
         g("SQ_INSTS_VMEM_RD") / g("SQ_WAVES"), g("SQ_INSTS_LDS") / g("SQ_WAVES"), g("SQ_LDS_BANK_CONFLICT") / max(g("SQ_INSTS_LDS"), 1), g("SQ_INSTS_SMEM") / g("SQ_WAVES")))
     print("   L1 (TCP): %.1f M accesses, %.1f M go on to L2 -> hit rate %.3f;  L2 (TCC): hit rate %.3f of %.1f M requests" % (
