@@ -2098,16 +2098,17 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
 
 // Compaction chain of slots [s0, s0 + m) of the group (match already written): per-block counts (+ information terms), per-pair
 // scan, stable compaction; the totals and the information terms come back to the pinned mirrors.  Records `done` on the stream.
-static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done) {
-  hipLaunchKernelGGL(k_count_blocks, dim3((mxb + kCountSlices - 1) / kCountSlices, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0, want_source ? 1 : 0,
+static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done, hipStream_t S = nullptr) {
+  if (!S) S = g->stream;
+  hipLaunchKernelGGL(k_count_blocks, dim3((mxb + kCountSlices - 1) / kCountSlices, m), dim3(kBlock), 0, S, g->d_pairs + s0, want_source ? 1 : 0,
                      want_target ? 1 : 0);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, g->stream, g->d_pairs + s0, g->d_totals + s0, g->d_info + (size_t)s0 * kAcc,
+  hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, S, g->d_pairs + s0, g->d_totals + s0, g->d_info + (size_t)s0 * kAcc,
                      (want_source || want_target) ? 1 : 0);
-  hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, g->stream, g->d_pairs + s0);
+  hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, S, g->d_pairs + s0);
   ER_HIP_TRY(hipGetLastError());
-  ER_HIP_TRY(hipMemcpyAsync(g->h_totals + s0, g->d_totals + s0, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, g->stream));
-  ER_HIP_TRY(hipMemcpyAsync(g->h_info + (size_t)s0 * kAcc, g->d_info + (size_t)s0 * kAcc, (size_t)m * kAcc * sizeof(double), hipMemcpyDeviceToHost, g->stream));
-  ER_HIP_TRY(hipEventRecord(done, g->stream));
+  ER_HIP_TRY(hipMemcpyAsync(g->h_totals + s0, g->d_totals + s0, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, S));
+  ER_HIP_TRY(hipMemcpyAsync(g->h_info + (size_t)s0 * kAcc, g->d_info + (size_t)s0 * kAcc, (size_t)m * kAcc * sizeof(double), hipMemcpyDeviceToHost, S));
+  ER_HIP_TRY(hipEventRecord(done, S));
   return 0;
 }
 
@@ -2214,8 +2215,11 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     // to hide and the whole group is ONE sub-group: 4 launches instead of 4 per 8 pairs, no partly filled last waves in between
     bool all_dev = true;
     for (int q = 0; q < m; q++) all_dev = all_dev && (capacity[i0 + q] <= 0 || direct[(size_t)(i0 + q)] == 2 || written[(size_t)(i0 + q)]);
+    // (sub-groups only serve to put list COPIES behind the next kernels; lists written in place need none -- dealing sub-groups to two compute streams so
+    //  that one's stores cross the link while the next one searches measured 2.25-2.64 against 2.15-2.5 ms: profiles/r06m_*)
     const int sub = all_dev ? std::max(m, 1) : kCorrSub;
     const int nsub = (m + sub - 1) / sub;
+    hipStream_t ks[2] = {g->stream, g->stream};
     while ((int)g->sub_ev.size() < nsub) {
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return er::fail("er_find_correspondence: hipEventCreate failed");
@@ -2227,8 +2231,8 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       const int s0 = s * sub, ms = std::min(sub, m - s0);
       int mxb = 1;
       for (int q = 0; q < ms; q++) mxb = std::max(mxb, g->h_pairs[s0 + q].nb);
-      hipLaunchKernelGGL(k_find_corr, dim3(mxb, ms), dim3(kBlock), 0, g->stream, g->d_pairs + s0, (float)dist, dist * dist, normal_cos);
-      return corr_chain(g, s0, ms, mxb, info36 != nullptr, false, evs[(size_t)s]);
+      hipLaunchKernelGGL(k_find_corr, dim3(mxb, ms), dim3(kBlock), 0, ks[s & 1], g->d_pairs + s0, (float)dist, dist * dist, normal_cos);
+      return corr_chain(g, s0, ms, mxb, info36 != nullptr, false, evs[(size_t)s], ks[s & 1]);
     };
     if (enqueue(0)) { cleanup(); return 1; }
     for (int s = 0; s < nsub; s++) {
