@@ -196,6 +196,8 @@ def compact_line(out):
             e = {"value": r.get("value"), "ms_per_step": r.get("ms_per_step"), "steps": r.get("steps"), "frames": r.get("frames"),
                  "units": r.get("volume_units_touched"), "roofline_frac": r.get("roofline_frac"),
                  "bit_exact": _get(r, "parity_checked", "bit_exact"), "cpu_value": _get(r, "cpu_baseline", "value")}
+            if r.get("scaling") == "strong" and r.get("rccl_ranks"):
+                e.update({"scaling": "strong", "rccl_ranks": r.get("rccl_ranks"), "merge_bytes_sent": _get(r, "merge_stats", "bytes_sent")})
             if r.get("icp"):
                 e["icp_pairs_per_s"] = r["icp"].get("pairs_per_s")
                 e["icp_parity_ok"] = _get(r["icp"], "parity_checked", "ok")
@@ -257,6 +259,70 @@ def emit(out, full_path):
         os.dup2(2, 1)                                      # (anything a library prints at exit stays off the line's pipe)
 
 
+
+def strong_scaling_leg(args, dist, dev, local, rank, world, comm, dry, stream):
+    """BASELINE.json configs[3] INSIDE an N > 1 run: the 10 000-frame job of the drifting path cut into `world` contiguous blocks,
+    every rank its block into a private volume, the merge (by unit owner; result distributed) inside the timed region -- the strong-scaling line of
+    the same communicator the headline just used, so that the driver's SCALE file carries the curve that matters.  Returns the object rank 0 attaches
+    as other_configs['configs[3]'] (None on the other ranks)."""
+    import numpy as np
+    import torch
+    from elasticreconstruction_amd import parallel, synth
+    from elasticreconstruction_amd.tsdf import TSDFVolume
+    I = args.interval
+    K, S = plan_steps(4, args.steps, 0, I, world)
+    n_frames = K * S
+    sc = synth.make_scenario(n_frames, interval=I, warp=True, frame_offset=rank * n_frames, total_frames=world * n_frames,
+                             revolutions=max(1.0, world * n_frames / float(CONFIG2_FRAMES)), radius_drift=1.5, room=(-1.5, 4.5), device=dev)
+    depth, px = sc["depth"], sc["depth"].shape[1]
+    warp_all = synth.warp_arrays(sc)
+    vol = DryVolume(rank, 4096) if dry else TSDFVolume(max_units=4096, device=local)
+    vol.set_stream(stream.cuda_stream if stream is not None else None)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    root = 0 if dry else args.merge_root
+
+    def one_pass():
+        vol.reset()
+        sync()
+        dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for s in range(K):
+            lo, hi = s * S, (s + 1) * S
+            gi = warp_all["grid_index"][lo:hi]
+            g0, g1 = int(gi.min()), int(gi.max()) + 1
+            w = dict(ctr=warp_all["ctr"][g0:g1], resolution=warp_all["resolution"], length=warp_all["length"], grid_index=gi - g0,
+                     seg=warp_all["seg"][lo:hi], madj=warp_all["madj"][lo:hi])
+            vol.IntegrateFrames(None, sc["traj"][lo:hi], w, device_ptr=depth.data_ptr() + lo * px * 2)
+        nu = comm.allreduce(vol, root=root) if comm is not None else parallel.merge_volumes(vol, dist, dev)
+        sync()
+        dist.barrier()
+        sync()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), nu
+    one_pass()                                                           # warm-up: buffers of the merge, the unit pool
+    passes, nu = [], 0
+    for _ in range(3):
+        dt, nu = one_pass()
+        passes.append(dt)
+    dt = float(np.median(passes))
+    distributed = comm is not None and not dry and root == -2
+    t = torch.tensor([vol.sum_weight() if (distributed or rank == max(root, 0)) else 0.0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    sum_w = float(t.item())
+    stats = comm.merge_stats() if comm is not None and hasattr(comm, "merge_stats") else None
+    vol.close()
+    if rank != 0:
+        return None
+    total = world * n_frames
+    bytes_pass = 16.0 * sum_w + (FRAME_BYTES_FIXED + 2 * FRAME_BYTES_RAW) * total
+    return {"value": total / dt, "unit": "frames/s", "scaling": "strong", "ms_per_step": 1e3 * dt / K, "steps": K, "frames": total, "frames_per_gpu": n_frames,
+            "volume_units_touched": int(nu), "roofline_frac": bytes_pass / dt / 1e9 / HBM_PEAK_GBS / world, "roofline_frac_definition": "per GPU: job bytes / time / (n_gpus x 8 TB/s)",
+            "pass_ms": [round(1e3 * p, 3) for p in passes], "merge_stats": stats, "rccl_ranks": world,
+            "workload": "configs[3]: 10 000 frames of the drifting path in %d contiguous blocks, merge by unit owner inside the timed region" % world}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,6 +372,9 @@ def main():
     ap.add_argument("--boundary", type=int, default=1,
                     help="(default run only) also time the drop-in PROGRAMS end to end -- bin/Integrate on configs[1] from files, bin/BuildCorrespondence on "
                          "the 50-pair list -- beside the reference's own programs on a bounded sample (0 = skip)")
+    ap.add_argument("--scaling-child", type=int, default=1,
+                    help="(--gpus N > 1, --config 2) after the weak-scaling headline also run configs[3]'s 10 000-frame job cut into N blocks over the same "
+                         "communicator and attach it as other_configs['configs[3]'] (0 = skip)")
     ap.add_argument("--full-json", default=os.path.join(ROOT, "bench_full.json"),
                     help="where rank 0 writes the FULL result object (per-phase tables, definitions, A/B leftovers, the children's objects); "
                          "stdout carries only the compact line (< 4 KB) made from it by compact_line()")
@@ -549,6 +618,13 @@ def main():
             icp["nn_queries_per_s"] = None
             icp["sharding"] = "%d GPUs x %d pairs, no collective; slowest rank's median pass" % (world, args.icp_pairs)
 
+    # N > 1: configs[3]'s strong-scaling job over the same communicator (every rank takes part; rank 0 gets the object)
+    strong = None
+    if world > 1 and args.config == 2 and args.scaling_child and not args.host_input:
+        try:
+            strong = strong_scaling_leg(args, dist, dev, local, rank, world, comm, dry, stream)
+        except Exception as ex:                                          # (every rank raises or none does only by luck: keep the headline, say what happened)
+            strong = {"error": repr(ex)[:300]} if rank == 0 else None
     if rank == 0:
         total_frames = world * n_frames
         out = {
@@ -742,6 +818,8 @@ def main():
             out["icp"] = icp
             if world == 1 and args.config == 2 and not dry:
                 out["fragment_optimizer"] = fopt_section(local)
+        if world > 1 and args.config == 2 and args.scaling_child and strong is not None:
+            out["other_configs"] = {"configs[3]": strong}
         if world == 1 and args.config == 2 and args.boundary and warp_on and n_frames == CONFIG2_FRAMES and not dry:
             vol.close()                                              # (the programs bring their own volumes)
             vol = None

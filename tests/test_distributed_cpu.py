@@ -293,7 +293,11 @@ def test_bench_dry_run_four_ranks_through_the_drivers_command_line():
     # after the reduce rank 0 holds every rank's updates: sum(weight) / world = one rank's share = 2 units x 100 frames x 64^3 voxels
     assert out["roofline"]["voxel_updates_per_pass"] == 2 * 100 * 64 ** 3
     assert out["icp"]["pairs"] == 20 and "4 GPUs x 5 pairs" in out["icp"]["sharding"]
-    assert "cpu_baseline" not in out and "other_configs" not in out
+    assert "cpu_baseline" not in out
+    # N > 1: configs[3]'s strong-scaling job ran over the same communicator: 10 000 frames in 4 blocks of 2500, whole-job value
+    sc3 = out["other_configs"]["configs[3]"]
+    assert sc3["scaling"] == "strong" and sc3["rccl_ranks"] == 4 and sc3["frames"] == 10000 and sc3["frames_per_gpu"] == 2500
+    assert abs(sc3["value"] * sc3["ms_per_step"] * 1e-3 * sc3["steps"] - 10000) < 1e-6 * 10000
 
 
 def test_compact_line_of_a_full_headline_object_stays_under_4k():
