@@ -70,7 +70,7 @@ typedef ER_GLOBAL int* gp_iw;
 #ifndef ER_NN_PAD_BATCH
 #define ER_NN_PAD_BATCH 4      // rows whose four bounds are in flight at a time (4 registers per row; 8 = all rows: +11 VGPRs, within the noise)
 #endif
-typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4), aligned(4)));   // (the four bounds of a row start at an arbitrary cell: 4-byte alignment only)
 struct Grid {
   const float4* pts;
   const int* cell_start;
