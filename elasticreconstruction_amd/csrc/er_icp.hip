@@ -571,8 +571,10 @@ __device__ void dev_icp_decide(const double* acc, IcpDev* st, IcpParams P) {
 }
 
 
-constexpr int kIcpPtsMax = 8;              // source points per thread of k_icp_iter (the 29 cross-lane sums are paid once per workgroup): the host
-                                           // picks 8 when the group still fills the chip with workgroups, fewer for short lists (PairDev::pts)
+constexpr int kIcpPtsMax = 2;              // slices of 256 source points per workgroup of k_icp_iter.  Round 6: two, not eight -- a workgroup of eight slices lasts
+                                           // ~150 us of a ~700 us launch, and the launch ends with its last workgroup: ICP phase of the kinfu-like list 3.97 -> 3.48 ms,
+                                           // hard list 5.17 -> 4.93, uniform 2.30 -> 2.21 (1: worse again; profiles/r06n_ab_icp_points_per_workgroup.txt).  Free to
+                                           // choose since the sums are order-independent: every digest identical.
 
 // Registration pre-check, CorresApp.cpp:257-264, for a group of pairs: counts[pair] = #{k : d2 < reg_dist^2}.  blockIdx.x
 // strides over the pair's points; ONE atomic per workgroup.
@@ -1314,11 +1316,14 @@ int nblocks_of(int n) { return (std::max(n, 1) + kBlock - 1) / kBlock; }
 #ifndef ER_ICP_FIXED_PTS
 #define ER_ICP_FIXED_PTS 0
 #endif
+#ifndef ER_PRECHECK_WGS
+#define ER_PRECHECK_WGS 16384    // workgroups of one k_count_inliers launch (each strides over its pair's slices; 8192: +3 % time, 32768: the same)
+#endif
 // Slices of 256 points per workgroup of k_icp_iter when `blocks` slices are to be searched in one launch (the 29 cross-lane sums are paid
 // once per workgroup, so more slices per workgroup are cheaper as long as the launch still fills the chip).
 int icp_pts(long blocks) {
   if (ER_ICP_FIXED_PTS) return ER_ICP_FIXED_PTS;
-  return blocks >= 8 * 1024 ? kIcpPtsMax : (blocks >= 4 * 1024 ? 4 : (blocks >= 1024 ? 2 : 1));
+  return blocks >= 1024 ? kIcpPtsMax : 1;
 }
 int nparts_of(int n, int pts) { return (std::max(n, 1) + kBlock * pts - 1) / (kBlock * pts); }
 
@@ -1938,7 +1943,7 @@ int er_icp_count_inliers_batch(int n, const er_cloud_t* src, const er_cloud_t* t
     const int mx = max_points(i0, m, src);
     if (mx > 0) {
       // a few thousand workgroups in flight fill the chip; each strides over its pair's points (one atomic per workgroup)
-      const int bx = std::max(1, std::min(nblocks_of(mx), std::max(64, 8192 / m)));
+      const int bx = std::max(1, std::min(nblocks_of(mx), std::max(64, ER_PRECHECK_WGS / m)));
       hipLaunchKernelGGL(k_count_inliers, dim3(bx, m), dim3(kBlock), 0, g->stream, g->d_pairs, (float)max_dist, max_dist * max_dist, g->d_counts);
       ER_HIP_TRY(hipGetLastError());
     }
