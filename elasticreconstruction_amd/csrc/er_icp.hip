@@ -1246,7 +1246,7 @@ struct Group {
   hipStream_t copy_more[2] = {nullptr, nullptr};    // ... and two more (round 6; created on first use): which SDMA engine a stream's copies run on is the
                                                     // runtime's choice, and two streams that share one engine move 83 MB of lists in 4.4 instead of 1.6 ms
   hipEvent_t ev = nullptr, ev2 = nullptr;
-  std::vector<hipEvent_t> sub_ev;  // one per sub-group of er_find_correspondence_batch (grown on demand)
+  std::vector<hipEvent_t> sub_ev, sub_ev2;  // per sub-group of er_find_correspondence_batch (grown on demand): done / scanned
   int cap_pairs = 0;
   size_t cap_points = 0, cap_blocks = 0, cap_parts = 0;
   // device
@@ -1305,6 +1305,8 @@ void group_destroy(Group* g) {
   if (g->ev) (void)hipEventDestroy(g->ev);
   if (g->ev2) (void)hipEventDestroy(g->ev2);
   for (hipEvent_t e : g->sub_ev)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : g->sub_ev2)
     if (e) (void)hipEventDestroy(e);
   if (g->stream) (void)hipStreamDestroy(g->stream);
   if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
@@ -2103,17 +2105,25 @@ int er_ransac_fitness_batch(er_cloud_t src, er_cloud_t tgt, int n_hyp, const flo
 
 // Compaction chain of slots [s0, s0 + m) of the group (match already written): per-block counts (+ information terms), per-pair
 // scan, stable compaction; the totals and the information terms come back to the pinned mirrors.  Records `done` on the stream.
-static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done, hipStream_t S = nullptr) {
+static int corr_chain(Group* g, int s0, int m, int mxb, bool want_source, bool want_target, hipEvent_t done, hipStream_t S = nullptr,
+                      hipStream_t compact_on = nullptr, hipEvent_t scanned = nullptr) {
   if (!S) S = g->stream;
   hipLaunchKernelGGL(k_count_blocks, dim3((mxb + kCountSlices - 1) / kCountSlices, m), dim3(kBlock), 0, S, g->d_pairs + s0, want_source ? 1 : 0,
                      want_target ? 1 : 0);
   hipLaunchKernelGGL(k_scan_blocks, dim3(m), dim3(1024), 0, S, g->d_pairs + s0, g->d_totals + s0, g->d_info + (size_t)s0 * kAcc,
                      (want_source || want_target) ? 1 : 0);
-  hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, S, g->d_pairs + s0);
   ER_HIP_TRY(hipGetLastError());
   ER_HIP_TRY(hipMemcpyAsync(g->h_totals + s0, g->d_totals + s0, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, S));
   ER_HIP_TRY(hipMemcpyAsync(g->h_info + (size_t)s0 * kAcc, g->d_info + (size_t)s0 * kAcc, (size_t)m * kAcc * sizeof(double), hipMemcpyDeviceToHost, S));
-  ER_HIP_TRY(hipEventRecord(done, S));
+  hipStream_t C = S;
+  if (compact_on && compact_on != S && scanned) {               // the compaction (PCIe-bound when it writes into host memory) leaves the compute stream
+    ER_HIP_TRY(hipEventRecord(scanned, S));
+    ER_HIP_TRY(hipStreamWaitEvent(compact_on, scanned, 0));
+    C = compact_on;
+  }
+  hipLaunchKernelGGL(k_compact, dim3(mxb, m), dim3(kBlock), 0, C, g->d_pairs + s0);
+  ER_HIP_TRY(hipGetLastError());
+  ER_HIP_TRY(hipEventRecord(done, C));
   return 0;
 }
 
@@ -2220,11 +2230,22 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
     // to hide and the whole group is ONE sub-group: 4 launches instead of 4 per 8 pairs, no partly filled last waves in between
     bool all_dev = true;
     for (int q = 0; q < m; q++) all_dev = all_dev && (capacity[i0 + q] <= 0 || direct[(size_t)(i0 + q)] == 2 || written[(size_t)(i0 + q)]);
-    // (sub-groups only serve to put list COPIES behind the next kernels; lists written in place need none -- dealing sub-groups to two compute streams so
-    //  that one's stores cross the link while the next one searches measured 2.25-2.64 against 2.15-2.5 ms: profiles/r06m_*)
-    const int sub = all_dev ? std::max(m, 1) : kCorrSub;
+    // Sub-groups put list COPIES behind the next kernels.  Lists that k_compact writes into HOST memory cross PCIe with its stores (1.5 ms for the 83 MB of
+    // a 50-pair list: the link's rate, scripts/ubench/d2h_paths.hip) while the searches need 0.7 ms of the GPU: the group is cut into ER_ICP_FC_SPLIT parts;
+    // searches, counts and scans stay on the compute stream, the compactions go to two side streams behind an event each, so that one part's stores
+    // leave while the next part searches.
+    bool host_written = false;
+    for (int q = 0; q < m; q++) host_written = host_written || (written[(size_t)(i0 + q)] && direct[(size_t)(i0 + q)] == 1);
+    static const int fc_split = [] { const char* e = getenv("ER_ICP_FC_SPLIT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 16 ? 16 : v); }();
+    const bool split = all_dev && host_written && fc_split > 1 && m >= 2 * fc_split;
+    const int sub = all_dev ? (split ? (m + fc_split - 1) / fc_split : std::max(m, 1)) : kCorrSub;
     const int nsub = (m + sub - 1) / sub;
     hipStream_t ks[2] = {g->stream, g->stream};
+    while (split && (int)g->sub_ev2.size() < nsub) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return er::fail("er_find_correspondence: hipEventCreate failed");
+      g->sub_ev2.push_back(e);
+    }
     while ((int)g->sub_ev.size() < nsub) {
       hipEvent_t e = nullptr;
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return er::fail("er_find_correspondence: hipEventCreate failed");
@@ -2237,11 +2258,15 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       int mxb = 1;
       for (int q = 0; q < ms; q++) mxb = std::max(mxb, g->h_pairs[s0 + q].nb);
       hipLaunchKernelGGL(k_find_corr, dim3(mxb, ms), dim3(kBlock), 0, ks[s & 1], g->d_pairs + s0, (float)dist, dist * dist, normal_cos);
-      return corr_chain(g, s0, ms, mxb, info36 != nullptr, false, evs[(size_t)s], ks[s & 1]);
+      return corr_chain(g, s0, ms, mxb, info36 != nullptr, false, evs[(size_t)s], ks[s & 1], split ? ((s & 1) ? g->copy_stream2 : g->copy_stream) : nullptr,
+                        split ? g->sub_ev2[(size_t)s] : nullptr);
     };
-    if (enqueue(0)) { cleanup(); return 1; }
+    if (split) {
+      for (int s = 0; s < nsub; s++)
+        if (enqueue(s)) { cleanup(); return 1; }
+    } else if (enqueue(0)) { cleanup(); return 1; }
     for (int s = 0; s < nsub; s++) {
-      if (s + 1 < nsub && enqueue(s + 1)) { cleanup(); return 1; }
+      if (!split && s + 1 < nsub && enqueue(s + 1)) { cleanup(); return 1; }
       const int s0 = s * sub, ms = std::min(sub, m - s0);
       if (hipEventSynchronize(evs[(size_t)s]) != hipSuccess) { cleanup(); return er::fail("er_find_correspondence: %s", hipGetErrorString(hipGetLastError())); }
       for (int q = 0; q < ms; q++) {
