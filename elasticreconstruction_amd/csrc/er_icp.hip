@@ -1535,6 +1535,11 @@ static int direct_lists() {
   static const int mode = [] { const char* e = getenv("ER_ICP_DIRECT_LISTS"); return e ? (e[0] == '0' ? 0 : (e[0] == 'd' ? 1 : 2)) : 2; }();
   return mode;                                                 // 0: never, 1: device destinations, 2: device and page-locked host destinations
 }
+// Set by er_registration_batch's share workers: several shares are in flight, each on a thread and workspace of its own, so a share's list copies run
+// behind the other shares' kernels -- and six shares' PCIe-bound compaction kernels at once are slower than their copies (fused list 6.05 against 4.28 ms,
+// profiles/r06q_fused_modes.txt).  A single caller has nothing to hide a copy behind: its lists are written in place.
+static thread_local bool tl_lists_by_copy = false;
+
 // Copy streams the list copies of one call are dealt to when lists ARE copied (pageable or too small destinations): ER_ICP_COPY_STREAMS = 1 .. 4,
 // default 2 (four streams: 2.5-3.0 ms whatever the engines do, two: 1.6 or 4.4 ms; profiles/r06j_fc_modes.txt).
 static int list_copy_streams() {
@@ -2205,7 +2210,7 @@ int er_find_correspondence_batch(int n, const er_cloud_t* src, const er_cloud_t*
       if (kind < 0) return er::fail("er_find_correspondence: the list buffer of pair %d lives on another GPU than its clouds", i);
       direct[(size_t)i] = (char)kind;                                           // 1: page-locked host, 2: device memory -- both are copied to directly
       if (!direct[(size_t)i]) stage_need += (size_t)std::min(capacity[i], src[i]->n) * 2;
-      if (kind > 0 && view && capacity[i] >= src[i]->n && ((uintptr_t)view & 7u) == 0 && direct_lists() >= (kind == 2 ? 1 : 2)) written[(size_t)i] = static_cast<int*>(view);
+      if (kind > 0 && view && capacity[i] >= src[i]->n && ((uintptr_t)view & 7u) == 0 && direct_lists() >= (kind == 2 ? 1 : 2) && !(kind == 1 && tl_lists_by_copy)) written[(size_t)i] = static_cast<int*>(view);
     }
   }
   GroupLease L;
@@ -2373,8 +2378,10 @@ int er_registration_batch(int n, const er_cloud_t* src, const er_cloud_t* tgt, c
       return;
     }
     for (size_t q = 0; q < (size_t)a * 16; q++) T2[q] = (double)f2[q];                                        // getFinalTransformation().cast<double>()
+    tl_lists_by_copy = shares > 1;
     const int frc = er_find_correspondence_batch(a, s2.data(), t2.data(), T2.data(), corr_dist, normal_cos, buf2.data(), cap2.data(), np2.data(),
                                                  info36 ? I2.data() : nullptr);
+    tl_lists_by_copy = false;
     for (int k = 0; k < a; k++) {
       const int i = idx[(size_t)k];
       memcpy(&T_final[(size_t)i * 16], &f2[(size_t)k * 16], 16 * sizeof(float));

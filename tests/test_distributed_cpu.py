@@ -344,3 +344,23 @@ def test_bench_step_plan_covers_the_jobs_frames_at_1_2_4_8_ranks():
         assert K * S == {1: 5000, 2: 2500, 4: 1250, 8: 650}[world] and S % 50 == 0
         assert bench.plan_steps(2, 20, 0, 50, world) == (20, 150)
     assert bench.plan_steps(2, 5, 0, 50, 1) == (5, 600) and bench.plan_steps(2, 7, 100, 50, 1) == (7, 100)
+
+
+def test_compact_line_sheds_appendices_before_it_loses_the_headline():
+    """Whatever the optional legs put into the full object, the stdout line stays under 4 KB and keeps metric / value / roofline / cpu_baseline: the
+    appendices (fragment_optimizer, boundary, streamed, other_configs, icp) are dropped, largest first, if they ever push it over."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r05o_bench_default.json")) as fh:
+        out = json.loads([l for l in fh.read().splitlines() if l.startswith("{")][-1])
+    out["other_configs"] = {"configs[%d]" % k: dict(out["other_configs"]["configs[3]"], workload="x" * 50) for k in range(3, 60)}   # 57 children
+    line = bench.compact_line(out)
+    assert len(line) < 4096
+    c = json.loads(line)
+    assert "other_configs" not in c and c["value"] > 0 and c["roofline"]["frac"] > 0 and c["cpu_baseline"]["kind"] == "reference"
+    # numbers only carry 8 significant digits, strings stay short, NaN / inf never reach the line
+    out2 = dict(out, other_configs=None)
+    out2["roofline"] = dict(out["roofline"], frac=float("nan"), achieved=float("inf"))
+    c2 = json.loads(bench.compact_line(out2))
+    assert c2["roofline"]["frac"] is None and c2["roofline"]["achieved"] is None
