@@ -749,16 +749,27 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
     d = tempfile.mkdtemp(prefix="er_boundary_", dir=base)
     bin_dir = os.path.join(ROOT, "elasticreconstruction_amd", "bin")
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
-    env = dict(os.environ, ER_ORACLE_QUIET="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+    env = dict(os.environ, ER_ORACLE_QUIET="1", ER_TIMING="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+    stages = {}
 
-    def timed(cmd, cwd, reps=1):
+    def timed(cmd, cwd, reps=1, tag=None):
+        # (ER_TIMING=1: the programs report the wall time of each of their stages on stderr -- kept for the fastest repetition)
         best, rc, err = None, 0, ""
         for _ in range(reps):
             t0 = time.perf_counter()
             r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=600)
             dt = time.perf_counter() - t0
-            rc, err = r.returncode, r.stderr.decode()[-300:]
-            best = dt if best is None else min(best, dt)
+            text = r.stderr.decode(errors="replace")
+            rc, err = r.returncode, "\n".join(l for l in text.splitlines() if not l.startswith("[timing]"))[-300:]
+            if best is None or dt < best:
+                best = dt
+                if tag:
+                    st = [l[len("[timing]"):].rsplit(None, 2) for l in text.splitlines() if l.startswith("[timing] ") and not l.startswith("[timing]   ")]
+                    stages[tag] = {k.strip(): float(v) for k, v, _ in st}
+                    stages[tag]["outside main() (exec, loader, exit)"] = round(dt * 1e3 - sum(stages[tag].values()), 1)
+                    detail = [l[len("[timing]"):].strip() for l in text.splitlines() if l.startswith("[timing]   ")]
+                    if detail:
+                        stages[tag]["detail"] = detail[:8]
         return best, rc, err
 
     try:
@@ -776,8 +787,9 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
                     "--resolution", str(sc["resolution"]), "--length", str(sc["length"]), "--interval", str(I)]
         host.tofile(os.path.join(d, "frames.raw"))
         a_full = write_inputs("full", n)
-        dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_full + ["-oni", "frames.raw", "--save_to", "world.pcd", "--max_units", "1024"], d, reps=2)
-        res["integrate"] = {"frames": n, "source": "raw uint16 stream (%.1f GB)" % (host.nbytes / 1e9), "wall_s": dt, "frames_per_s": n / dt, "rc": rc}
+        dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_full + ["-oni", "frames.raw", "--save_to", "world.pcd", "--max_units", "1024"], d, reps=2, tag="integrate")
+        res["integrate"] = {"frames": n, "source": "raw uint16 stream (%.1f GB)" % (host.nbytes / 1e9), "wall_s": dt, "frames_per_s": n / dt, "rc": rc,
+                            "stages_ms": stages.get("integrate")}
         if rc:
             res["integrate"]["stderr"] = err
         try:
@@ -790,8 +802,9 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
                     f.write("f%05d.png\n" % i)
             t_png = time.perf_counter() - t0
             a_png = write_inputs("png", m)
-            dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=2)
-            res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": 8, "png_written_in_s": t_png}
+            dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=2, tag="integrate_png")
+            res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": 8, "png_written_in_s": t_png,
+                                    "stages_ms": stages.get("integrate_png")}
             dt1, rc1, _ = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024",
                                                                                  "--decode_threads", "1"], d)
             res["integrate_png"]["one_decode_thread_frames_per_s"] = m / dt1
@@ -813,11 +826,11 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
         formats.save_log(os.path.join(d, "init.log"), log)
         formats.save_log(os.path.join(d, "init_ref.log"), log[:ref_pairs])
         bc = ["--registration", "--reg_dist", "0.03", "--output_information"]
-        dt, rc, err = timed([os.path.join(bin_dir, "BuildCorrespondence"), "--reg_traj", os.path.join(d, "init.log")] + bc, d, reps=2)
+        dt, rc, err = timed([os.path.join(bin_dir, "BuildCorrespondence"), "--reg_traj", os.path.join(d, "init.log")] + bc, d, reps=2, tag="bc")
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("corres_"))
         res["build_correspondence"] = {"pairs": len(pairs), "fragments": len(frs), "wall_s": dt, "pairs_per_s": len(pairs) / dt, "rc": rc,
                                        "pcd_bytes_read": sum(os.path.getsize(os.path.join(d, "cloud_bin_%d.pcd" % i)) for i in range(len(frs))),
-                                       "corres_txt_bytes_written": out_bytes}
+                                       "corres_txt_bytes_written": out_bytes, "stages_ms": stages.get("bc")}
         if rc:
             res["build_correspondence"]["stderr"] = err
         ref_bin = os.path.join(ref_dir, "BuildCorrespondence_ref")

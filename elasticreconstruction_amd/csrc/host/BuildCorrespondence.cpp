@@ -17,11 +17,14 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <future>
 #include <iostream>
 #include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../er_mat4.h"
 #include "er_formats.h"
@@ -51,6 +54,33 @@ int print_help() {
   std::cout << "MI355X options:" << std::endl;
   std::cout << "    --gpus <n> (1)  --device <first gpu> (0)  --icp_stop_rule <0: PCL 1.7 | 1: PCL <= 1.6> (0)" << std::endl;
   return 0;
+}
+
+// corres_<i>_<j>.txt, CorresApp.cpp:175-184: one "%d %d\n" line per correspondence -- the same bytes as fprintf, formatted by hand into 1 MB
+// blocks (fprintf costs ~100 ns per line; a 50-pair list is 10 M lines).
+bool write_pair_lines(const char* fn, const int* pl, int nk) {
+  FILE* f = fopen(fn, "w");
+  if (!f) return false;
+  std::vector<char> buf((1u << 20) + 32);
+  size_t at = 0;
+  auto put = [&](int v) {
+    char tmp[12];
+    int len = 0;
+    unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+    do { tmp[len++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) buf[at++] = '-';
+    while (len) buf[at++] = tmp[--len];
+  };
+  bool ok = true;
+  for (int q = 0; q < nk; q++) {
+    put(pl[2 * (size_t)q]);
+    buf[at++] = ' ';
+    put(pl[2 * (size_t)q + 1]);
+    buf[at++] = '\n';
+    if (at >= (1u << 20)) { ok = fwrite(buf.data(), 1, at, f) == at && ok; at = 0; }
+  }
+  if (at) ok = fwrite(buf.data(), 1, at, f) == at && ok;
+  return fclose(f) == 0 && ok;
 }
 
 struct HostCloud {
@@ -182,13 +212,17 @@ struct App {
   bool Upload() {
     const float cell = (float)std::max(reg_dist_, dist_thresh_);
     pointclouds_.assign((size_t)gpus_, std::vector<er_cloud_t>((size_t)num_, nullptr));
-    for (int g = 0; g < gpus_; g++)
-      for (int i = 0; i < num_; i++) {
-        const HostCloud& h = host_[(size_t)i];
-        if (er_cloud_create(h.xyz.data(), h.nrm.data(), (int)h.size(), cell, device0_ + g, &pointclouds_[(size_t)g][(size_t)i]) != 0) {
-          fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
-          return false;
-        }
+    std::vector<const float*> xyz((size_t)num_), nrm((size_t)num_);
+    std::vector<int> counts((size_t)num_);
+    for (int i = 0; i < num_; i++) {
+      xyz[(size_t)i] = host_[(size_t)i].xyz.data();
+      nrm[(size_t)i] = host_[(size_t)i].nrm.data();
+      counts[(size_t)i] = (int)host_[(size_t)i].size();
+    }
+    for (int g = 0; g < gpus_; g++)                                    // one call per GPU: uploads queued up front, grids built in chunks of 8 clouds
+      if (er_cloud_create_batch(num_, xyz.data(), nrm.data(), counts.data(), cell, device0_ + g, pointclouds_[(size_t)g].data()) != 0) {
+        fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
+        return false;
       }
     return true;
   }
@@ -335,13 +369,18 @@ struct App {
         if (Blacklisted(ft) || ft.frame == -1) continue;
         live.push_back(i);
       }
+      // The lists of a chunk land in ONE page-locked block (er_host_alloc), reused by the next chunk: the library writes them in place
+      // (include/er_hip.h: no staging pass, no second copy), and pageable vectors would cost a page fault per 4 KB on top.
+      int* block = nullptr;
+      size_t block_ints = 0;
       for (size_t c0 = 0; c0 < live.size(); c0 += kChunk) {
         const int m = (int)std::min<size_t>(kChunk, live.size() - c0);
         std::vector<er_cloud_t> src((size_t)m), tgt((size_t)m);
         std::vector<double> T((size_t)m * 16), info((size_t)m * 36, 0.0);
-        std::vector<std::vector<int>> pairs((size_t)m);
         std::vector<int*> bufs((size_t)m);
         std::vector<int> cap((size_t)m), n((size_t)m, 0);
+        std::vector<size_t> at((size_t)m);
+        size_t need = 0;
         for (int k = 0; k < m; k++) {
           const FramedTransformation& ft = corres_traj_[(size_t)live[c0 + (size_t)k]];
           printf("Processing pair <%d, %d>\n", ft.id1, ft.id2);
@@ -349,9 +388,22 @@ struct App {
           src[(size_t)k] = pointclouds_[(size_t)g][(size_t)ft.id2];
           memcpy(&T[(size_t)k * 16], ft.T, sizeof ft.T);
           cap[(size_t)k] = std::max(er_cloud_size(src[(size_t)k]), 1);
-          pairs[(size_t)k].resize((size_t)cap[(size_t)k] * 2);
-          bufs[(size_t)k] = pairs[(size_t)k].data();
+          at[(size_t)k] = need;
+          need += ((size_t)cap[(size_t)k] * 2 + 63) & ~(size_t)63;       // 256-byte aligned lists
         }
+        if (need > block_ints) {
+          if (block) er_host_free(block);
+          block = (int*)er_host_alloc(need * sizeof(int));
+          block_ints = block ? need : 0;
+          if (!block) {
+            fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
+#pragma omp atomic write
+            ok = false;
+            break;
+          }
+        }
+        for (int k = 0; k < m; k++) bufs[(size_t)k] = block + at[(size_t)k];
+        const auto tc0 = std::chrono::steady_clock::now();
         if (er_find_correspondence_batch(m, src.data(), tgt.data(), T.data(), dist_thresh_, normal_thresh_, bufs.data(), cap.data(), n.data(),
                                          output_information_ ? info.data() : nullptr) != 0) {
           fprintf(stderr, "BuildCorrespondence: %s\n", er_last_error());
@@ -359,6 +411,7 @@ struct App {
           ok = false;
           continue;
         }
+        const auto tc1 = std::chrono::steady_clock::now();
 #pragma omp parallel for num_threads(8) schedule(dynamic)
         for (int k = 0; k < m; k++) {
           const int i = live[c0 + (size_t)k];
@@ -374,18 +427,19 @@ struct App {
           if (save_corres_) {                                          // :175-184
             char fn[1024];
             snprintf(fn, sizeof fn, "%scorres_%d_%d.txt", m_pDirName.c_str(), ft.id1, ft.id2);
-            if (FILE* f = fopen(fn, "w")) {
-              const std::vector<int>& pl = pairs[(size_t)k];
-              for (int q = 0; q < nk; q++) fprintf(f, "%d %d\n", pl[2 * (size_t)q], pl[2 * (size_t)q + 1]);
-              fclose(f);
-            }
+            if (!write_pair_lines(fn, bufs[(size_t)k], nk)) fprintf(stderr, "BuildCorrespondence: cannot write %s\n", fn);
           }
           if (output_information_) {                                   // :186-208
             corres_info_[(size_t)i].frame = ft.frame;
             memcpy(corres_info_[(size_t)i].info, &info[(size_t)k * 36], 36 * sizeof(double));
           }
         }
+        if (getenv("ER_TIMING"))
+          fprintf(stderr, "[timing]   chunk of %d pairs: er_find_correspondence_batch %.1f ms, corres_*.txt %.1f ms\n", m,
+                  std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
+                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count());
       }
+      if (block) er_host_free(block);
     }
     return ok;
   }
@@ -399,9 +453,13 @@ struct App {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  erfmt::stage_done("process start");
   er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
+
+  // The HIP runtime takes ~0.1 s to come up: it does so on a side thread while this one reads the fragment files.
+  std::future<int> hip_up = std::async(std::launch::async, [] { return er_device_count(); });
 
   App app;
   if (find_switch(argc, argv, "--save_xyzn")) app.save_xyzn_ = true;
@@ -412,17 +470,13 @@ int main(int argc, char* argv[]) {
   parse_argument(argc, argv, "--device", app.device0_);
   parse_argument(argc, argv, "--icp_stop_rule", app.stop_rule_);
   if (app.gpus_ < 1) app.gpus_ = 1;
-  const int visible = er_device_count();
-  if (visible <= 0) {
-    fprintf(stderr, "BuildCorrespondence: no HIP device available (there is no CPU fallback)\n");
-    return 1;
-  }
-  if (app.device0_ + app.gpus_ > visible) app.gpus_ = std::max(1, visible - app.device0_);
 
   int rc = 0;
-  if ((parse_argument(argc, argv, "--traj", log_file) > 0 && parse_argument(argc, argv, "--num", num) > 0) ||
-      parse_argument(argc, argv, "--reg_traj", reg_log_file) > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
+  const bool job = (parse_argument(argc, argv, "--traj", log_file) > 0 && parse_argument(argc, argv, "--num", num) > 0) ||
+                   parse_argument(argc, argv, "--reg_traj", reg_log_file) > 0;
+  const auto t0 = std::chrono::steady_clock::now();
+  bool ok = true;
+  if (job) {
     if (parse_argument(argc, argv, "--reg_dist", reg_dist) > 0) {
       app.reg_dist_ = reg_dist;
       app.dist_thresh_ = reg_dist / 2.0;                               // BuildCorrespondence.cpp:52-55
@@ -431,9 +485,19 @@ int main(int argc, char* argv[]) {
     if (parse_argument(argc, argv, "--reg_num", reg_num) > 0) app.reg_num_ = reg_num;
     parse_argument(argc, argv, "--length", app.length_);
     parse_argument(argc, argv, "--interval", app.interval_);
-
-    bool ok = reg_log_file.length() > 0 ? app.LoadData(reg_log_file, -1) : app.LoadData(log_file, num);
+    ok = reg_log_file.length() > 0 ? app.LoadData(reg_log_file, -1) : app.LoadData(log_file, num);
+    stage_done("LoadData (PCD files)");
+  }
+  const int visible = hip_up.get();
+  stage_done("HIP runtime up (rest of the wait)");
+  if (visible <= 0) {
+    fprintf(stderr, "BuildCorrespondence: no HIP device available (there is no CPU fallback)\n");
+    return 1;
+  }
+  if (app.device0_ + app.gpus_ > visible) app.gpus_ = std::max(1, visible - app.device0_);
+  if (job) {
     ok = ok && app.Upload();
+    stage_done("Upload (er_cloud_create_batch)");
     if (ok) {
       if (parse_argument(argc, argv, "--blacklist", blacklist_file) > 0 || parse_argument(argc, argv, "--blasklist", blacklist_file) > 0)
         app.Blacklist(blacklist_file);
@@ -444,11 +508,17 @@ int main(int argc, char* argv[]) {
         ok = app.Registration();
         std::cerr << "Neat Registration took " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count() << "ms." << std::endl;
       }
+      stage_done("Registration");
       ok = app.FindCorrespondence() && ok;
+      stage_done("FindCorrespondence + corres");
       app.Finalize();
+      stage_done("Finalize (reg_output.*)");
     }
     std::cerr << "Registration All took " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() << "ms." << std::endl;
     rc = ok ? 0 : 1;
   }
-  return rc;
+  // Every output file is closed: leave without the destructors (clouds, pooled workspaces, the HIP runtime's own teardown: ~0.1 s that a
+  // pipeline script would wait for; the driver reclaims the device memory of a process that exits).
+  fflush(nullptr);
+  _exit(rc);
 }

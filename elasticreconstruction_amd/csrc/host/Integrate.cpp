@@ -39,6 +39,8 @@
 #include <vector>
 
 #include "../er_mat4.h"
+#include <unistd.h>
+
 #include "er_formats.h"
 #include "er_hip.h"
 
@@ -376,6 +378,7 @@ bool SaveWorldSharded(std::vector<App>& apps, const std::string& filename) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
+  erfmt::stage_done("process start");
   er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
@@ -461,6 +464,7 @@ int main(int argc, char* argv[]) {
     apps[(size_t)g].unit_shard_ = unit_shard;
     if (!apps[(size_t)g].Init()) return 1;
   }
+  stage_done("Init (logs, .ctr, volume)");
   const bool merge = !unit_shard && (gpus > 1 || force_merge);
   std::vector<er_comm_t> comms((size_t)gpus, nullptr);
   if (merge) {
@@ -522,6 +526,7 @@ int main(int argc, char* argv[]) {
     for (int g = 0; g < gpus; g++) th.emplace_back(worker, g);
     for (auto& t : th) t.join();
   }
+  stage_done("frames (read, integrate, sync)");
   long frames_integrated = 0;
   int last_id = 0;
   for (int g = 0; g < gpus; g++) {
@@ -534,12 +539,15 @@ int main(int argc, char* argv[]) {
     if (gpus > 1 && (unit_shard || (merge && merge_root == ER_MERGE_DISTRIBUTED))) { if (!SaveWorldSharded(apps, app.pcd_filename_)) rc = 1; }
     else if (!apps[(size_t)(merge && merge_root >= 0 ? merge_root : 0)].SaveWorld()) rc = 1;
   }
+  stage_done("SaveWorld");
   std::cout << "Total " << last_id << " frames processed." << std::endl;
   const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   std::cerr << "Integrate All took " << ms << "ms." << std::endl;
   if (ms > 0 && frames_integrated > 0)
     std::cerr << frames_integrated << " frames integrated, " << 1000.0 * frames_integrated / ms << " frames/s end to end (incl. file I/O)" << std::endl;
   for (er_comm_t c : comms) er_comm_destroy(c);
-  for (App& w : apps) er_tsdf_destroy(w.volume_);
-  return rc;
+  // world.pcd is closed: leave without freeing the volumes or running the HIP runtime's teardown (~0.1 s a pipeline script would wait for; the
+  // driver reclaims the device memory of a process that exits).
+  fflush(nullptr);
+  _exit(rc);
 }

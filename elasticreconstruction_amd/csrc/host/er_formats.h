@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -477,6 +478,15 @@ inline int parse_argument(int argc, char** argv, const char* name, double& v) {
   int i = find_argument(argc, argv, name);
   if (i > 0 && i + 1 < argc) { v = atof(argv[i + 1]); return i; }
   return -1;
+}
+
+// ER_TIMING=1 in the environment: the wall time of each stage of a host program on stderr (bench.py's boundary leg reads them).
+inline void stage_done(const char* what) {
+  static const bool on = getenv("ER_TIMING") != nullptr;
+  static auto last = std::chrono::steady_clock::now();
+  const auto now = std::chrono::steady_clock::now();
+  if (on) fprintf(stderr, "[timing] %-32s %9.1f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+  last = now;
 }
 
 }  // namespace erfmt
