@@ -185,11 +185,8 @@ namespace {
 // single-wave workgroups that return at once unless a frame of the batch is flagged -- practically never -- and otherwise share the
 // pixels of the flagged frames: every source pixel is warped again and scattered into zfix under the replay rule.  One phase, no
 // ordering between workgroups; the consumer merges (take_z below) and re-arms lastzero / zfix, k_plan (or the single-frame entry
-// point) clears the flag words.  History: round 1 ran three passes (forget, re-scatter, re-arm) as three launches, then as one
-// 256-thread workgroup; round 3 as ONE wave with a capped register budget, because a 256-thread workgroup with 83 VGPRs waited 46 us
-// on average (max 237 us, profiles/r03a_kernel_stats.csv) for four free wave slots on one CU next to the persistent k_integrate
-// workgroups and the other stream's pre-pass -- but a flagged batch then cost that one wave n_frames * cols * rows serial replays
-// (ADVICE round 3).  Single waves still find room at once, and now 256 of them share the flagged frames only.
+// point) clears the flag words.  Single-wave workgroups with a capped register budget: they find a free wave slot at once next to the
+// persistent k_integrate workgroups (a 256-thread workgroup waited 46 us on average for four slots on one CU).
 constexpr int kFixThreads = 64;
 constexpr int kFixBlocks = 256;
 __global__ __launch_bounds__(kFixThreads) __attribute__((amdgpu_num_vgpr(48))) void k_reproject_fix(ReprojArgs A) {
@@ -239,12 +236,9 @@ __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restric
 constexpr int kScaledPad = 64;
 constexpr int kTile = 32;
 // Granularity of tile_lo_fine, the second-level per-tile MINIMUM of the scaled depth behind k_integrate's "full" verdict: 2^kLoShift pixels.
-// Round 4: 16-pixel tiles next to the 32-pixel tiles of tile_max / tile_lo (measured: 16 px 167.2 k frames/s, 8 px 165.5 k, none 165.5 k) -- a pixel without usable depth (the warp's scatter leaves holes) spoils the minimum of its
-// whole tile, and the CPU replay (tests/hostcheck, hc_set_lo_shift) counts 39 % of the kept (patch, frame) visits as full with 8-pixel tiles
-// against 27 % with 32 (34 % with 16; with 4 the verdict's cap of 64 tiles per patch hull cuts in: 22 %), zero violations either way.
-// The fine tiles are the SECOND level of the verdict (er_tsdf_math.h: patch_may_update_box): the 32-pixel minimum decides first, the fine
-// ones are read only when it fails for a patch that lies clearly in front of everything under it -- consulting them for every (patch,
-// frame) made the culling preamble as much slower as the frame loop got faster (profiles/r04q_ab_tile_lo.txt).
+// 16-pixel tiles next to the 32-pixel tiles of tile_max / tile_lo: a pixel without usable depth (the warp's scatter leaves holes) spoils the
+// minimum of its whole tile.  The fine tiles are the SECOND level of the verdict (er_tsdf_math.h: patch_may_update_box): the 32-pixel minimum
+// decides first, the fine ones are read only when it fails for a patch that lies clearly in front of everything under it.
 #ifndef ER_TILE_LO_SHIFT
 #define ER_TILE_LO_SHIFT 4
 #endif
@@ -1416,9 +1410,8 @@ int sync_all(er_tsdf_t h) {
 //   aux stream b mod 2: wait int_done[p] -> [k_reset(p) of batch n-3] -> [H2D constants] -> k_reproject_* -> k_prepare(p) -> k_plan(p) -> event pre_done[p]
 //   main stream       : wait pre_done[p] -> k_integrate(p) -> event int_done[p]            (ONE kernel per batch: it is the critical path)
 // so the pre-passes of batches n+1 and n+2 (latency / float64 bound, each a serial chain of launches) overlap each other and
-// k_integrate of batch n (float32 VALU bound).  Round 1 ran one pre-pass stream (+23 % over no overlap); since the compact
-// patches of round 2 made k_integrate shorter than the pre-pass chain, the second pre-pass stream keeps the chip busy while
-// the voxel pass waits (profiles/r02l_*).  Batches still reach the volume strictly in order (main stream).
+// k_integrate of batch n (float32 VALU bound): k_integrate is shorter than one pre-pass chain, so two chains run side by side.
+// Batches still reach the volume strictly in order (main stream).
 int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, const er_warp* warp, int frame0) {
   const int p = (int)(h->batch_no % kDepth), a = (int)(h->batch_no % kAux);
   h->batch_no++;

@@ -136,10 +136,6 @@ ER_HD int touch_key(int u, int v, uint16_t d, const Camera& c, const CameraInv& 
   return touch_key_exact(u, v, d, c, T);
 }
 
-// (A float32 first try of this key -- full-rate fused multiply-adds from per-frame constants, a per-pixel error bound as the
-//  guard, this function as the fallback for the 0.1 % of the pixels next to a unit border -- was built, proven and stress-tested
-//  in round 3; it decided 99.9 % of the pixels correctly and changed neither k_prepare's place in the pipeline nor the job:
-//  140.9 k vs 140.8 k frames/s, profiles/r03s_ab_key32_and_fma_probe.txt.  The pre-pass kernels are not what the job waits for.)
 // Owner of a volume unit when the volume is sharded BY UNIT over `world` GPUs (bit-exact alternative):
 // diagonal stripes of the unit lattice, so the ~30-60 units a frustum touches spread evenly over the GPUs.
 ER_HD int unit_owner(int key, int world) {
@@ -162,8 +158,7 @@ ER_HD float grid_coord(int i, float shift) { return (float)((double)i * kUnitLen
 // 0 / inf / NaN; otherwise the bare Newton core below executes the SAME operations and returns the same bits.
 // The callers state why their operands stay inside that domain (or why the result does not matter outside);
 // tests/hip/arith_check.hip compares cores and operators on the GPU, exhaustively for sqrt.  On the host
-// (tests/hostcheck) the plain operators are used.  Measured: k_integrate 0.50 -> 0.43 ms per 50-frame launch
-// (v_rcp/v_sqrt issue at half rate on MI355X, every other f32/f64 VALU op at full rate: scripts/ubench).
+// (tests/hostcheck) the plain operators are used.
 ER_HD void div2_inrange(float n0, float n1, float d, float& q0, float& q1) {
 #if defined(__HIP_DEVICE_COMPILE__)
   float r = __builtin_amdgcn_rcpf(d);
@@ -273,9 +268,7 @@ ER_HD bool pixel_index(float x, float lim_m_half, int& p) {
 // Same arithmetic as the reference, arranged for a SIMT machine: the projection is evaluated
 // unconditionally (lanes with t2 <= 0 are discarded by the predicate), the five range tests are folded
 // into ONE predicate and the depth / truncation tests into a second one, so a voxel costs 2-3 divergent
-// regions instead of 6.  Measured A/B on MI355X (same box, interleaved, profiles/r01_ab_variants.txt):
-// folded predicates 0.565 ms per 50-frame launch vs 0.600 ms test by test; extra-branch "shortcuts"
-// (skipping the update division when S == 1, guarded multiply for the band division) were slower.
+// regions instead of 6.
 //
 // Split in two so that a thread can issue the depth gathers of all its rows before it needs the first one
 // (k_integrate keeps kRows voxels per thread; the gather's L2 latency then overlaps the other rows' arithmetic):
@@ -299,7 +292,7 @@ ER_HD bool voxel_project(float g0, float g1, float g2, const FrameXform& f, cons
   // :78-80  round( float expr ) and the image-range test, see pixel_index.
   int px, py;
   const bool vx = pixel_index(qu + c.cx, (float)cols - 0.5f, px), vy = pixel_index(qv + c.cy, (float)rows - 0.5f, py);
-  pixel = (unsigned)(py * cols + px);                                   // (a 24-bit multiply-add here was measured: 0.8 % slower, round 4)
+  pixel = (unsigned)(py * cols + px);
   return (t2 > 0.0f) & vx & vy;                                          // :77,:80
 }
 
@@ -336,8 +329,6 @@ ER_HD bool voxel_finish_d2(float& S, float& W, float dp, float d2) {
   // sdf < 0.03 <=> sdf <= 0.03f -- float compares, no conversion on the common path.
   static_assert((double)0.03f < kTsdfTrunc && (double)0.030000003f > kTsdfTrunc, "float neighbours of tsdf_trunc_");
   if (!((dp > 0.001f) & (sdf >= -0.03f))) return false;
-  // (A branch-FREE form -- update computed for every lane, committed by two selects -- was measured: k_integrate 0.413 ms
-  //  instead of 0.357 ms per 50-frame launch, profiles/r02f_ab_k_integrate_variants.txt.  The branch stays.)
   // :88 std::min<float>( 1.0f, sdf / tsdf_trunc_ ).  sdf >= trunc  <=>  the float64 quotient is >= 1
   // <=> min(1, q) == 1, so the (slow) float64 division is only evaluated inside the truncation band;
   // the value is identical either way.
@@ -686,8 +677,5 @@ ER_HD bool reproject_px(int u, int v, uint16_t d, const Camera& c, const CameraI
   return true;
 }
 
-// (A float32 ESTIMATE of the warp with a per-pixel proof in front of this exact chain was built and validated four times in
-//  round 2 and was slower every time -- hipcc needs ~180 VALU instructions for the estimate plus its proof against 231 for the
-//  exact chain; records: profiles/r02b_ab_tiered_reproject_v1.txt, r02c_*, r02z_ab_tiered_reproject_v3_v4.txt.  The code left with round 3.)
 
 }  // namespace er
