@@ -40,14 +40,14 @@ PY
 echo "== gate: pytest $PRC smoke $SRC bench $BRC at t=${SECONDS}s (HEAD $HEAD_ID)"
 if [ "${GATE_ONLY:-0}" != "1" ]; then
   echo "== t=${SECONDS}s stats"
-  if [ $SECONDS -lt $((LIMIT - 90)) ]; then bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 --other-configs 0 --min-seconds 0.1 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -12; fi
+  if [ $SECONDS -lt $((LIMIT - 90)) ]; then bash scripts/gpu_prof.sh $TAG --steps 20 --warmup 2 --cpu-sample 0 --icp-pairs 0 --other-configs 0 --boundary 0 --min-seconds 0.1 > /dev/null 2>&1; python scripts/kstats.py gpurun_out/prof_$TAG/${TAG}_kernel_stats.csv 2>&1 | head -12; fi
   echo "== t=${SECONDS}s pmc"
   # three short passes (the MI355X guide: --pmc runs carry --kernel-trace only): SQ instruction counts + clock, FETCH_SIZE, WRITE_SIZE -- what scripts/pmc_latest.py needs
   if [ $SECONDS -lt $((LIMIT - 150)) ]; then
     OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT; i=0
     for CS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
       i=$((i+1))
-      ( cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $R/bench.py --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --other-configs 0 --no-streamed --no-alone --min-seconds 0.01 > $OUT/run_$i.log 2>&1 )
+      ( cd /tmp && export TMPDIR=/tmp && timeout 200 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d /tmp/pmc_${TAG}_$i -o p$i -- python $R/bench.py --steps 20 --warmup 1 --cpu-sample 0 --icp-pairs 0 --other-configs 0 --boundary 0 --no-streamed --no-alone --min-seconds 0.01 > $OUT/run_$i.log 2>&1 )
       for f in $(find /tmp/pmc_${TAG}_$i -name "*counter_collection.csv"); do cp "$f" $OUT/pass${i}_counter_collection.csv; done
     done
     python scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1; rm -f $OUT/pass*_counter_collection.csv
