@@ -735,7 +735,7 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
     """SURVEY.md 8b / VERDICT round 5 (7): the throughput a pipeline script sees at the drop-in boundary -- process start, file reads, the GPU work, file
     writes -- for the two programs, each beside the reference's OWN program (oracle/_ref/*_ref, compiled in place) on a bounded sample of the same files:
       bin/Integrate            configs[1] (all frames of `sc`) from a raw uint16 stream, pose.log / seg.log / .ctr in, world.pcd out; and its first
-                               `png_frames` frames from a --depth_list of 16-bit PNGs (inflated ahead by 8 host threads);
+                               `png_frames` frames from a --depth_list of 16-bit PNGs (inflated ahead by host threads);
       Integrate_ref            the first `ref_frames` frames of the same raw stream (8 OpenMP threads as hard-coded);
       bin/BuildCorrespondence  the 50-pair / 25-fragment list of configs[2]: cloud_bin_<i>.pcd in, reg_output.log / .info and 50 corres_<i>_<j>.txt out;
       BuildCorrespondence_ref  the first `ref_pairs` pairs of the same list (it still loads all 25 fragments).
@@ -803,11 +803,14 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
             t_png = time.perf_counter() - t0
             a_png = write_inputs("png", m)
             dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=2, tag="integrate_png")
-            res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": 8, "png_written_in_s": t_png,
-                                    "stages_ms": stages.get("integrate_png")}
+            res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": "default (hardware threads / 8, 8..32)", "png_written_in_s": t_png,
+                                    "stages_ms": stages.get("integrate_png"), "host_hardware_threads": os.cpu_count()}
             dt1, rc1, _ = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024",
                                                                                  "--decode_threads", "1"], d)
             res["integrate_png"]["one_decode_thread_frames_per_s"] = m / dt1
+            dt8, rc8, _ = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024",
+                                                                                 "--decode_threads", "8"], d)
+            res["integrate_png"]["eight_decode_threads_frames_per_s"] = m / dt8
         except Exception as ex:
             res["integrate_png"] = {"error": repr(ex)[:200]}
         ref_bin = os.path.join(ref_dir, "Integrate_ref")

@@ -9,7 +9,7 @@
 // so the depth stream comes from one of (additive flags):
 //   -oni <file> | --depth_raw <file>   raw stream of 640x480 little-endian uint16 frames, FrameID = 1,2,...
 //                                      (-oni with a real OpenNI recording is rejected with a clear message)
-//   --depth_list <txt>                 one 16-bit grayscale PNG path per line, line i = frame i (inflated ahead by --decode_threads <n> (8) host threads)
+//   --depth_list <txt>                 one 16-bit grayscale PNG path per line, line i = frame i (inflated ahead by --decode_threads <n> host threads; default: an eighth of the host's hardware threads, 8..32)
 // New, additive: --device <gpu> (0), --max_units <n> (2048), --batch <frames fused per launch> (64),
 //   --gpus <N>            N GPUs (devices --device ... --device + N - 1), one host thread per GPU
 //   --shard frame|unit    frame (default, what BASELINE.json names): the active frame range is cut into N contiguous blocks,
@@ -35,6 +35,7 @@
 #include <string>
 #include <condition_variable>
 #include <mutex>
+#include <future>
 #include <thread>
 #include <vector>
 
@@ -102,7 +103,7 @@ struct RawStream : DepthSource {
 };
 
 // 16-bit PNG list.  Inflating one 640 x 480 frame takes a host core 3-5 ms -- two orders of magnitude more than the GPU needs to integrate it -- so the
-// files are decoded AHEAD by a few host threads (--decode_threads, default 8): thread-safe claim of the next file, a ring of finished frames, next()
+// files are decoded AHEAD by a few host threads (--decode_threads): thread-safe claim of the next file, a ring of finished frames, next()
 // hands them out strictly in list order (the frame ids and their order are the reference's, IntegrateApp.cpp:190-226).
 struct PngList : DepthSource {
   std::vector<std::string> files;
@@ -216,14 +217,7 @@ struct App {
   bool Init() {                                                        // IntegrateApp.cpp:43-79
     float cam[6];
     erfmt::load_camera(erfmt::file_exists(camera_filename_) ? camera_filename_ : std::string(), cam);
-    if (er_tsdf_create(cols_, rows_, cam, max_units_, device_, &volume_) != 0) {
-      fprintf(stderr, "Integrate: %s\n", er_last_error());
-      return false;
-    }
-    if (unit_shard_ && gpus_ > 1 && er_tsdf_set_unit_shard(volume_, rank_, gpus_) != 0) {
-      fprintf(stderr, "Integrate: %s\n", er_last_error());
-      return false;
-    }
+    // (the files first: main() brings the HIP runtime up on a side thread meanwhile)
     if (ctr_num_ > 0 && erfmt::file_exists(ctr_filename_) && erfmt::file_exists(seg_filename_)) {
       erfmt::load_ctr(ctr_filename_, ctr_num_, ctr_resolution_, grids_);
     } else {
@@ -246,6 +240,14 @@ struct App {
           }
         if (rank_ == 0) printf("Trajectory created from pose and segment trajectories.\n");
       }
+    }
+    if (er_tsdf_create(cols_, rows_, cam, max_units_, device_, &volume_) != 0) {
+      fprintf(stderr, "Integrate: %s\n", er_last_error());
+      return false;
+    }
+    if (unit_shard_ && gpus_ > 1 && er_tsdf_set_unit_shard(volume_, rank_, gpus_) != 0) {
+      fprintf(stderr, "Integrate: %s\n", er_last_error());
+      return false;
     }
     return true;
   }
@@ -382,6 +384,8 @@ int main(int argc, char* argv[]) {
   er_request_hw_queues(8);                                  // before the first HIP call (include/er_hip.h)
   using namespace erfmt;
   if (argc == 1 || find_switch(argc, argv, "--help") || find_switch(argc, argv, "-h")) return print_help();
+  // The HIP runtime takes ~0.1 s to come up: it does so on a side thread while this one parses the trajectory and .ctr files.
+  std::future<int> hip_up = std::async(std::launch::async, [] { return er_device_count(); });
 
   App app;
   std::string raw_file, list_file, dev_name, shard = "frame";
@@ -397,7 +401,8 @@ int main(int argc, char* argv[]) {
                  "raw uint16 frames (--depth_raw) or 16-bit PNGs (--depth_list))" << std::endl;
     return -1;
   }
-  int decode_threads = 8;                                               // --decode_threads <n>: host threads that inflate the PNGs of --depth_list ahead
+  // --decode_threads <n>: host threads that inflate the PNGs of --depth_list ahead (600 frames: 148 ms with 8, 85 ms with 32 on a 256-thread host)
+  int decode_threads = (int)std::min(32u, std::max(8u, std::thread::hardware_concurrency() / 8));
   parse_argument(argc, argv, "--decode_threads", decode_threads);
   const size_t px = (size_t)app.cols_ * app.rows_;
   long source_frames = 0;
