@@ -739,7 +739,7 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
       Integrate_ref            the first `ref_frames` frames of the same raw stream (8 OpenMP threads as hard-coded);
       bin/BuildCorrespondence  the 50-pair / 25-fragment list of configs[2]: cloud_bin_<i>.pcd in, reg_output.log / .info and 50 corres_<i>_<j>.txt out;
       BuildCorrespondence_ref  the first `ref_pairs` pairs of the same list (it still loads all 25 fragments).
-    Wall times of subprocess.run; inputs live in /dev/shm when it has room (page cache either way)."""
+    Wall times of subprocess.run (the fastest of three runs for the two programs: process start-up and exit vary by 0.1-0.2 s on these boxes); inputs live in /dev/shm when it has room (page cache either way)."""
     import shutil
     import subprocess
     import numpy as np
@@ -787,7 +787,7 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
                     "--resolution", str(sc["resolution"]), "--length", str(sc["length"]), "--interval", str(I)]
         host.tofile(os.path.join(d, "frames.raw"))
         a_full = write_inputs("full", n)
-        dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_full + ["-oni", "frames.raw", "--save_to", "world.pcd", "--max_units", "1024"], d, reps=2, tag="integrate")
+        dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_full + ["-oni", "frames.raw", "--save_to", "world.pcd", "--max_units", "1024"], d, reps=3, tag="integrate")
         res["integrate"] = {"frames": n, "source": "raw uint16 stream (%.1f GB)" % (host.nbytes / 1e9), "wall_s": dt, "frames_per_s": n / dt, "rc": rc,
                             "stages_ms": stages.get("integrate")}
         if rc:
@@ -802,7 +802,7 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
                     f.write("f%05d.png\n" % i)
             t_png = time.perf_counter() - t0
             a_png = write_inputs("png", m)
-            dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=2, tag="integrate_png")
+            dt, rc, err = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024"], d, reps=3, tag="integrate_png")
             res["integrate_png"] = {"frames": m, "wall_s": dt, "frames_per_s": m / dt, "rc": rc, "decode_threads": "default (hardware threads / 8, 8..32)", "png_written_in_s": t_png,
                                     "stages_ms": stages.get("integrate_png"), "host_hardware_threads": os.cpu_count()}
             dt1, rc1, _ = timed([os.path.join(bin_dir, "Integrate")] + a_png + ["--depth_list", "list.txt", "--save_to", "world_png.pcd", "--max_units", "1024",
@@ -829,7 +829,7 @@ def boundary_section(sc, depth, device, png_frames=600, ref_frames=100, ref_pair
         formats.save_log(os.path.join(d, "init.log"), log)
         formats.save_log(os.path.join(d, "init_ref.log"), log[:ref_pairs])
         bc = ["--registration", "--reg_dist", "0.03", "--output_information"]
-        dt, rc, err = timed([os.path.join(bin_dir, "BuildCorrespondence"), "--reg_traj", os.path.join(d, "init.log")] + bc, d, reps=2, tag="bc")
+        dt, rc, err = timed([os.path.join(bin_dir, "BuildCorrespondence"), "--reg_traj", os.path.join(d, "init.log")] + bc, d, reps=3, tag="bc")
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.startswith("corres_"))
         res["build_correspondence"] = {"pairs": len(pairs), "fragments": len(frs), "wall_s": dt, "pairs_per_s": len(pairs) / dt, "rc": rc,
                                        "pcd_bytes_read": sum(os.path.getsize(os.path.join(d, "cloud_bin_%d.pcd" % i)) for i in range(len(frs))),
