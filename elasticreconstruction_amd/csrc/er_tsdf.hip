@@ -505,10 +505,12 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // Items come from ONE global work queue in cost order (k_plan), claimed when the workgroup is free.  (Static deals, per-XCD queues and look-ahead
 // claims were all measured slower: profiles/HISTORY.md "Path A: the schedule of k_integrate".)
 #ifndef ER_INT_MIN_BLOCKS
-#define ER_INT_MIN_BLOCKS 4
+#define ER_INT_MIN_BLOCKS 5
 #endif
-constexpr int kIntMinBlocks = ER_INT_MIN_BLOCKS;          // register budget: room for 4 workgroups of 4 waves per CU (the kernel uses 93 VGPRs); the grid launches
-                                          // ER_INT_BLOCKS_PER_CU = 3 of them per CU -- the freed registers go to the co-running pre-pass kernels
+constexpr int kIntMinBlocks = ER_INT_MIN_BLOCKS;          // register budget handed to the compiler: 5 workgroups of 4 waves per CU = 102 VGPRs (the kernel uses 93 with 3, 4
+                                          // or 5; with 6 it spills).  Same instructions, another register assignment: +1.0 % on the job against 4, five
+                                          // interleaved runs out of five (profiles/r06v_ab_min_blocks.txt).  The grid launches ER_INT_BLOCKS_PER_CU = 3
+                                          // workgroups per CU -- the free registers go to the co-running pre-pass kernels
 // kSure: the square-root-free "sure" path of the frame loop (voxel_classify needs dp < 64 m; the host picks the instantiation
 // from integration_trunc, which bounds every scaled depth).
 }  // namespace
