@@ -605,3 +605,64 @@ def test_nearest_neighbour_straight_behind_a_cell_face(gpu):
     assert pg.shape == (40, 2) and np.array_equal(pg, po), "%d of 40 rows differ from the oracle" % int((pg != po).any(1).sum())
     assert np.array_equal(pg[:, 0], expect)
     assert count_inliers(cs, ct, np.eye(4), 0.03) == 40
+
+
+def _fuzz_cloud(rng, kind, cell):
+    """Adversarial inputs for the exact search: what nn_block's pruning, tie rule and cell arithmetic depend on."""
+    if kind == 0:                       # lattice with dyadic spacing, points ON cell faces (cell = 2^-5): distance ties, face cases
+        m = int(rng.integers(6, 14))
+        g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+        x = g * np.float32(cell / float(rng.choice([1, 2, 4]))) + rng.integers(0, 4, 3).astype(np.float32) * np.float32(cell)
+        x = x[rng.random(len(x)) < 0.7]
+    elif kind == 1:                     # a few very dense clusters (hundreds of points per cell) + sparse background
+        c = rng.uniform(0.2, 1.0, (int(rng.integers(2, 6)), 3))
+        x = np.concatenate([c[k] + rng.normal(0, 0.004, (int(rng.integers(200, 1500)), 3)) for k in range(len(c))] + [rng.uniform(0.0, 1.2, (800, 3))]).astype(np.float32)
+    elif kind == 2:                     # a noisy sheet far from the origin (float32 resolution 4e-6 m at 40 m), negative coordinates
+        uv = rng.uniform(-0.6, 0.6, (int(rng.integers(2000, 9000)), 2))
+        x = np.stack([uv[:, 0], uv[:, 1], 0.1 * np.sin(3 * uv[:, 0]) + rng.normal(0, 0.002, len(uv))], 1) + np.array([-40.0, 17.0, 33.0])
+        x = x.astype(np.float32)
+    else:                               # tiny clouds: 1 .. 5 points, duplicates
+        x = rng.uniform(0.0, 0.05, (int(rng.integers(1, 6)), 3)).astype(np.float32)
+        x = np.concatenate([x, x[:1]])
+    n = rng.normal(0, 1, x.shape)
+    n = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+    return np.ascontiguousarray(x), np.ascontiguousarray(n)
+
+
+def test_randomised_clouds_against_the_oracle(gpu):
+    """Seeded fuzz of the exact search against the oracle's unpruned 27-cell scan: lattices whose points lie on cell faces at dyadic spacings (ties ->
+    lower index), clusters of hundreds of points per cell, sheets 40 m from the origin, clouds of one to five points; source = an independent cloud of
+    the same kind or the target moved by a small rigid motion; radii from a tenth of the cell up to the cell.  Pre-check counts and correspondence
+    lists (index pairs in file order) must be EQUAL.  ER_FUZZ_SEED / ER_FUZZ_CASES widen the sweep (one-off runs: profiles/r06x_fuzz_sweep.txt)."""
+    rng = np.random.default_rng(int(os.environ.get("ER_FUZZ_SEED", "606")))
+    cell = 0.03125
+    rows_compared = 0
+    for case in range(int(os.environ.get("ER_FUZZ_CASES", "12"))):
+        kind = case % 4
+        xt, nt = _fuzz_cloud(rng, kind, cell)
+        if case % 3 == 0:
+            xs, ns = _fuzz_cloud(rng, kind, cell)
+        else:
+            sel = rng.random(len(xt)) < 0.8
+            xs, ns = np.ascontiguousarray(xt[sel]), np.ascontiguousarray(nt[sel])
+        c = xt.mean(0).astype(np.float64)
+        P = synth.perturbation(int(rng.integers(1 << 30)), float(rng.choice([0.0, 0.5, 5.0])), float(rng.choice([0.0, 0.002, 0.02])))
+        Tc = np.eye(4)
+        Tc[:3, 3] = c
+        T = Tc @ P @ np.linalg.inv(Tc)                                   # the motion about the cloud's centre (a 5 degree turn about the origin moves a sheet at 40 m by metres)
+        if case % 5 == 4:
+            T = np.eye(4)                                                # exact coincidences: zero distances, duplicates
+        tgt, src, otgt, osrc = Cloud(xt, nt, cell), Cloud(xs, ns, cell), IcpOracle(xt, nt, cell), IcpOracle(xs, ns, cell)
+        for r in (cell, 0.5 * cell, 0.1 * cell):
+            cg, co = count_inliers(src, tgt, T, r), osrc.count_inliers(otgt, T, r)
+            assert cg == co, "fuzz case %d (kind %d, %d -> %d points, radius %g): count %d vs %d" % (case, kind, len(xs), len(xt), r, cg, co)
+            pg, _ = find_correspondence(src, tgt, T, r, -1.0)            # every pair within the radius (no normal filter): the NN index itself
+            po, _ = osrc.find_correspondence(otgt, T, r, -1.0)
+            assert pg.shape == po.shape and np.array_equal(pg, po), "fuzz case %d (kind %d, radius %g): %d of %d rows differ" % (
+                case, kind, r, int((pg != po).any(1).sum()) if pg.shape == po.shape else -1, len(po))
+            rows_compared += len(po)
+        for h in (tgt, src):
+            h.close()
+        for h in (otgt, osrc):
+            h.close()
+    assert rows_compared > 2000, rows_compared                        # (the sweep is not vacuous)
