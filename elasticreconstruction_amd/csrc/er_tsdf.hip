@@ -22,7 +22,7 @@
 //   k_plan         hands new units their pool slots, writes one record {key, slot, frame mask} per unit of the batch in cost order
 //                  (frames in the mask) and resets the work queue k_integrate claims its items from
 //  main stream:
-//   k_integrate    per wave a 4 x 8 x 8 box of a unit: each voxel is loaded ONCE, run against every (A4)
+//   k_integrate    per wave an 8 x 4 x 8 box of a unit: each voxel is loaded ONCE, run against every (A4)
 //                  frame whose bit is set IN FRAME ORDER, stored once -> bit-identical to the reference's
 //                  frame-by-frame loop with 1/batch of its HBM traffic
 // All kernels are HBM/latency/VALU work on scattered voxels and pixels: no MFMA.
@@ -407,8 +407,8 @@ namespace {
 // Work plan of one batch (single workgroup; a batch touches at most a few hundred units): the units of the
 // batch list sorted by DESCENDING cost = popcount(frame mask) -- the order in which the persistent workgroups of k_integrate
 // claim their items from the work queue (longest-processing-time first) -- and the queue head reset to 0.
-constexpr int kRows = 4;                  // register rows per lane of k_integrate: a wave owns a 4 x 8 x 8 box of voxels
-constexpr int kItemsPerUnit = 256;       // work items per unit: 4 slabs x 16 x 16 voxels per 256-thread workgroup
+constexpr int kRows = 4;                  // register rows per lane of k_integrate: a wave owns an 8 x 4 x 8 box of voxels (2 x 4 x 8 lanes x 4 rows)
+constexpr int kItemsPerUnit = 256;       // work items per unit: 8 x 8 x 16 voxels per 256-thread workgroup
 
 }  // namespace
 namespace er_tsdf_k {
@@ -500,10 +500,13 @@ __global__ __launch_bounds__(256) void k_plan(const int* __restrict__ batch, con
 // ------------------------------------------------------------------------------------------------
 // IntegrateVolumeUnit (TSDFVolume.cpp:69-102) for every touched unit of the batch.
 // Work item = 1024 voxels of a unit for one 256-thread workgroup (256 items per unit); each wave owns 256 of them in kRows = 4 register rows of 64 -- a
-// 4 x 8 x 8 box (mapping below).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform loop:
+// 8 x 4 x 8 box (mapping below).  The voxels stay in registers while the wave walks the unit's frame mask in ASCENDING frame order (wave-uniform loop:
 // the frame constants arrive by scalar loads) -- per voxel exactly the reference's frame-by-frame sequence.
 // Items come from ONE global work queue in cost order (k_plan), claimed when the workgroup is free.  (Static deals, per-XCD queues and look-ahead
 // claims were all measured slower: profiles/HISTORY.md "Path A: the schedule of k_integrate".)
+#ifndef ER_INT_LANE_SHAPE
+#define ER_INT_LANE_SHAPE 1              // lanes of a wave of k_integrate: 1 = 2 x 4 x 8 voxels (ships), 0 = 1 x 8 x 8 (rounds 2-5)
+#endif
 #ifndef ER_INT_MIN_BLOCKS
 #define ER_INT_MIN_BLOCKS 5
 #endif
@@ -546,14 +549,28 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     const int item = s_item;
     if (item >= n_items) break;
     const PlanRec rec = plan_rec[item >> 8];                              // (wave-uniform: one 16-byte scalar load)
-    // The wave owns a COMPACT 4 x 8 x 8 BOX of the unit: register row r = slab i + r, lane = 8 jj + kk (eight 64-byte segments per
-    // access; the neighbouring wave of the workgroup takes the other half of each 128-byte line); the workgroup = 4 slabs x 16 x 16
-    // voxels.  A compact box has a tight pixel hull (culling, the "inside" verdict), few idle lanes at surfaces and frustum borders and few patches
-    // that cross a surface; four rows per lane keep the longest items short and the kernel at 93 VGPRs (shapes tried: profiles/HISTORY.md).
+    // The wave owns a COMPACT 8 x 4 x 8 BOX of the unit.  Lanes = 2 slabs x 4 x 8 voxels (il, jl, kl), register row r = the next pair of slabs
+    // (i = i0 + il + 2 r); the workgroup's item = 8 x 8 x 16 voxels (waves: 2 along j, 2 along k).  Why this shape: a depth gather costs the vector L1
+    // ~0.6 clocks per DISTINCT address (profiles/r06y_gather_rates.txt) and k_integrate lives on its gathers (every gather issued twice: -19 % frames/s,
+    // profiles/r06z_ab_lane_shape.txt); the 64 voxels of an 8 x 8 plane -- rounds 2-5: lanes = one slab, rows = 4 slabs -- project onto 64 distinct pixels
+    // seen face-on, a 2 x 4 x 8 block onto fewer from every direction.  +4 % on the job against the 1 x 8 x 8 lanes (ER_INT_LANE_SHAPE 0, kept for that
+    // comparison); 4 x 4 x 4, 2 x 8 x 4, 2 x 2 x 16, 4 x 2 x 8, 1 x 4 x 16 lanes and two other item shapes measured behind it.  A compact box keeps a tight
+    // pixel hull (culling, the "inside" verdict), few idle lanes at surfaces and frustum borders and few patches that cross a surface; four rows per lane
+    // keep the longest items short and the kernel at 93 VGPRs.  Voxel accesses: eight 8-byte voxels = one 64-byte segment per (il, jl).
+#if ER_INT_LANE_SHAPE == 0
+    const int ilane = 0;
     const int i = ((item >> 4) & 15) * 4;
     const int j0 = ((item >> 2) & 3) * 16 + (wave >> 1) * 8;
     const int jlane = lane >> 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
-    constexpr int jspan = 8, kspan = 8, ispan = kRows;
+    constexpr int jspan = 8, kspan = 8, ispan = kRows, istep = 1;
+#else
+    const int ilane = lane >> 5;
+    const int i = ((item >> 5) & 7) * 8 + ilane;
+    const int j0 = ((item >> 2) & 7) * 8 + (wave >> 1) * 4;
+    const int jlane = (lane >> 3) & 3, k0 = (item & 3) * 16 + (wave & 1) * 8, klane = lane & 7;
+    constexpr int jspan = 4, kspan = 8, ispan = 2 * kRows, istep = 2;
+#endif
+    const int ibox = i - ilane;                                          // (wave-uniform: the box's first slab)
     const int key = rec.key, slot = rec.slot;
     if (slot < 0) continue;                                             // pool overflow: reported by the host
     unsigned long long m = rec.mask;
@@ -561,11 +578,11 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     const float xs = unit_shift(xi), ys = unit_shift(yi), zs = unit_shift(zi);
     const float g2 = grid_coord(k0 + klane, zs);
     float2* __restrict__ slab = pool + (size_t)slot * kUnitVox + (size_t)i * (kUnitRes * kUnitRes) + (j0 + jlane) * kUnitRes + k0 + klane;
-    float S[kRows], W[kRows], W0[kRows], g0[kRows];                      // g0 per register row (wave-uniform), g1 / g2 per lane
+    float S[kRows], W[kRows], W0[kRows], g0[kRows];                      // g0 per register row and slab of the lane, g1 / g2 per lane
     const float g1 = grid_coord(j0 + jlane, ys);
 #pragma unroll
-    for (int r = 0; r < kRows; r++) g0[r] = grid_coord(i + r, xs);
-    constexpr int row_stride = kUnitRes * kUnitRes;
+    for (int r = 0; r < kRows; r++) g0[r] = grid_coord(i + r * istep, xs);
+    constexpr int row_stride = istep * kUnitRes * kUnitRes;
 #pragma unroll
     for (int r = 0; r < kRows; r++) {                                   // loads in flight while the culling preamble computes
       const float2 v = slab[r * row_stride];                      // (loading only the surviving patches, after the culling,
@@ -584,7 +601,7 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     {
       bool keep = ((m >> lane) & 1ull) != 0ull, inside = false, full = false;
       if (keep)
-        keep = patch_may_update_box(grid_coord(i, xs), grid_coord(i + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
+        keep = patch_may_update_box(grid_coord(ibox, xs), grid_coord(ibox + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
                                     grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), frames[lane], cam, cols, rows,
                                     tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside,
                                     tile_lo + (size_t)lane * tiles_x * tiles_y, &full, kLoShift, lo_tiles_x,
