@@ -233,6 +233,12 @@ __global__ void k_zbuf_to_depth(uint32_t* __restrict__ zbuf, uint16_t* __restric
 // few hash entries with device-scope atomics at the same moment (measured: 90 % of wave time waiting).
 // Frames of the scaled-depth buffer are kScaledPad floats apart beyond their pixels; the pad stays 0.0f for ever (zero-filled at
 // create, never written): a voxel whose projection misses the image gathers from it instead of taking a predicated load.
+#ifndef ER_FRAMES_TRANSPOSED
+#define ER_FRAMES_TRANSPOSED 1           // k_integrate's culling reads the frame constants component-major (Staging::fxT); 0: frames[lane]
+#endif
+#ifndef ER_TILE_FRAME_FASTEST
+#define ER_TILE_FRAME_FASTEST 1          // tile_max / tile_lo / tile_lo_fine as [tile][frame of the batch] (0: [frame][tile], rounds 1-5)
+#endif
 constexpr int kScaledPad = 64;
 constexpr int kTile = 32;
 // Granularity of tile_lo_fine, the second-level per-tile MINIMUM of the scaled depth behind k_integrate's "full" verdict: 2^kLoShift pixels.
@@ -379,7 +385,11 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     float m = 0.0f, lo = 3.0e38f;
     for (int w = 0; w < kPrepThreads / 64; w++) m = fmaxf(m, s_wmax[w]);
     for (int e = 0; e < kLoSub * kLoSub * (kPrepThreads / 64); e++) lo = fminf(lo, (&s_wlo[0][0][0])[e]);
+#if ER_TILE_FRAME_FASTEST
+    const size_t t = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ER_MAX_BATCH + f;      // [tile][frame]: see k_integrate's culling
+#else
     const size_t t = ((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#endif
     tile_max[t] = m;
     tile_lo[t] = lo;                                      // the 32-pixel minimum: first level of the full verdict
   }
@@ -389,7 +399,11 @@ __global__ __launch_bounds__(kPrepThreads) void k_prepare(
     for (int w = 0; w < kPrepThreads / 64; w++) lo = fminf(lo, s_wlo[sr][sg][w]);
     const int lx = blockIdx.x * kLoSub + sg, ly = blockIdx.y * kLoSub + sr;
     const int lo_tx = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_ty = (rows + (1 << kLoShift) - 1) >> kLoShift;
+#if ER_TILE_FRAME_FASTEST
+    if (lx < lo_tx && ly < lo_ty) tile_lo_fine[((size_t)ly * lo_tx + lx) * ER_MAX_BATCH + f] = lo;
+#else
     if (lx < lo_tx && ly < lo_ty) tile_lo_fine[((size_t)f * lo_ty + ly) * lo_tx + lx] = lo;
+#endif
   }
   const int n = min(s_n, kTileKeys);
   if ((int)threadIdx.x < n) {
@@ -534,7 +548,10 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int pixels = cols * rows;
-  const int lo_tiles_x = (cols + (1 << kLoShift) - 1) >> kLoShift, lo_tiles = lo_tiles_x * ((rows + (1 << kLoShift) - 1) >> kLoShift);
+  const int lo_tiles_x = (cols + (1 << kLoShift) - 1) >> kLoShift;
+#if !ER_TILE_FRAME_FASTEST
+  const int lo_tiles = lo_tiles_x * ((rows + (1 << kLoShift) - 1) >> kLoShift);
+#endif
   const int n_items = plan->n_units * kItemsPerUnit;
   // Work queue: the items are sorted by descending cost (k_plan) and every workgroup claims the next one when it is done with its own (one atomic per
   // item and workgroup; 3 persistent workgroups per CU): longest-processing-time-first.  The culling and the full / sure shortcuts make the real cost of
@@ -600,12 +617,35 @@ __global__ __launch_bounds__(kBlock, kIntMinBlocks) void k_integrate(
     unsigned long long m_in, m_full;
     {
       bool keep = ((m >> lane) & 1ull) != 0ull, inside = false, full = false;
+#if ER_FRAMES_TRANSPOSED
+      // lane f tests frame f: its 16 constants come from the component-major copy behind frames[] (Staging::fxT) -- 64 lanes x 4 consecutive bytes per
+      // load where frames[lane] is one 64-byte line per lane
+      FrameXform fl;
+      if (keep) {
+        const float* __restrict__ fT = reinterpret_cast<const float*>(frames + ER_MAX_BATCH) + lane;
+#pragma unroll
+        for (int q = 0; q < 12; q++) fl.mi[q] = fT[q * ER_MAX_BATCH];
+        fl.tx = fT[12 * ER_MAX_BATCH];
+        fl.ty = fT[13 * ER_MAX_BATCH];
+        fl.tz = fT[14 * ER_MAX_BATCH];
+        fl.pad = 0.f;
+      }
+#else
+      const FrameXform& fl = frames[lane];
+#endif
       if (keep)
         keep = patch_may_update_box(grid_coord(ibox, xs), grid_coord(ibox + ispan - 1, xs), grid_coord(j0, ys), grid_coord(j0 + jspan - 1, ys),
-                                    grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), frames[lane], cam, cols, rows,
+                                    grid_coord(k0, zs), grid_coord(k0 + kspan - 1, zs), fl, cam, cols, rows,
+#if ER_TILE_FRAME_FASTEST
+                                    // tiles FRAME-fastest: lane f of this test is frame f, and consecutive frames of a sweep see the box under the
+                                    // same tiles -- 64 lanes x 4 consecutive bytes per load instead of 64 lines 1.2 KB apart
+                                    tile_max + lane, tiles_x, tiles_y, &inside, tile_lo + lane, &full, kLoShift, lo_tiles_x,
+                                    kLoShift < 5 ? tile_lo_fine + lane : (const float*)nullptr, ER_MAX_BATCH);
+#else
                                     tile_max + (size_t)lane * tiles_x * tiles_y, tiles_x, tiles_y, &inside,
                                     tile_lo + (size_t)lane * tiles_x * tiles_y, &full, kLoShift, lo_tiles_x,
                                     kLoShift < 5 ? tile_lo_fine + (size_t)lane * lo_tiles : (const float*)nullptr);
+#endif
       m = __ballot(keep);
       m_in = __ballot(keep && inside);
       m_full = __ballot(keep && full);
@@ -1395,6 +1435,7 @@ void undrop(er_tsdf_t h, const int* keys, int n) {
 // Host staging layout of one batch's constants inside the pinned buffer of its parity.
 struct Staging {
   er::FrameXform fx[ER_MAX_BATCH];
+  float fxT[16][ER_MAX_BATCH];                     // the same constants component-major, DIRECTLY behind fx (k_integrate's culling reads them with lane = frame)
   double t12[ER_MAX_BATCH * 12];
   double seg[ER_MAX_BATCH * 16];
   double madj[ER_MAX_BATCH * 12];
@@ -1452,7 +1493,9 @@ int run_batch(er_tsdf_t h, int n, const uint16_t* depth_dev, const double* T, co
     st->fx[f].ty = (float)Tf[7];
     st->fx[f].tz = (float)Tf[11];
     st->fx[f].pad = 0.f;
+    for (int q = 0; q < 16; q++) st->fxT[q][f] = reinterpret_cast<const float*>(&st->fx[f])[q];
   }
+  static_assert(offsetof(Staging, fxT) == sizeof(er::FrameXform) * ER_MAX_BATCH && sizeof(er::FrameXform) == 64, "fxT lies directly behind fx");
   hipStream_t X = h->aux_stream[a], S = h->stream;
   int* nbatch = h->counters + kNbatchSlot[p];
 

@@ -392,7 +392,8 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 //     (a planar convex patch in front of the camera projects inside the convex hull of its corners)
 //   * M = max of the scaled depth over the 32x32-pixel tiles under the box is <= 0.001 -> :82 fails everywhere
 //   * M - (distance from the camera centre to the rectangle) < -trunc - 1e-4          -> :87 fails everywhere
-// tile_max: per frame, tiles_x * tiles_y floats written by k_prepare.  Returns false only if provably dead.
+// tile_max: per frame, tiles_x * tiles_y floats written by k_prepare, tstride floats apart (1: one frame's tiles in a row; k_integrate keeps the tiles
+// FRAME-fastest, tstride = the batch capacity: its lanes are the frames of the batch and mostly read the same tile).  Returns false only if provably dead.
 //
 // *inside (second verdict, for the frames that stay): true only if EVERY voxel of the patch provably passes the tests of
 // voxel_project -- t2 > 0, t2 inside [2^-30, 2^30], -0.5 <= u < cols - 0.5, -0.5 <= v < rows - 0.5 -- so that k_integrate may
@@ -431,7 +432,7 @@ ER_HD bool voxel_update(float& S, float& W, float g0, float g1, float g2, const 
 ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, float g2lo, float g2hi, const FrameXform& f, const Camera& c,
                                 int cols, int rows, const float* __restrict__ tile_max, int tiles_x, int tiles_y, bool* inside,
                                 const float* __restrict__ tile_lo = nullptr, bool* full = nullptr, int lo_shift = 5, int lo_tiles_x = 0,
-                                const float* __restrict__ tile_lo_fine = nullptr) {
+                                const float* __restrict__ tile_lo_fine = nullptr, int tstride = 1) {
   *inside = false;
   if (full) *full = false;
   float lo_tile = 0.0f;                                   // min of the scaled depth over every pixel a voxel can sample (0: unknown)
@@ -479,8 +480,8 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
       float m = 0.0f, lo = 3.0e38f;
       for (int ty = y0; ty <= y1; ty++)
         for (int tx = x0; tx <= x1; tx++) {
-          m = fmaxf(m, tile_max[ty * tiles_x + tx]);
-          if (tile_lo) lo = fminf(lo, tile_lo[ty * tiles_x + tx]);
+          m = fmaxf(m, tile_max[(ty * tiles_x + tx) * tstride]);
+          if (tile_lo) lo = fminf(lo, tile_lo[(ty * tiles_x + tx) * tstride]);
         }
       dmax_tile = m;
       if (tile_lo) lo_tile = lo;
@@ -521,7 +522,7 @@ ER_HD bool patch_may_update_box(float g0lo, float g0hi, float g1lo, float g1hi, 
       if ((a1 - a0 + 1) * (b1 - b0 + 1) <= 64) {
         float lo = 3.0e38f;
         for (int ty = b0; ty <= b1; ty++)
-          for (int tx = a0; tx <= a1; tx++) lo = fminf(lo, tile_lo_fine[ty * lo_tiles_x + tx]);
+          for (int tx = a0; tx <= a1; tx++) lo = fminf(lo, tile_lo_fine[(ty * lo_tiles_x + tx) * tstride]);
         *full = (lo > 0.001f) & (lo - dfar > need);
       }
     }
